@@ -1,0 +1,762 @@
+/*
+ * jst_oracle.c -- CPU restatement of the CyberEther (Jetstream) hot-path modules.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (cyberether_amd/, bench.py's
+ * timed GPU leg) may call into this file.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and there only as the checker / CPU baseline.
+ *
+ * Every function restates, in plain C with IEEE-754 binary32/binary64 arithmetic and
+ * NO fused multiply-add (build with -ffp-contract=off), the arithmetic of one reference
+ * CPU module.  Citations are relative to /root/reference (CyberEther 1.9.1).
+ *
+ * Parity pinning: tests/test_oracle_*.py check this file against
+ *   (1) the known-answer vectors in the reference's own module tests (tests/golden/*.json,
+ *       transcribed with file:line citations), and
+ *   (2) oracle/_ref/libref_pocketfft.so -- the reference's vendored pocketfft.hh compiled
+ *       in place from /root/reference (bit-exact comparison of the FFT restatement).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define JST_PI 3.14159265358979323846 /* include/jetstream/types.hh:52-53 */
+
+#define ORACLE_MAX_RANK 8
+
+/* ------------------------------------------------------------------------------------------
+ * Strided N-ary traversal.
+ * Restates include/jetstream/tools/automatic_iterator.hh:108-343: elements are visited in
+ * row-major order over the (common) shape; every tensor has its own element strides.  All
+ * the specialised 1D/contiguous/2D/3D iterators there produce the same visiting order as the
+ * generic coordinate-odometer at :207-231, which is what is restated here.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t rank;
+    uint64_t shape[ORACLE_MAX_RANK];
+    uint64_t coord[ORACLE_MAX_RANK];
+} odometer_t;
+
+static uint64_t odo_init(odometer_t* o, uint32_t rank, const uint64_t* shape) {
+    uint64_t size = 1;
+    o->rank = rank;
+    for (uint32_t i = 0; i < rank; ++i) {
+        o->shape[i] = shape[i];
+        o->coord[i] = 0;
+        size *= shape[i];
+    }
+    return size;
+}
+
+static uint64_t odo_offset(const odometer_t* o, const uint64_t* stride) {
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < o->rank; ++i) off += o->coord[i] * stride[i];
+    return off;
+}
+
+static void odo_step(odometer_t* o) {
+    for (uint32_t axis = o->rank; axis-- > 0;) {
+        if (o->coord[axis] + 1 < o->shape[axis]) {
+            o->coord[axis]++;
+            return;
+        }
+        o->coord[axis] = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Window (Blackman).  src/domains/dsp/window/module_impl_native_cpu.cc:20-37.
+ * F64 evaluation, symmetric (N-1) denominator, imag = +0; N == 1 -> (1, 0).
+ * out: interleaved CF32[n].
+ * ---------------------------------------------------------------------------------------- */
+void jst_oracle_window(float* out, uint64_t n) {
+    if (n == 1) {
+        out[0] = 1.0f;
+        out[1] = 0.0f;
+        return;
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        const double tap = 0.42 - 0.50 * cos(2.0 * JST_PI * i / (n - 1)) +
+                           0.08 * cos(4.0 * JST_PI * i / (n - 1));
+        out[2 * i] = (float)tap;
+        out[2 * i + 1] = 0.0f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Invert.  src/domains/dsp/invert/module_impl_native_cpu.cc:79-103.
+ * Flat index 'index' runs over the (contiguous-order) element sequence; the coordinate on the
+ * resolved sample axis is (index / inner) % length.  Even length: negate odd coordinates
+ * (unary minus flips the sign of BOTH parts, so +0 imag becomes -0).  Odd length: multiply by
+ * the F64-evaluated phasor exp(j*2*pi*floor(length/2)*n/length) cast to F32, using the
+ * std::complex<float> product (re = a*c - b*d, im = a*d + b*c; see multiply below).
+ * in/out interleaved CF32, contiguous, 'count' elements.  f32 variant promotes to (x, +0).
+ * ---------------------------------------------------------------------------------------- */
+static void cmul_f32(float a, float b, float c, float d, float* re, float* im);
+
+void jst_oracle_invert_cf32(const float* in, float* out, uint64_t count, uint64_t inner,
+                            uint64_t length) {
+    for (uint64_t index = 0; index < count; ++index) {
+        const uint64_t coord = (index / inner) % length;
+        const float re = in[2 * index], im = in[2 * index + 1];
+        if ((length & 1ull) == 0) {
+            if (coord & 1ull) {
+                out[2 * index] = -re;
+                out[2 * index + 1] = -im;
+            } else {
+                out[2 * index] = re;
+                out[2 * index + 1] = im;
+            }
+        } else {
+            const double phase =
+                2.0 * JST_PI * (double)(length / 2) * (double)coord / (double)length;
+            cmul_f32(re, im, (float)cos(phase), (float)sin(phase), &out[2 * index],
+                     &out[2 * index + 1]);
+        }
+    }
+}
+
+void jst_oracle_invert_f32(const float* in, float* out, uint64_t count, uint64_t inner,
+                           uint64_t length) {
+    for (uint64_t index = 0; index < count; ++index) {
+        const uint64_t coord = (index / inner) % length;
+        const float re = in[index], im = 0.0f;
+        if ((length & 1ull) == 0) {
+            if (coord & 1ull) {
+                out[2 * index] = -re;
+                out[2 * index + 1] = -im;
+            } else {
+                out[2 * index] = re;
+                out[2 * index + 1] = im;
+            }
+        } else {
+            const double phase =
+                2.0 * JST_PI * (double)(length / 2) * (double)coord / (double)length;
+            cmul_f32(re, im, (float)cos(phase), (float)sin(phase), &out[2 * index],
+                     &out[2 * index + 1]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Multiply (broadcast, strided).  src/domains/core/multiply/module_impl.cc:10-84 (broadcast
+ * views: stride 0 on expanded axes) and module_impl_native_cpu.cc:86-100 (c = a * b).
+ * CF32 product is std::complex<float>::operator*, i.e. libgcc __mulsc3: the four products
+ * ac, bd, ad, bc are rounded individually, re = ac - bd, im = ad + bc, and only if BOTH
+ * results are NaN is the C99 Annex G infinity-recovery path taken.  Restated here for finite
+ * inputs plus the recovery path (so inf/NaN inputs also match).
+ * Strides are in ELEMENTS (src/memory/tensor.cc:94-109).
+ * ---------------------------------------------------------------------------------------- */
+static void cmul_f32(float a, float b, float c, float d, float* re, float* im) {
+    float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+    float x = ac - bd, y = ad + bc;
+    if (isnan(x) && isnan(y)) {
+        int recalc = 0;
+        if (isinf(a) || isinf(b)) {
+            a = copysignf(isinf(a) ? 1.0f : 0.0f, a);
+            b = copysignf(isinf(b) ? 1.0f : 0.0f, b);
+            if (isnan(c)) c = copysignf(0.0f, c);
+            if (isnan(d)) d = copysignf(0.0f, d);
+            recalc = 1;
+        }
+        if (isinf(c) || isinf(d)) {
+            c = copysignf(isinf(c) ? 1.0f : 0.0f, c);
+            d = copysignf(isinf(d) ? 1.0f : 0.0f, d);
+            if (isnan(a)) a = copysignf(0.0f, a);
+            if (isnan(b)) b = copysignf(0.0f, b);
+            recalc = 1;
+        }
+        if (!recalc && (isinf(ac) || isinf(bd) || isinf(ad) || isinf(bc))) {
+            if (isnan(a)) a = copysignf(0.0f, a);
+            if (isnan(b)) b = copysignf(0.0f, b);
+            if (isnan(c)) c = copysignf(0.0f, c);
+            if (isnan(d)) d = copysignf(0.0f, d);
+            recalc = 1;
+        }
+        if (recalc) {
+            x = INFINITY * (a * c - b * d);
+            y = INFINITY * (a * d + b * c);
+        }
+    }
+    *re = x;
+    *im = y;
+}
+
+void jst_oracle_multiply_cf32(uint32_t rank, const uint64_t* shape, const float* a,
+                              const uint64_t* sa, const float* b, const uint64_t* sb, float* c,
+                              const uint64_t* sc) {
+    odometer_t o;
+    const uint64_t size = odo_init(&o, rank, shape);
+    for (uint64_t i = 0; i < size; ++i) {
+        const uint64_t ia = odo_offset(&o, sa), ib = odo_offset(&o, sb), ic = odo_offset(&o, sc);
+        cmul_f32(a[2 * ia], a[2 * ia + 1], b[2 * ib], b[2 * ib + 1], &c[2 * ic], &c[2 * ic + 1]);
+        odo_step(&o);
+    }
+}
+
+void jst_oracle_multiply_f32(uint32_t rank, const uint64_t* shape, const float* a,
+                             const uint64_t* sa, const float* b, const uint64_t* sb, float* c,
+                             const uint64_t* sc) {
+    odometer_t o;
+    const uint64_t size = odo_init(&o, rank, shape);
+    for (uint64_t i = 0; i < size; ++i) {
+        c[odo_offset(&o, sc)] = a[odo_offset(&o, sa)] * b[odo_offset(&o, sb)];
+        odo_step(&o);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FFT, complex-to-complex, single precision, UNNORMALISED in both directions.
+ * The reference calls pocketfft::c2c(..., fct = 1.0f) (src/domains/dsp/fft/
+ * module_impl_native_cpu.cc:125-140) on its vendored src/domains/dsp/fft/pocketfft.hh
+ * (in-tree, BSD-3; so no unpinned third-party dependency).  For lengths whose only prime
+ * factor is 2 the plan is cfftp (pocketfft.hh:819-1560):
+ *   factorize()   :1476-1497  -> 8s first, then 4s, then one 2 moved to the FRONT
+ *   comp_twiddle():1513-1535  -> tw[(j-1)*(ido-1)+i-1] = twiddle[j*l1*i]
+ *   sincos_2pibyn :296-372    -> twiddles from two F64 tables multiplied in F64, cast to F32
+ *   pass_all      :1420-1468  -> Stockham passes ping-ponging between c and ch
+ *   pass2/4/8     :843-872, :929-975, :1141-1223 with special_mul<fwd> (:266-272, conj for fwd)
+ * This restatement covers exactly those lengths (n = 2^m, m >= 0); other lengths are checked
+ * against oracle/_ref only.  It is verified BIT-EXACT against oracle/_ref for every m in
+ * 0..16, both directions (tests/test_oracle_fft.py).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double r, i;
+} c64;
+typedef struct {
+    float r, i;
+} c32;
+
+typedef struct {
+    uint64_t N, mask, shift;
+    c64 *v1, *v2;
+} sincos_t;
+
+static c64 sincos_calc(uint64_t x, uint64_t n, double ang) { /* pocketfft.hh:303-339 */
+    c64 o;
+    x <<= 3;
+    if (x < 4 * n) {
+        if (x < 2 * n) {
+            if (x < n) {
+                o.r = cos((double)x * ang);
+                o.i = sin((double)x * ang);
+                return o;
+            }
+            o.r = sin((double)(2 * n - x) * ang);
+            o.i = cos((double)(2 * n - x) * ang);
+            return o;
+        } else {
+            x -= 2 * n;
+            if (x < n) {
+                o.r = -sin((double)x * ang);
+                o.i = cos((double)x * ang);
+                return o;
+            }
+            o.r = -cos((double)(2 * n - x) * ang);
+            o.i = sin((double)(2 * n - x) * ang);
+            return o;
+        }
+    } else {
+        x = 8 * n - x;
+        if (x < 2 * n) {
+            if (x < n) {
+                o.r = cos((double)x * ang);
+                o.i = -sin((double)x * ang);
+                return o;
+            }
+            o.r = sin((double)(2 * n - x) * ang);
+            o.i = -cos((double)(2 * n - x) * ang);
+            return o;
+        } else {
+            x -= 2 * n;
+            if (x < n) {
+                o.r = -sin((double)x * ang);
+                o.i = -cos((double)x * ang);
+                return o;
+            }
+            o.r = -cos((double)(2 * n - x) * ang);
+            o.i = -sin((double)(2 * n - x) * ang);
+            return o;
+        }
+    }
+}
+
+static void sincos_init(sincos_t* s, uint64_t n) { /* pocketfft.hh:342-360 */
+    const long double pi = 3.141592653589793238462643383279502884197L;
+    const double ang = (double)(0.25L * pi / n);
+    const uint64_t nval = (n + 2) / 2;
+    s->N = n;
+    s->shift = 1;
+    while ((((uint64_t)1) << s->shift) * (((uint64_t)1) << s->shift) < nval) ++s->shift;
+    s->mask = (((uint64_t)1) << s->shift) - 1;
+    const uint64_t n1 = s->mask + 1;
+    const uint64_t n2 = (nval + s->mask) / (s->mask + 1);
+    s->v1 = (c64*)malloc(n1 * sizeof(c64));
+    s->v2 = (c64*)malloc(n2 * sizeof(c64));
+    s->v1[0].r = 1.0;
+    s->v1[0].i = 0.0;
+    for (uint64_t i = 1; i < n1; ++i) s->v1[i] = sincos_calc(i, n, ang);
+    s->v2[0].r = 1.0;
+    s->v2[0].i = 0.0;
+    for (uint64_t i = 1; i < n2; ++i) s->v2[i] = sincos_calc(i * (s->mask + 1), n, ang);
+}
+
+static c32 sincos_get(const sincos_t* s, uint64_t idx) { /* pocketfft.hh:362-372 */
+    c32 o;
+    if (2 * idx <= s->N) {
+        const c64 x1 = s->v1[idx & s->mask], x2 = s->v2[idx >> s->shift];
+        o.r = (float)(x1.r * x2.r - x1.i * x2.i);
+        o.i = (float)(x1.r * x2.i + x1.i * x2.r);
+        return o;
+    }
+    idx = s->N - idx;
+    const c64 x1 = s->v1[idx & s->mask], x2 = s->v2[idx >> s->shift];
+    o.r = (float)(x1.r * x2.r - x1.i * x2.i);
+    o.i = -(float)(x1.r * x2.i + x1.i * x2.r);
+    return o;
+}
+
+static void sincos_free(sincos_t* s) {
+    free(s->v1);
+    free(s->v2);
+}
+
+/* Fills tw[n] with exp(+j*2*pi*k/n) exactly as pocketfft's sincos_2pibyn<float>(n)[k].
+ * Exposed so tests can pin the product's twiddle generator against the same table. */
+void jst_oracle_fft_twiddles(float* tw, uint64_t n) {
+    sincos_t s;
+    sincos_init(&s, n);
+    for (uint64_t k = 0; k < n; ++k) {
+        const c32 w = sincos_get(&s, k);
+        tw[2 * k] = w.r;
+        tw[2 * k + 1] = w.i;
+    }
+    sincos_free(&s);
+}
+
+/* Factor list for n = 2^m (pocketfft.hh:1476-1497).  Returns count. */
+int jst_oracle_fft_factors(uint64_t n, uint32_t* fact) {
+    int nf = 0;
+    uint64_t len = n;
+    if (len <= 1) return 0;
+    while ((len & 7) == 0) {
+        fact[nf++] = 8;
+        len >>= 3;
+    }
+    while ((len & 3) == 0) {
+        fact[nf++] = 4;
+        len >>= 2;
+    }
+    if ((len & 1) == 0) {
+        len >>= 1;
+        fact[nf++] = 2;
+        const uint32_t t = fact[0];
+        fact[0] = fact[nf - 1];
+        fact[nf - 1] = t;
+    }
+    return (len == 1) ? nf : -1; /* -1: not a power of two -> not restated */
+}
+
+static inline c32 cadd(c32 a, c32 b) {
+    c32 o = {a.r + b.r, a.i + b.i};
+    return o;
+}
+static inline c32 csub(c32 a, c32 b) {
+    c32 o = {a.r - b.r, a.i - b.i};
+    return o;
+}
+/* special_mul<fwd> (pocketfft.hh:266-272): forward multiplies by conj(w). */
+static inline c32 special_mul(c32 v, c32 w, int fwd) {
+    c32 o;
+    if (fwd) {
+        o.r = v.r * w.r + v.i * w.i;
+        o.i = v.i * w.r - v.r * w.i;
+    } else {
+        o.r = v.r * w.r - v.i * w.i;
+        o.i = v.r * w.i + v.i * w.r;
+    }
+    return o;
+}
+/* ROTX90<fwd> (pocketfft.hh:290-291): fwd -> multiply by -j, bwd -> by +j. */
+static inline c32 rotx90(c32 a, int fwd) {
+    c32 o;
+    if (fwd) {
+        o.r = a.i;
+        o.i = -a.r;
+    } else {
+        o.r = -a.i;
+        o.i = a.r;
+    }
+    return o;
+}
+/* ROTX45 / ROTX135 (pocketfft.hh:1124-1139). */
+static inline c32 rotx45(c32 a, int fwd) {
+    const float hsqt2 = (float)0.707106781186547524400844362104849L;
+    c32 o;
+    if (fwd) {
+        o.r = hsqt2 * (a.r + a.i);
+        o.i = hsqt2 * (a.i - a.r);
+    } else {
+        o.r = hsqt2 * (a.r - a.i);
+        o.i = hsqt2 * (a.i + a.r);
+    }
+    return o;
+}
+static inline c32 rotx135(c32 a, int fwd) {
+    const float hsqt2 = (float)0.707106781186547524400844362104849L;
+    c32 o;
+    if (fwd) {
+        o.r = hsqt2 * (a.i - a.r);
+        o.i = hsqt2 * (-a.r - a.i);
+    } else {
+        o.r = hsqt2 * (-a.r - a.i);
+        o.i = hsqt2 * (a.r - a.i);
+    }
+    return o;
+}
+
+#define CC(a, b, c) cc[(a) + ido * ((b) + ip * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + l1 * (c))]
+#define WA(x, i) wa[(i)-1 + (x) * (ido - 1)]
+
+static void pass2(uint64_t ido, uint64_t l1, const c32* cc, c32* ch, const c32* wa, int fwd) {
+    const uint64_t ip = 2; /* pocketfft.hh:843-872 */
+    for (uint64_t k = 0; k < l1; ++k) {
+        CH(0, k, 0) = cadd(CC(0, 0, k), CC(0, 1, k));
+        CH(0, k, 1) = csub(CC(0, 0, k), CC(0, 1, k));
+        for (uint64_t i = 1; i < ido; ++i) {
+            CH(i, k, 0) = cadd(CC(i, 0, k), CC(i, 1, k));
+            CH(i, k, 1) = special_mul(csub(CC(i, 0, k), CC(i, 1, k)), WA(0, i), fwd);
+        }
+    }
+}
+
+static void pass4(uint64_t ido, uint64_t l1, const c32* cc, c32* ch, const c32* wa, int fwd) {
+    const uint64_t ip = 4; /* pocketfft.hh:929-975 */
+    for (uint64_t k = 0; k < l1; ++k) {
+        for (uint64_t i = 0; i < ido; ++i) {
+            c32 t1, t2, t3, t4;
+            const c32 cc0 = CC(i, 0, k), cc1 = CC(i, 1, k), cc2 = CC(i, 2, k), cc3 = CC(i, 3, k);
+            t2 = cadd(cc0, cc2);
+            t1 = csub(cc0, cc2);
+            t3 = cadd(cc1, cc3);
+            t4 = csub(cc1, cc3);
+            t4 = rotx90(t4, fwd);
+            if (i == 0) {
+                CH(0, k, 0) = cadd(t2, t3);
+                CH(0, k, 2) = csub(t2, t3);
+                CH(0, k, 1) = cadd(t1, t4);
+                CH(0, k, 3) = csub(t1, t4);
+            } else {
+                CH(i, k, 0) = cadd(t2, t3);
+                CH(i, k, 1) = special_mul(cadd(t1, t4), WA(0, i), fwd);
+                CH(i, k, 2) = special_mul(csub(t2, t3), WA(1, i), fwd);
+                CH(i, k, 3) = special_mul(csub(t1, t4), WA(2, i), fwd);
+            }
+        }
+    }
+}
+
+static void pass8(uint64_t ido, uint64_t l1, const c32* cc, c32* ch, const c32* wa, int fwd) {
+    const uint64_t ip = 8; /* pocketfft.hh:1141-1223 */
+    for (uint64_t k = 0; k < l1; ++k) {
+        for (uint64_t i = 0; i < ido; ++i) {
+            c32 a0, a1, a2, a3, a4, a5, a6, a7, t;
+            /* PM(a1,a5,CC1,CC5); PM(a3,a7,CC3,CC7) */
+            a1 = cadd(CC(i, 1, k), CC(i, 5, k));
+            a5 = csub(CC(i, 1, k), CC(i, 5, k));
+            a3 = cadd(CC(i, 3, k), CC(i, 7, k));
+            a7 = csub(CC(i, 3, k), CC(i, 7, k));
+            /* The i==0 and i>0 bodies order ROTX90(a7) differently relative to
+             * PMINPLACE(a1,a3), but those touch disjoint values: same arithmetic. */
+            a7 = rotx90(a7, fwd);
+            t = a1; /* PMINPLACE(a1,a3) */
+            a1 = cadd(a1, a3);
+            a3 = csub(t, a3);
+            a3 = rotx90(a3, fwd);
+            t = a5; /* PMINPLACE(a5,a7) */
+            a5 = cadd(a5, a7);
+            a7 = csub(t, a7);
+            a5 = rotx45(a5, fwd);
+            a7 = rotx135(a7, fwd);
+            a0 = cadd(CC(i, 0, k), CC(i, 4, k));
+            a4 = csub(CC(i, 0, k), CC(i, 4, k));
+            a2 = cadd(CC(i, 2, k), CC(i, 6, k));
+            a6 = csub(CC(i, 2, k), CC(i, 6, k));
+            if (i == 0) {
+                /* pocketfft.hh:1166-1172 */
+                const c32 s02 = cadd(a0, a2), d02 = csub(a0, a2);
+                CH(0, k, 0) = cadd(s02, a1);
+                CH(0, k, 4) = csub(s02, a1);
+                CH(0, k, 2) = cadd(d02, a3);
+                CH(0, k, 6) = csub(d02, a3);
+                a6 = rotx90(a6, fwd);
+                const c32 s46 = cadd(a4, a6), d46 = csub(a4, a6);
+                CH(0, k, 1) = cadd(s46, a5);
+                CH(0, k, 5) = csub(s46, a5);
+                CH(0, k, 3) = cadd(d46, a7);
+                CH(0, k, 7) = csub(d46, a7);
+            } else {
+                /* pocketfft.hh:1210-1220 */
+                t = a0; /* PMINPLACE(a0,a2) */
+                a0 = cadd(a0, a2);
+                a2 = csub(t, a2);
+                CH(i, k, 0) = cadd(a0, a1);
+                CH(i, k, 4) = special_mul(csub(a0, a1), WA(3, i), fwd);
+                CH(i, k, 2) = special_mul(cadd(a2, a3), WA(1, i), fwd);
+                CH(i, k, 6) = special_mul(csub(a2, a3), WA(5, i), fwd);
+                a6 = rotx90(a6, fwd);
+                t = a4; /* PMINPLACE(a4,a6) */
+                a4 = cadd(a4, a6);
+                a6 = csub(t, a6);
+                CH(i, k, 1) = special_mul(cadd(a4, a5), WA(0, i), fwd);
+                CH(i, k, 5) = special_mul(csub(a4, a5), WA(4, i), fwd);
+                CH(i, k, 3) = special_mul(cadd(a6, a7), WA(2, i), fwd);
+                CH(i, k, 7) = special_mul(csub(a6, a7), WA(6, i), fwd);
+            }
+        }
+    }
+}
+#undef CC
+#undef CH
+#undef WA
+
+/* in/out: interleaved CF32, 'batch' contiguous rows of n.  Returns 0, or -1 if n is not 2^m. */
+int jst_oracle_fft_c2c(const float* in, float* out, uint64_t n, uint64_t batch, int forward) {
+    uint32_t fact[64];
+    const int nf = jst_oracle_fft_factors(n, fact);
+    if (n == 0 || nf < 0) return -1;
+    if (n == 1) {
+        memcpy(out, in, batch * 2 * sizeof(float));
+        return 0;
+    }
+    /* twiddles, laid out per pass exactly like cfftp::mem (pocketfft.hh:1513-1535) */
+    sincos_t s;
+    sincos_init(&s, n);
+    c32* mem = (c32*)malloc((n + 64) * sizeof(c32));
+    const c32* tw[64];
+    {
+        uint64_t l1 = 1, memofs = 0;
+        for (int k = 0; k < nf; ++k) {
+            const uint64_t ip = fact[k], ido = n / (l1 * ip);
+            tw[k] = mem + memofs;
+            for (uint64_t j = 1; j < ip; ++j)
+                for (uint64_t i = 1; i < ido; ++i)
+                    mem[memofs + (j - 1) * (ido - 1) + i - 1] = sincos_get(&s, j * l1 * i);
+            memofs += (ip - 1) * (ido - 1);
+            l1 *= ip;
+        }
+    }
+    c32* c = (c32*)malloc(n * sizeof(c32));
+    c32* ch = (c32*)malloc(n * sizeof(c32));
+    for (uint64_t b = 0; b < batch; ++b) {
+        memcpy(c, in + 2 * b * n, n * sizeof(c32));
+        c32 *p1 = c, *p2 = ch;
+        uint64_t l1 = 1;
+        for (int k = 0; k < nf; ++k) { /* pass_all, pocketfft.hh:1420-1468 */
+            const uint64_t ip = fact[k], l2 = ip * l1, ido = n / l2;
+            if (ip == 8)
+                pass8(ido, l1, p1, p2, tw[k], forward);
+            else if (ip == 4)
+                pass4(ido, l1, p1, p2, tw[k], forward);
+            else
+                pass2(ido, l1, p1, p2, tw[k], forward);
+            c32* t = p1;
+            p1 = p2;
+            p2 = t;
+            l1 = l2;
+        }
+        memcpy(out + 2 * b * n, p1, n * sizeof(c32)); /* fct == 1: plain copy */
+    }
+    free(c);
+    free(ch);
+    free(mem);
+    sincos_free(&s);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Amplitude.  src/domains/dsp/amplitude/module_impl.cc:44-60 (coefficient) and
+ * module_impl_native_cpu.cc:73-99 (kernels); Backend::ApproxLog10 is
+ * include/jetstream/backend/devices/cpu/helpers.hh:59-74 (frexpf + cubic, separate mul/add).
+ * ---------------------------------------------------------------------------------------- */
+float jst_oracle_approx_log10(float x) {
+    float y, f;
+    int e;
+    f = frexpf(fabsf(x), &e);
+    y = 1.23149591368684f;
+    y *= f;
+    y += -4.11852516267426f;
+    y *= f;
+    y += 6.02197014179219f;
+    y *= f;
+    y += -3.13396450166353f;
+    y += e;
+    return y * 0.3010299956639812f;
+}
+
+float jst_oracle_amplitude_coeff(uint64_t normalization_size) {
+    return 20.0f * log10f(1.0f / (float)normalization_size);
+}
+
+void jst_oracle_amplitude_cf32(uint32_t rank, const uint64_t* shape, const float* in,
+                               const uint64_t* sin_, float* out, const uint64_t* sout,
+                               float coeff) {
+    odometer_t o;
+    const uint64_t size = odo_init(&o, rank, shape);
+    for (uint64_t i = 0; i < size; ++i) {
+        const uint64_t ii = odo_offset(&o, sin_), io = odo_offset(&o, sout);
+        const float re = in[2 * ii], im = in[2 * ii + 1];
+        const float mag = sqrtf((re * re) + (im * im));
+        out[io] = (mag == 0.0f) ? -INFINITY : 20.0f * jst_oracle_approx_log10(mag) + coeff;
+        odo_step(&o);
+    }
+}
+
+void jst_oracle_amplitude_f32(uint32_t rank, const uint64_t* shape, const float* in,
+                              const uint64_t* sin_, float* out, const uint64_t* sout,
+                              float coeff) {
+    odometer_t o;
+    const uint64_t size = odo_init(&o, rank, shape);
+    for (uint64_t i = 0; i < size; ++i) {
+        const float mag = fabsf(in[odo_offset(&o, sin_)]);
+        out[odo_offset(&o, sout)] =
+            (mag == 0.0f) ? -INFINITY : 20.0f * jst_oracle_approx_log10(mag) + coeff;
+        odo_step(&o);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Range.  src/domains/core/range/module_impl.cc:51-62 (coefficients) and
+ * module_impl_native_cpu.cc:67-82 (kernel, libm tanhf).
+ * ---------------------------------------------------------------------------------------- */
+void jst_oracle_range_coeffs(float min, float max, float* scale, float* offset) {
+    const float lower = min < max ? min : max;
+    const float upper = min < max ? max : min;
+    if (lower == upper) {
+        *scale = 0.0f;
+        *offset = 0.5f;
+        return;
+    }
+    *scale = 1.0f / (upper - lower);
+    *offset = -lower * *scale;
+}
+
+void jst_oracle_range_f32(uint32_t rank, const uint64_t* shape, const float* in,
+                          const uint64_t* sin_, float* out, const uint64_t* sout, float scale,
+                          float offset) {
+    odometer_t o;
+    const uint64_t size = odo_init(&o, rank, shape);
+    for (uint64_t i = 0; i < size; ++i) {
+        const uint64_t io = odo_offset(&o, sout);
+        if (scale == 0.0f) {
+            out[io] = 0.5f;
+        } else {
+            const float normalized = in[odo_offset(&o, sin_)] * scale + offset;
+            out[io] = 0.5f + 0.5f * tanhf(4.0f * (normalized - 0.5f));
+        }
+        odo_step(&o);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Spectrogram.  src/domains/visualization/spectrogram/module_impl.cc:104 (decay) and
+ * module_impl_native_cpu.cc:61-87 (compute).  State 'bins' is F32 laid out [height][width]
+ * (index x + idx*width) although the tensor shape is {width, height} (module_impl.cc:108).
+ *
+ * The reference computes  index = static_cast<U64>(in * (F32)height)  and accepts
+ * 0 < index < height.  That cast is undefined for negative/NaN/huge values; on x86-64 (the
+ * reference's CPU target) values in (-1,1) truncate to 0, values <= -1 wrap to >= 2^63, NaN
+ * gives 0x8000000000000000 and +inf gives 0 -- all rejected.  The defined-behaviour statement
+ * of the same rule, used here and by the HIP kernel, is:
+ *     f = in * (float)height;  hit  <=>  (f >= 1.0f && f < (float)height);  index = (u64)f.
+ * ---------------------------------------------------------------------------------------- */
+float jst_oracle_spectrogram_decay(uint64_t batches) { return powf(0.999f, (float)batches); }
+
+void jst_oracle_spectrogram(float* bins, const float* in, uint64_t batches, uint64_t width,
+                            uint64_t height, uint64_t batch_stride, uint64_t elem_stride,
+                            float decay) {
+    const uint64_t total = width * height;
+    for (uint64_t i = 0; i < total; ++i) bins[i] *= decay;
+    const float fh = (float)height;
+    for (uint64_t b = 0; b < batches; ++b) {
+        for (uint64_t x = 0; x < width; ++x) {
+            const float f = in[b * batch_stride + x * elem_stride] * fh;
+            if (f >= 1.0f && f < fh) {
+                const uint64_t index = (uint64_t)f;
+                float* val = &bins[x + index * width];
+                const float v = *val + 0.02f;
+                *val = v < 1.0f ? v : 1.0f; /* std::min(val + 0.02f, 1.0f) */
+            }
+        }
+    }
+}
+
+/* Raw x86-64 cast variant, for tests that pin the rule above against the literal cast on the
+ * values where the cast is defined (f in [0, 2^63)). */
+uint64_t jst_oracle_cast_u64(float f) { return (uint64_t)f; }
+
+/* ------------------------------------------------------------------------------------------
+ * Waterfall.  src/domains/visualization/waterfall/ring_state.hh:16-56 (plan + ring state),
+ * module_impl_native_cpu.cc:53-78 (row copies).  bins: F32 [height][width] ring.
+ * state[0] = writeIndex, state[1] = dirtyRows.
+ * ---------------------------------------------------------------------------------------- */
+void jst_oracle_waterfall_plan(uint64_t write_index, uint64_t batches, uint64_t height,
+                               uint64_t* plan /* sourceRow, destinationRow, rowCount */) {
+    const uint64_t retained = batches < height ? batches : height;
+    const uint64_t source = batches - retained;
+    plan[0] = source;
+    plan[1] = (write_index + (source % height)) % height;
+    plan[2] = retained;
+}
+
+void jst_oracle_waterfall_advance(uint64_t* state, uint64_t batches, uint64_t height) {
+    state[0] = (state[0] + (batches % height)) % height;
+    const uint64_t room = height - state[1];
+    state[1] += batches < room ? batches : room;
+}
+
+void jst_oracle_waterfall_dirty_plan(const uint64_t* state, uint64_t height,
+                                     uint64_t* plan /* startRow, first, second */) {
+    const uint64_t start = (state[0] + height - state[1]) % height;
+    const uint64_t first = state[1] < height - start ? state[1] : height - start;
+    plan[0] = start;
+    plan[1] = first;
+    plan[2] = state[1] - first;
+}
+
+void jst_oracle_waterfall(float* bins, uint64_t* state, const float* in, uint64_t batches,
+                          uint64_t width, uint64_t height, uint64_t batch_stride,
+                          uint64_t elem_stride) {
+    uint64_t plan[3];
+    jst_oracle_waterfall_plan(state[0], batches, height, plan);
+    for (uint64_t row = 0; row < plan[2]; ++row) {
+        const uint64_t src = plan[0] + row;
+        const uint64_t dst = (plan[1] + row) % height;
+        for (uint64_t col = 0; col < width; ++col)
+            bins[dst * width + col] = in[src * batch_stride + col * elem_stride];
+    }
+    jst_oracle_waterfall_advance(state, batches, height);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Signal generator, cosine CF32 (the CW-tone input generator for the BASELINE configs).
+ * src/domains/dsp/signal_generator/module_impl_native_cpu.cc:20-23 (WrapPhase),
+ * :159-163 (advancePhase), :222-231 (kernelCosineCF32).  *phase carries across calls.
+ * ---------------------------------------------------------------------------------------- */
+static double wrap_phase(double value, double period) {
+    const double w = fmod(value, period);
+    return w < 0.0 ? w + period : w;
+}
+
+void jst_oracle_signal_cosine_cf32(float* out, uint64_t count, double amplitude,
+                                   double frequency, double sample_rate, double dc_offset,
+                                   double* phase) {
+    double ph = wrap_phase(*phase, 2.0 * JST_PI);
+    for (uint64_t i = 0; i < count; ++i) {
+        out[2 * i] = (float)(amplitude * cos(ph) + dc_offset);
+        out[2 * i + 1] = (float)(amplitude * sin(ph));
+        ph = wrap_phase(ph + 2.0 * JST_PI * frequency / sample_rate, 2.0 * JST_PI);
+    }
+    *phase = ph;
+}

@@ -1,0 +1,293 @@
+"""numpy front-end for the CPU oracle (oracle/jst_oracle.c) and the compiled reference
+pocketfft (oracle/_ref/libref_pocketfft.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (cyberether_amd) must never import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libjst_oracle.so")
+_REF_PATH = os.path.join(_HERE, "_ref", "libref_pocketfft.so")
+
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+_f32p = C.POINTER(C.c_float)
+
+
+def build(force: bool = False) -> None:
+    """Compile the restatement (and, when /root/reference exists, the reference pocketfft)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "jst_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "libjst_oracle.so"], stdout=subprocess.DEVNULL)
+    if (force or not os.path.exists(_REF_PATH)) and os.path.exists(
+        "/root/reference/src/domains/dsp/fft/pocketfft.hh"
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.jst_oracle_approx_log10.restype = C.c_float
+        _lib.jst_oracle_approx_log10.argtypes = [C.c_float]
+        _lib.jst_oracle_amplitude_coeff.restype = C.c_float
+        _lib.jst_oracle_amplitude_coeff.argtypes = [C.c_uint64]
+        _lib.jst_oracle_spectrogram_decay.restype = C.c_float
+        _lib.jst_oracle_spectrogram_decay.argtypes = [C.c_uint64]
+        _lib.jst_oracle_cast_u64.restype = C.c_uint64
+        _lib.jst_oracle_cast_u64.argtypes = [C.c_float]
+        _lib.jst_oracle_fft_c2c.restype = C.c_int
+    return _lib
+
+
+def have_ref() -> bool:
+    build()
+    return os.path.exists(_REF_PATH)
+
+
+def ref() -> C.CDLL:
+    global _ref
+    if _ref is None:
+        build()
+        _ref = C.CDLL(_REF_PATH)
+        for name in ("ref_fft_c2c", "ref_fft_r2c", "ref_fft_r2r_fftpack"):
+            getattr(_ref, name).restype = C.c_int
+    return _ref
+
+
+def _p(a: np.ndarray, t=_f32p):
+    return a.ctypes.data_as(t)
+
+
+def _u64(v) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(v, dtype=np.uint64))
+
+
+def _elem_strides(a: np.ndarray) -> np.ndarray:
+    return _u64([s // a.itemsize for s in a.strides])
+
+
+# ----------------------------------------------------------------------------------- window
+def window(n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.complex64)
+    lib().jst_oracle_window(_p(out), C.c_uint64(n))
+    return out
+
+
+# ----------------------------------------------------------------------------------- invert
+def invert(x: np.ndarray, axis: int = -1) -> np.ndarray:
+    """x: contiguous F32 or CF32 array; axis = resolved sample axis."""
+    x = np.ascontiguousarray(x)
+    axis = axis % x.ndim
+    inner = int(np.prod(x.shape[axis + 1:], dtype=np.uint64)) if axis + 1 < x.ndim else 1
+    length = x.shape[axis]
+    out = np.empty(x.shape, dtype=np.complex64)
+    if x.dtype == np.complex64:
+        lib().jst_oracle_invert_cf32(_p(x), _p(out), C.c_uint64(x.size), C.c_uint64(inner),
+                                     C.c_uint64(length))
+    elif x.dtype == np.float32:
+        lib().jst_oracle_invert_f32(_p(x), _p(out), C.c_uint64(x.size), C.c_uint64(inner),
+                                    C.c_uint64(length))
+    else:
+        raise TypeError(x.dtype)
+    return out
+
+
+# --------------------------------------------------------------------------------- multiply
+def multiply(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """numpy-style right-aligned broadcast product, reference arithmetic (no FMA, __mulsc3)."""
+    shape = np.broadcast_shapes(a.shape, b.shape)
+    av, bv = np.broadcast_to(a, shape), np.broadcast_to(b, shape)
+    out = np.empty(shape, dtype=a.dtype)
+    sh = _u64(shape)
+    fn = {np.dtype(np.complex64): lib().jst_oracle_multiply_cf32,
+          np.dtype(np.float32): lib().jst_oracle_multiply_f32}[a.dtype]
+    sa, sb, sc = _elem_strides(av), _elem_strides(bv), _elem_strides(out)
+    fn(C.c_uint32(len(shape)), _p(sh, _u64p), _p(av), _p(sa, _u64p), _p(bv), _p(sb, _u64p),
+       _p(out), _p(sc, _u64p))
+    return out
+
+
+# -------------------------------------------------------------------------------------- fft
+def fft_factors(n: int):
+    f = (C.c_uint32 * 64)()
+    nf = lib().jst_oracle_fft_factors(C.c_uint64(n), f)
+    return None if nf < 0 else [int(f[i]) for i in range(nf)]
+
+
+def fft_twiddles(n: int) -> np.ndarray:
+    tw = np.empty(n, dtype=np.complex64)
+    lib().jst_oracle_fft_twiddles(_p(tw), C.c_uint64(n))
+    return tw
+
+
+def fft_c2c(x: np.ndarray, forward: bool = True) -> np.ndarray:
+    """Restated pocketfft c2c over the LAST axis (power-of-two lengths only)."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    n = x.shape[-1]
+    batch = x.size // n if n else 0
+    out = np.empty_like(x)
+    rc = lib().jst_oracle_fft_c2c(_p(x), _p(out), C.c_uint64(n), C.c_uint64(batch),
+                                  C.c_int(1 if forward else 0))
+    if rc != 0:
+        raise ValueError(f"oracle restatement covers power-of-two lengths only (n={n})")
+    return out
+
+
+def _ref_call(fn, x: np.ndarray, out: np.ndarray, axis: int, forward: bool) -> np.ndarray:
+    sh = _u64(x.shape)
+    si = np.ascontiguousarray(np.asarray(x.strides, dtype=np.int64))
+    so = np.ascontiguousarray(np.asarray(out.strides, dtype=np.int64))
+    rc = fn(C.c_uint32(x.ndim), _p(sh, _u64p), _p(si, _i64p), _p(so, _i64p),
+            C.c_uint64(axis % x.ndim), C.c_int(1 if forward else 0), _p(x), _p(out))
+    if rc != 0:
+        raise RuntimeError("reference pocketfft raised")
+    return out
+
+
+def ref_fft_c2c(x: np.ndarray, axis: int = -1, forward: bool = True) -> np.ndarray:
+    """The reference's own pocketfft (compiled from /root/reference), any length/strides."""
+    assert x.dtype == np.complex64
+    return _ref_call(ref().ref_fft_c2c, x, np.empty(x.shape, np.complex64), axis, forward)
+
+
+def ref_fft_r2c(x: np.ndarray, axis: int = -1) -> np.ndarray:
+    assert x.dtype == np.float32
+    axis = axis % x.ndim
+    oshape = list(x.shape)
+    oshape[axis] = x.shape[axis] // 2 + 1
+    return _ref_call(ref().ref_fft_r2c, x, np.empty(oshape, np.complex64), axis, True)
+
+
+def ref_fft_r2r(x: np.ndarray, axis: int = -1, forward: bool = True) -> np.ndarray:
+    assert x.dtype == np.float32
+    return _ref_call(ref().ref_fft_r2r_fftpack, x, np.empty(x.shape, np.float32), axis, forward)
+
+
+# -------------------------------------------------------------------------------- amplitude
+def approx_log10(x: float) -> float:
+    return float(lib().jst_oracle_approx_log10(C.c_float(x)))
+
+
+def amplitude_coeff(n: int) -> float:
+    return float(lib().jst_oracle_amplitude_coeff(C.c_uint64(n)))
+
+
+def amplitude(x: np.ndarray, norm_size: int) -> np.ndarray:
+    """x: F32 or CF32 (any strides); norm_size = extent of the sample axis (1 if channel-only)."""
+    out = np.empty(x.shape, dtype=np.float32)
+    coeff = C.c_float(amplitude_coeff(norm_size))
+    sh, si, so = _u64(x.shape), _elem_strides(x), _elem_strides(out)
+    fn = {np.dtype(np.complex64): lib().jst_oracle_amplitude_cf32,
+          np.dtype(np.float32): lib().jst_oracle_amplitude_f32}[x.dtype]
+    fn(C.c_uint32(x.ndim), _p(sh, _u64p), _p(x), _p(si, _u64p), _p(out), _p(so, _u64p), coeff)
+    return out
+
+
+# ------------------------------------------------------------------------------------ range
+def range_coeffs(vmin: float, vmax: float):
+    s, o = C.c_float(), C.c_float()
+    lib().jst_oracle_range_coeffs(C.c_float(vmin), C.c_float(vmax), C.byref(s), C.byref(o))
+    return float(s.value), float(o.value)
+
+
+def range_(x: np.ndarray, vmin: float, vmax: float) -> np.ndarray:
+    assert x.dtype == np.float32
+    s, o = range_coeffs(vmin, vmax)
+    out = np.empty(x.shape, dtype=np.float32)
+    sh, si, so = _u64(x.shape), _elem_strides(x), _elem_strides(out)
+    lib().jst_oracle_range_f32(C.c_uint32(x.ndim), _p(sh, _u64p), _p(x), _p(si, _u64p), _p(out),
+                               _p(so, _u64p), C.c_float(s), C.c_float(o))
+    return out
+
+
+# ------------------------------------------------------------------------------ spectrogram
+def spectrogram_decay(batches: int) -> float:
+    return float(lib().jst_oracle_spectrogram_decay(C.c_uint64(batches)))
+
+
+def spectrogram(bins: np.ndarray, x: np.ndarray, height: int, batch_axis=0, elem_axis=1) -> None:
+    """In-place update of bins (F32, flat [height*width], layout [height][width]).
+    x: F32 rank-1 (no batch axis: batch_axis=None) or rank-2 with the given axes."""
+    assert x.dtype == np.float32 and bins.dtype == np.float32 and bins.flags.c_contiguous
+    if x.ndim == 1 or batch_axis is None:
+        batches, bstride = 1, 0
+        width, estride = x.shape[-1], x.strides[-1] // 4
+    else:
+        batches, bstride = x.shape[batch_axis], x.strides[batch_axis] // 4
+        width, estride = x.shape[elem_axis], x.strides[elem_axis] // 4
+    assert bins.size == width * height
+    lib().jst_oracle_spectrogram(_p(bins), _p(x), C.c_uint64(batches), C.c_uint64(width),
+                                 C.c_uint64(height), C.c_uint64(bstride), C.c_uint64(estride),
+                                 C.c_float(spectrogram_decay(batches)))
+
+
+# -------------------------------------------------------------------------------- waterfall
+def waterfall_plan(write_index: int, batches: int, height: int):
+    p = (C.c_uint64 * 3)()
+    lib().jst_oracle_waterfall_plan(C.c_uint64(write_index), C.c_uint64(batches),
+                                    C.c_uint64(height), p)
+    return tuple(int(v) for v in p)
+
+
+def waterfall_advance(state, batches: int, height: int):
+    s = (C.c_uint64 * 2)(*state)
+    lib().jst_oracle_waterfall_advance(s, C.c_uint64(batches), C.c_uint64(height))
+    return (int(s[0]), int(s[1]))
+
+
+def waterfall_dirty_plan(state, height: int):
+    s = (C.c_uint64 * 2)(*state)
+    p = (C.c_uint64 * 3)()
+    lib().jst_oracle_waterfall_dirty_plan(s, C.c_uint64(height), p)
+    return tuple(int(v) for v in p)
+
+
+def waterfall(bins: np.ndarray, state, x: np.ndarray, height: int):
+    """bins F32 [height, width] updated in place; returns the new (writeIndex, dirtyRows)."""
+    assert x.dtype == np.float32 and x.ndim == 2 and bins.flags.c_contiguous
+    s = (C.c_uint64 * 2)(*state)
+    lib().jst_oracle_waterfall(_p(bins), s, _p(x), C.c_uint64(x.shape[0]), C.c_uint64(x.shape[1]),
+                               C.c_uint64(height), C.c_uint64(x.strides[0] // 4),
+                               C.c_uint64(x.strides[1] // 4))
+    return (int(s[0]), int(s[1]))
+
+
+# ------------------------------------------------------------------------- signal generator
+def signal_cosine(count: int, amplitude_: float, frequency: float, sample_rate: float,
+                  dc_offset: float = 0.0, phase: float = 0.0):
+    out = np.empty(count, dtype=np.complex64)
+    ph = C.c_double(phase)
+    lib().jst_oracle_signal_cosine_cf32(_p(out), C.c_uint64(count), C.c_double(amplitude_),
+                                        C.c_double(frequency), C.c_double(sample_rate),
+                                        C.c_double(dc_offset), C.byref(ph))
+    return out, float(ph.value)
+
+
+# ------------------------------------------------------------------------- composed chains
+def spectrum_chain(x: np.ndarray, range_min=None, range_max=None):
+    """Window -> Invert -> (reshape) -> Multiply -> FFT -> Amplitude -> [Range] over the last axis
+    (src/domains/dsp/spectrum_engine/block_impl.cc:120-217).  Returns dict of every stage."""
+    n = x.shape[-1]
+    w = invert(window(n))
+    prod = multiply(x, w.reshape((1,) * (x.ndim - 1) + (n,)))
+    spec = fft_c2c(prod, True)
+    amp = amplitude(spec, n)
+    out = {"window": w, "product": prod, "fft": spec, "amplitude": amp}
+    if range_min is not None:
+        out["range"] = range_(amp, range_min, range_max)
+    return out
