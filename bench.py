@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X Jetstream backend.
+
+Workload (BASELINE.json configs[1]): Window -> 4096-pt FFT -> Amplitude -> Range -> Spectrogram on
+1024 batches of cf32 IQ per compute cycle, the whole cycle captured in a hipGraph.  One "step" =
+one compute cycle over one batch tensor CF32[1024, 4096] that is ALREADY RESIDENT IN HBM: a ring
+of `--slots` distinct batches (default 16 x 32 MiB = 512 MiB, larger than the 256 MiB Infinity
+Cache, so every step's input really comes from HBM).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (the fused spectrum kernel): algorithmic bytes per launch
+                  (12 B per complex sample: 8 B cf32 read + 4 B f32 write) over its
+                  mean launch duration measured with hipEvent pairs recorded on the runtime's own
+                  stream inside the timed region (in-graph event nodes).
+  cpu_baseline -- the CPU restatement of the reference path (oracle/, kind "port") timed on this
+                  host, 1 core (the reference's compute path is single-threaded,
+                  fft/module_impl_native_cpu.cc:1-2), on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_FFT = 4096
+BATCHES = 1024
+HEIGHT = 256
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+ALGO_BYTES_PER_SAMPLE = 12.0    # 8 B cf32 in + 4 B f32 out (SURVEY 8d / DESIGN.md section 4)
+
+
+def synth_slot(rng: np.random.Generator, slot: int) -> np.ndarray:
+    """CF32[BATCHES, N_FFT]: row r = unit CW tone at bin 100.25 + r (+ slot) + AWGN sigma 1e-3."""
+    n = np.arange(N_FFT, dtype=np.float64)
+    bins = (100.25 + np.arange(BATCHES, dtype=np.float64) + slot) % N_FFT
+    phase = 2.0 * np.pi * bins[:, None] * n[None, :] / N_FFT
+    x = np.empty((BATCHES, N_FFT), np.complex64)
+    x.real = np.cos(phase)
+    x.imag = np.sin(phase)
+    noise = rng.standard_normal((BATCHES, N_FFT, 2), dtype=np.float32) * np.float32(1e-3)
+    x.real += noise[..., 0]
+    x.imag += noise[..., 1]
+    return x
+
+
+def cpu_baseline(seconds: float = 12.0) -> dict:
+    """Oracle chain (window, invert, multiply, FFT, amplitude, range, spectrogram) on 1 core."""
+    from oracle import oracle
+    rng = np.random.default_rng(4321)
+    rows = 64
+    x = synth_slot(rng, 0)[:rows]
+    bins = np.zeros(N_FFT * HEIGHT, np.float32)
+    oracle.spectrum_chain(x[:4], -100.0, 0.0)  # warm: builds libs, touches pages
+    done, t0 = 0, time.perf_counter()
+    while True:
+        out = oracle.spectrum_chain(x, -100.0, 0.0)["range"]
+        oracle.spectrogram(bins, out, HEIGHT)
+        done += rows
+        elapsed = time.perf_counter() - t0
+        if elapsed >= seconds:
+            break
+    return {"value": done * N_FFT / elapsed / 1e6, "unit": "MS/s", "cores": 1, "kind": "port",
+            "sample": f"{done} batches x {N_FFT}-pt through the oracle chain "
+                      f"(window/invert/multiply/FFT/amplitude/range/spectrogram) in {elapsed:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=320)
+    ap.add_argument("--warmup", type=int, default=48)
+    ap.add_argument("--slots", type=int, default=16)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+
+    import cyberether_amd.jetstream as js  # fails loudly if the HIP library is missing
+    js.set_device(local_rank)
+
+    # ---- build the flowgraph: ring_source -> spectrum_engine -> spectrogram --------------------
+    source = js.Module("ring_source", {"batches": BATCHES, "samples": N_FFT, "slots": args.slots},
+                       {}, "source")
+    buf = source.output("buffer")
+    rng = np.random.default_rng(1234 + rank)
+    for s in range(args.slots):  # independent IQ per rank and slot, resident before timing
+        buf.ring_select(s).copy_from(synth_slot(rng, s))
+    buf.ring_select(0)
+    engine = js.SpectrumEngine(buf, enable_scale=True, range_min=-100.0, range_max=0.0)
+    spectrogram = js.Module("spectrogram", {"height": HEIGHT}, {"signal": engine.buffer},
+                            "spectrogram")
+    rt = js.Runtime([source] + engine.modules + [spectrogram], graph=not args.no_graph,
+                    fuse=not args.no_fuse, timing=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    rt.compute(args.warmup, sync=True)
+    rt.reset_timing()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    rt.compute(args.steps, sync=False)
+    rt.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples = float(args.steps) * BATCHES * N_FFT * world
+    dominant = "spectrum_fused" if not args.no_fuse else "spectrum.fft"
+    kernel_ms = rt.unit_mean_ms(dominant)
+    spec_ms = rt.unit_mean_ms("spectrogram")
+    algo_bytes = ALGO_BYTES_PER_SAMPLE * BATCHES * N_FFT
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from a --pmc pass
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("spectrum_fused_hbm_bytes_per_launch")
+        line = {
+            "metric": "MS/s complex IQ through Window->FFT->Amplitude->Range->Spectrogram @4096-pt",
+            "value": samples / elapsed / 1e6,
+            "unit": "MS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: Window->4096-pt FFT->Amplitude->Range->Spectrogram(h=256), "
+                                   "1024 batches cf32 per step, hipGraph capture",
+                       "batches": BATCHES, "fft_size": N_FFT, "ring_slots": args.slots,
+                       "graph": rt.graph_active, "fused": not args.no_fuse,
+                       "units": rt.units, "spectrogram_kernel_ms": spec_ms,
+                       "sharding": "independent batches per GPU, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": traffic, "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    rt.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,466 @@
+// module.cc -- Module framework entry, Registry and the NativeHip Runtime (see module.hh).
+#include "module.hh"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "../modules/modules.hh"
+
+namespace jst {
+
+// ---- config helpers ----------------------------------------------------------------------------
+bool ConfigBool(const Config& c, const std::string& key, bool fallback, bool* ok) {
+    if (ok) *ok = true;
+    auto it = c.find(key);
+    if (it == c.end()) return fallback;
+    std::string v = it->second;
+    std::transform(v.begin(), v.end(), v.begin(), [](unsigned char ch) { return std::tolower(ch); });
+    if (v == "true" || v == "1" || v == "yes" || v == "on") return true;
+    if (v == "false" || v == "0" || v == "no" || v == "off") return false;
+    if (ok) *ok = false;
+    return fallback;
+}
+U64 ConfigU64(const Config& c, const std::string& key, U64 fallback, bool* ok) {
+    if (ok) *ok = true;
+    auto it = c.find(key);
+    if (it == c.end()) return fallback;
+    char* end = nullptr;
+    const std::string& v = it->second;
+    if (v.empty() || v[0] == '-') {
+        if (ok) *ok = false;
+        return fallback;
+    }
+    const unsigned long long r = std::strtoull(v.c_str(), &end, 10);
+    if (end == v.c_str() || *end != '\0') {
+        if (ok) *ok = false;
+        return fallback;
+    }
+    return r;
+}
+F64 ConfigF64(const Config& c, const std::string& key, F64 fallback, bool* ok) {
+    if (ok) *ok = true;
+    auto it = c.find(key);
+    if (it == c.end()) return fallback;
+    char* end = nullptr;
+    const double r = std::strtod(it->second.c_str(), &end);
+    if (end == it->second.c_str() || *end != '\0') {
+        if (ok) *ok = false;
+        return fallback;
+    }
+    return r;
+}
+std::string ConfigStr(const Config& c, const std::string& key, const std::string& fallback) {
+    auto it = c.find(key);
+    return it == c.end() ? fallback : it->second;
+}
+
+// ---- Module ------------------------------------------------------------------------------------
+Result Module::construct(const std::string& name, const Config& config,
+                         const std::map<std::string, Tensor>& inputs) {
+    name_ = name;
+    config_ = config;
+    inputs_ = inputs;
+    outputs_.clear();
+    input_ports_.clear();
+    output_ports_.clear();
+    created_ = false;
+
+    JST_CHECK(validate());
+    JST_CHECK(define());
+
+    const bool discontiguous = (taint_ & DISCONTIGUOUS) != 0;
+    const bool cross_device = (taint_ & CROSS_DEVICE) != 0;
+
+    for (const auto& port : input_ports_) {  // src/module.cc:124-129
+        if (!inputs_.count(port)) {
+            JST_ERROR("[MODULE] Module '%s' requested missing input '%s'.", name_.c_str(),
+                      port.c_str());
+            return Result::ERROR;
+        }
+    }
+    for (const auto& [port, tensor] : inputs_) {  // src/module.cc:133-155
+        if (tensor.device() != device() && !cross_device) {
+            JST_ERROR("[MODULE] Input tensor device ('%s', DeviceType::%s) doesn't match the module "
+                      "device ('%s', DeviceType::%s).",
+                      port.c_str(), DeviceName(tensor.device()), name_.c_str(), DeviceName(device()));
+            return Result::ERROR;
+        }
+        if (!tensor.validShape()) {
+            JST_ERROR("[MODULE] Input tensor ('%s') is invalid.", port.c_str());
+            return Result::ERROR;
+        }
+        if (tensor.size() == 0) {
+            JST_ERROR("[MODULE] Module ('%s') input tensor ('%s') size is zero.", name_.c_str(),
+                      port.c_str());
+            return Result::ERROR;
+        }
+        if (!tensor.contiguous() && !discontiguous) {
+            JST_ERROR("[MODULE] Contiguous tensor expected for module ('%s') input tensor ('%s').",
+                      name_.c_str(), port.c_str());
+            return Result::ERROR;
+        }
+    }
+
+    JST_CHECK(create());
+
+    for (const auto& port : output_ports_) {
+        if (!outputs_.count(port)) {
+            JST_ERROR("[MODULE] Module '%s' did not produce output '%s'.", name_.c_str(),
+                      port.c_str());
+            return Result::ERROR;
+        }
+    }
+    created_ = true;
+    return Result::SUCCESS;
+}
+
+Result Module::teardown() {
+    if (!created_) return Result::SUCCESS;
+    created_ = false;
+    return destroy();
+}
+
+// ---- Registry ----------------------------------------------------------------------------------
+namespace {
+std::string registry_key(const std::string& type, DeviceType d, RuntimeType r,
+                         const std::string& provider) {
+    return type + "|" + DeviceName(d) + "|" + (r == RuntimeType::NATIVE ? "native" : "?") + "|" +
+           provider;
+}
+}  // namespace
+
+Registry& Registry::instance() {
+    static Registry r;
+    return r;
+}
+void Registry::add(const std::string& type, DeviceType device, RuntimeType runtime,
+                   const std::string& provider, ModuleFactory factory) {
+    factories_[registry_key(type, device, runtime, provider)] = std::move(factory);
+}
+std::unique_ptr<Module> Registry::build(const std::string& type, DeviceType device,
+                                        RuntimeType runtime, const std::string& provider) const {
+    auto it = factories_.find(registry_key(type, device, runtime, provider));
+    if (it == factories_.end()) {
+        JST_ERROR("[REGISTRY] No module '%s' registered for (device=%s, runtime=native, "
+                  "provider=%s).",
+                  type.c_str(), DeviceName(device), provider.c_str());
+        return nullptr;
+    }
+    return it->second();
+}
+std::vector<std::string> Registry::listAvailableModules(const std::string& type) const {
+    std::vector<std::string> out;
+    for (const auto& kv : factories_) {
+        if (type.empty() || kv.first.compare(0, type.size() + 1, type + "|") == 0)
+            out.push_back(kv.first);
+    }
+    return out;
+}
+
+// ---- Runtime -----------------------------------------------------------------------------------
+Runtime::Runtime() = default;
+Runtime::~Runtime() { (void)destroy(); }
+
+Result Runtime::planOrder(const std::vector<Module*>& modules) {
+    // Kahn's algorithm over "module B reads storage that module A produced"
+    // (src/scheduler_synchronous.cc:574-696).  Ties keep insertion order.
+    const size_t n = modules.size();
+    std::map<const void*, size_t> producer;
+    for (size_t i = 0; i < n; ++i)
+        for (const auto& kv : modules[i]->outputs()) {
+            if (kv.second.storageId()) producer.emplace(kv.second.storageId(), i);
+        }
+    std::vector<std::set<size_t>> deps(n);
+    std::vector<std::vector<size_t>> users(n);
+    for (size_t i = 0; i < n; ++i)
+        for (const auto& kv : modules[i]->inputs()) {
+            auto it = producer.find(kv.second.storageId());
+            if (it != producer.end() && it->second != i && deps[i].insert(it->second).second)
+                users[it->second].push_back(i);
+        }
+    std::vector<size_t> indeg(n);
+    for (size_t i = 0; i < n; ++i) indeg[i] = deps[i].size();
+    std::vector<bool> done(n, false);
+    ordered_.clear();
+    for (size_t placed = 0; placed < n; ++placed) {
+        size_t pick = n;
+        for (size_t i = 0; i < n; ++i)
+            if (!done[i] && indeg[i] == 0) {
+                pick = i;
+                break;
+            }
+        if (pick == n) {
+            JST_ERROR("[SCHEDULER] Module graph contains a cycle.");
+            return Result::ERROR;
+        }
+        done[pick] = true;
+        ordered_.push_back(modules[pick]);
+        for (size_t u : users[pick]) --indeg[u];
+    }
+    order_names_.clear();
+    for (Module* m : ordered_) order_names_.push_back(m->name());
+    return Result::SUCCESS;
+}
+
+Result Runtime::planUnits() {
+    units_.clear();
+    // Static settlement: a STATIC_OUTPUT module with no inputs, or a STATELESS/STATIC module
+    // whose inputs all come from settled producers, runs once
+    // (src/scheduler_synchronous.cc:534-546,670-693).
+    std::set<const void*> static_storage;
+    std::vector<bool> is_static(ordered_.size(), false);
+    for (size_t i = 0; i < ordered_.size(); ++i) {
+        Module* m = ordered_[i];
+        const bool eligible = (m->taint() & (STATIC_OUTPUT | STATELESS)) != 0;
+        bool all_inputs_static = true;
+        for (const auto& kv : m->inputs())
+            if (!static_storage.count(kv.second.storageId())) all_inputs_static = false;
+        const bool source_static = m->inputs().empty() && (m->taint() & STATIC_OUTPUT);
+        if (eligible && (source_static || (!m->inputs().empty() && all_inputs_static))) {
+            is_static[i] = true;
+            for (const auto& kv : m->outputs()) static_storage.insert(kv.second.storageId());
+        }
+    }
+    for (size_t i = 0; i < ordered_.size();) {
+        Unit u;
+        size_t consumed = 0;
+        if ((flags_ & FUSE) && !is_static[i] && tryFuseSpectrum(i, u, consumed)) {
+            units_.push_back(std::move(u));
+            i += consumed;
+            continue;
+        }
+        Module* m = ordered_[i];
+        u.name = m->name();
+        u.modules = {m};
+        u.submit = [m](hipStream_t s) { return m->computeSubmit(s); };
+        u.is_static = is_static[i];
+        units_.push_back(std::move(u));
+        ++i;
+    }
+    unit_names_.clear();
+    for (auto& u : units_) {
+        unit_names_.push_back(u.name);
+        u.span.name = u.name;
+        if (flags_ & TIMING) {
+            u.span.begin.assign(period_, nullptr);
+            u.span.end.assign(period_, nullptr);
+            u.span.recorded.assign(period_, false);
+            for (U64 s = 0; s < period_; ++s) {
+                JST_HIP_CHECK(hipEventCreate(&u.span.begin[s]), "hipEventCreate");
+                JST_HIP_CHECK(hipEventCreate(&u.span.end[s]), "hipEventCreate");
+            }
+        }
+    }
+    return Result::SUCCESS;
+}
+
+// Recognise multiply(a = signal, b = static broadcast window) -> fft(forward, CF32) -> amplitude
+// [-> range] laid out consecutively in the order, with no other consumer of the intermediates
+// (the block wiring of src/domains/dsp/spectrum_engine/block_impl.cc:120-217).
+bool Runtime::tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed) {
+    return modules::TryFuseSpectrum(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
+}
+
+Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
+    if (created_) JST_CHECK(destroy());
+    flags_ = flags;
+    for (Module* m : modules) {
+        if (!m || !m->created()) {
+            JST_ERROR("[RUNTIME] Every module must be created before Runtime::create.");
+            return Result::ERROR;
+        }
+    }
+    JST_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    JST_CHECK(planOrder(modules));
+    for (Module* m : ordered_) {
+        const Result r = m->computeInitialize();
+        if (r != Result::SUCCESS) {
+            JST_ERROR("[RUNTIME] computeInitialize failed for module '%s': %s", m->name().c_str(),
+                      last_error());
+            return r;
+        }
+    }
+    period_ = 1;
+    for (Module* m : ordered_) {  // least common multiple of the modules' host-state periods
+        U64 a = period_, b = m->cyclePeriod() ? m->cyclePeriod() : 1;
+        while (b) { const U64 t = a % b; a = b; b = t; }
+        period_ = period_ / a * (m->cyclePeriod() ? m->cyclePeriod() : 1);
+    }
+    JST_CHECK(planUnits());
+    cycles_ = 0;
+    created_ = true;
+    return Result::SUCCESS;
+}
+
+Result Runtime::destroy() {
+    if (!created_) return Result::SUCCESS;
+    created_ = false;
+    (void)hipStreamSynchronize(stream_);
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+    graph_exec_ = nullptr;
+    graph_ = nullptr;
+    for (auto& u : units_) {
+        for (hipEvent_t e : u.span.begin) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : u.span.end) if (e) (void)hipEventDestroy(e);
+    }
+    units_.clear();
+    for (size_t i = ordered_.size(); i-- > 0;)  // reverse order (native/cuda/impl.cc:126-137)
+        (void)ordered_[i]->computeDeinitialize();
+    ordered_.clear();
+    if (stream_) (void)hipStreamDestroy(stream_);
+    stream_ = nullptr;
+    return Result::SUCCESS;
+}
+
+Result Runtime::submitAll(bool record_events, U64 slot) {
+    for (auto& u : units_) {
+        if (u.is_static && u.settled) continue;
+        const bool rec = record_events && slot < u.span.begin.size();
+        if (rec) JST_HIP_CHECK(hipEventRecord(u.span.begin[slot], stream_), "hipEventRecord");
+        const Result r = u.submit(stream_);
+        if (r != Result::SUCCESS && r != Result::RELOAD) {
+            JST_ERROR("[RUNTIME] computeSubmit failed in '%s' (%s): %s", u.name.c_str(),
+                      ResultName(r), last_error());
+            return r;
+        }
+        if (rec) {
+            JST_HIP_CHECK(hipEventRecord(u.span.end[slot], stream_), "hipEventRecord");
+            u.span.recorded[slot] = true;
+        }
+        for (Module* m : u.modules) m->timing.cycles++;
+    }
+    return Result::SUCCESS;
+}
+
+Result Runtime::harvestTiming() {
+    if (!timing_pending_) return Result::SUCCESS;
+    timing_pending_ = false;
+    for (auto& u : units_) {
+        for (size_t s = 0; s < u.span.begin.size(); ++s) {
+            if (!u.span.recorded[s]) continue;
+            u.span.recorded[s] = false;
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, u.span.begin[s], u.span.end[s]) == hipSuccess) {
+                u.span.totalMs += ms;
+                u.span.count += 1;
+                for (Module* m : u.modules) m->timing.computeTimeMs += ms / (F64)u.modules.size();
+            }
+        }
+    }
+    return Result::SUCCESS;
+}
+
+Result Runtime::eagerCycle(bool& needs_sync) {
+    const bool timing = (flags_ & TIMING) != 0;
+    bool any_unsettled_static = false;
+    for (auto& u : units_) any_unsettled_static |= (u.is_static && !u.settled);
+    // Event pairs rotate over the period_ slots; the host only waits when a slot that still holds
+    // an unread sample is about to be re-recorded (once per period_ cycles, not per cycle).
+    const U64 slot = cycles_ % period_;
+    if (timing) {
+        bool busy = false;
+        for (auto& u : units_) busy |= (slot < u.span.recorded.size() && u.span.recorded[slot]);
+        if (busy) {
+            JST_HIP_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+            timing_pending_ = true;
+            JST_CHECK(harvestTiming());
+        }
+    }
+    JST_CHECK(submitAll(timing, slot));
+    timing_pending_ = timing_pending_ || timing;
+    ++cycles_;
+    // STATIC modules settle after one successful cycle (scheduler_synchronous.cc:534-546).
+    for (auto& u : units_)
+        if (u.is_static) u.settled = true;
+    needs_sync |= any_unsettled_static;
+    return Result::SUCCESS;
+}
+
+Result Runtime::compute(U64 cycles, bool sync) {
+    if (!created_) {
+        JST_ERROR("[RUNTIME] compute() before create().");
+        return Result::ERROR;
+    }
+    const bool timing = (flags_ & TIMING) != 0;
+    bool needs_sync = sync;
+    while (cycles > 0) {
+        bool any_unsettled_static = false;
+        for (auto& u : units_) any_unsettled_static |= (u.is_static && !u.settled);
+        bool use_graph = (flags_ & GRAPH) && !any_unsettled_static && cycles >= period_;
+        if (use_graph && !graph_exec_) {
+            bool capturable = true;
+            for (auto& u : units_)
+                for (Module* m : u.modules) capturable &= (u.is_static || m->capturable());
+            if (!capturable) {
+                flags_ &= ~GRAPH;  // a module needs per-cycle host arguments: stay eager
+                use_graph = false;
+            } else {
+                // Capture period_ consecutive cycles.  Host-side cursors (ring sources) advance
+                // during capture exactly as they would while running, so after the capture they
+                // are back at the phase they started from and the replay starts there too.
+                capture_phase_ = cycles_ % period_;
+                JST_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal),
+                              "hipStreamBeginCapture");
+                Result r = Result::SUCCESS;
+                for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c) r = submitAll(timing, c);
+                hipGraph_t g = nullptr;
+                const hipError_t e = hipStreamEndCapture(stream_, &g);
+                if (r != Result::SUCCESS) {
+                    if (g) (void)hipGraphDestroy(g);
+                    return r;
+                }
+                JST_HIP_CHECK(e, "hipStreamEndCapture");
+                graph_ = g;
+                JST_HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0),
+                              "hipGraphInstantiate");
+                for (auto& u : units_)  // nothing ran yet: the capture only recorded nodes
+                    std::fill(u.span.recorded.begin(), u.span.recorded.end(), false);
+            }
+        }
+        if (use_graph && (cycles_ % period_) == capture_phase_) {
+            // No harvest between replays: the in-graph event nodes are simply re-recorded, and the
+            // final synchronise reads the last replay's period_ samples per unit.  Replays
+            // therefore queue back to back with no host round trip.
+            JST_HIP_CHECK(hipGraphLaunch(graph_exec_, stream_), "hipGraphLaunch");
+            for (auto& u : units_) {  // (the in-graph nodes overwrite any unread eager samples)
+                if (u.is_static && u.settled) continue;
+                for (Module* m : u.modules) m->timing.cycles += period_;
+                if (timing) std::fill(u.span.recorded.begin(), u.span.recorded.end(), true);
+            }
+            timing_pending_ = timing;
+            cycles_ += period_;
+            cycles -= period_;
+            continue;
+        }
+        JST_CHECK(eagerCycle(needs_sync));
+        --cycles;
+    }
+    if (needs_sync) {
+        JST_HIP_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        JST_CHECK(harvestTiming());
+    }
+    return Result::SUCCESS;
+}
+
+Result Runtime::synchronize() {
+    if (!stream_) return Result::SUCCESS;
+    JST_HIP_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    return harvestTiming();
+}
+
+F64 Runtime::unitMeanMs(const std::string& name) {
+    for (auto& u : units_)
+        if (u.name == name && u.span.count) return u.span.totalMs / (F64)u.span.count;
+    return -1.0;
+}
+
+void Runtime::resetTiming() {
+    for (auto& u : units_) {
+        u.span.totalMs = 0.0;
+        u.span.count = 0;
+    }
+}
+
+}  // namespace jst

@@ -1,0 +1,185 @@
+// module.hh -- Module contract, 4-key Registry, per-segment NativeHip Runtime and the synchronous
+// Scheduler of the MI355X backend.
+//
+// The contract is the reference's:
+//   lifecycle  validate -> define -> create -> destroy            src/module.cc:47-212,
+//                                                                 include/jetstream/detail/module_impl.hh:43-47
+//   compute    computeInitialize / computeSubmit(stream) / computeDeinitialize
+//                                                                 include/jetstream/runtime_context_native_cuda.hh:32-34
+//   registry   exact (type, device, runtime, provider) lookup     src/registry.cc:583-622
+//   runtime    one stream per segment, per-module events, ONE host sync per cycle
+//                                                                 src/runtime/native/cuda/impl.cc:185-272
+//   scheduler  Kahn order, STATIC_OUTPUT settlement               src/scheduler_synchronous.cc:534-546,574-696
+// What is new (MI355X-first): the runtime captures the steady-state cycle into a hipGraph and
+// replays it, and the scheduler recognises the spectrum chain Multiply(window) -> FFT ->
+// Amplitude [-> Range] and submits it as ONE kernel (8 B in + 4 B out per sample).
+#pragma once
+
+#include <functional>
+#include <set>
+
+#include "tensor.hh"
+
+namespace jst {
+
+using Config = std::map<std::string, std::string>;
+
+bool ConfigBool(const Config& c, const std::string& key, bool fallback, bool* ok = nullptr);
+U64 ConfigU64(const Config& c, const std::string& key, U64 fallback, bool* ok = nullptr);
+F64 ConfigF64(const Config& c, const std::string& key, F64 fallback, bool* ok = nullptr);
+std::string ConfigStr(const Config& c, const std::string& key, const std::string& fallback);
+
+struct Timing {  // include/jetstream/module.hh:25-31
+    U64 cycles = 0;
+    F64 computeTimeMs = 0.0;
+};
+
+class Module {
+ public:
+    virtual ~Module() = default;
+
+    // Framework entry (src/module.cc:47-212): config -> validate -> define -> input checks ->
+    // create.  On failure the module is left uncreated and the error is in last_error().
+    Result construct(const std::string& name, const Config& config,
+                     const std::map<std::string, Tensor>& inputs);
+    Result teardown();
+
+    // ---- Module::Impl hooks --------------------------------------------------------------------
+    virtual const char* type() const = 0;
+    virtual Result validate() { return Result::SUCCESS; }
+    virtual Result define() = 0;
+    virtual Result create() = 0;
+    virtual Result destroy() { return Result::SUCCESS; }
+
+    // ---- NativeHipRuntimeContext ---------------------------------------------------------------
+    virtual Result computeInitialize() { return Result::SUCCESS; }
+    virtual Result computeSubmit(hipStream_t stream) = 0;
+    virtual Result computeDeinitialize() { return Result::SUCCESS; }
+    // True when computeSubmit touches no device state through the host (graph-capturable).
+    virtual bool capturable() const { return true; }
+    // Number of consecutive cycles after which this module's host-side state repeats (a ring
+    // source with R slots: R).  The runtime captures that many cycles into one hipGraph.
+    virtual U64 cyclePeriod() const { return 1; }
+    // Named internal state tensors (spectrogram/waterfall "frequencyBins"), for read-back.
+    virtual const Tensor* state(const std::string&) const { return nullptr; }
+
+    const std::string& name() const { return name_; }
+    DeviceType device() const { return DeviceType::HIP; }
+    const Config& config() const { return config_; }
+    const std::map<std::string, Tensor>& inputs() const { return inputs_; }
+    const std::map<std::string, Tensor>& outputs() const { return outputs_; }
+    U64 taint() const { return taint_; }
+    bool created() const { return created_; }
+    Timing timing;
+
+ protected:
+    Result defineTaint(U64 taint) { taint_ = taint; return Result::SUCCESS; }
+    Result defineInterfaceInput(const std::string& port) { input_ports_.push_back(port); return Result::SUCCESS; }
+    Result defineInterfaceOutput(const std::string& port) { output_ports_.push_back(port); return Result::SUCCESS; }
+    void produced(const std::string& port, const Tensor& t) { outputs_[port] = t; }
+
+    std::string name_;
+    Config config_;
+    std::map<std::string, Tensor> inputs_;
+    std::map<std::string, Tensor> outputs_;
+    std::vector<std::string> input_ports_, output_ports_;
+    U64 taint_ = CLEAN;
+    bool created_ = false;
+};
+
+// ---- Registry ----------------------------------------------------------------------------------
+using ModuleFactory = std::function<std::unique_ptr<Module>()>;
+
+class Registry {
+ public:
+    static Registry& instance();
+    void add(const std::string& type, DeviceType device, RuntimeType runtime,
+             const std::string& provider, ModuleFactory factory);
+    // Exact 4-key match, no fallback (src/registry.cc:605-618).
+    std::unique_ptr<Module> build(const std::string& type, DeviceType device, RuntimeType runtime,
+                                  const std::string& provider) const;
+    std::vector<std::string> listAvailableModules(const std::string& type = "") const;
+
+ private:
+    std::map<std::string, ModuleFactory> factories_;
+};
+
+struct ModuleRegistrar {
+    ModuleRegistrar(const char* type, DeviceType device, RuntimeType runtime, const char* provider,
+                    ModuleFactory f) {
+        Registry::instance().add(type, device, runtime, provider, std::move(f));
+    }
+};
+
+#define JST_REGISTER_MODULE(Impl, type_string, device, runtime, provider)                  \
+    static ::jst::ModuleRegistrar jst_registrar_##Impl(type_string, device, runtime, provider, \
+                                                       [] { return std::unique_ptr<::jst::Module>(new Impl()); })
+
+// ---- Runtime -----------------------------------------------------------------------------------
+struct KernelSpan {  // hipEvent pairs around one execution unit, for live per-kernel timing
+    std::string name;
+    std::vector<hipEvent_t> begin, end;  // one pair per cycle of the capture period
+    std::vector<bool> recorded;
+    F64 totalMs = 0.0;
+    U64 count = 0;
+};
+
+class Runtime {
+ public:
+    enum Flags : U32 { NONE = 0, GRAPH = 1 << 0, FUSE = 1 << 1, TIMING = 1 << 2 };
+
+    Runtime();
+    ~Runtime();
+
+    // Takes the modules of one device segment (not owned).  Orders them (Kahn over tensor
+    // storage identity), runs computeInitialize, plans static settlement and fusion.
+    Result create(const std::vector<Module*>& modules, U32 flags);
+    Result destroy();
+
+    // 'cycles' compute cycles: submit every unsettled unit on the segment stream, or replay the
+    // captured hipGraph (which holds period() cycles).  sync=true ends with the reference's
+    // stream synchronise (src/runtime/native/cuda/impl.cc:244); sync=false leaves the work
+    // queued so consecutive calls run back to back.
+    Result compute(U64 cycles, bool sync);
+    Result synchronize();
+    U64 period() const { return period_; }
+
+    hipStream_t stream() const { return stream_; }
+    const std::vector<std::string>& order() const { return order_names_; }
+    const std::vector<std::string>& units() const { return unit_names_; }
+    bool graphActive() const { return graph_exec_ != nullptr; }
+    // Mean device time (ms) of the named unit over the cycles run with TIMING; <0 if unknown.
+    F64 unitMeanMs(const std::string& name);
+    void resetTiming();
+
+ private:
+    struct Unit {
+        std::string name;
+        std::vector<Module*> modules;      // 1 module, or the fused chain
+        std::function<Result(hipStream_t)> submit;
+        bool is_static = false;            // STATIC_OUTPUT with settled inputs: runs once
+        bool settled = false;
+        KernelSpan span;
+    };
+    Result planOrder(const std::vector<Module*>& modules);
+    Result planUnits();
+    bool tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed);
+    Result submitAll(bool record_events, U64 event_slot);
+    Result harvestTiming();
+    Result eagerCycle(bool& needs_sync);
+
+    hipStream_t stream_ = nullptr;
+    U32 flags_ = 0;
+    std::vector<Module*> ordered_;
+    std::vector<std::string> order_names_, unit_names_;
+    std::vector<Unit> units_;
+    hipGraph_t graph_ = nullptr;
+    hipGraphExec_t graph_exec_ = nullptr;
+    U64 cycles_ = 0;
+    U64 period_ = 1;
+    U64 capture_phase_ = 0;
+    bool timing_pending_ = false;
+    bool created_ = false;
+};
+
+}  // namespace jst

@@ -1,0 +1,278 @@
+// device_math.hh -- gfx950 device-side scalar math shared by every Jetstream HIP kernel.
+//
+// Every routine here computes, operation by operation, what the reference's CPU module
+// computes (IEEE-754 binary32, round-to-nearest, no fused multiply-add: the whole library is
+// built with -ffp-contract=off), so results are bit-identical to the reference CPU path, not
+// merely close.  Citations are relative to the CyberEther 1.9.1 tree.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jst::dev {
+
+using f2 = float2;
+
+__device__ __forceinline__ f2 mk(float r, float i) { return make_float2(r, i); }
+__device__ __forceinline__ f2 cadd(f2 a, f2 b) { return mk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ f2 csub(f2 a, f2 b) { return mk(a.x - b.x, a.y - b.y); }
+
+// std::complex<float>::operator* for finite operands (multiply/module_impl_native_cpu.cc:94-100):
+// four individually rounded products, re = ac - bd, im = ad + bc.  The C99 Annex G recovery
+// branch (only taken when both parts come out NaN) is in cmul_full().
+__device__ __forceinline__ f2 cmul(f2 a, f2 b) {
+    const float ac = a.x * b.x, bd = a.y * b.y, ad = a.x * b.y, bc = a.y * b.x;
+    return mk(ac - bd, ad + bc);
+}
+
+__device__ inline f2 cmul_full(f2 p, f2 q) {
+    float a = p.x, b = p.y, c = q.x, d = q.y;
+    const float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+    float x = ac - bd, y = ad + bc;
+    if (__builtin_isnan(x) && __builtin_isnan(y)) {
+        bool recalc = false;
+        if (__builtin_isinf(a) || __builtin_isinf(b)) {
+            a = __builtin_copysignf(__builtin_isinf(a) ? 1.0f : 0.0f, a);
+            b = __builtin_copysignf(__builtin_isinf(b) ? 1.0f : 0.0f, b);
+            if (__builtin_isnan(c)) c = __builtin_copysignf(0.0f, c);
+            if (__builtin_isnan(d)) d = __builtin_copysignf(0.0f, d);
+            recalc = true;
+        }
+        if (__builtin_isinf(c) || __builtin_isinf(d)) {
+            c = __builtin_copysignf(__builtin_isinf(c) ? 1.0f : 0.0f, c);
+            d = __builtin_copysignf(__builtin_isinf(d) ? 1.0f : 0.0f, d);
+            if (__builtin_isnan(a)) a = __builtin_copysignf(0.0f, a);
+            if (__builtin_isnan(b)) b = __builtin_copysignf(0.0f, b);
+            recalc = true;
+        }
+        if (!recalc && (__builtin_isinf(ac) || __builtin_isinf(bd) || __builtin_isinf(ad) ||
+                        __builtin_isinf(bc))) {
+            if (__builtin_isnan(a)) a = __builtin_copysignf(0.0f, a);
+            if (__builtin_isnan(b)) b = __builtin_copysignf(0.0f, b);
+            if (__builtin_isnan(c)) c = __builtin_copysignf(0.0f, c);
+            if (__builtin_isnan(d)) d = __builtin_copysignf(0.0f, d);
+            recalc = true;
+        }
+        if (recalc) {
+            x = __builtin_inff() * (a * c - b * d);
+            y = __builtin_inff() * (a * d + b * c);
+        }
+    }
+    return mk(x, y);
+}
+
+// ---- pocketfft butterfly helpers (fft/pocketfft.hh:266-272, :290-291, :1124-1139) -----------
+template <bool FWD>
+__device__ __forceinline__ f2 special_mul(f2 v, f2 w) {
+    if constexpr (FWD) return mk(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y);
+    else return mk(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+}
+template <bool FWD>
+__device__ __forceinline__ f2 rotx90(f2 a) {
+    if constexpr (FWD) return mk(a.y, -a.x);
+    else return mk(-a.y, a.x);
+}
+template <bool FWD>
+__device__ __forceinline__ f2 rotx45(f2 a) {
+    constexpr float h = 0.707106781186547524400844362104849f;
+    if constexpr (FWD) return mk(h * (a.x + a.y), h * (a.y - a.x));
+    else return mk(h * (a.x - a.y), h * (a.y + a.x));
+}
+template <bool FWD>
+__device__ __forceinline__ f2 rotx135(f2 a) {
+    constexpr float h = 0.707106781186547524400844362104849f;
+    if constexpr (FWD) return mk(h * (a.y - a.x), h * (-a.x - a.y));
+    else return mk(h * (-a.x - a.y), h * (a.x - a.y));
+}
+
+// Radix-2/4/8 butterflies WITHOUT the output twiddles: x[b] = CC(i,b,k) in, x[c] = the value
+// pocketfft multiplies by WA(c-1,i) (or stores directly when i == 0) out.
+// pass2 :843-872, pass4 :929-975, pass8 :1141-1223.
+template <bool FWD>
+__device__ __forceinline__ void butterfly2(f2 (&x)[2]) {
+    const f2 a = x[0], b = x[1];
+    x[0] = cadd(a, b);
+    x[1] = csub(a, b);
+}
+template <bool FWD>
+__device__ __forceinline__ void butterfly4(f2 (&x)[4]) {
+    const f2 t2 = cadd(x[0], x[2]), t1 = csub(x[0], x[2]);
+    const f2 t3 = cadd(x[1], x[3]);
+    const f2 t4 = rotx90<FWD>(csub(x[1], x[3]));
+    x[0] = cadd(t2, t3);
+    x[2] = csub(t2, t3);
+    x[1] = cadd(t1, t4);
+    x[3] = csub(t1, t4);
+}
+template <bool FWD>
+__device__ __forceinline__ void butterfly8(f2 (&x)[8]) {
+    f2 a1 = cadd(x[1], x[5]), a5 = csub(x[1], x[5]);
+    f2 a3 = cadd(x[3], x[7]), a7 = csub(x[3], x[7]);
+    a7 = rotx90<FWD>(a7);
+    f2 t = a1;
+    a1 = cadd(a1, a3);
+    a3 = rotx90<FWD>(csub(t, a3));
+    t = a5;
+    a5 = cadd(a5, a7);
+    a7 = csub(t, a7);
+    a5 = rotx45<FWD>(a5);
+    a7 = rotx135<FWD>(a7);
+    f2 a0 = cadd(x[0], x[4]), a4 = csub(x[0], x[4]);
+    f2 a2 = cadd(x[2], x[6]), a6 = csub(x[2], x[6]);
+    t = a0;
+    a0 = cadd(a0, a2);
+    a2 = csub(t, a2);
+    x[0] = cadd(a0, a1);
+    x[4] = csub(a0, a1);
+    x[2] = cadd(a2, a3);
+    x[6] = csub(a2, a3);
+    a6 = rotx90<FWD>(a6);
+    t = a4;
+    a4 = cadd(a4, a6);
+    a6 = csub(t, a6);
+    x[1] = cadd(a4, a5);
+    x[5] = csub(a4, a5);
+    x[3] = cadd(a6, a7);
+    x[7] = csub(a6, a7);
+}
+template <int IP, bool FWD>
+__device__ __forceinline__ void butterfly(f2 (&x)[IP]) {
+    if constexpr (IP == 8) butterfly8<FWD>(x);
+    else if constexpr (IP == 4) butterfly4<FWD>(x);
+    else butterfly2<FWD>(x);
+}
+
+// ---- Amplitude -----------------------------------------------------------------------------
+// Backend::ApproxLog10 (include/jetstream/backend/devices/cpu/helpers.hh:59-74): frexpf + cubic,
+// separate multiplies and adds.  v_frexp_mant_f32 / v_frexp_exp_i32_f32 give exactly C frexpf
+// (mantissa in [0.5,1), subnormals handled, inf/NaN -> exponent 0 like glibc).
+__device__ __forceinline__ float approx_log10(float x) {
+    int e;
+    const float f = __builtin_frexpf(__builtin_fabsf(x), &e);
+    float y = 1.23149591368684f;
+    y *= f;
+    y += -4.11852516267426f;
+    y *= f;
+    y += 6.02197014179219f;
+    y *= f;
+    y += -3.13396450166353f;
+    y += (float)e;
+    return y * 0.3010299956639812f;
+}
+
+// amplitude/module_impl_native_cpu.cc:73-86 (CF32) and :88-99 (F32).  sqrtf is the correctly
+// rounded device sqrt (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), == libm sqrtf.
+__device__ __forceinline__ float amplitude_cf32(f2 v, float coeff) {
+    const float mag = __builtin_sqrtf((v.x * v.x) + (v.y * v.y));
+    return (mag == 0.0f) ? -__builtin_inff() : 20.0f * approx_log10(mag) + coeff;
+}
+__device__ __forceinline__ float amplitude_f32(float v, float coeff) {
+    const float mag = __builtin_fabsf(v);
+    return (mag == 0.0f) ? -__builtin_inff() : 20.0f * approx_log10(mag) + coeff;
+}
+
+// ---- Range ---------------------------------------------------------------------------------
+// The reference calls libm tanhf (range/module_impl_native_cpu.cc:67-82).  On the reference's
+// CPU target (x86-64 glibc, the image this repo builds and runs in ships 2.35) that is the
+// FDLIBM single-precision tanhf -> expm1f pair, which is NOT correctly rounded, so a device
+// tanh "to within an ulp" cannot be bit-identical.  libm_tanhf()/libm_expm1f() below restate
+// that published algorithm (Sun FDLIBM s_tanhf.c / s_expm1f.c, float version as shipped by
+// glibc sysdeps/ieee754/flt-32) operation by operation; tests/test_gpu_elementwise.py sweeps
+// the float range against the host libm and requires equal bits.
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+__device__ inline float libm_expm1f(float x) {
+    constexpr float one = 1.0f, ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f,
+                    invln2 = 1.4426950216e+00f, Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f,
+                    Q3 = -7.9365076090e-05f, Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+    float y, hi, lo, c = 0.0f, t, e, hxs, hfx, r1;
+    int32_t k;
+    uint32_t hx = f2u(x);
+    const uint32_t xsb = hx & 0x80000000u;
+    hx &= 0x7fffffffu;
+    if (hx >= 0x4195b844u) {      /* |x| >= 27 ln2 */
+        if (hx >= 0x42b17218u) {  /* |x| >= 88.72 */
+            if (hx > 0x7f800000u) return x + x;
+            if (hx == 0x7f800000u) return xsb == 0 ? x : -1.0f;
+            if (x > 8.8721679688e+01f) return __builtin_inff();
+        }
+        if (xsb != 0) return 1.0e-30f - one;
+    }
+    if (hx > 0x3eb17218u) {       /* |x| > 0.5 ln2 */
+        if (hx < 0x3F851592u) {   /* |x| < 1.5 ln2 */
+            if (xsb == 0) { hi = x - ln2_hi; lo = ln2_lo; k = 1; }
+            else { hi = x + ln2_hi; lo = -ln2_lo; k = -1; }
+        } else {
+            k = (int32_t)(invln2 * x + ((xsb == 0) ? 0.5f : -0.5f));
+            t = (float)k;
+            hi = x - t * ln2_hi;
+            lo = t * ln2_lo;
+        }
+        x = hi - lo;
+        c = (hi - x) - lo;
+    } else if (hx < 0x33000000u) { /* |x| < 2^-25 */
+        return x;
+    } else {
+        k = 0;
+    }
+    hfx = 0.5f * x;
+    hxs = x * hfx;
+    r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+    t = 3.0f - r1 * hfx;
+    e = hxs * ((r1 - t) / (6.0f - x * t));
+    if (k == 0) return x - (x * e - hxs);
+    e = (x * (e - c) - c);
+    e -= hxs;
+    if (k == -1) return 0.5f * (x - e) - 0.5f;
+    if (k == 1) {
+        if (x < -0.25f) return -2.0f * (e - (x + 0.5f));
+        return one + 2.0f * (x - e);
+    }
+    if (k <= -2 || k > 56) {
+        y = one - (e - x);
+        y = u2f(f2u(y) + ((uint32_t)k << 23));
+        return y - one;
+    }
+    if (k < 23) {
+        t = u2f(0x3f800000u - (0x1000000u >> k));
+        y = t - (e - x);
+        y = u2f(f2u(y) + ((uint32_t)k << 23));
+    } else {
+        t = u2f((uint32_t)(0x7f - k) << 23);
+        y = x - (e + t);
+        y += one;
+        y = u2f(f2u(y) + ((uint32_t)k << 23));
+    }
+    return y;
+}
+
+__device__ inline float libm_tanhf(float x) {
+    float t, z;
+    const int32_t jx = (int32_t)f2u(x);
+    const int32_t ix = jx & 0x7fffffff;
+    if (ix >= 0x7f800000) return (jx >= 0) ? 1.0f / x + 1.0f : 1.0f / x - 1.0f;
+    if (ix < 0x41b00000) { /* |x| < 22 */
+        if (ix == 0) return x;
+        if (ix < 0x24000000) return x * (1.0f + x);
+        if (ix >= 0x3f800000) {
+            t = libm_expm1f(2.0f * __builtin_fabsf(x));
+            z = 1.0f - 2.0f / (t + 2.0f);
+        } else {
+            t = libm_expm1f(-2.0f * __builtin_fabsf(x));
+            z = -t / (t + 2.0f);
+        }
+    } else {
+        z = 1.0f - 1.0e-30f;
+    }
+    return (jx >= 0) ? z : -z;
+}
+
+// range/module_impl_native_cpu.cc:67-82.
+__device__ __forceinline__ float range_f32(float v, float scale, float offset) {
+    if (scale == 0.0f) return 0.5f;
+    const float normalized = v * scale + offset;
+    return 0.5f + 0.5f * libm_tanhf(4.0f * (normalized - 0.5f));
+}
+
+}  // namespace jst::dev

@@ -1,0 +1,193 @@
+// elementwise.hip -- strided N-ary elementwise kernels: Multiply, Amplitude, Range,
+// MultiplyConstant, Invert, Window.  These are the module-by-module ("API-literal") forms of the
+// ops that fft_lds.hh also offers fused into the FFT; same arithmetic (device_math.hh).
+//
+// Traversal: one thread per output element, grid-stride; flat index -> coordinates by a
+// mixed-radix decode over the common shape (row-major, like AutomaticIterator's odometer,
+// include/jetstream/tools/automatic_iterator.hh:207-231); dense operands skip the decode.
+#include "device_math.hh"
+#include "kernels.hh"
+
+namespace jst::kernels {
+
+using namespace jst::dev;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+template <int NOPS>
+__device__ __forceinline__ void decode(const EwLayout& L, uint64_t idx, int64_t (&off)[NOPS]) {
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) off[o] = (int64_t)L.offset[o];
+    if (L.contiguous) {
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) off[o] += (int64_t)idx;
+        return;
+    }
+    for (int a = L.rank - 1; a >= 0; --a) {
+        const uint64_t c = idx % L.shape[a];
+        idx /= L.shape[a];
+#pragma unroll
+        for (int o = 0; o < NOPS; ++o) off[o] += (int64_t)c * L.stride[o][a];
+    }
+}
+
+template <class TO, class TA, class F>
+__global__ __launch_bounds__(kBlock) void ew_unary(const EwLayout L, TO* __restrict__ out,
+                                                   const TA* __restrict__ a, const F f) {
+    const uint64_t step = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < L.size; idx += step) {
+        int64_t off[2];
+        decode<2>(L, idx, off);
+        out[off[0]] = f(idx, a[off[1]]);
+    }
+}
+
+template <class TO, class TA, class TB, class F>
+__global__ __launch_bounds__(kBlock) void ew_binary(const EwLayout L, TO* __restrict__ out,
+                                                    const TA* __restrict__ a,
+                                                    const TB* __restrict__ b, const F f) {
+    const uint64_t step = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < L.size; idx += step) {
+        int64_t off[3];
+        decode<3>(L, idx, off);
+        out[off[0]] = f(idx, a[off[1]], b[off[2]]);
+    }
+}
+
+inline unsigned grid_for(uint64_t size) {
+    const uint64_t need = (size + kBlock - 1) / kBlock;
+    const uint64_t cap = 256ull * 16ull;  // 16 workgroups of 4 waves per CU
+    return (unsigned)(need < cap ? (need ? need : 1) : cap);
+}
+
+template <class TO, class TA, class F>
+hipError_t run_unary(const EwLayout& L, TO* out, const TA* a, const F& f, hipStream_t s) {
+    if (L.size == 0) return hipSuccess;
+    hipLaunchKernelGGL((ew_unary<TO, TA, F>), dim3(grid_for(L.size)), dim3(kBlock), 0, s, L, out, a,
+                       f);
+    return hipGetLastError();
+}
+template <class TO, class TA, class TB, class F>
+hipError_t run_binary(const EwLayout& L, TO* out, const TA* a, const TB* b, const F& f,
+                      hipStream_t s) {
+    if (L.size == 0) return hipSuccess;
+    hipLaunchKernelGGL((ew_binary<TO, TA, TB, F>), dim3(grid_for(L.size)), dim3(kBlock), 0, s, L,
+                       out, a, b, f);
+    return hipGetLastError();
+}
+
+struct MulCF32 {
+    __device__ float2 operator()(uint64_t, float2 a, float2 b) const { return cmul_full(a, b); }
+};
+struct MulF32 {
+    __device__ float operator()(uint64_t, float a, float b) const { return a * b; }
+};
+struct AmpCF32 {
+    float coeff;
+    __device__ float operator()(uint64_t, float2 v) const { return amplitude_cf32(v, coeff); }
+};
+struct AmpF32 {
+    float coeff;
+    __device__ float operator()(uint64_t, float v) const { return amplitude_f32(v, coeff); }
+};
+struct RangeF32 {
+    float scale, offset;
+    __device__ float operator()(uint64_t, float v) const { return range_f32(v, scale, offset); }
+};
+// multiply_constant/module_impl_native_cpu.cc:92-100: CF32 * F32 scalar = (re*c, im*c).
+struct MulConstCF32 {
+    float c;
+    __device__ float2 operator()(uint64_t, float2 v) const { return mk(v.x * c, v.y * c); }
+};
+struct MulConstF32 {
+    float c;
+    __device__ float operator()(uint64_t, float v) const { return v * c; }
+};
+struct TanhProbe {
+    __device__ float operator()(uint64_t, float v) const { return libm_tanhf(v); }
+};
+
+// invert/module_impl_native_cpu.cc:79-103.
+template <class TIN>
+struct InvertOp {
+    uint64_t inner, length;
+    __device__ float2 operator()(uint64_t index, TIN in) const {
+        float2 value;
+        if constexpr (sizeof(TIN) == sizeof(float2)) value = in;
+        else value = mk(in, 0.0f);
+        const uint64_t coord = (index / inner) % length;
+        if ((length & 1ull) == 0) return (coord & 1ull) ? mk(-value.x, -value.y) : value;
+        const double phase = 2.0 * 3.14159265358979323846 * (double)(length / 2) * (double)coord /
+                             (double)length;
+        return cmul_full(value, mk((float)cos(phase), (float)sin(phase)));
+    }
+};
+
+// window/module_impl_native_cpu.cc:20-37 -- Blackman, F64 evaluation, symmetric denominator.
+__global__ __launch_bounds__(kBlock) void window_kernel(float2* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (n == 1) {
+        out[0] = mk(1.0f, 0.0f);
+        return;
+    }
+    const double pi = 3.14159265358979323846;
+    const double tap = 0.42 - 0.50 * cos(2.0 * pi * (double)i / (double)(n - 1)) +
+                       0.08 * cos(4.0 * pi * (double)i / (double)(n - 1));
+    out[i] = mk((float)tap, 0.0f);
+}
+
+}  // namespace
+
+hipError_t launch_multiply_cf32(const EwLayout& L, float2* c, const float2* a, const float2* b,
+                                hipStream_t s) {
+    return run_binary(L, c, a, b, MulCF32{}, s);
+}
+hipError_t launch_multiply_f32(const EwLayout& L, float* c, const float* a, const float* b,
+                               hipStream_t s) {
+    return run_binary(L, c, a, b, MulF32{}, s);
+}
+hipError_t launch_amplitude_cf32(const EwLayout& L, float* out, const float2* in, float coeff,
+                                 hipStream_t s) {
+    return run_unary(L, out, in, AmpCF32{coeff}, s);
+}
+hipError_t launch_amplitude_f32(const EwLayout& L, float* out, const float* in, float coeff,
+                                hipStream_t s) {
+    return run_unary(L, out, in, AmpF32{coeff}, s);
+}
+hipError_t launch_range_f32(const EwLayout& L, float* out, const float* in, float scale,
+                            float offset, hipStream_t s) {
+    return run_unary(L, out, in, RangeF32{scale, offset}, s);
+}
+hipError_t launch_multiply_constant_cf32(const EwLayout& L, float2* out, const float2* in,
+                                         float constant, hipStream_t s) {
+    return run_unary(L, out, in, MulConstCF32{constant}, s);
+}
+hipError_t launch_multiply_constant_f32(const EwLayout& L, float* out, const float* in,
+                                        float constant, hipStream_t s) {
+    return run_unary(L, out, in, MulConstF32{constant}, s);
+}
+hipError_t launch_invert(const EwLayout& L, float2* out, const void* in, bool in_is_complex,
+                         uint64_t inner, uint64_t length, hipStream_t s) {
+    if (in_is_complex)
+        return run_unary(L, out, static_cast<const float2*>(in), InvertOp<float2>{inner, length}, s);
+    return run_unary(L, out, static_cast<const float*>(in), InvertOp<float>{inner, length}, s);
+}
+hipError_t launch_window(float2* out, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(window_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       s, out, n);
+    return hipGetLastError();
+}
+hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipStream_t s) {
+    EwLayout L{};
+    L.size = count;
+    L.rank = 1;
+    L.contiguous = 1;
+    L.shape[0] = count;
+    return run_unary(L, out, in, TanhProbe{}, s);
+}
+
+}  // namespace jst::kernels

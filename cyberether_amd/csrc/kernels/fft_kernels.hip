@@ -1,0 +1,114 @@
+// fft_kernels.hip -- instantiations and host launchers of the LDS Stockham FFT (fft_lds.hh).
+#include "fft_lds.hh"
+#include "kernels.hh"
+
+namespace jst::kernels {
+
+using namespace jst::dev;
+
+namespace {
+
+inline bool window_contig(const LoadCF32&) { return true; }
+inline bool window_contig(const LoadCF32TimesWindow& p) { return p.wstride == 1; }
+
+template <int N, bool FWD, class Pro, class Epi>
+hipError_t launch_one(const FftLayout& L, const float2* W, const Pro& pro, const Epi& epi,
+                      hipStream_t stream) {
+    constexpr int TPB = fft_transforms_per_block(N);
+    constexpr size_t lds = fft_lds_bytes(N);
+    const bool contig = L.in_axis_stride == 1 && L.out_axis_stride == 1 && window_contig(pro);
+    auto kernel = contig ? fft_lds_kernel<N, FWD, true, Pro, Epi> : fft_lds_kernel<N, FWD, false, Pro, Epi>;
+    if constexpr (lds > 64 * 1024) {
+        static bool raised[2] = {false, false};  // per instantiation; the attribute is sticky
+        if (!raised[contig]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds);
+            if (e != hipSuccess) return e;
+            raised[contig] = true;
+        }
+    }
+    const uint64_t blocks_needed = (L.transforms + TPB - 1) / TPB;
+    // Enough workgroups to occupy every CU several times over, grid-stride beyond that.
+    const uint64_t blocks = blocks_needed < 8192 ? blocks_needed : 8192;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(fft_block_threads(N)), lds, stream, L,
+                       W, pro, epi);
+    return hipGetLastError();
+}
+
+template <bool FWD, class Pro, class Epi>
+hipError_t dispatch_n(uint64_t n, const FftLayout& L, const float2* W, const Pro& pro,
+                      const Epi& epi, hipStream_t stream) {
+    switch (n) {
+#define JST_FFT_CASE(NN) \
+    case NN:             \
+        return launch_one<NN, FWD, Pro, Epi>(L, W, pro, epi, stream);
+        JST_FFT_CASE(1)
+        JST_FFT_CASE(2)
+        JST_FFT_CASE(4)
+        JST_FFT_CASE(8)
+        JST_FFT_CASE(16)
+        JST_FFT_CASE(32)
+        JST_FFT_CASE(64)
+        JST_FFT_CASE(128)
+        JST_FFT_CASE(256)
+        JST_FFT_CASE(512)
+        JST_FFT_CASE(1024)
+        JST_FFT_CASE(2048)
+        JST_FFT_CASE(4096)
+        JST_FFT_CASE(8192)
+        JST_FFT_CASE(16384)
+#undef JST_FFT_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
+template <class Pro, class Epi>
+hipError_t dispatch_fused_n(uint64_t n, const FftLayout& L, const float2* W, const Pro& pro,
+                            const Epi& epi, hipStream_t stream) {
+    switch (n) {
+#define JST_FFT_CASE(NN) \
+    case NN:             \
+        return launch_one<NN, true, Pro, Epi>(L, W, pro, epi, stream);
+        JST_FFT_CASE(256)
+        JST_FFT_CASE(512)
+        JST_FFT_CASE(1024)
+        JST_FFT_CASE(2048)
+        JST_FFT_CASE(4096)
+        JST_FFT_CASE(8192)
+        JST_FFT_CASE(16384)
+#undef JST_FFT_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+bool fft_lds_supported(uint64_t n) { return n >= 1 && n <= 16384 && (n & (n - 1)) == 0; }
+bool fft_fused_supported(uint64_t n) { return n >= 256 && fft_lds_supported(n); }
+
+hipError_t launch_fft_c2c(uint64_t n, bool forward, const FftLayout& L, const float2* W,
+                          const float2* in, float2* out, hipStream_t stream) {
+    const LoadCF32 pro{in};
+    const StoreCF32 epi{out};
+    return forward ? dispatch_n<true>(n, L, W, pro, epi, stream)
+                   : dispatch_n<false>(n, L, W, pro, epi, stream);
+}
+
+hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W,
+                                 const float2* in, const float2* window, int64_t window_stride,
+                                 float* out, float amp_coeff, bool with_range, float range_scale,
+                                 float range_offset, hipStream_t stream) {
+    const LoadCF32TimesWindow pro{in, window, window_stride};
+    if (with_range) {
+        const StoreAmplitudeRange epi{out, amp_coeff, range_scale, range_offset};
+        return dispatch_fused_n(n, L, W, pro, epi, stream);
+    }
+    const StoreAmplitude epi{out, amp_coeff};
+    return dispatch_fused_n(n, L, W, pro, epi, stream);
+}
+
+}  // namespace jst::kernels

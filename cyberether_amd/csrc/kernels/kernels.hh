@@ -1,0 +1,99 @@
+// kernels.hh -- host-visible launch interface of the gfx950 kernels.  Plain structs and
+// functions; the module layer (../modules) is the only caller.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jst::dev {
+
+constexpr int kMaxOuterRank = 7;
+constexpr int kMaxRank = 8;
+
+// Addressing of the batch ("outer") axes around the transform axis.  Strides in ELEMENTS of the
+// respective tensor (src/memory/tensor.cc:94-109); offsets already include Tensor::offset()
+// because a device Tensor::data() does not (tensor.cc:1090-1095).
+struct FftLayout {
+    uint64_t transforms;  // product of outer shape
+    int32_t outer_rank;   // 0..kMaxOuterRank
+    uint64_t outer_shape[kMaxOuterRank];
+    int64_t in_outer_stride[kMaxOuterRank];
+    int64_t out_outer_stride[kMaxOuterRank];
+    int64_t in_axis_stride;
+    int64_t out_axis_stride;
+    uint64_t in_offset;
+    uint64_t out_offset;
+};
+
+// N-ary strided elementwise traversal (the device counterpart of
+// include/jetstream/tools/automatic_iterator.hh:108-343): a common shape, per-operand element
+// strides (0 on broadcast axes) and element offsets.  Operand 0 is the output.
+struct EwLayout {
+    uint64_t size;
+    int32_t rank;
+    int32_t contiguous;  // every operand dense row-major with the common shape
+    uint64_t shape[kMaxRank];
+    int64_t stride[3][kMaxRank];
+    uint64_t offset[3];
+};
+
+}  // namespace jst::dev
+
+namespace jst::kernels {
+
+using jst::dev::EwLayout;
+using jst::dev::FftLayout;
+
+// ---- FFT (fft_kernels.hip) ---------------------------------------------------------------------
+bool fft_lds_supported(uint64_t n);
+bool fft_fused_supported(uint64_t n);
+hipError_t launch_fft_c2c(uint64_t n, bool forward, const FftLayout& L, const float2* W,
+                          const float2* in, float2* out, hipStream_t stream);
+// Multiply(window) -> FFT(forward) -> Amplitude [-> Range] in one pass over HBM.
+hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W,
+                                 const float2* in, const float2* window, int64_t window_stride,
+                                 float* out, float amp_coeff, bool with_range, float range_scale,
+                                 float range_offset, hipStream_t stream);
+
+// ---- elementwise modules (elementwise.hip) -----------------------------------------------------
+hipError_t launch_multiply_cf32(const EwLayout& L, float2* c, const float2* a, const float2* b,
+                                hipStream_t stream);
+hipError_t launch_multiply_f32(const EwLayout& L, float* c, const float* a, const float* b,
+                               hipStream_t stream);
+hipError_t launch_amplitude_cf32(const EwLayout& L, float* out, const float2* in, float coeff,
+                                 hipStream_t stream);
+hipError_t launch_amplitude_f32(const EwLayout& L, float* out, const float* in, float coeff,
+                                hipStream_t stream);
+hipError_t launch_range_f32(const EwLayout& L, float* out, const float* in, float scale,
+                            float offset, hipStream_t stream);
+hipError_t launch_multiply_constant_cf32(const EwLayout& L, float2* out, const float2* in,
+                                         float constant, hipStream_t stream);
+hipError_t launch_multiply_constant_f32(const EwLayout& L, float* out, const float* in,
+                                        float constant, hipStream_t stream);
+// Invert: flat (row-major) index -> coordinate on the sample axis = (index / inner) % length
+// (invert/module_impl_native_cpu.cc:79-103).  Output always CF32.
+hipError_t launch_invert(const EwLayout& L, float2* out, const void* in, bool in_is_complex,
+                         uint64_t inner, uint64_t length, hipStream_t stream);
+// Window: Blackman taps evaluated in F64 (window/module_impl_native_cpu.cc:20-37).
+hipError_t launch_window(float2* out, uint64_t n, hipStream_t stream);
+// libm-faithful tanhf sweep helper for the parity tests (out[i] = libm_tanhf(in[i])).
+hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipStream_t stream);
+
+// ---- Spectrogram (spectrogram.hip) -------------------------------------------------------------
+// bins: F32 [height][width] state, updated in place:
+//   bins *= decay; for every (batch, x): f = in*height; if 1 <= f < height: bins[x + (u64)f*width]
+//   = min(bins + 0.02, 1)   (spectrogram/module_impl_native_cpu.cc:61-87)
+size_t spectrogram_lds_bytes(uint64_t height);
+hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, uint64_t batches,
+                              uint64_t width, uint64_t height, int64_t batch_stride,
+                              int64_t elem_stride, float decay, hipStream_t stream);
+
+// ---- Waterfall (waterfall.hip) -----------------------------------------------------------------
+// ring: F32 [height][width]; state: device u64[4] = {writeIndex, dirtyRows, ticket, pad}.
+// waterfall/ring_state.hh:16-56 + module_impl_native_cpu.cc:53-78, cursor kept on the device so
+// that the launch is hipGraph-replayable.
+hipError_t launch_waterfall(float* ring, uint64_t* state, const float* in, uint64_t in_offset,
+                            uint64_t batches, uint64_t width, uint64_t height,
+                            int64_t batch_stride, int64_t elem_stride, hipStream_t stream);
+
+}  // namespace jst::kernels

@@ -1,0 +1,98 @@
+// spectrogram.hip -- the Spectrogram module's compute (decaying 2-D persistence histogram) as a
+// column-tiled LDS histogram on gfx950.  The reference has a CPU implementation only
+// (src/domains/visualization/spectrogram/module_impl_native_cpu.cc:61-87):
+//
+//     for all bins: bins *= decay
+//     for b, x:  index = (U64)(in[b,x] * height);  if 0 < index < height:
+//                bins[x + index*width] = min(bins[...] + 0.02f, 1.0f)
+//
+// The float update is the SAME operation repeated once per hit, so the result depends only on
+// the hit COUNT per bin, not on the order: we count hits with integer LDS atomics (exact, order
+// free) and then apply min(v + 0.02f, 1.0f) count-times to the decayed value -- bit-identical
+// to the sequential CPU loop.  The bin index rule is stated without the reference's undefined
+// float->U64 cast: hit <=> 1.0f <= f < (float)height, index = (u32)f ("hard
+// parts"; on x86-64 every other input fails 0 < index < height).
+//
+// Mapping: one workgroup owns a tile of TW adjacent columns for ALL batches (the only place a
+// bin's hits can come from), so no inter-workgroup communication exists.  Rows of the F32[B,N]
+// input are read TW*4 bytes at a time (64 B at TW = 16) -- they were just written by the
+// spectrum kernel and sit in L2 / Infinity Cache.  The state tile is read-modified-written once.
+#include "device_math.hh"
+#include "kernels.hh"
+
+namespace jst::kernels {
+
+namespace {
+
+constexpr int kThreads = 1024;
+
+template <int TW>
+__global__ __launch_bounds__(kThreads) void spectrogram_kernel(
+    float* __restrict__ bins, const float* __restrict__ in, uint64_t in_offset, uint32_t batches,
+    uint32_t width, uint32_t height, int64_t batch_stride, int64_t elem_stride, float decay) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);  // [height][TW]
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cells = height * TW;
+    for (uint32_t e = tid; e < cells; e += kThreads) hist[e] = 0u;
+    __syncthreads();
+
+    const uint32_t c = tid % TW;
+    const uint32_t x = blockIdx.x * TW + c;
+    const float fh = (float)height;
+    if (x < width) {
+        const float* col = in + in_offset + (int64_t)x * elem_stride;
+        constexpr uint32_t rows_per_iter = kThreads / TW;
+        for (uint32_t b = tid / TW; b < batches; b += rows_per_iter) {
+            const float f = col[(int64_t)b * batch_stride] * fh;
+            if (f >= 1.0f && f < fh) atomicAdd(&hist[(uint32_t)f * TW + c], 1u);
+        }
+    }
+    __syncthreads();
+
+    for (uint32_t e = tid; e < cells; e += kThreads) {
+        const uint32_t idx = e / TW;
+        const uint32_t xx = blockIdx.x * TW + (e % TW);
+        if (xx >= width) continue;
+        float* cell = bins + (uint64_t)idx * width + xx;
+        float v = *cell * decay;
+        uint32_t k = hist[e];
+        k = k < 64u ? k : 64u;  // 0.02 * 51 > 1: the value is pinned at 1.0f long before 64 hits
+        for (uint32_t n = 0; n < k; ++n) {
+            const float t = v + 0.02f;
+            v = (1.0f < t) ? 1.0f : t;  // std::min(val + 0.02f, 1.0f)
+        }
+        *cell = v;
+    }
+}
+
+}  // namespace
+
+size_t spectrogram_lds_bytes(uint64_t height) {
+    const int tw = height <= 1024 ? 16 : 8;
+    return (size_t)height * tw * sizeof(uint32_t);
+}
+
+hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, uint64_t batches,
+                              uint64_t width, uint64_t height, int64_t batch_stride,
+                              int64_t elem_stride, float decay, hipStream_t stream) {
+    if (width == 0 || height == 0) return hipSuccess;
+    if (height > 2048 || batches > 0xffffffffull || width > 0xffffffffull)
+        return hipErrorInvalidValue;
+    const size_t lds = spectrogram_lds_bytes(height);
+    if (height <= 1024) {
+        const unsigned tiles = (unsigned)((width + 15) / 16);
+        hipLaunchKernelGGL(spectrogram_kernel<16>, dim3(tiles), dim3(kThreads), lds, stream, bins,
+                           in, in_offset, (uint32_t)batches, (uint32_t)width, (uint32_t)height,
+                           batch_stride, elem_stride, decay);
+    } else {
+        const unsigned tiles = (unsigned)((width + 7) / 8);
+        hipLaunchKernelGGL(spectrogram_kernel<8>, dim3(tiles), dim3(kThreads), lds, stream, bins,
+                           in, in_offset, (uint32_t)batches, (uint32_t)width, (uint32_t)height,
+                           batch_stride, elem_stride, decay);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace jst::kernels

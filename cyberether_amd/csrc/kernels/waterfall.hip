@@ -1,0 +1,73 @@
+// waterfall.hip -- the Waterfall module's compute: copy the newest min(B, H) rows of an F32[B,N]
+// spectrum batch into a ring of H rows (src/domains/visualization/waterfall/ring_state.hh:16-56,
+// module_impl_native_cpu.cc:53-78; CUDA analogue module_impl_native_cuda.cc:18-42,108-149).
+//
+// Unlike the reference's CUDA path (cursor on the host, passed as a kernel argument every cycle)
+// the ring cursor lives in device memory, so one captured launch is replayable from a hipGraph:
+// every workgroup reads the cursor at entry, copies, then takes a ticket; the LAST workgroup to
+// arrive -- by which time every workgroup has read the cursor -- advances it.  All index work is
+// 64-bit integer and identical to PlanWaterfallWrite / WaterfallRingState::advance.
+#include "device_math.hh"
+#include "kernels.hh"
+
+namespace jst::kernels {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void waterfall_kernel(
+    float* __restrict__ ring, uint64_t* state, const float* __restrict__ in, uint64_t in_offset,
+    uint64_t batches, uint64_t width, uint64_t height, int64_t batch_stride, int64_t elem_stride) {
+    const uint64_t write_index =
+        __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // PlanWaterfallWrite (ring_state.hh:16-28)
+    const uint64_t retained = batches < height ? batches : height;
+    const uint64_t source_row = batches - retained;
+    const uint64_t destination_row = (write_index + (source_row % height)) % height;
+
+    const uint64_t total = retained * width;
+    const uint64_t step = (uint64_t)gridDim.x * kThreads;
+    for (uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x; e < total; e += step) {
+        const uint64_t row = e / width, column = e - row * width;
+        const uint64_t dst = (destination_row + row) % height;
+        ring[dst * width + column] =
+            in[in_offset + (int64_t)(source_row + row) * batch_stride + (int64_t)column * elem_stride];
+    }
+
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint64_t ticket =
+            __hip_atomic_fetch_add(&state[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == (uint64_t)gridDim.x - 1) {
+            // WaterfallRingState::advance (ring_state.hh:40-43)
+            const uint64_t dirty =
+                __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t room = height - dirty;
+            __hip_atomic_store(&state[0], (write_index + (batches % height)) % height,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&state[1], dirty + (batches < room ? batches : room),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&state[2], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_waterfall(float* ring, uint64_t* state, const float* in, uint64_t in_offset,
+                            uint64_t batches, uint64_t width, uint64_t height,
+                            int64_t batch_stride, int64_t elem_stride, hipStream_t stream) {
+    if (height == 0) return hipErrorInvalidValue;
+    const uint64_t retained = batches < height ? batches : height;
+    const uint64_t total = retained * width;
+    uint64_t blocks = (total + kThreads - 1) / kThreads;
+    if (blocks == 0) blocks = 1;  // the cursor still advances on an empty copy
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(waterfall_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, ring,
+                       state, in, in_offset, batches, width, height, batch_stride, elem_stride);
+    return hipGetLastError();
+}
+
+}  // namespace jst::kernels

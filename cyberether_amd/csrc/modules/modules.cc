@@ -1,0 +1,841 @@
+// modules.cc -- host side of the hot-path modules (see modules.hh): validation, output
+// allocation and kernel submission.  No arithmetic on tensor data happens on the host.
+#include "modules.hh"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+namespace jst::modules {
+
+using dev::EwLayout;
+using dev::FftLayout;
+
+// ---- helpers -----------------------------------------------------------------------------------
+bool MakeEwLayout(const Tensor& out, const Tensor* a, const Tensor* b, EwLayout& L) {
+    std::memset(&L, 0, sizeof(L));
+    if (out.rank() > (Index)dev::kMaxRank) return false;
+    L.size = out.size();
+    L.rank = (int32_t)out.rank();
+    const Tensor* ops[3] = {&out, a, b};
+    bool dense = true;
+    for (int o = 0; o < 3; ++o) {
+        if (!ops[o]) continue;
+        if (ops[o]->rank() != out.rank()) return false;
+        L.offset[o] = ops[o]->offset();
+        for (Index ax = 0; ax < out.rank(); ++ax) {
+            if (ops[o]->shape(ax) != out.shape(ax)) return false;
+            L.stride[o][ax] = (int64_t)ops[o]->stride(ax);
+        }
+        dense = dense && ops[o]->contiguous();
+    }
+    for (Index ax = 0; ax < out.rank(); ++ax) L.shape[ax] = out.shape(ax);
+    L.contiguous = dense ? 1 : 0;
+    return true;
+}
+
+namespace {
+
+template <class T>
+T* ptr(const Tensor& t) {
+    return static_cast<T*>(t.data());
+}
+
+Result parse_shape(const std::string& s, Shape& out, const char* tag) {
+    out.clear();
+    if (s.size() < 2 || s.front() != '[' || s.back() != ']') {
+        JST_ERROR("[%s] Shape must use bracket notation.", tag);
+        return Result::ERROR;
+    }
+    size_t pos = 1;
+    const size_t close = s.size() - 1;
+    auto skip = [&] { while (pos < close && std::isspace((unsigned char)s[pos])) ++pos; };
+    skip();
+    if (pos == close) {
+        JST_ERROR("[%s] Shape must have at least one dimension.", tag);
+        return Result::ERROR;
+    }
+    while (pos < close) {
+        const size_t begin = pos;
+        U64 dim = 0;
+        while (pos < close && s[pos] >= '0' && s[pos] <= '9') {
+            if (dim > (~0ull - 9) / 10) {
+                JST_ERROR("[%s] Shape dimension exceeds the supported numeric range.", tag);
+                return Result::ERROR;
+            }
+            dim = dim * 10 + (U64)(s[pos] - '0');
+            ++pos;
+        }
+        if (begin == pos) {
+            JST_ERROR("[%s] Invalid shape syntax '%s'.", tag, s.c_str());
+            return Result::ERROR;
+        }
+        if (dim == 0) {
+            JST_ERROR("[%s] Shape dimensions cannot be zero.", tag);
+            return Result::ERROR;
+        }
+        out.push_back(dim);
+        skip();
+        if (pos == close) break;
+        if (s[pos] != ',') {
+            JST_ERROR("[%s] Invalid shape syntax '%s'.", tag, s.c_str());
+            return Result::ERROR;
+        }
+        ++pos;
+        skip();
+        if (pos == close) {
+            JST_ERROR("[%s] Invalid shape syntax '%s'.", tag, s.c_str());
+            return Result::ERROR;
+        }
+    }
+    return Result::SUCCESS;
+}
+
+Result hip_result(hipError_t e, const char* what) {
+    if (e == hipSuccess) return Result::SUCCESS;
+    JST_ERROR("[HIP] %s failed: %s", what, hipGetErrorString(e));
+    return Result::ERROR;
+}
+
+}  // namespace
+
+// ---- twiddles ----------------------------------------------------------------------------------
+// pocketfft's sincos_2pibyn<float> (fft/pocketfft.hh:296-372): exp(2 pi j k/n) as the double
+// product of two short tables (fine x coarse), each entry evaluated with an octant reduction so
+// the cos/sin arguments stay in [0, pi/4], then rounded to float.  Restated here so the device
+// table is bit-identical to the one the reference CPU path multiplies by.
+namespace {
+struct cd {
+    double r, i;
+};
+cd octant_sincos(U64 x, U64 n, double ang) {
+    U64 y = x << 3;
+    bool neg_im = false, rot = false;
+    if (y >= 4 * n) {
+        y = 8 * n - y;
+        neg_im = true;
+    }
+    if (y >= 2 * n) {
+        y -= 2 * n;
+        rot = true;
+    }
+    double c, s;
+    if (y < n) {
+        c = std::cos((double)y * ang);
+        s = std::sin((double)y * ang);
+    } else {
+        c = std::sin((double)(2 * n - y) * ang);
+        s = std::cos((double)(2 * n - y) * ang);
+    }
+    if (rot) {
+        const double t = c;
+        c = -s;
+        s = t;
+    }
+    if (neg_im) s = -s;
+    return {c, s};
+}
+}  // namespace
+
+void ComputeTwiddles(U64 n, float* out) {
+    const long double pi = 3.141592653589793238462643383279502884197L;
+    const double ang = (double)(0.25L * pi / (long double)n);
+    const U64 nval = (n + 2) / 2;
+    U64 shift = 1;
+    while ((U64(1) << shift) * (U64(1) << shift) < nval) ++shift;
+    const U64 mask = (U64(1) << shift) - 1;
+    std::vector<cd> fine(mask + 1), coarse((nval + mask) / (mask + 1));
+    fine[0] = {1.0, 0.0};
+    for (U64 i = 1; i < fine.size(); ++i) fine[i] = octant_sincos(i, n, ang);
+    coarse[0] = {1.0, 0.0};
+    for (U64 i = 1; i < coarse.size(); ++i) coarse[i] = octant_sincos(i * (mask + 1), n, ang);
+    for (U64 k = 0; k < n; ++k) {
+        const bool mirror = 2 * k > n;
+        const U64 idx = mirror ? n - k : k;
+        const cd a = fine[idx & mask], b = coarse[idx >> shift];
+        const float re = (float)(a.r * b.r - a.i * b.i);
+        const float im = (float)(a.r * b.i + a.i * b.r);
+        out[2 * k] = re;
+        out[2 * k + 1] = mirror ? -im : im;
+    }
+}
+
+Result GetTwiddles(U64 n, const float2** table) {
+    static std::mutex mu;
+    static std::map<U64, float2*> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(n);
+    if (it == cache.end()) {
+        std::vector<float> host(2 * n);
+        ComputeTwiddles(n, host.data());
+        float2* d = nullptr;
+        JST_HIP_CHECK(hipMalloc(&d, n * sizeof(float2)), "hipMalloc(twiddles)");
+        JST_HIP_CHECK(hipMemcpy(d, host.data(), n * sizeof(float2), hipMemcpyHostToDevice),
+                      "hipMemcpy(twiddles)");
+        it = cache.emplace(n, d).first;
+    }
+    *table = it->second;
+    return Result::SUCCESS;
+}
+
+// ---- Window ------------------------------------------------------------------------------------
+Result Window::validate() {
+    bool ok = true;
+    size = ConfigU64(config_, "size", 1024, &ok);
+    if (!ok || size == 0) {
+        JST_ERROR("[MODULE_WINDOW] Window size cannot be zero.");
+        return Result::ERROR;
+    }
+    return Result::SUCCESS;
+}
+Result Window::define() {
+    JST_CHECK(defineTaint(STATIC_OUTPUT));
+    return defineInterfaceOutput("window");
+}
+Result Window::create() {
+    JST_CHECK(output.create(device(), DataType::CF32, {size}));
+    JST_CHECK(SetSignalAxes(output, {.sample = Index{0}}));
+    produced("window", output);
+    return Result::SUCCESS;
+}
+Result Window::computeSubmit(hipStream_t stream) {
+    return hip_result(kernels::launch_window(ptr<float2>(output) + output.offset(), size, stream),
+                      "window kernel");
+}
+
+// ---- Invert ------------------------------------------------------------------------------------
+Result Invert::validate() {
+    if (!inputs_.count("signal")) return Result::SUCCESS;
+    const Tensor& in = inputs_.at("signal");
+    if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+    SignalAxes axes;
+    if (ResolveSignalAxes(in, axes) != Result::SUCCESS) {
+        JST_ERROR("[MODULE_INVERT] Input must contain valid signal axis metadata.");
+        return Result::ERROR;
+    }
+    if (in.dtype() != DataType::F32 && in.dtype() != DataType::CF32) {
+        JST_ERROR("[MODULE_INVERT_NATIVE_HIP] Unsupported data type '%s'.", DataTypeName(in.dtype()));
+        return Result::ERROR;
+    }
+    resolvedAxis = *axes.sample;
+    return Result::SUCCESS;
+}
+Result Invert::define() {
+    JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+    JST_CHECK(defineInterfaceInput("signal"));
+    return defineInterfaceOutput("signal");
+}
+Result Invert::create() {
+    input = inputs_.at("signal");
+    JST_CHECK(output.create(device(), DataType::CF32, input.shape()));
+    JST_CHECK(output.propagateAttributes(input));
+    axisInnerSize = 1;
+    for (Index ax = resolvedAxis + 1; ax < input.rank(); ++ax) axisInnerSize *= input.shape(ax);
+    axisLength = input.shape(resolvedAxis);
+    produced("signal", output);
+    return Result::SUCCESS;
+}
+Result Invert::computeSubmit(hipStream_t stream) {
+    EwLayout L;
+    if (!MakeEwLayout(output, &input, nullptr, L)) {
+        JST_ERROR("[MODULE_INVERT] Unsupported tensor rank.");
+        return Result::ERROR;
+    }
+    return hip_result(kernels::launch_invert(L, ptr<float2>(output), input.data(),
+                                             input.dtype() == DataType::CF32, axisInnerSize,
+                                             axisLength, stream),
+                      "invert kernel");
+}
+
+// ---- Reshape / Cast (views) --------------------------------------------------------------------
+Result Reshape::validate() {
+    JST_CHECK(parse_shape(ConfigStr(config_, "shape", "[]"), target, "MODULE_RESHAPE"));
+    if (!inputs_.count("buffer")) return Result::SUCCESS;
+    const Tensor& in = inputs_.at("buffer");
+    U64 n = 1;
+    for (U64 d : target) n *= d;
+    if (in.validShape() && n != in.size()) {
+        JST_ERROR("[MODULE_RESHAPE] Cannot reshape %s into %s.", ShapeToString(in.shape()).c_str(),
+                  ShapeToString(target).c_str());
+        return Result::ERROR;
+    }
+    return Result::SUCCESS;
+}
+Result Reshape::define() {
+    JST_CHECK(defineTaint(STATELESS));
+    JST_CHECK(defineInterfaceInput("buffer"));
+    return defineInterfaceOutput("buffer");
+}
+Result Reshape::create() {
+    Tensor view = inputs_.at("buffer").clone();
+    JST_CHECK(view.reshape(target));
+    // Axis roles are positional: a reshape invalidates them (the block re-tags the view,
+    // spectrum_engine/block_impl.cc:167-170).
+    view.removeAttribute(SampleAxisAttribute);
+    view.removeAttribute(BatchAxisAttribute);
+    view.removeAttribute(ChannelAxisAttribute);
+    produced("buffer", view);
+    return Result::SUCCESS;
+}
+
+Result Cast::validate() {
+    if (!inputs_.count("buffer")) return Result::SUCCESS;
+    const std::string want = ConfigStr(config_, "outputType", "CF32");
+    if (want != DataTypeName(inputs_.at("buffer").dtype())) {
+        JST_ERROR("[MODULE_CAST_NATIVE_HIP] Only same-type passthrough (%s) is implemented, "
+                  "requested '%s'.",
+                  DataTypeName(inputs_.at("buffer").dtype()), want.c_str());
+        return Result::ERROR;
+    }
+    return Result::SUCCESS;
+}
+Result Cast::define() {
+    JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+    JST_CHECK(defineInterfaceInput("buffer"));
+    return defineInterfaceOutput("buffer");
+}
+Result Cast::create() {
+    produced("buffer", inputs_.at("buffer"));  // output aliases input (cast/module_impl.cc:99)
+    return Result::SUCCESS;
+}
+
+// ---- Multiply ----------------------------------------------------------------------------------
+namespace {
+// MapSignalAxes with a right-aligned axis map (axis.cc:315-359).
+Result map_axes_right_aligned(const Tensor& t, Index out_rank, SignalAxes& axes) {
+    SignalAxes in;
+    JST_CHECK(MapSignalAxes(t, in));
+    const Index shift = out_rank - t.rank();
+    axes = {};
+    if (in.sample) axes.sample = *in.sample + shift;
+    if (in.batch) axes.batch = *in.batch + shift;
+    if (in.channel) axes.channel = *in.channel + shift;
+    return Result::SUCCESS;
+}
+Result merge_broadcast_axes(const Tensor& ta, const Tensor& tb, Tensor& out) {
+    SignalAxes aa, ab, ao;
+    JST_CHECK(map_axes_right_aligned(ta, out.rank(), aa));
+    JST_CHECK(map_axes_right_aligned(tb, out.rank(), ab));
+    auto merge = [](const std::optional<Index>& x, const std::optional<Index>& y,
+                    std::optional<Index>& o) {
+        if (x && y && *x != *y) {
+            JST_ERROR("[MEMORY:AXIS] Signal roles map to conflicting output axes.");
+            return Result::ERROR;
+        }
+        o = x ? x : y;
+        return Result::SUCCESS;
+    };
+    JST_CHECK(merge(aa.sample, ab.sample, ao.sample));
+    JST_CHECK(merge(aa.batch, ab.batch, ao.batch));
+    JST_CHECK(merge(aa.channel, ab.channel, ao.channel));
+    return SetSignalAxes(out, ao);
+}
+}  // namespace
+
+Result Multiply::validate() {
+    a = Tensor();
+    b = Tensor();
+    outputShape.clear();
+    if (!inputs_.count("a") || !inputs_.count("b")) return Result::SUCCESS;
+    const Tensor& ta = inputs_.at("a");
+    const Tensor& tb = inputs_.at("b");
+    if (!ta.validShape() || !tb.validShape() || ta.size() == 0 || tb.size() == 0)
+        return Result::SUCCESS;
+    if (ta.dtype() != tb.dtype() || (ta.dtype() != DataType::F32 && ta.dtype() != DataType::CF32)) {
+        JST_ERROR("[MODULE_MULTIPLY_NATIVE_HIP] Unsupported data types '%s' x '%s'.",
+                  DataTypeName(ta.dtype()), DataTypeName(tb.dtype()));
+        return Result::ERROR;
+    }
+    const U64 ra = ta.rank(), rb = tb.rank(), mr = std::max(ra, rb);
+    Shape os(mr == 0 ? 1 : mr, 1);
+    for (U64 i = 0; i < mr; ++i) {
+        const U64 da = ra > i ? ta.shape(ra - 1 - i) : 1;
+        const U64 db = rb > i ? tb.shape(rb - 1 - i) : 1;
+        if (da != db && da != 1 && db != 1) {
+            JST_ERROR("[MODULE_MULTIPLY] Input shapes %s and %s are not broadcastable.",
+                      ShapeToString(ta.shape()).c_str(), ShapeToString(tb.shape()).c_str());
+            return Result::ERROR;
+        }
+        os[os.size() - 1 - i] = std::max(da, db);
+    }
+    Tensor ba = ta.clone(), bb = tb.clone();
+    if (ba.broadcastTo(os) != Result::SUCCESS || bb.broadcastTo(os) != Result::SUCCESS) {
+        JST_ERROR("[MODULE_MULTIPLY] Failed to construct validated broadcast views.");
+        return Result::ERROR;
+    }
+    a = ba;
+    b = bb;
+    outputShape = os;
+    return Result::SUCCESS;
+}
+Result Multiply::define() {
+    JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+    JST_CHECK(defineInterfaceOutput("product"));
+    JST_CHECK(defineInterfaceInput("a"));
+    return defineInterfaceInput("b");
+}
+Result Multiply::create() {
+    JST_CHECK(c.create(device(), a.dtype(), outputShape));
+    JST_CHECK(c.propagateAttributes(inputs_.at("a")));
+    JST_CHECK(merge_broadcast_axes(inputs_.at("a"), inputs_.at("b"), c));
+    produced("product", c);
+    return Result::SUCCESS;
+}
+Result Multiply::computeSubmit(hipStream_t stream) {
+    EwLayout L;
+    if (!MakeEwLayout(c, &a, &b, L)) {
+        JST_ERROR("[MODULE_MULTIPLY] Unsupported tensor rank.");
+        return Result::ERROR;
+    }
+    if (a.dtype() == DataType::CF32)
+        return hip_result(kernels::launch_multiply_cf32(L, ptr<float2>(c), ptr<const float2>(a),
+                                                        ptr<const float2>(b), stream),
+                          "multiply kernel");
+    return hip_result(kernels::launch_multiply_f32(L, ptr<float>(c), ptr<const float>(a),
+                                                   ptr<const float>(b), stream),
+                      "multiply kernel");
+}
+
+// ---- MultiplyConstant --------------------------------------------------------------------------
+Result MultiplyConstant::validate() {
+    bool ok = true;
+    constant = (F32)ConfigF64(config_, "constant", 1.0, &ok);
+    if (!ok) {
+        JST_ERROR("[MODULE_MULTIPLY_CONSTANT] Invalid constant.");
+        return Result::ERROR;
+    }
+    if (!inputs_.count("factor")) return Result::SUCCESS;
+    const DataType dt = inputs_.at("factor").dtype();
+    if (dt != DataType::F32 && dt != DataType::CF32) {
+        JST_ERROR("[MODULE_MULTIPLY_CONSTANT_NATIVE_HIP] Unsupported data type '%s'.",
+                  DataTypeName(dt));
+        return Result::ERROR;
+    }
+    return Result::SUCCESS;
+}
+Result MultiplyConstant::define() {
+    JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+    JST_CHECK(defineInterfaceInput("factor"));
+    return defineInterfaceOutput("product");
+}
+Result MultiplyConstant::create() {
+    input = inputs_.at("factor");
+    JST_CHECK(output.create(device(), input.dtype(), input.shape()));
+    JST_CHECK(output.propagateAttributes(input));
+    produced("product", output);
+    return Result::SUCCESS;
+}
+Result MultiplyConstant::computeSubmit(hipStream_t stream) {
+    EwLayout L;
+    if (!MakeEwLayout(output, &input, nullptr, L)) return Result::ERROR;
+    if (input.dtype() == DataType::CF32)
+        return hip_result(kernels::launch_multiply_constant_cf32(
+                              L, ptr<float2>(output), ptr<const float2>(input), constant, stream),
+                          "multiply_constant kernel");
+    return hip_result(kernels::launch_multiply_constant_f32(L, ptr<float>(output),
+                                                            ptr<const float>(input), constant,
+                                                            stream),
+                      "multiply_constant kernel");
+}
+
+// ---- FFT ---------------------------------------------------------------------------------------
+Result Fft::validate() {
+    bool ok1 = true, ok2 = true;
+    forward = ConfigBool(config_, "forward", true, &ok1);
+    complexOutput = ConfigBool(config_, "complexOutput", false, &ok2);
+    if (!ok1 || !ok2) {
+        JST_ERROR("[MODULE_FFT] Invalid boolean configuration value.");
+        return Result::ERROR;
+    }
+    if (!inputs_.count("signal")) return Result::SUCCESS;
+    const Tensor& in = inputs_.at("signal");
+    if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+    SignalAxes axes;
+    if (ResolveSignalAxes(in, axes) != Result::SUCCESS) {
+        JST_ERROR("[MODULE_FFT] Input must contain valid signal axis metadata.");
+        return Result::ERROR;
+    }
+    if (in.dtype() != DataType::CF32) {
+        JST_ERROR("[MODULE_FFT_NATIVE_HIP] Data type '%s' is not implemented on the HIP device "
+                  "(CF32 complex-to-complex only).",
+                  DataTypeName(in.dtype()));
+        return Result::ERROR;
+    }
+    const U64 n = in.shape(*axes.sample);
+    if (!kernels::fft_lds_supported(n)) {
+        JST_ERROR("[MODULE_FFT_NATIVE_HIP] Transform length %llu is not implemented on the HIP "
+                  "device (powers of two up to 16384).",
+                  (unsigned long long)n);
+        return Result::ERROR;
+    }
+    if (in.rank() - 1 > (Index)dev::kMaxOuterRank) {
+        JST_ERROR("[MODULE_FFT] Output shape exceeds the supported layout range.");
+        return Result::ERROR;
+    }
+    resolvedAxis = *axes.sample;
+    return Result::SUCCESS;
+}
+Result Fft::define() {
+    JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+    JST_CHECK(defineInterfaceInput("signal"));
+    return defineInterfaceOutput("signal");
+}
+Result Fft::create() {
+    input = inputs_.at("signal");
+    JST_CHECK(output.create(device(), input.dtype(), input.shape()));
+    JST_CHECK(output.propagateAttributes(input));
+    produced("signal", output);
+    return Result::SUCCESS;
+}
+Result Fft::computeInitialize() { return GetTwiddles(input.shape(resolvedAxis), &twiddles); }
+Result Fft::layout(FftLayout& L) const {
+    std::memset(&L, 0, sizeof(L));
+    L.transforms = 1;
+    int r = 0;
+    for (Index ax = 0; ax < input.rank(); ++ax) {
+        if (ax == resolvedAxis) continue;
+        L.outer_shape[r] = input.shape(ax);
+        L.in_outer_stride[r] = (int64_t)input.stride(ax);
+        L.out_outer_stride[r] = (int64_t)output.stride(ax);
+        L.transforms *= input.shape(ax);
+        ++r;
+    }
+    L.outer_rank = r;
+    L.in_axis_stride = (int64_t)input.stride(resolvedAxis);
+    L.out_axis_stride = (int64_t)output.stride(resolvedAxis);
+    L.in_offset = input.offset();
+    L.out_offset = output.offset();
+    return Result::SUCCESS;
+}
+Result Fft::computeSubmit(hipStream_t stream) {
+    FftLayout L;
+    JST_CHECK(layout(L));
+    return hip_result(kernels::launch_fft_c2c(input.shape(resolvedAxis), forward, L, twiddles,
+                                              ptr<const float2>(input), ptr<float2>(output), stream),
+                      "fft kernel");
+}
+
+// ---- Amplitude ---------------------------------------------------------------------------------
+Result Amplitude::validate() {
+    normalizationSize = 1;
+    if (!inputs_.count("signal")) return Result::SUCCESS;
+    const Tensor& in = inputs_.at("signal");
+    SignalAxes axes;
+    if (MapSignalAxes(in, axes) != Result::SUCCESS) {
+        JST_ERROR("[MODULE_AMPLITUDE] Input must contain valid signal axis metadata.");
+        return Result::ERROR;
+    }
+    if (!axes.sample && !axes.channel) {
+        JST_ERROR("[MODULE_AMPLITUDE] Input must contain sampleAxis or channelAxis metadata.");
+        return Result::ERROR;
+    }
+    if (in.dtype() != DataType::F32 && in.dtype() != DataType::CF32) {
+        JST_ERROR("[MODULE_AMPLITUDE_NATIVE_HIP] Unsupported data type '%s'.",
+                  DataTypeName(in.dtype()));
+        return Result::ERROR;
+    }
+    if (axes.sample) normalizationSize = in.shape(*axes.sample);
+    return Result::SUCCESS;
+}
+Result Amplitude::define() {
+    JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+    JST_CHECK(defineInterfaceInput("signal"));
+    return defineInterfaceOutput("signal");
+}
+Result Amplitude::create() {
+    input = inputs_.at("signal");
+    scalingCoeff = 20.0f * std::log10(1.0f / static_cast<F32>(normalizationSize));
+    JST_CHECK(output.create(device(), DataType::F32, input.shape()));
+    JST_CHECK(output.propagateAttributes(input));
+    produced("signal", output);
+    return Result::SUCCESS;
+}
+Result Amplitude::computeSubmit(hipStream_t stream) {
+    EwLayout L;
+    if (!MakeEwLayout(output, &input, nullptr, L)) return Result::ERROR;
+    if (input.dtype() == DataType::CF32)
+        return hip_result(kernels::launch_amplitude_cf32(L, ptr<float>(output),
+                                                         ptr<const float2>(input), scalingCoeff,
+                                                         stream),
+                          "amplitude kernel");
+    return hip_result(kernels::launch_amplitude_f32(L, ptr<float>(output), ptr<const float>(input),
+                                                    scalingCoeff, stream),
+                      "amplitude kernel");
+}
+
+// ---- Range -------------------------------------------------------------------------------------
+Result Range::validate() {
+    bool ok1 = true, ok2 = true;
+    min = (F32)ConfigF64(config_, "min", -1.0, &ok1);
+    max = (F32)ConfigF64(config_, "max", 1.0, &ok2);
+    if (!ok1 || !ok2) {
+        JST_ERROR("[MODULE_RANGE] Invalid min/max.");
+        return Result::ERROR;
+    }
+    if (inputs_.count("signal") && inputs_.at("signal").dtype() != DataType::F32) {
+        JST_ERROR("[MODULE_RANGE_NATIVE_HIP] Unsupported data type '%s'.",
+                  DataTypeName(inputs_.at("signal").dtype()));
+        return Result::ERROR;
+    }
+    return Result::SUCCESS;
+}
+Result Range::define() {
+    JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+    JST_CHECK(defineInterfaceOutput("signal"));
+    return defineInterfaceInput("signal");
+}
+Result Range::create() {
+    input = inputs_.at("signal");
+    const F32 lower = std::min(min, max), upper = std::max(min, max);  // range/module_impl.cc:51-62
+    if (lower == upper) {
+        scalingCoeff = 0.0f;
+        offsetCoeff = 0.5f;
+    } else {
+        scalingCoeff = 1.0f / (upper - lower);
+        offsetCoeff = -lower * scalingCoeff;
+    }
+    JST_CHECK(output.create(device(), input.dtype(), input.shape()));
+    JST_CHECK(output.propagateAttributes(input));
+    produced("signal", output);
+    return Result::SUCCESS;
+}
+Result Range::computeSubmit(hipStream_t stream) {
+    EwLayout L;
+    if (!MakeEwLayout(output, &input, nullptr, L)) return Result::ERROR;
+    return hip_result(kernels::launch_range_f32(L, ptr<float>(output), ptr<const float>(input),
+                                                scalingCoeff, offsetCoeff, stream),
+                      "range kernel");
+}
+
+// ---- Spectrogram / Waterfall -------------------------------------------------------------------
+namespace {
+Result validate_surface_input(const char* tag, const Config& cfg, U64 default_height,
+                              const std::map<std::string, Tensor>& inputs, U64& height, U64& width,
+                              U64& batches, U64& estride, U64& bstride) {
+    bool ok = true;
+    height = ConfigU64(cfg, "height", default_height, &ok);
+    if (!ok || height == 0 || height > 2048) {
+        JST_ERROR("[%s] Invalid height value '%s', must be between 1 and 2048.", tag,
+                  ConfigStr(cfg, "height", "?").c_str());
+        return Result::ERROR;
+    }
+    width = batches = estride = bstride = 0;
+    if (!inputs.count("signal")) return Result::SUCCESS;
+    const Tensor& in = inputs.at("signal");
+    if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+    SignalAxes axes;
+    if (MapSignalAxes(in, axes) != Result::SUCCESS) {
+        JST_ERROR("[%s] Input must contain valid signal axis metadata.", tag);
+        return Result::ERROR;
+    }
+    if (axes.sample && axes.channel) {
+        JST_ERROR("[%s] Input cannot contain both sampleAxis and channelAxis.", tag);
+        return Result::ERROR;
+    }
+    const auto element = axes.sample ? axes.sample : axes.channel;
+    if (!element) {
+        JST_ERROR("[%s] Input must contain sampleAxis or channelAxis.", tag);
+        return Result::ERROR;
+    }
+    for (Index ax = 0; ax < in.rank(); ++ax) {
+        if (ax != *element && (!axes.batch || ax != *axes.batch)) {
+            JST_ERROR("[%s] Unsupported auxiliary input axis %llu. Every dimension must be the "
+                      "element axis or batchAxis.",
+                      tag, (unsigned long long)ax);
+            return Result::ERROR;
+        }
+    }
+    if (in.dtype() != DataType::F32) {
+        JST_ERROR("[%s] Input must be F32.", tag);
+        return Result::ERROR;
+    }
+    width = in.shape(*element);
+    if (width > 0xffffffffull / height) {
+        JST_ERROR("[%s] Render bin count exceeds the supported range.", tag);
+        return Result::ERROR;
+    }
+    batches = axes.batch ? in.shape(*axes.batch) : 1;
+    estride = in.stride(*element);
+    bstride = axes.batch ? in.stride(*axes.batch) : 0;
+    return Result::SUCCESS;
+}
+}  // namespace
+
+Result Spectrogram::validate() {
+    return validate_surface_input("MODULE_SPECTROGRAM", config_, 256, inputs_, height,
+                                  numberOfElements, numberOfBatches, inputElementStride,
+                                  inputBatchStride);
+}
+Result Spectrogram::define() {
+    JST_CHECK(defineTaint(SURFACE));
+    return defineInterfaceInput("signal");
+}
+Result Spectrogram::create() {
+    input = inputs_.at("signal");
+    decayFactor = std::pow(0.999f, static_cast<F32>(numberOfBatches));  // module_impl.cc:104
+    JST_CHECK(frequencyBins.create(device(), DataType::F32, {numberOfElements, height}));
+    return Result::SUCCESS;
+}
+Result Spectrogram::computeSubmit(hipStream_t stream) {
+    return hip_result(
+        kernels::launch_spectrogram(ptr<float>(frequencyBins), ptr<const float>(input),
+                                    input.offset(), numberOfBatches, numberOfElements, height,
+                                    (int64_t)inputBatchStride, (int64_t)inputElementStride,
+                                    decayFactor, stream),
+        "spectrogram kernel");
+}
+
+Result Waterfall::validate() {
+    return validate_surface_input("MODULE_WATERFALL", config_, 512, inputs_, height,
+                                  numberOfElements, numberOfBatches, inputElementStride,
+                                  inputBatchStride);
+}
+Result Waterfall::define() {
+    JST_CHECK(defineTaint(SURFACE));
+    return defineInterfaceInput("signal");
+}
+Result Waterfall::create() {
+    input = inputs_.at("signal");
+    JST_CHECK(frequencyBins.create(device(), DataType::F32, {height, numberOfElements}));
+    JST_CHECK(ringState.create(device(), DataType::U64, {4}));  // zeroed: ringState = {}
+    return Result::SUCCESS;
+}
+Result Waterfall::computeSubmit(hipStream_t stream) {
+    return hip_result(
+        kernels::launch_waterfall(ptr<float>(frequencyBins), ptr<uint64_t>(ringState),
+                                  ptr<const float>(input), input.offset(), numberOfBatches,
+                                  numberOfElements, height, (int64_t)inputBatchStride,
+                                  (int64_t)inputElementStride, stream),
+        "waterfall kernel");
+}
+
+// ---- RingSource --------------------------------------------------------------------------------
+Result RingSource::validate() {
+    bool o1 = true, o2 = true, o3 = true;
+    batches = ConfigU64(config_, "batches", 8, &o1);
+    samples = ConfigU64(config_, "samples", 2048, &o2);
+    slots = ConfigU64(config_, "slots", 1, &o3);
+    if (!o1 || !o2 || !o3 || batches == 0 || samples == 0 || slots == 0) {
+        JST_ERROR("[MODULE_RING_SOURCE] batches, samples and slots must be positive integers.");
+        return Result::ERROR;
+    }
+    return Result::SUCCESS;
+}
+Result RingSource::define() { return defineInterfaceOutput("buffer"); }
+Result RingSource::create() {
+    JST_CHECK(output.createRing(device(), DataType::CF32, {batches, samples}, slots));
+    JST_CHECK(SetSignalAxes(output, {.sample = Index{1}, .batch = Index{0}}));
+    output.setAttribute("sampleRate", AttrValue{ConfigF64(config_, "sampleRate", 2.0e6)});
+    output.setAttribute("frequency", AttrValue{ConfigF64(config_, "frequency", 96.9e6)});
+    cursor = 0;
+    first = true;
+    produced("buffer", output);
+    return Result::SUCCESS;
+}
+Result RingSource::computeSubmit(hipStream_t) {
+    // First cycle exposes slot 0, then round-robin; no data moves.
+    if (first) first = false;
+    else cursor = (cursor + 1) % slots;
+    return output.ringSelect(cursor);
+}
+
+// ---- fusion ------------------------------------------------------------------------------------
+bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string& name,
+                     std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
+                     size_t& consumed) {
+    if (at + 2 >= ordered.size()) return false;
+    auto* mul = dynamic_cast<Multiply*>(ordered[at]);
+    auto* fft = dynamic_cast<Fft*>(ordered[at + 1]);
+    auto* amp = dynamic_cast<Amplitude*>(ordered[at + 2]);
+    if (!mul || !fft || !amp) return false;
+    Range* rng = at + 3 < ordered.size() ? dynamic_cast<Range*>(ordered[at + 3]) : nullptr;
+
+    // dataflow: mul.c -> fft.input, fft.output -> amp.input [, amp.output -> rng.input]
+    if (fft->input.storageId() != mul->c.storageId() ||
+        amp->input.storageId() != fft->output.storageId())
+        return false;
+    if (rng && rng->input.storageId() != amp->output.storageId()) rng = nullptr;
+    if (mul->c.dtype() != DataType::CF32 || !fft->forward) return false;
+    // intermediates must be plain dense tensors nobody else reads
+    auto sole_consumer = [&](const Tensor& t, const Module* consumer) {
+        for (const Module* m : ordered) {
+            if (m == consumer) continue;
+            for (const auto& kv : m->inputs())
+                if (kv.second.storageId() == t.storageId()) return false;
+        }
+        return true;
+    };
+    if (!sole_consumer(mul->c, fft) || !sole_consumer(fft->output, amp)) return false;
+    if (rng && !sole_consumer(amp->output, rng)) rng = nullptr;
+
+    // geometry: transform along the LAST axis of dense tensors; window broadcast over all outer
+    // axes (stride 0) and equal to the signal only along the transform axis.
+    const Tensor& sig = mul->a;
+    const Tensor& win = mul->b;
+    const Index axis = fft->resolvedAxis;
+    const U64 n = sig.shape(axis);
+    if (!kernels::fft_fused_supported(n)) return false;
+    if (!fft->input.contiguous() || !fft->output.contiguous() || !amp->output.contiguous())
+        return false;
+    for (Index ax = 0; ax < win.rank(); ++ax)
+        if (ax != axis && win.stride(ax) != 0) return false;
+    if (amp->normalizationSize != n) return false;
+    if (sig.rank() - 1 > (Index)dev::kMaxOuterRank) return false;
+
+    Tensor final_out = rng ? rng->output : amp->output;
+    if (!final_out.contiguous()) return false;
+
+    members = {mul, fft, amp};
+    if (rng) members.push_back(rng);
+    consumed = members.size();
+    name = "spectrum_fused(" + mul->name() + "+" + fft->name() + "+" + amp->name() +
+           (rng ? "+" + rng->name() : "") + ")";
+
+    submit = [mul, fft, amp, rng, axis, n](hipStream_t stream) -> Result {
+        const Tensor& sig = mul->a;
+        const Tensor& win = mul->b;
+        const Tensor& out = rng ? rng->output : amp->output;
+        FftLayout L;
+        std::memset(&L, 0, sizeof(L));
+        L.transforms = 1;
+        int r = 0;
+        for (Index ax = 0; ax < sig.rank(); ++ax) {
+            if (ax == axis) continue;
+            L.outer_shape[r] = sig.shape(ax);
+            L.in_outer_stride[r] = (int64_t)sig.stride(ax);
+            L.out_outer_stride[r] = (int64_t)out.stride(ax);
+            L.transforms *= sig.shape(ax);
+            ++r;
+        }
+        L.outer_rank = r;
+        L.in_axis_stride = (int64_t)sig.stride(axis);
+        L.out_axis_stride = (int64_t)out.stride(axis);
+        L.in_offset = sig.offset();
+        L.out_offset = out.offset();
+        return hip_result(
+            kernels::launch_spectrum_fused(
+                n, L, fft->twiddles, static_cast<const float2*>(sig.data()),
+                static_cast<const float2*>(win.data()) + win.offset(), (int64_t)win.stride(axis),
+                static_cast<float*>(out.data()), amp->scalingCoeff, rng != nullptr,
+                rng ? rng->scalingCoeff : 0.0f, rng ? rng->offsetCoeff : 0.0f, stream),
+            "fused spectrum kernel");
+    };
+    return true;
+}
+
+// ---- registration ------------------------------------------------------------------------------
+JST_REGISTER_MODULE(Window, "window", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Invert, "invert", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Reshape, "reshape", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Cast, "cast", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Multiply, "multiply", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(MultiplyConstant, "multiply_constant", DeviceType::HIP, RuntimeType::NATIVE,
+                    "generic");
+JST_REGISTER_MODULE(Fft, "fft", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Amplitude, "amplitude", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Range, "range", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Spectrogram, "spectrogram", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Waterfall, "waterfall", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(RingSource, "ring_source", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+
+}  // namespace jst::modules

@@ -1,0 +1,190 @@
+// modules.hh -- the Jetstream DSP/visualization modules of the hot path, registered for
+// (DeviceType::HIP, RuntimeType::NATIVE, "generic").  One class per reference module; each header
+// comment names the reference files it stands in for.  Port names, config keys, validation rules
+// and error texts follow the reference so a flowgraph node only has to switch `device:`.
+#pragma once
+
+#include "../jst/module.hh"
+#include "../kernels/kernels.hh"
+
+namespace jst::modules {
+
+// Device-resident pocketfft twiddle table W[k] = exp(+j 2 pi k / n), k in [0,n), cached per n.
+Result GetTwiddles(U64 n, const float2** table);
+// Host generator (exposed for tests through the C ABI): pocketfft sincos_2pibyn<float> scheme.
+void ComputeTwiddles(U64 n, float* interleaved);
+
+bool MakeEwLayout(const Tensor& out, const Tensor* a, const Tensor* b, dev::EwLayout& L);
+
+// Scheduler hook: recognise multiply -> fft -> amplitude [-> range] starting at ordered[at].
+bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string& name,
+                     std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
+                     size_t& consumed);
+
+// src/domains/dsp/window/{module_impl.cc, module_impl_native_cpu.cc, module_impl_native_cuda.cc}
+class Window : public Module {
+ public:
+    const char* type() const override { return "window"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t stream) override;
+    Tensor output;
+    U64 size = 1024;
+};
+
+// src/domains/dsp/invert/{module_impl.cc, module_impl_native_cpu.cc:79-103}
+class Invert : public Module {
+ public:
+    const char* type() const override { return "invert"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t stream) override;
+    Tensor input, output;
+    Index resolvedAxis = 0;
+    U64 axisInnerSize = 1, axisLength = 1;
+};
+
+// src/domains/core/reshape/{module_impl.cc, module_impl_native_cpu.cc:17-19} -- view only
+class Reshape : public Module {
+ public:
+    const char* type() const override { return "reshape"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t) override { return Result::SUCCESS; }
+    Shape target;
+};
+
+// src/domains/core/cast -- same-dtype passthrough only (cast/module_impl.cc:99)
+class Cast : public Module {
+ public:
+    const char* type() const override { return "cast"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t) override { return Result::SUCCESS; }
+};
+
+// src/domains/core/multiply/{module_impl.cc:10-132, module_impl_native_cpu.cc:86-100}
+class Multiply : public Module {
+ public:
+    const char* type() const override { return "multiply"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t stream) override;
+    Tensor a, b, c;  // a, b are the validated broadcast views
+    Shape outputShape;
+};
+
+// src/domains/core/multiply_constant/{module_impl.cc, module_impl_native_cpu.cc:92-100}
+class MultiplyConstant : public Module {
+ public:
+    const char* type() const override { return "multiply_constant"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t stream) override;
+    Tensor input, output;
+    F32 constant = 1.0f;
+};
+
+// src/domains/dsp/fft/{module_impl.cc:8-86, module_impl_native_cpu.cc:90-167,
+// module_impl_native_cuda.cc:307-519}
+class Fft : public Module {
+ public:
+    const char* type() const override { return "fft"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeInitialize() override;
+    Result computeSubmit(hipStream_t stream) override;
+    Result layout(dev::FftLayout& L) const;
+    Tensor input, output;
+    bool forward = true, complexOutput = false;
+    Index resolvedAxis = 0;
+    const float2* twiddles = nullptr;
+};
+
+// src/domains/dsp/amplitude/{module_impl.cc:8-60, module_impl_native_cpu.cc:73-99}
+class Amplitude : public Module {
+ public:
+    const char* type() const override { return "amplitude"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t stream) override;
+    Tensor input, output;
+    U64 normalizationSize = 1;
+    F32 scalingCoeff = 0.0f;
+};
+
+// src/domains/core/range/{module_impl.cc:16-62, module_impl_native_cpu.cc:67-82}
+class Range : public Module {
+ public:
+    const char* type() const override { return "range"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t stream) override;
+    Tensor input, output;
+    F32 min = -1.0f, max = 1.0f, scalingCoeff = 0.0f, offsetCoeff = 0.5f;
+};
+
+// src/domains/visualization/spectrogram/{module_impl.cc:16-114, module_impl_native_cpu.cc:61-87}
+// (the reference has no GPU implementation of this module)
+class Spectrogram : public Module {
+ public:
+    const char* type() const override { return "spectrogram"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t stream) override;
+    const Tensor* state(const std::string& key) const override {
+        return key == "frequencyBins" ? &frequencyBins : nullptr;
+    }
+    Tensor input, frequencyBins;  // state: F32 {width, height}, laid out [height][width]
+    U64 height = 256, numberOfElements = 0, numberOfBatches = 0;
+    U64 inputElementStride = 0, inputBatchStride = 0;
+    F32 decayFactor = 1.0f;
+};
+
+// src/domains/visualization/waterfall/{module_impl.cc, ring_state.hh:16-56,
+// module_impl_native_cpu.cc:53-78, module_impl_native_cuda.cc:18-149}
+class Waterfall : public Module {
+ public:
+    const char* type() const override { return "waterfall"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t stream) override;
+    const Tensor* state(const std::string& key) const override {
+        if (key == "frequencyBins") return &frequencyBins;
+        if (key == "ringState") return &ringState;
+        return nullptr;
+    }
+    Tensor input, frequencyBins, ringState;  // ringState: device U64[4]
+    U64 height = 512, numberOfElements = 0, numberOfBatches = 0;
+    U64 inputElementStride = 0, inputBatchStride = 0;
+};
+
+// Synthetic stand-in for the Soapy source's OUTPUT CONTRACT (src/domains/io/soapy/
+// module_impl.cc:197-201): CF32 [batches, samples], batchAxis 0, sampleAxis 1, attributes
+// sampleRate / frequency -- backed by an HBM-resident ring of `slots` batches.  Each compute
+// cycle exposes the next slot (no copy: downstream kernels read the slot in place).
+class RingSource : public Module {
+ public:
+    const char* type() const override { return "ring_source"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t stream) override;
+    U64 cyclePeriod() const override { return slots; }
+    Tensor output;
+    U64 batches = 8, samples = 2048, slots = 1, cursor = 0;
+    bool first = true;
+};
+
+}  // namespace jst::modules

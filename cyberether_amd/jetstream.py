@@ -1,0 +1,459 @@
+"""Python host mirror of the Jetstream module interface over the C ABI (include/jetstream_hip.h).
+
+Names follow the reference: ``Tensor`` (include/jetstream/memory/tensor.hh), ``Module`` built
+through the registry with ``(type, device, runtime, provider)`` (include/jetstream/registry.hh:
+119-125), ``Runtime`` (include/jetstream/runtime.hh:22-40) and the ``SpectrumEngine`` block
+wiring (src/domains/dsp/spectrum_engine/block_impl.cc:120-217).  Every call goes through
+``libjetstream_hip.so``; nothing is computed in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libjetstream_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the HIP extension has not been built "
+        "(run `make -C cyberether_amd/csrc`). There is no CPU fallback."
+    )
+
+_lib = C.CDLL(LIB_PATH)
+
+MAX_RANK = 8
+DEVICE = {"none": 1, "cpu": 2, "hip": 64}
+DEVICE_NAME = {v: k for k, v in DEVICE.items()}
+DTYPE = {"F32": 1, "CF32": 2, "F64": 3, "U64": 4}
+NP_DTYPE = {1: np.float32, 2: np.complex64, 3: np.float64, 4: np.uint64}
+DTYPE_OF_NP = {np.dtype(np.float32): 1, np.dtype(np.complex64): 2, np.dtype(np.float64): 3,
+               np.dtype(np.uint64): 4}
+RESULT_NAMES = ["SUCCESS", "ERROR", "WARNING", "FATAL", "SKIP", "YIELD", "RELOAD", "RECREATE",
+                "TIMEOUT", "INCOMPLETE"]
+
+RUNTIME_GRAPH, RUNTIME_FUSE, RUNTIME_TIMING = 1, 2, 4
+
+TAINT = {"IN_PLACE": 1, "DISCONTIGUOUS": 2, "SURFACE": 4, "CROSS_DEVICE": 16,
+         "STATIC_OUTPUT": 64, "STATELESS": 128}
+
+
+class JetstreamError(RuntimeError):
+    """A non-SUCCESS Result crossed the ABI; .result is the reference Result name."""
+
+    def __init__(self, result: int, message: str):
+        self.result = RESULT_NAMES[result] if result < len(RESULT_NAMES) else str(result)
+        super().__init__(f"{self.result}: {message}")
+
+
+class _Desc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("offset", C.c_uint64), ("dtype", C.c_uint8),
+                ("device", C.c_uint8), ("rank", C.c_uint32), ("shape", C.c_uint64 * MAX_RANK),
+                ("stride", C.c_uint64 * MAX_RANK), ("sample_axis", C.c_int64),
+                ("batch_axis", C.c_int64), ("channel_axis", C.c_int64)]
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(_lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_u64p = C.POINTER(C.c_uint64)
+_h = C.c_void_p
+_hp = C.POINTER(C.c_void_p)
+_strs = C.POINTER(C.c_char_p)
+R = C.c_uint16
+
+_sig("jst_version", C.c_char_p)
+_sig("jst_last_error", C.c_char_p)
+_sig("jst_device_count", C.c_int)
+_sig("jst_device_set", R, C.c_int)
+_sig("jst_registry_list", C.c_size_t, C.c_char_p, C.c_size_t)
+_sig("jst_tensor_create", R, C.c_uint8, C.c_uint8, C.c_uint32, _u64p, _hp)
+_sig("jst_tensor_create_ring", R, C.c_uint8, C.c_uint8, C.c_uint32, _u64p, C.c_uint64, _hp)
+_sig("jst_tensor_wrap", R, C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint8, C.c_uint32, _u64p, _u64p,
+     C.c_uint64, _hp)
+_sig("jst_tensor_clone", R, _h, _hp)
+_sig("jst_tensor_destroy", R, _h)
+_sig("jst_tensor_describe", R, _h, C.POINTER(_Desc))
+_sig("jst_tensor_ring_select", R, _h, C.c_uint64)
+_sig("jst_tensor_reshape", R, _h, C.c_uint32, _u64p)
+_sig("jst_tensor_expand_dims", R, _h, C.c_uint64)
+_sig("jst_tensor_squeeze_dims", R, _h, C.c_uint64)
+_sig("jst_tensor_slice", R, _h, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64)
+_sig("jst_tensor_permute", R, _h, C.c_uint32, _u64p)
+_sig("jst_tensor_broadcast_to", R, _h, C.c_uint32, _u64p)
+_sig("jst_tensor_set_attribute_u64", R, _h, C.c_char_p, C.c_uint64)
+_sig("jst_tensor_set_attribute_f64", R, _h, C.c_char_p, C.c_double)
+_sig("jst_tensor_remove_attribute", R, _h, C.c_char_p)
+_sig("jst_tensor_copy_from_host", R, _h, C.c_void_p, C.c_size_t)
+_sig("jst_tensor_copy_to_host", R, _h, C.c_void_p, C.c_size_t)
+_sig("jst_tensor_copy_from_host_async", R, _h, C.c_void_p, C.c_size_t)
+_sig("jst_module_create", R, C.c_char_p, C.c_uint8, C.c_char_p, C.c_char_p, _strs, C.c_uint32,
+     _strs, _hp, C.c_uint32, _hp)
+_sig("jst_module_destroy", R, _h)
+_sig("jst_module_output", R, _h, C.c_char_p, _hp)
+_sig("jst_module_state", R, _h, C.c_char_p, _hp)
+_sig("jst_module_taint", C.c_uint64, _h)
+_sig("jst_module_timing", R, _h, _u64p, C.POINTER(C.c_double))
+_sig("jst_module_compute_initialize", R, _h)
+_sig("jst_module_compute_submit", R, _h, C.c_void_p)
+_sig("jst_module_compute_deinitialize", R, _h)
+_sig("jst_runtime_create", R, _hp, C.c_uint32, C.c_uint32, _hp)
+_sig("jst_runtime_destroy", R, _h)
+_sig("jst_runtime_compute", R, _h, C.c_uint64, C.c_int)
+_sig("jst_runtime_synchronize", R, _h)
+_sig("jst_runtime_stream", C.c_void_p, _h)
+_sig("jst_runtime_period", C.c_uint64, _h)
+_sig("jst_runtime_graph_active", C.c_int, _h)
+_sig("jst_runtime_order", C.c_size_t, _h, C.c_char_p, C.c_size_t)
+_sig("jst_runtime_units", C.c_size_t, _h, C.c_char_p, C.c_size_t)
+_sig("jst_runtime_unit_mean_ms", C.c_double, _h, C.c_char_p)
+_sig("jst_runtime_reset_timing", R, _h)
+_sig("jst_fft_twiddles", R, C.c_uint64, C.POINTER(C.c_float))
+_sig("jst_probe_tanhf", R, C.c_void_p, C.c_void_p, C.c_uint64)
+
+
+def _check(result: int) -> None:
+    if result not in (0, 6):  # SUCCESS | RELOAD
+        raise JetstreamError(result, _lib.jst_last_error().decode(errors="replace"))
+
+
+def _arr(values: Sequence[int]):
+    return (C.c_uint64 * max(len(values), 1))(*[int(v) for v in values])
+
+
+def version() -> str:
+    return _lib.jst_version().decode()
+
+
+def device_count() -> int:
+    return int(_lib.jst_device_count())
+
+
+def set_device(ordinal: int) -> None:
+    _check(_lib.jst_device_set(ordinal))
+
+
+def list_available_modules() -> List[str]:
+    buf = C.create_string_buffer(1 << 16)
+    _lib.jst_registry_list(buf, len(buf))
+    return [l for l in buf.value.decode().split("\n") if l]
+
+
+def fft_twiddles(n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.complex64)
+    _check(_lib.jst_fft_twiddles(n, out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+class Tensor:
+    """Handle to a Jetstream tensor (shape/stride/offset in elements, shared storage)."""
+
+    def __init__(self, handle: int):
+        self._h = C.c_void_p(handle)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.jst_tensor_destroy(h)
+
+    # -- construction ---------------------------------------------------------------------
+    @staticmethod
+    def create(device: str, dtype: str, shape: Sequence[int], slots: int = 1) -> "Tensor":
+        out = C.c_void_p()
+        _check(_lib.jst_tensor_create_ring(DEVICE[device], DTYPE[dtype], len(shape), _arr(shape),
+                                           slots, C.byref(out)))
+        return Tensor(out.value)
+
+    @staticmethod
+    def from_numpy(array: np.ndarray, device: str = "hip", **axes) -> "Tensor":
+        array = np.ascontiguousarray(array)
+        t = Tensor.create(device, {v: k for k, v in DTYPE.items()}[DTYPE_OF_NP[array.dtype]],
+                          array.shape)
+        t.copy_from(array)
+        if axes:
+            t.set_axes(**axes)
+        return t
+
+    @staticmethod
+    def wrap(ptr: int, nbytes: int, device: str, dtype: str, shape: Sequence[int],
+             stride: Optional[Sequence[int]] = None, offset: int = 0) -> "Tensor":
+        """Borrow external memory (e.g. ``torch_tensor.data_ptr()``); the caller keeps it alive."""
+        out = C.c_void_p()
+        _check(_lib.jst_tensor_wrap(C.c_void_p(ptr), nbytes, DEVICE[device], DTYPE[dtype],
+                                    len(shape), _arr(shape), _arr(stride) if stride else None,
+                                    offset, C.byref(out)))
+        return Tensor(out.value)
+
+    def clone(self) -> "Tensor":
+        out = C.c_void_p()
+        _check(_lib.jst_tensor_clone(self._h, C.byref(out)))
+        return Tensor(out.value)
+
+    # -- introspection --------------------------------------------------------------------
+    def _desc(self) -> _Desc:
+        d = _Desc()
+        _check(_lib.jst_tensor_describe(self._h, C.byref(d)))
+        return d
+
+    @property
+    def shape(self):
+        d = self._desc()
+        return tuple(int(d.shape[i]) for i in range(d.rank))
+
+    @property
+    def stride(self):
+        d = self._desc()
+        return tuple(int(d.stride[i]) for i in range(d.rank))
+
+    @property
+    def offset(self) -> int:
+        return int(self._desc().offset)
+
+    @property
+    def dtype(self) -> str:
+        return {v: k for k, v in DTYPE.items()}[self._desc().dtype]
+
+    @property
+    def device(self) -> str:
+        return DEVICE_NAME[self._desc().device]
+
+    @property
+    def data_ptr(self) -> int:
+        return int(self._desc().data or 0)
+
+    @property
+    def axes(self) -> Dict[str, Optional[int]]:
+        d = self._desc()
+        f = lambda v: None if v < 0 else int(v)
+        return {"sample": f(d.sample_axis), "batch": f(d.batch_axis), "channel": f(d.channel_axis)}
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape, dtype=np.uint64)) if self.shape else 0
+
+    # -- views (mutating, like the reference) -----------------------------------------------
+    def reshape(self, shape):
+        _check(_lib.jst_tensor_reshape(self._h, len(shape), _arr(shape)))
+        return self
+
+    def expand_dims(self, axis):
+        _check(_lib.jst_tensor_expand_dims(self._h, axis))
+        return self
+
+    def squeeze_dims(self, axis):
+        _check(_lib.jst_tensor_squeeze_dims(self._h, axis))
+        return self
+
+    def slice(self, axis, begin, end, step=1):
+        _check(_lib.jst_tensor_slice(self._h, axis, begin, end, step))
+        return self
+
+    def permute(self, axes):
+        _check(_lib.jst_tensor_permute(self._h, len(axes), _arr(axes)))
+        return self
+
+    def broadcast_to(self, shape):
+        _check(_lib.jst_tensor_broadcast_to(self._h, len(shape), _arr(shape)))
+        return self
+
+    def ring_select(self, slot: int):
+        _check(_lib.jst_tensor_ring_select(self._h, slot))
+        return self
+
+    # -- attributes -----------------------------------------------------------------------
+    def set_axes(self, sample=None, batch=None, channel=None):
+        for key, v in (("sampleAxis", sample), ("batchAxis", batch), ("channelAxis", channel)):
+            if v is None:
+                _check(_lib.jst_tensor_remove_attribute(self._h, key.encode()))
+            else:
+                _check(_lib.jst_tensor_set_attribute_u64(self._h, key.encode(), int(v)))
+        return self
+
+    def set_attribute(self, key: str, value):
+        if isinstance(value, (int, np.integer)):
+            _check(_lib.jst_tensor_set_attribute_u64(self._h, key.encode(), int(value)))
+        else:
+            _check(_lib.jst_tensor_set_attribute_f64(self._h, key.encode(), float(value)))
+        return self
+
+    # -- data movement (dense only) -------------------------------------------------------------
+    def copy_from(self, array: np.ndarray, asynchronous: bool = False):
+        array = np.ascontiguousarray(array, dtype=NP_DTYPE[self._desc().dtype])
+        fn = _lib.jst_tensor_copy_from_host_async if asynchronous else _lib.jst_tensor_copy_from_host
+        _check(fn(self._h, array.ctypes.data_as(C.c_void_p), array.nbytes))
+        return self
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=NP_DTYPE[self._desc().dtype])
+        _check(_lib.jst_tensor_copy_to_host(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+
+class Module:
+    """Registry::BuildModule + Module::create in one step (src/module.cc:47-212)."""
+
+    def __init__(self, type: str, config: Optional[dict] = None,
+                 inputs: Optional[Dict[str, Tensor]] = None, name: Optional[str] = None,
+                 device: str = "hip", provider: str = "generic"):
+        self.type = type
+        self.name = name or type
+        self._inputs = dict(inputs or {})  # keep the tensor handles alive
+        cfg = [f"{k}={_cfg_value(v)}".encode() for k, v in (config or {}).items()]
+        ports = [k.encode() for k in self._inputs]
+        handles = [t._h for t in self._inputs.values()]
+        out = C.c_void_p()
+        cfg_arr = (C.c_char_p * max(len(cfg), 1))(*cfg)
+        port_arr = (C.c_char_p * max(len(ports), 1))(*ports)
+        h_arr = (C.c_void_p * max(len(handles), 1))(*handles)
+        self._h = None
+        _check(_lib.jst_module_create(type.encode(), DEVICE[device], provider.encode(),
+                                      self.name.encode(), cfg_arr, len(cfg), port_arr, h_arr,
+                                      len(ports), C.byref(out)))
+        self._h = C.c_void_p(out.value)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.jst_module_destroy(h)
+
+    def output(self, port: str) -> Tensor:
+        out = C.c_void_p()
+        _check(_lib.jst_module_output(self._h, port.encode(), C.byref(out)))
+        return Tensor(out.value)
+
+    def state(self, key: str) -> Tensor:
+        out = C.c_void_p()
+        _check(_lib.jst_module_state(self._h, key.encode(), C.byref(out)))
+        return Tensor(out.value)
+
+    @property
+    def taint(self) -> int:
+        return int(_lib.jst_module_taint(self._h))
+
+    @property
+    def timing(self):
+        cycles, ms = C.c_uint64(), C.c_double()
+        _check(_lib.jst_module_timing(self._h, C.byref(cycles), C.byref(ms)))
+        return {"cycles": cycles.value, "computeTime": ms.value}
+
+
+def _cfg_value(v) -> str:
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, float):
+        return repr(v)
+    if isinstance(v, (list, tuple)):
+        return "[" + ", ".join(str(int(x)) for x in v) + "]"
+    return str(v)
+
+
+class Runtime:
+    """One device segment: ordered modules on one HIP stream, optionally as a hipGraph."""
+
+    def __init__(self, modules: Iterable[Module], graph: bool = False, fuse: bool = False,
+                 timing: bool = False):
+        self.modules = list(modules)
+        flags = (RUNTIME_GRAPH if graph else 0) | (RUNTIME_FUSE if fuse else 0) | \
+                (RUNTIME_TIMING if timing else 0)
+        arr = (C.c_void_p * max(len(self.modules), 1))(*[m._h for m in self.modules])
+        out = C.c_void_p()
+        self._h = None
+        _check(_lib.jst_runtime_create(arr, len(self.modules), flags, C.byref(out)))
+        self._h = C.c_void_p(out.value)
+
+    def __del__(self):
+        self.destroy()
+
+    def destroy(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.jst_runtime_destroy(h)
+
+    def compute(self, cycles: int = 1, sync: bool = True):
+        _check(_lib.jst_runtime_compute(self._h, cycles, 1 if sync else 0))
+
+    def synchronize(self):
+        _check(_lib.jst_runtime_synchronize(self._h))
+
+    @property
+    def stream(self) -> int:
+        return int(_lib.jst_runtime_stream(self._h) or 0)
+
+    @property
+    def period(self) -> int:
+        return int(_lib.jst_runtime_period(self._h))
+
+    @property
+    def graph_active(self) -> bool:
+        return bool(_lib.jst_runtime_graph_active(self._h))
+
+    def _lines(self, fn) -> List[str]:
+        buf = C.create_string_buffer(1 << 14)
+        fn(self._h, buf, len(buf))
+        return [l for l in buf.value.decode().split("\n") if l]
+
+    @property
+    def order(self) -> List[str]:
+        return self._lines(_lib.jst_runtime_order)
+
+    @property
+    def units(self) -> List[str]:
+        return self._lines(_lib.jst_runtime_units)
+
+    def unit_mean_ms(self, prefix: str) -> float:
+        return float(_lib.jst_runtime_unit_mean_ms(self._h, prefix.encode()))
+
+    def reset_timing(self):
+        _check(_lib.jst_runtime_reset_timing(self._h))
+
+
+class SpectrumEngine:
+    """The spectrum_engine BLOCK: cast -> window -> invert -> reshape -> multiply -> fft ->
+    amplitude -> [range], wired exactly as src/domains/dsp/spectrum_engine/block_impl.cc:120-217
+    (AGC branch omitted: enableAgc defaults to false, spectrum_engine/block.hh:9)."""
+
+    def __init__(self, buffer: Tensor, enable_scale: bool = True, range_min: float = -100.0,
+                 range_max: float = 0.0, name: str = "spectrum"):
+        axes = buffer.axes
+        rank = len(buffer.shape)
+        axis = axes["sample"] if axes["sample"] is not None else (0 if rank == 1 else None)
+        if axis is None:
+            raise JetstreamError(1, "[BLOCK_SPECTRUM_ENGINE] Input validation plan is unavailable.")
+        n = buffer.shape[axis]
+        p = name + "."
+        self.cast = Module("cast", {"outputType": "CF32"}, {"buffer": buffer}, p + "cast_input")
+        complex_input = self.cast.output("buffer")
+        self.window = Module("window", {"size": n}, {}, p + "window")
+        window_out = self.window.output("window").set_axes(sample=0)
+        self.invert = Module("invert", {}, {"signal": window_out}, p + "invert")
+        shape = [n if d == axis else 1 for d in range(rank)]
+        self.reshape = Module("reshape", {"shape": shape},
+                              {"buffer": self.invert.output("signal")}, p + "reshape_window")
+        reshaped = self.reshape.output("buffer").set_axes(sample=axis)
+        self.multiply = Module("multiply", {}, {"a": complex_input, "b": reshaped}, p + "multiply")
+        self.fft = Module("fft", {"forward": True}, {"signal": self.multiply.output("product")},
+                          p + "fft")
+        self.amplitude = Module("amplitude", {}, {"signal": self.fft.output("signal")},
+                                p + "amplitude")
+        self.range = None
+        if enable_scale:
+            self.range = Module("range", {"min": range_min, "max": range_max},
+                                {"signal": self.amplitude.output("signal")}, p + "range")
+            self.buffer = self.range.output("signal")
+        else:
+            self.buffer = self.amplitude.output("signal")
+
+    @property
+    def modules(self) -> List[Module]:
+        ms = [self.cast, self.window, self.invert, self.reshape, self.multiply, self.fft,
+              self.amplitude]
+        if self.range is not None:
+            ms.append(self.range)
+        return ms

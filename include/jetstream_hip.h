@@ -1,0 +1,176 @@
+/*
+ * jetstream_hip.h -- C ABI of libjetstream_hip.so, the MI355X (gfx950) compute backend for
+ * CyberEther's Jetstream DSP module graph.
+ *
+ * The reference's module interface is a C++ virtual ABI inside libjetstream and is not stable
+ * across compilers; what crosses a DSO boundary there is ONE C symbol, jetstream_plugin_abi
+ * (include/jetstream/plugin.hh:48-87, validated at src/plugin.cc:1190-1224).  This header is the
+ * flat equivalent of the calls the framework makes on a module of the hot path, so that a
+ * binding (C++, ctypes, cgo...) can drive the HIP modules with plain pointers and sizes:
+ *
+ *   Registry::BuildModule(type, device, runtime, provider)   include/jetstream/registry.hh:119-125
+ *   Module::create(name, config, inputs)                      src/module.cc:47-212
+ *   outputs()["port"]                                         include/jetstream/tensor_link.hh:22-34
+ *   Runtime::create(modules) / Runtime::compute()             include/jetstream/runtime.hh:22-40
+ *   NativeCudaRuntimeContext::compute{Initialize,Submit,Deinitialize}
+ *                                                             include/jetstream/runtime_context_native_cuda.hh:32-34
+ *   Tensor(device, dtype, shape) / views / attributes / copy  include/jetstream/memory/tensor.hh:24-135
+ *
+ * Conventions: every call returns a jst_result (the reference's Result enum,
+ * include/jetstream/types.hh:19-30); the text of the last error on the calling thread is
+ * jst_last_error() (what JST_ERROR logged).  Handles are opaque and owned by the caller until
+ * the matching *_destroy.  Tensors handed to a module are shared (ref-counted storage): a
+ * module never writes its inputs.  Shapes, strides and offsets are in ELEMENTS.
+ * Nothing here needs torch; device pointers may be borrowed from any allocator
+ * (jst_tensor_wrap).
+ */
+#ifndef JETSTREAM_HIP_H
+#define JETSTREAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t jst_result; /* include/jetstream/types.hh:19-30 */
+enum {
+    JST_SUCCESS = 0,
+    JST_ERROR_ = 1,
+    JST_WARNING = 2,
+    JST_FATAL = 3,
+    JST_SKIP = 4,
+    JST_YIELD = 5,
+    JST_RELOAD = 6,
+    JST_RECREATE = 7,
+    JST_TIMEOUT = 8,
+    JST_INCOMPLETE = 9
+};
+
+/* include/jetstream/memory/types.hh:22-29; HIP uses the free bit 1<<6. */
+enum { JST_DEVICE_NONE = 1 << 0, JST_DEVICE_CPU = 1 << 1, JST_DEVICE_HIP = 1 << 6 };
+
+enum { JST_DTYPE_F32 = 1, JST_DTYPE_CF32 = 2, JST_DTYPE_F64 = 3, JST_DTYPE_U64 = 4 };
+
+/* Runtime flags. */
+enum {
+    JST_RUNTIME_GRAPH = 1 << 0,  /* capture the steady-state cycle(s) into a hipGraph */
+    JST_RUNTIME_FUSE = 1 << 1,   /* submit Multiply->FFT->Amplitude[->Range] as one kernel */
+    JST_RUNTIME_TIMING = 1 << 2  /* hipEvent pair around every execution unit */
+};
+
+typedef struct jst_tensor_s* jst_tensor;
+typedef struct jst_module_s* jst_module;
+typedef struct jst_runtime_s* jst_runtime;
+
+#define JST_MAX_RANK 8
+
+/* The fields a module reads from a Tensor (tensor.hh:56-79, axis.hh:19-23). axis = -1: unset. */
+typedef struct jst_tensor_desc {
+    void* data;       /* buffer base of the selected ring slot (device tensors: NOT offset) */
+    uint64_t offset;  /* elements */
+    uint8_t dtype;
+    uint8_t device;
+    uint32_t rank;
+    uint64_t shape[JST_MAX_RANK];
+    uint64_t stride[JST_MAX_RANK];
+    int64_t sample_axis, batch_axis, channel_axis;
+} jst_tensor_desc;
+
+/* ---- library ---------------------------------------------------------------------------- */
+/* The plugin handshake symbol the reference's loader looks up (plugin.hh:48-87). */
+typedef struct JetstreamPluginAbi {
+    uint32_t magic;   /* 0x4a535450 "JSTP" */
+    uint32_t size;    /* sizeof(JetstreamPluginAbi) */
+    uint32_t abi_version; /* 1 */
+} JetstreamPluginAbi;
+extern const JetstreamPluginAbi jetstream_plugin_abi;
+
+const char* jst_version(void);
+const char* jst_last_error(void);
+const char* jst_result_name(jst_result r);
+/* Number of visible HIP devices (0 without a GPU); jst_device_set selects one per process. */
+int jst_device_count(void);
+jst_result jst_device_set(int ordinal);
+/* Registry::ListAvailableModules: writes "type|device|runtime|provider" lines. Returns count. */
+size_t jst_registry_list(char* buffer, size_t capacity);
+
+/* ---- tensors (src/memory/tensor.cc) ----------------------------------------------------- */
+jst_result jst_tensor_create(uint8_t device, uint8_t dtype, uint32_t rank, const uint64_t* shape,
+                             jst_tensor* out);
+jst_result jst_tensor_create_ring(uint8_t device, uint8_t dtype, uint32_t rank,
+                                  const uint64_t* shape, uint64_t slots, jst_tensor* out);
+/* Borrow external memory (e.g. a torch tensor's data_ptr).  stride may be NULL (dense). */
+jst_result jst_tensor_wrap(void* ptr, size_t bytes, uint8_t device, uint8_t dtype, uint32_t rank,
+                           const uint64_t* shape, const uint64_t* stride, uint64_t offset,
+                           jst_tensor* out);
+jst_result jst_tensor_clone(jst_tensor t, jst_tensor* out); /* new view, shared storage */
+jst_result jst_tensor_destroy(jst_tensor t);
+jst_result jst_tensor_describe(jst_tensor t, jst_tensor_desc* out);
+jst_result jst_tensor_ring_select(jst_tensor t, uint64_t slot);
+/* views, mutating the handle (tensor.cc:196-306) */
+jst_result jst_tensor_reshape(jst_tensor t, uint32_t rank, const uint64_t* shape);
+jst_result jst_tensor_expand_dims(jst_tensor t, uint64_t axis);
+jst_result jst_tensor_squeeze_dims(jst_tensor t, uint64_t axis);
+jst_result jst_tensor_slice(jst_tensor t, uint64_t axis, uint64_t begin, uint64_t end,
+                            uint64_t step);
+jst_result jst_tensor_permute(jst_tensor t, uint32_t rank, const uint64_t* axes);
+jst_result jst_tensor_broadcast_to(jst_tensor t, uint32_t rank, const uint64_t* shape);
+/* attributes: "sampleAxis" | "batchAxis" | "channelAxis" (Index), "sampleRate", ... (F64) */
+jst_result jst_tensor_set_attribute_u64(jst_tensor t, const char* key, uint64_t value);
+jst_result jst_tensor_set_attribute_f64(jst_tensor t, const char* key, double value);
+jst_result jst_tensor_remove_attribute(jst_tensor t, const char* key);
+/* dense copies, synchronous on return (tensor.cc:882-963) */
+jst_result jst_tensor_copy_from_host(jst_tensor t, const void* src, size_t bytes);
+jst_result jst_tensor_copy_to_host(jst_tensor t, void* dst, size_t bytes);
+/* asynchronous H2D on the library's side stream (pinned source recommended); the returned
+ * work is ordered before the next jst_runtime_compute of any runtime via an event. */
+jst_result jst_tensor_copy_from_host_async(jst_tensor t, const void* src, size_t bytes);
+
+/* ---- modules (src/module.cc, include/jetstream/registry.hh) ------------------------------ */
+/* config: "key=value" strings (the reference's Parser::Map of the module's JST_MODULE_PARAMS).
+ * inputs: parallel arrays of port names and tensors. */
+jst_result jst_module_create(const char* type, uint8_t device, const char* provider,
+                             const char* name, const char* const* config, uint32_t n_config,
+                             const char* const* input_ports, const jst_tensor* input_tensors,
+                             uint32_t n_inputs, jst_module* out);
+jst_result jst_module_destroy(jst_module m);
+jst_result jst_module_output(jst_module m, const char* port, jst_tensor* out);
+/* internal state tensors: spectrogram/waterfall "frequencyBins", waterfall "ringState" */
+jst_result jst_module_state(jst_module m, const char* key, jst_tensor* out);
+uint64_t jst_module_taint(jst_module m);
+/* Module::Timing (include/jetstream/module.hh:25-31) */
+jst_result jst_module_timing(jst_module m, uint64_t* cycles, double* compute_time_ms);
+/* direct runtime-context hooks, for harnesses that own the stream */
+jst_result jst_module_compute_initialize(jst_module m);
+jst_result jst_module_compute_submit(jst_module m, void* hip_stream);
+jst_result jst_module_compute_deinitialize(jst_module m);
+
+/* ---- runtime (src/runtime/native/cuda/impl.cc + src/scheduler_synchronous.cc) ------------ */
+jst_result jst_runtime_create(const jst_module* modules, uint32_t n, uint32_t flags,
+                              jst_runtime* out);
+jst_result jst_runtime_destroy(jst_runtime r);
+/* run `cycles` compute cycles; sync != 0 ends with a stream synchronise */
+jst_result jst_runtime_compute(jst_runtime r, uint64_t cycles, int sync);
+jst_result jst_runtime_synchronize(jst_runtime r);
+void* jst_runtime_stream(jst_runtime r);
+uint64_t jst_runtime_period(jst_runtime r);
+int jst_runtime_graph_active(jst_runtime r);
+/* newline-separated names: execution order of modules / execution units after fusion */
+size_t jst_runtime_order(jst_runtime r, char* buffer, size_t capacity);
+size_t jst_runtime_units(jst_runtime r, char* buffer, size_t capacity);
+/* mean device milliseconds of a unit (prefix match on its name), JST_RUNTIME_TIMING only */
+double jst_runtime_unit_mean_ms(jst_runtime r, const char* unit_prefix);
+jst_result jst_runtime_reset_timing(jst_runtime r);
+
+/* ---- test/bench probes -------------------------------------------------------------------- */
+/* Host twiddle generator used for the FFT tables: W[k] = exp(+j 2 pi k/n), interleaved. */
+jst_result jst_fft_twiddles(uint64_t n, float* interleaved_out);
+/* out[i] = device restatement of libm tanhf(in[i]); both DEVICE pointers. */
+jst_result jst_probe_tanhf(const float* in_device, float* out_device, uint64_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JETSTREAM_HIP_H */

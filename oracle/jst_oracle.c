@@ -686,7 +686,7 @@ void jst_oracle_spectrogram(float* bins, const float* in, uint64_t batches, uint
                 const uint64_t index = (uint64_t)f;
                 float* val = &bins[x + index * width];
                 const float v = *val + 0.02f;
-                *val = v < 1.0f ? v : 1.0f; /* std::min(val + 0.02f, 1.0f) */
+                *val = (1.0f < v) ? 1.0f : v; /* std::min(val + 0.02f, 1.0f) = (b < a) ? b : a */
             }
         }
     }

@@ -1,0 +1,119 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/jetstream_hip.h
+declares, registers every hot-path module for (hip, native, generic), builds the reference's
+twiddle table bit-exactly, mirrors the reference's validation errors, and FAILS LOUDLY (no CPU
+fallback) when asked to compute without a GPU.  No kernel runs here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_every_declared_symbol(js):
+    header = open(os.path.join(ROOT, "include", "jetstream_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = set(re.findall(r"\b(jst_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 45
+    lib = C.CDLL(js.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_plugin_handshake_symbol(js):
+    # include/jetstream/plugin.hh:48-87: {magic 0x4a535450, size 12, abi_version 1}
+    lib = C.CDLL(js.LIB_PATH)
+    abi = (C.c_uint32 * 3).in_dll(lib, "jetstream_plugin_abi")
+    assert list(abi) == [0x4A535450, 12, 1]
+
+
+def test_registry_has_the_hot_path_modules(js):
+    listed = js.list_available_modules()
+    for t in ("window", "invert", "reshape", "cast", "multiply", "multiply_constant", "fft",
+              "amplitude", "range", "spectrogram", "waterfall", "ring_source"):
+        assert f"{t}|hip|native|generic" in listed, t
+
+
+def test_unknown_registration_is_an_error_not_a_fallback(js):
+    with pytest.raises(js.JetstreamError, match="No module 'fft' registered"):
+        js.Module("fft", {}, {}, provider="does-not-exist")
+    with pytest.raises(js.JetstreamError, match="No module 'fft' registered"):
+        js.Module("fft", {}, {}, device="cpu")  # the CPU path is the reference's, not ours
+
+
+@pytest.mark.parametrize("m", range(0, 17))
+def test_twiddle_table_bit_exact_vs_oracle(js, oracle, m):
+    n = 1 << m
+    mine, ref = js.fft_twiddles(n), oracle.fft_twiddles(n)
+    assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+
+
+def _host_view(js, array, **axes):
+    """A tensor that CLAIMS to be on the HIP device but borrows host memory: good enough for
+    validate(), which must not touch data or allocate (fft/module_impl.cc:15-22)."""
+    t = js.Tensor.wrap(array.ctypes.data, array.nbytes, "hip",
+                       {np.dtype(np.complex64): "CF32", np.dtype(np.float32): "F32"}[array.dtype],
+                       array.shape)
+    if axes:
+        t.set_axes(**axes)
+    return t
+
+
+def test_validation_errors_mirror_the_reference(js):
+    x = np.zeros((2, 12), np.complex64)
+    with pytest.raises(js.JetstreamError, match=r"\[MODULE_FFT\] Input must contain valid signal axis"):
+        js.Module("fft", {}, {"signal": _host_view(js, x)})  # rank 2 without axes (axis.cc:231-245)
+    with pytest.raises(js.JetstreamError, match="Transform length 12 is not implemented"):
+        js.Module("fft", {}, {"signal": _host_view(js, x, sample=1, batch=0)})
+    with pytest.raises(js.JetstreamError, match=r"\[MODULE_SPECTROGRAM\] Invalid height value"):
+        js.Module("spectrogram", {"height": 0}, {})
+    with pytest.raises(js.JetstreamError, match=r"\[MODULE_SPECTROGRAM\] Invalid height value"):
+        js.Module("spectrogram", {"height": 4096}, {})
+    with pytest.raises(js.JetstreamError, match=r"\[MODULE_WINDOW\] Window size cannot be zero"):
+        js.Module("window", {"size": 0}, {})
+    a = np.zeros((2, 3), np.complex64)
+    b = np.zeros((4,), np.complex64)
+    with pytest.raises(js.JetstreamError, match="are not broadcastable"):
+        js.Module("multiply", {}, {"a": _host_view(js, a), "b": _host_view(js, b)})
+    f = np.zeros((4, 5, 6), np.float32)
+    with pytest.raises(js.JetstreamError, match="Unsupported auxiliary input axis"):
+        js.Module("spectrogram", {}, {"signal": _host_view(js, f, sample=2, batch=0)})
+    with pytest.raises(js.JetstreamError, match="cannot contain both sampleAxis and channelAxis"):
+        js.Module("waterfall", {}, {"signal": _host_view(js, f[0], sample=1, channel=0)})
+    with pytest.raises(js.JetstreamError, match="sampleAxis or channelAxis metadata"):
+        js.Module("amplitude", {}, {"signal": _host_view(js, f[0])})
+    with pytest.raises(js.JetstreamError, match=r"requested missing input 'signal'"):
+        js.Module("fft", {}, {})
+    with pytest.raises(js.JetstreamError, match="Shape must use bracket notation"):
+        js.Module("reshape", {"shape": "4,4"}, {"buffer": _host_view(js, a)})
+
+
+def test_views_strides_and_axes_are_in_elements(js):
+    base = np.arange(4 * 6 * 8, dtype=np.float32)
+    t = js.Tensor.wrap(base.ctypes.data, base.nbytes, "cpu", "F32", (4, 6, 8))
+    assert t.stride == (48, 8, 1) and t.offset == 0
+    t.slice(1, 2, 6, 2)
+    assert t.shape == (4, 2, 8) and t.stride == (48, 16, 1) and t.offset == 16
+    t.permute((2, 0, 1))
+    assert t.shape == (8, 4, 2) and t.stride == (1, 48, 16)
+    with pytest.raises(js.JetstreamError, match="non-contiguous"):
+        t.reshape((64,))
+    u = js.Tensor.wrap(base.ctypes.data, base.nbytes, "cpu", "F32", (8,))
+    u.expand_dims(0).broadcast_to((3, 8))
+    assert u.shape == (3, 8) and u.stride == (0, 1)
+    u.set_axes(sample=1, batch=0)
+    assert u.axes == {"sample": 1, "batch": 0, "channel": None}
+    with pytest.raises(js.JetstreamError, match="exceeds"):
+        js.Tensor.wrap(base.ctypes.data, 16, "cpu", "F32", (8,))
+
+
+def test_no_gpu_means_loud_failure(js):
+    if js.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(js.JetstreamError, match="hipMalloc"):
+        js.Tensor.create("hip", "CF32", (8, 64))
+    x = np.zeros((1, 64), np.complex64)
+    with pytest.raises(js.JetstreamError):  # create() must allocate its output on the device
+        js.Module("fft", {}, {"signal": _host_view(js, x, sample=1, batch=0)})

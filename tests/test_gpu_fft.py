@@ -1,0 +1,105 @@
+"""HIP FFT module vs the oracle (bit-exact) -- sizes, directions, batches, layouts.
+Mirrors the matrix of src/domains/dsp/fft/module_tests.cc (DC spike :52-93, roundtrip :95-147,
+batched / strided / permuted / offset variants :225-271,395-443,445-536,596-700)."""
+import numpy as np
+import pytest
+
+from util import assert_bit_equal, csignal, run_module
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m", range(0, 15))
+@pytest.mark.parametrize("forward", [True, False])
+def test_c2c_bit_exact_all_sizes(js, oracle, m, forward):
+    n = 1 << m
+    rng = np.random.default_rng(1000 + m)
+    batch = 7 if n <= 2048 else 3
+    x = csignal(rng, (batch, n))
+    src = js.Tensor.from_numpy(x, sample=1, batch=0)
+    _, out = run_module(js, "fft", {"forward": forward}, {"signal": src})
+    assert_bit_equal(out["signal"], oracle.fft_c2c(x, forward), f"n={n} fwd={forward}")
+
+
+def test_rank1_default_axis_and_dc_spike(js, oracle):
+    x = np.ones(64, np.complex64)
+    _, out = run_module(js, "fft", {}, {"signal": js.Tensor.from_numpy(x)})  # rank 1: sampleAxis 0
+    y = out["signal"]
+    assert abs(y[0].real - 64) < 1e-3 and np.max(np.abs(y[1:])) < 1e-3
+    assert_bit_equal(y, oracle.fft_c2c(x))
+
+
+def test_roundtrip_is_unnormalised(js):
+    rng = np.random.default_rng(5)
+    x = csignal(rng, (4, 1024))
+    src = js.Tensor.from_numpy(x, sample=1, batch=0)
+    f = js.Module("fft", {"forward": True}, {"signal": src}, "fwd")
+    i = js.Module("fft", {"forward": False}, {"signal": f.output("signal")}, "inv")
+    rt = js.Runtime([f, i])
+    rt.compute()
+    back = i.output("signal").numpy()
+    assert np.max(np.abs(back - 1024 * x)) < 1e-2 * 1024 / 64
+    assert f.output("signal").axes == {"sample": 1, "batch": 0, "channel": None}  # propagated
+
+
+def test_large_batch_grid_stride(js, oracle):
+    rng = np.random.default_rng(6)
+    x = csignal(rng, (9000, 64))  # more transforms than the launch's workgroup cap covers at once
+    _, out = run_module(js, "fft", {}, {"signal": js.Tensor.from_numpy(x, sample=1, batch=0)})
+    assert_bit_equal(out["signal"], oracle.fft_c2c(x))
+
+
+def test_transform_along_leading_axis(js, oracle):
+    # sampleAxis = 0 of a [N, B] tensor: element stride B along the transform
+    rng = np.random.default_rng(7)
+    x = csignal(rng, (256, 5))
+    src = js.Tensor.from_numpy(x, sample=0, batch=1)
+    _, out = run_module(js, "fft", {}, {"signal": src})
+    ref = np.ascontiguousarray(oracle.fft_c2c(np.ascontiguousarray(x.T)).T)
+    assert_bit_equal(out["signal"], ref)
+
+
+def test_strided_offset_permuted_views(js, oracle):
+    rng = np.random.default_rng(8)
+    store = csignal(rng, (6, 4, 512))
+    t = js.Tensor.from_numpy(store)
+    t.slice(0, 1, 6, 2).slice(2, 128, 384, 1).permute((1, 0, 2)).set_axes(sample=2)
+    host = np.ascontiguousarray(store[1:6:2, :, 128:384].transpose(1, 0, 2))
+    assert t.shape == host.shape == (4, 3, 256) and t.offset == 4 * 512 + 128
+    _, out = run_module(js, "fft", {}, {"signal": t})
+    assert_bit_equal(out["signal"], oracle.fft_c2c(host))
+    # every-other-sample view along the transform axis
+    u = js.Tensor.from_numpy(store)
+    u.slice(2, 0, 512, 2).set_axes(sample=2, batch=0, channel=1)
+    _, out = run_module(js, "fft", {}, {"signal": u})
+    assert_bit_equal(out["signal"], oracle.fft_c2c(np.ascontiguousarray(store[:, :, ::2])))
+
+
+def test_rank4_outer_axes(js, oracle):
+    rng = np.random.default_rng(9)
+    x = csignal(rng, (2, 3, 4, 128))
+    src = js.Tensor.from_numpy(x, sample=3, batch=0, channel=1)
+    _, out = run_module(js, "fft", {}, {"signal": src})
+    assert_bit_equal(out["signal"], oracle.fft_c2c(x))
+
+
+def test_special_values_propagate_like_the_cpu(js, oracle):
+    x = np.zeros((2, 16), np.complex64)
+    x[0, 3] = np.inf
+    x[1, 5] = complex(np.nan, 1.0)
+    x[1, 0] = -0.0
+    _, out = run_module(js, "fft", {}, {"signal": js.Tensor.from_numpy(x, sample=1, batch=0)})
+    ref = oracle.fft_c2c(x)
+    got = out["signal"]
+    assert np.array_equal(np.isnan(got.view(np.float32)), np.isnan(ref.view(np.float32)))
+    fin = ~np.isnan(ref.view(np.float32))
+    assert np.array_equal(got.view(np.uint32)[fin], ref.view(np.uint32)[fin])
+
+
+def test_unsupported_cases_fail_loudly(js):
+    x = np.zeros((2, 12), np.complex64)
+    with pytest.raises(js.JetstreamError, match="not implemented"):
+        js.Module("fft", {}, {"signal": js.Tensor.from_numpy(x, sample=1, batch=0)})
+    r = np.zeros((2, 16), np.float32)
+    with pytest.raises(js.JetstreamError, match="not implemented"):
+        js.Module("fft", {}, {"signal": js.Tensor.from_numpy(r, sample=1, batch=0)})

@@ -1,0 +1,131 @@
+"""Spectrogram and Waterfall HIP modules vs the oracle (exact): layouts, heights, edge inputs,
+multi-cycle state, ring KATs (spectrogram/module_tests.cc:250-329, waterfall/module_tests.cc:186-260)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from util import assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+def spec_run(js, x, height, cycles=1, **axes):
+    t = js.Tensor.from_numpy(x, **axes)
+    m = js.Module("spectrogram", {"height": height}, {"signal": t})
+    rt = js.Runtime([m])
+    rt.compute(cycles)
+    return m.state("frequencyBins").numpy().reshape(-1)
+
+
+def test_reference_layout_kat_exact_equality(js, oracle):
+    kat = KATS["spectrogram"][0]
+    lead, trail = np.array(kat["leading"], np.float32), np.array(kat["trailing"], np.float32)
+    for role in ("sample", "channel"):
+        a = spec_run(js, lead, 256, **{"batch": 0, role: 1})
+        b = spec_run(js, np.ascontiguousarray(trail), 256, **{"batch": 1, role: 0})
+        assert_bit_equal(a, b, "leading vs trailing layout")
+        ref = np.zeros(3 * 256, np.float32)
+        oracle.spectrogram(ref, lead, 256)
+        assert_bit_equal(a, ref)
+
+
+@pytest.mark.parametrize("height", [1, 2, 64, 256, 1024, 2048])
+@pytest.mark.parametrize("width,batches", [(3, 2), (100, 37), (4096, 64)])
+def test_random_inputs_all_heights(js, oracle, height, width, batches):
+    rng = np.random.default_rng(height * 7 + width)
+    x = rng.uniform(-0.2, 1.2, (batches, width)).astype(np.float32)
+    x[0, 0], x[1 % batches, 1 % width] = np.nan, np.inf
+    x[0, 2 % width] = -np.inf
+    got = spec_run(js, x, height, cycles=3, sample=1, batch=0)
+    ref = np.zeros(width * height, np.float32)
+    for _ in range(3):
+        oracle.spectrogram(ref, x, height)
+    assert_bit_equal(got, ref, f"h={height} w={width} b={batches}")
+
+
+def test_saturation_and_decay(js, oracle):
+    # one column hit 200 times per cycle saturates at exactly 1.0f, then decays by 0.999^B
+    x = np.full((200, 16), 0.5, np.float32)
+    got = spec_run(js, x, 32, cycles=2, sample=1, batch=0)
+    ref = np.zeros(16 * 32, np.float32)
+    oracle.spectrogram(ref, x, 32)
+    oracle.spectrogram(ref, x, 32)
+    assert_bit_equal(got, ref)
+    assert got.reshape(32, 16)[16].max() == 1.0
+
+
+def test_rank1_no_batch_axis_and_boundaries(js, oracle):
+    h = 256
+    edge = np.array([0.0, 1 / 256, np.nextafter(np.float32(1 / 256), np.float32(0)), 0.99999994, 1.0,
+                     255 / 256, -1e-9, 0.5], np.float32)
+    got = spec_run(js, edge, h, sample=0)
+    ref = np.zeros(edge.size * h, np.float32)
+    oracle.spectrogram(ref, edge, h)
+    assert_bit_equal(got, ref)
+    assert got.reshape(h, -1)[0].sum() == 0
+
+
+def test_strided_input(js, oracle):
+    rng = np.random.default_rng(3)
+    store = rng.uniform(0, 1, (10, 600)).astype(np.float32)
+    t = js.Tensor.from_numpy(store)
+    t.slice(0, 1, 10, 2).slice(1, 50, 562, 2).set_axes(sample=1, batch=0)
+    m = js.Module("spectrogram", {"height": 128}, {"signal": t})
+    rt = js.Runtime([m])
+    rt.compute()
+    ref = np.zeros(256 * 128, np.float32)
+    oracle.spectrogram(ref, np.ascontiguousarray(store[1:10:2, 50:562:2]), 128)
+    assert_bit_equal(m.state("frequencyBins").numpy().reshape(-1), ref)
+
+
+def test_waterfall_ring_kat_on_device(js, oracle):
+    kat = KATS["waterfall"][0]
+    height, width = kat["height"], 70
+    ring_ref = np.zeros((height, width), np.float32)
+    state_ref = (0, 0)
+    nxt = 1
+    for count in kat["batch_counts"]:
+        rows = (np.arange(nxt, nxt + count, dtype=np.float32)[:, None] +
+                np.linspace(0, 0.5, width, dtype=np.float32)[None, :]).astype(np.float32)
+        nxt += count
+        # one module instance per batch count would reset the cursor; the reference test drives
+        # the ring state directly, so do the same through a persistent device ring:
+        if count == kat["batch_counts"][0]:
+            mods = {}
+        key = count
+        t = js.Tensor.from_numpy(rows, sample=1, batch=0)
+        m = js.Module("waterfall", {"height": height}, {"signal": t})
+        # carry the ring + cursor over from the previous module (same shapes)
+        if mods:
+            prev = mods["last"]
+            m.state("frequencyBins").copy_from(prev.state("frequencyBins").numpy())
+            m.state("ringState").copy_from(prev.state("ringState").numpy())
+        rt = js.Runtime([m])
+        rt.compute()
+        mods["last"] = m
+        state_ref = oracle.waterfall(ring_ref, state_ref, rows, height)
+        assert_bit_equal(m.state("frequencyBins").numpy(), ring_ref, f"ring after {count}")
+        st = m.state("ringState").numpy()
+        assert (int(st[0]), int(st[1]), int(st[2])) == (state_ref[0], state_ref[1], 0)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_waterfall_cursor_advances_under_graph_replay(js, oracle, graph):
+    rng = np.random.default_rng(9)
+    height, width, batches = 16, 300, 5
+    x = rng.standard_normal((batches, width)).astype(np.float32)
+    t = js.Tensor.from_numpy(x, sample=1, batch=0)
+    m = js.Module("waterfall", {"height": height}, {"signal": t})
+    rt = js.Runtime([m], graph=graph)
+    ring, state = np.zeros((height, width), np.float32), (0, 0)
+    for cycle in range(9):
+        x = rng.standard_normal((batches, width)).astype(np.float32)
+        t.copy_from(x)
+        rt.compute()
+        state = oracle.waterfall(ring, state, x, height)
+        assert_bit_equal(m.state("frequencyBins").numpy(), ring, f"cycle {cycle}")
+    assert int(m.state("ringState").numpy()[0]) == state[0] == (9 * batches) % height
+    assert rt.graph_active == graph
