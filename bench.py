@@ -163,7 +163,8 @@ def main() -> None:
                                    "1024 batches cf32 per step, hipGraph capture",
                        "batches": BATCHES, "fft_size": N_FFT, "ring_slots": args.slots,
                        "graph": rt.graph_active, "fused": not args.no_fuse,
-                       "units": rt.units, "spectrogram_kernel_ms": spec_ms,
+                       "units_ms": {u.split("(")[0]: rt.unit_mean_ms(u) for u in rt.units
+                                    if rt.unit_mean_ms(u) > 0},
                        "sharding": "independent batches per GPU, no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -15,11 +15,13 @@ struct jst_tensor_s {
     Tensor t;
 };
 struct jst_module_s {
-    std::unique_ptr<Module> m;
+    std::shared_ptr<Module> m;  // shared with every runtime the module was handed to
     bool initialized = false;
 };
 struct jst_runtime_s {
     Runtime rt;
+    std::vector<std::shared_ptr<Module>> keep;  // modules outlive the runtime that runs them
+    ~jst_runtime_s() { (void)rt.destroy(); }    // before 'keep' lets go of them
 };
 
 extern "C" {
@@ -277,16 +279,18 @@ jst_result jst_module_create(const char* type, uint8_t device, const char* provi
     const Result r = m->construct(name, cfg, inputs);
     if (r != Result::SUCCESS) return R(r);
     auto h = std::make_unique<jst_module_s>();
-    h->m = std::move(m);
+    h->m = std::shared_ptr<Module>(m.release(), [](Module* p) {
+        (void)p->teardown();  // Module::destroy() runs when the last owner lets go
+        delete p;
+    });
     *out = h.release();
     return R(Result::SUCCESS);
 }
 jst_result jst_module_destroy(jst_module m) {
     if (!m) return R(Result::SUCCESS);
     if (m->initialized) (void)m->m->computeDeinitialize();
-    const Result r = m->m->teardown();
     delete m;
-    return R(r);
+    return R(Result::SUCCESS);
 }
 jst_result jst_module_output(jst_module m, const char* port, jst_tensor* out) {
     JST_ARG(m && port && out, "null argument");
@@ -345,6 +349,7 @@ jst_result jst_runtime_create(const jst_module* modules, uint32_t n, uint32_t fl
         ms.push_back(modules[i]->m.get());
     }
     auto h = std::make_unique<jst_runtime_s>();
+    for (uint32_t i = 0; i < n; ++i) h->keep.push_back(modules[i]->m);
     const Result r = h->rt.create(ms, flags);
     if (r != Result::SUCCESS) return R(r);
     *out = h.release();

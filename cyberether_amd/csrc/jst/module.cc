@@ -314,7 +314,7 @@ Result Runtime::destroy() {
     return Result::SUCCESS;
 }
 
-Result Runtime::submitAll(bool record_events, U64 slot) {
+Result Runtime::submitAll(bool record_events, U64 slot, bool count_cycles) {
     for (auto& u : units_) {
         if (u.is_static && u.settled) continue;
         const bool rec = record_events && slot < u.span.begin.size();
@@ -329,7 +329,8 @@ Result Runtime::submitAll(bool record_events, U64 slot) {
             JST_HIP_CHECK(hipEventRecord(u.span.end[slot], stream_), "hipEventRecord");
             u.span.recorded[slot] = true;
         }
-        for (Module* m : u.modules) m->timing.cycles++;
+        if (count_cycles)
+            for (Module* m : u.modules) m->timing.cycles++;
     }
     return Result::SUCCESS;
 }
@@ -368,7 +369,7 @@ Result Runtime::eagerCycle(bool& needs_sync) {
             JST_CHECK(harvestTiming());
         }
     }
-    JST_CHECK(submitAll(timing, slot));
+    JST_CHECK(submitAll(timing, slot, true));
     timing_pending_ = timing_pending_ || timing;
     ++cycles_;
     // STATIC modules settle after one successful cycle (scheduler_synchronous.cc:534-546).
@@ -404,7 +405,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
                 JST_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal),
                               "hipStreamBeginCapture");
                 Result r = Result::SUCCESS;
-                for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c) r = submitAll(timing, c);
+                for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c) r = submitAll(timing, c, false);
                 hipGraph_t g = nullptr;
                 const hipError_t e = hipStreamEndCapture(stream_, &g);
                 if (r != Result::SUCCESS) {

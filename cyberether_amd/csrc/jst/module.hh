@@ -164,7 +164,7 @@ class Runtime {
     Result planOrder(const std::vector<Module*>& modules);
     Result planUnits();
     bool tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed);
-    Result submitAll(bool record_events, U64 event_slot);
+    Result submitAll(bool record_events, U64 event_slot, bool count_cycles);
     Result harvestTiming();
     Result eagerCycle(bool& needs_sync);
 

@@ -57,10 +57,12 @@ int log_level() {
 }  // namespace
 
 void log_error(const char* fmt, ...) {
+    char buf[sizeof(g_last_error)];  // arguments may point into g_last_error itself
     va_list ap;
     va_start(ap, fmt);
-    std::vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    std::vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
+    std::memcpy(g_last_error, buf, sizeof(buf));
     if (log_level() >= 1) std::fprintf(stderr, "[jetstream-hip] ERROR %s\n", g_last_error);
 }
 void log_debug(const char* fmt, ...) {

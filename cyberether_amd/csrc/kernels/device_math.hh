@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "libm_float.hh"
+
 namespace jst::dev {
 
 using f2 = float2;
@@ -25,7 +27,7 @@ __device__ __forceinline__ f2 cmul(f2 a, f2 b) {
     return mk(ac - bd, ad + bc);
 }
 
-__device__ inline f2 cmul_full(f2 p, f2 q) {
+__device__ __attribute__((noinline)) f2 cmul_recover(f2 p, f2 q) {
     float a = p.x, b = p.y, c = q.x, d = q.y;
     const float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
     float x = ac - bd, y = ad + bc;
@@ -59,6 +61,14 @@ __device__ inline f2 cmul_full(f2 p, f2 q) {
         }
     }
     return mk(x, y);
+}
+
+// Full std::complex<float> product: the plain formula, and -- only when a part came out NaN,
+// which finite data never does -- the Annex G recovery path, kept out of line (cold).
+__device__ __forceinline__ f2 cmul_full(f2 p, f2 q) {
+    const f2 r = cmul(p, q);
+    if (__builtin_expect(__builtin_isunordered(r.x, r.y), 0)) return cmul_recover(p, q);
+    return r;
 }
 
 // ---- pocketfft butterfly helpers (fft/pocketfft.hh:266-272, :290-291, :1124-1139) -----------
@@ -172,102 +182,7 @@ __device__ __forceinline__ float amplitude_f32(float v, float coeff) {
 }
 
 // ---- Range ---------------------------------------------------------------------------------
-// The reference calls libm tanhf (range/module_impl_native_cpu.cc:67-82).  On the reference's
-// CPU target (x86-64 glibc, the image this repo builds and runs in ships 2.35) that is the
-// FDLIBM single-precision tanhf -> expm1f pair, which is NOT correctly rounded, so a device
-// tanh "to within an ulp" cannot be bit-identical.  libm_tanhf()/libm_expm1f() below restate
-// that published algorithm (Sun FDLIBM s_tanhf.c / s_expm1f.c, float version as shipped by
-// glibc sysdeps/ieee754/flt-32) operation by operation; tests/test_gpu_elementwise.py sweeps
-// the float range against the host libm and requires equal bits.
-__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
-__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
-
-__device__ inline float libm_expm1f(float x) {
-    constexpr float one = 1.0f, ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f,
-                    invln2 = 1.4426950216e+00f, Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f,
-                    Q3 = -7.9365076090e-05f, Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
-    float y, hi, lo, c = 0.0f, t, e, hxs, hfx, r1;
-    int32_t k;
-    uint32_t hx = f2u(x);
-    const uint32_t xsb = hx & 0x80000000u;
-    hx &= 0x7fffffffu;
-    if (hx >= 0x4195b844u) {      /* |x| >= 27 ln2 */
-        if (hx >= 0x42b17218u) {  /* |x| >= 88.72 */
-            if (hx > 0x7f800000u) return x + x;
-            if (hx == 0x7f800000u) return xsb == 0 ? x : -1.0f;
-            if (x > 8.8721679688e+01f) return __builtin_inff();
-        }
-        if (xsb != 0) return 1.0e-30f - one;
-    }
-    if (hx > 0x3eb17218u) {       /* |x| > 0.5 ln2 */
-        if (hx < 0x3F851592u) {   /* |x| < 1.5 ln2 */
-            if (xsb == 0) { hi = x - ln2_hi; lo = ln2_lo; k = 1; }
-            else { hi = x + ln2_hi; lo = -ln2_lo; k = -1; }
-        } else {
-            k = (int32_t)(invln2 * x + ((xsb == 0) ? 0.5f : -0.5f));
-            t = (float)k;
-            hi = x - t * ln2_hi;
-            lo = t * ln2_lo;
-        }
-        x = hi - lo;
-        c = (hi - x) - lo;
-    } else if (hx < 0x33000000u) { /* |x| < 2^-25 */
-        return x;
-    } else {
-        k = 0;
-    }
-    hfx = 0.5f * x;
-    hxs = x * hfx;
-    r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
-    t = 3.0f - r1 * hfx;
-    e = hxs * ((r1 - t) / (6.0f - x * t));
-    if (k == 0) return x - (x * e - hxs);
-    e = (x * (e - c) - c);
-    e -= hxs;
-    if (k == -1) return 0.5f * (x - e) - 0.5f;
-    if (k == 1) {
-        if (x < -0.25f) return -2.0f * (e - (x + 0.5f));
-        return one + 2.0f * (x - e);
-    }
-    if (k <= -2 || k > 56) {
-        y = one - (e - x);
-        y = u2f(f2u(y) + ((uint32_t)k << 23));
-        return y - one;
-    }
-    if (k < 23) {
-        t = u2f(0x3f800000u - (0x1000000u >> k));
-        y = t - (e - x);
-        y = u2f(f2u(y) + ((uint32_t)k << 23));
-    } else {
-        t = u2f((uint32_t)(0x7f - k) << 23);
-        y = x - (e + t);
-        y += one;
-        y = u2f(f2u(y) + ((uint32_t)k << 23));
-    }
-    return y;
-}
-
-__device__ inline float libm_tanhf(float x) {
-    float t, z;
-    const int32_t jx = (int32_t)f2u(x);
-    const int32_t ix = jx & 0x7fffffff;
-    if (ix >= 0x7f800000) return (jx >= 0) ? 1.0f / x + 1.0f : 1.0f / x - 1.0f;
-    if (ix < 0x41b00000) { /* |x| < 22 */
-        if (ix == 0) return x;
-        if (ix < 0x24000000) return x * (1.0f + x);
-        if (ix >= 0x3f800000) {
-            t = libm_expm1f(2.0f * __builtin_fabsf(x));
-            z = 1.0f - 2.0f / (t + 2.0f);
-        } else {
-            t = libm_expm1f(-2.0f * __builtin_fabsf(x));
-            z = -t / (t + 2.0f);
-        }
-    } else {
-        z = 1.0f - 1.0e-30f;
-    }
-    return (jx >= 0) ? z : -z;
-}
-
+// tanhf: see libm_float.hh (select-form restatement of the host libm's FDLIBM tanhf/expm1f).
 // range/module_impl_native_cpu.cc:67-82.
 __device__ __forceinline__ float range_f32(float v, float scale, float offset) {
     if (scale == 0.0f) return 0.5f;

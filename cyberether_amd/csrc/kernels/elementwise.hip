@@ -65,6 +65,7 @@ inline unsigned grid_for(uint64_t size) {
 template <class TO, class TA, class F>
 hipError_t run_unary(const EwLayout& L, TO* out, const TA* a, const F& f, hipStream_t s) {
     if (L.size == 0) return hipSuccess;
+    (void)hipGetLastError();  // drop any stale error: only this launch is judged
     hipLaunchKernelGGL((ew_unary<TO, TA, F>), dim3(grid_for(L.size)), dim3(kBlock), 0, s, L, out, a,
                        f);
     return hipGetLastError();
@@ -73,6 +74,7 @@ template <class TO, class TA, class TB, class F>
 hipError_t run_binary(const EwLayout& L, TO* out, const TA* a, const TB* b, const F& f,
                       hipStream_t s) {
     if (L.size == 0) return hipSuccess;
+    (void)hipGetLastError();  // drop any stale error: only this launch is judged
     hipLaunchKernelGGL((ew_binary<TO, TA, TB, F>), dim3(grid_for(L.size)), dim3(kBlock), 0, s, L,
                        out, a, b, f);
     return hipGetLastError();
@@ -177,6 +179,7 @@ hipError_t launch_invert(const EwLayout& L, float2* out, const void* in, bool in
 }
 hipError_t launch_window(float2* out, uint64_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
+    (void)hipGetLastError();  // drop any stale error: only this launch is judged
     hipLaunchKernelGGL(window_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        s, out, n);
     return hipGetLastError();

@@ -32,6 +32,7 @@ hipError_t launch_one(const FftLayout& L, const float2* W, const Pro& pro, const
     // Enough workgroups to occupy every CU several times over, grid-stride beyond that.
     const uint64_t blocks = blocks_needed < 8192 ? blocks_needed : 8192;
     if (blocks == 0) return hipSuccess;
+    (void)hipGetLastError();  // drop any stale error: only this launch is judged
     hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(fft_block_threads(N)), lds, stream, L,
                        W, pro, epi);
     return hipGetLastError();

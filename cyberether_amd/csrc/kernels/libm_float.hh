@@ -1,0 +1,98 @@
+// libm_float.hh -- select-form (branch-free) restatement of the host libm's single-precision
+// tanhf, for use inside gfx950 kernels.  No HIP dependency: the same text compiles for the host
+// (tests/test_libm_float.py builds it with g++ and sweeps it against libm.so.6 bit for bit).
+//
+// Why: the Range module calls libm tanhf (src/domains/core/range/module_impl_native_cpu.cc:67-82).
+// On the reference's CPU target (x86-64 glibc; this image ships 2.35) that is the FDLIBM float
+// pair tanhf -> expm1f (Sun Microsystems' s_tanhf.c / s_expm1f.c as carried in glibc
+// sysdeps/ieee754/flt-32), which is accurate to ~1 ulp but NOT correctly rounded, so only a
+// restatement of the same operation sequence reproduces its bits.  The published algorithm is a
+// ladder of data-dependent branches; on a 64-lane wavefront every lane would walk every taken
+// branch, so all alternatives are computed and selected (v_cndmask), with identical arithmetic in
+// the selected lane: one rounding per written operation, no FMA (-ffp-contract=off).
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define JST_FN __host__ __device__ __forceinline__
+#else
+#define JST_FN static inline
+#endif
+
+namespace jst::dev {
+
+JST_FN uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+JST_FN float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// expm1f(x) for the arguments tanhf feeds it: x = 2|a| with 1 <= |a| < 22, or x = -2|a| with
+// 2^-55 <= |a| < 1.  (Other x produce an unspecified value that the caller discards.)
+JST_FN float libm_expm1f_for_tanh(float x) {
+    constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f,
+                    invln2 = 1.4426950216e+00f, Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f,
+                    Q3 = -7.9365076090e-05f, Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+    const uint32_t bits = f2u(x);
+    const uint32_t hx = bits & 0x7fffffffu;
+    const bool neg = (bits >> 31) != 0;
+    const bool red = hx > 0x3eb17218u;  // |x| > 0.5 ln2: argument reduction
+    const bool mid = hx < 0x3F851592u;  // ... and |x| < 1.5 ln2: k = +-1
+
+    const int32_t kg = (int32_t)(invln2 * x + (neg ? -0.5f : 0.5f));
+    const float tg = (float)kg;
+    const float hi_g = x - tg * ln2_hi, lo_g = tg * ln2_lo;
+    const float hi_m = neg ? x + ln2_hi : x - ln2_hi;
+    const float lo_m = neg ? -ln2_lo : ln2_lo;
+    const float hi = mid ? hi_m : hi_g, lo = mid ? lo_m : lo_g;
+    const int32_t k = red ? (mid ? (neg ? -1 : 1) : kg) : 0;
+    const float xr_red = hi - lo;
+    const float c_red = (hi - xr_red) - lo;
+    const float xr = red ? xr_red : x;
+    const float c = red ? c_red : 0.0f;
+
+    const float hfx = 0.5f * xr;
+    const float hxs = xr * hfx;
+    const float r1 = 1.0f + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+    const float t = 3.0f - r1 * hfx;
+    const float e = hxs * ((r1 - t) / (6.0f - xr * t));
+
+    const float res_0 = xr - (xr * e - hxs);  // k == 0 (c is 0)
+    float e2 = (xr * (e - c) - c);
+    e2 -= hxs;
+    const float res_m1 = 0.5f * (xr - e2) - 0.5f;
+    const float res_p1 = (xr < -0.25f) ? -2.0f * (e2 - (xr + 0.5f)) : 1.0f + 2.0f * (xr - e2);
+    const uint32_t kshift = (uint32_t)k << 23;  // "add k to y's exponent"
+    const float d = e2 - xr;
+    const float y_far = u2f(f2u(1.0f - d) + kshift) - 1.0f;  // k <= -2 or k > 56
+    const float t_lo = u2f(0x3f800000u - (0x1000000u >> ((uint32_t)k & 31u)));  // 1 - 2^-k
+    const float y_lo = u2f(f2u(t_lo - d) + kshift);                              // 2 <= k < 23
+    const float t_hi = u2f((uint32_t)(0x7f - k) << 23);                          // 2^-k
+    float y_hi = xr - (e2 + t_hi);                                               // 23 <= k <= 56
+    y_hi += 1.0f;
+    y_hi = u2f(f2u(y_hi) + kshift);
+
+    float r = (k < 23) ? y_lo : y_hi;
+    r = (k <= -2 || k > 56) ? y_far : r;
+    r = (k == 1) ? res_p1 : r;
+    r = (k == -1) ? res_m1 : r;
+    r = (k == 0) ? res_0 : r;
+    r = (hx < 0x33000000u) ? x : r;  // |x| < 2^-25 (only reached unreduced)
+    return r;
+}
+
+JST_FN float libm_tanhf(float x) {
+    const uint32_t jx = f2u(x);
+    const uint32_t ix = jx & 0x7fffffffu;
+    const float ax = u2f(ix);
+    const bool ge1 = ix >= 0x3f800000u;
+    const float two_ax = 2.0f * ax;
+    const float t = libm_expm1f_for_tanh(ge1 ? two_ax : -two_ax);
+    const float q = (ge1 ? 2.0f : t) / (t + 2.0f);
+    float z = ge1 ? 1.0f - q : -q;             // one - two/(t+two)   |   -t/(t+two)
+    z = (ix >= 0x41b00000u) ? 1.0f : z;        // |x| >= 22 (and +-inf): one - tiny == 1.0f
+    float r = ((jx >> 31) != 0) ? -z : z;
+    r = (ix < 0x24000000u) ? x * (1.0f + x) : r;  // |x| < 2^-55, including +-0
+    r = (ix > 0x7f800000u) ? x + x : r;           // NaN
+    return r;
+}
+
+}  // namespace jst::dev

@@ -83,12 +83,14 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
     const size_t lds = spectrogram_lds_bytes(height);
     if (height <= 1024) {
         const unsigned tiles = (unsigned)((width + 15) / 16);
-        hipLaunchKernelGGL(spectrogram_kernel<16>, dim3(tiles), dim3(kThreads), lds, stream, bins,
+        (void)hipGetLastError();  // drop any stale error: only this launch is judged
+    hipLaunchKernelGGL(spectrogram_kernel<16>, dim3(tiles), dim3(kThreads), lds, stream, bins,
                            in, in_offset, (uint32_t)batches, (uint32_t)width, (uint32_t)height,
                            batch_stride, elem_stride, decay);
     } else {
         const unsigned tiles = (unsigned)((width + 7) / 8);
-        hipLaunchKernelGGL(spectrogram_kernel<8>, dim3(tiles), dim3(kThreads), lds, stream, bins,
+        (void)hipGetLastError();  // drop any stale error: only this launch is judged
+    hipLaunchKernelGGL(spectrogram_kernel<8>, dim3(tiles), dim3(kThreads), lds, stream, bins,
                            in, in_offset, (uint32_t)batches, (uint32_t)width, (uint32_t)height,
                            batch_stride, elem_stride, decay);
     }

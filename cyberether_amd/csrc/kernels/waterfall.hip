@@ -65,6 +65,7 @@ hipError_t launch_waterfall(float* ring, uint64_t* state, const float* in, uint6
     uint64_t blocks = (total + kThreads - 1) / kThreads;
     if (blocks == 0) blocks = 1;  // the cursor still advances on an empty copy
     if (blocks > 4096) blocks = 4096;
+    (void)hipGetLastError();  // drop any stale error: only this launch is judged
     hipLaunchKernelGGL(waterfall_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, ring,
                        state, in, in_offset, batches, width, height, batch_stride, elem_stride);
     return hipGetLastError();

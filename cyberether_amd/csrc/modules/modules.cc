@@ -778,7 +778,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     if (!fft->input.contiguous() || !fft->output.contiguous() || !amp->output.contiguous())
         return false;
     for (Index ax = 0; ax < win.rank(); ++ax)
-        if (ax != axis && win.stride(ax) != 0) return false;
+        if (ax != axis && win.shape(ax) != 1 && win.stride(ax) != 0) return false;
     if (amp->normalizationSize != n) return false;
     if (sig.rank() - 1 > (Index)dev::kMaxOuterRank) return false;
 

@@ -23,6 +23,14 @@ if not os.path.exists(LIB_PATH):
         "(run `make -C cyberether_amd/csrc`). There is no CPU fallback."
     )
 
+# PyTorch-ROCm bundles its own libamdhip64; whichever copy is loaded FIRST serves the whole process.
+# Loading torch's before ours keeps one HIP runtime in the process, so torch tensors / streams /
+# torch.distributed (RCCL) and this library see the same device context.
+try:  # plumbing only -- nothing below needs torch
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 _lib = C.CDLL(LIB_PATH)
 
 MAX_RANK = 8

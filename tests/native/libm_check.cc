@@ -1,0 +1,24 @@
+// Host-side checker for cyberether_amd/csrc/kernels/libm_float.hh (the branch-free tanhf used by
+// the Range epilogue on the GPU): counts bit mismatches against this host's libm tanhf.
+#include <math.h>
+#include <stdint.h>
+
+#include "../../cyberether_amd/csrc/kernels/libm_float.hh"
+
+extern "C" uint64_t jst_tanhf_mismatches(uint32_t start, uint32_t stride, uint64_t count,
+                                         uint32_t* first_bad) {
+    uint64_t bad = 0;
+    uint32_t u = start;
+    for (uint64_t i = 0; i < count; ++i, u += stride) {
+        const float x = jst::dev::u2f(u);
+        const float a = tanhf(x), b = jst::dev::libm_tanhf(x);
+        if (isnan(a) && isnan(b)) continue;
+        if (jst::dev::f2u(a) != jst::dev::f2u(b)) {
+            if (bad == 0 && first_bad) *first_bad = u;
+            ++bad;
+        }
+    }
+    return bad;
+}
+
+extern "C" float jst_tanhf_select(float x) { return jst::dev::libm_tanhf(x); }
