@@ -82,6 +82,9 @@ def main() -> None:
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-fuse", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--provider", default="generic", choices=["generic", "fast"],
+                    help="amplitude/range arithmetic: generic = bit-identical to the reference CPU "
+                         "path; fast = hardware transcendentals (within 3e-7 of it)")
     args = ap.parse_args()
 
     import torch
@@ -108,7 +111,8 @@ def main() -> None:
     for s in range(args.slots):  # independent IQ per rank and slot, resident before timing
         buf.ring_select(s).copy_from(synth_slot(rng, s))
     buf.ring_select(0)
-    engine = js.SpectrumEngine(buf, enable_scale=True, range_min=-100.0, range_max=0.0)
+    engine = js.SpectrumEngine(buf, enable_scale=True, range_min=-100.0, range_max=0.0,
+                               provider=args.provider)
     spectrogram = js.Module("spectrogram", {"height": HEIGHT}, {"signal": engine.buffer},
                             "spectrogram")
     rt = js.Runtime([source] + engine.modules + [spectrogram], graph=not args.no_graph,
@@ -163,6 +167,7 @@ def main() -> None:
                                    "1024 batches cf32 per step, hipGraph capture",
                        "batches": BATCHES, "fft_size": N_FFT, "ring_slots": args.slots,
                        "graph": rt.graph_active, "fused": not args.no_fuse,
+                       "provider": args.provider,
                        "units_ms": {u.split("(")[0]: rt.unit_mean_ms(u) for u in rt.units
                                     if rt.unit_mean_ms(u) > 0},
                        "sharding": "independent batches per GPU, no data-path collective"},

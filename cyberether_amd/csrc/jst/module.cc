@@ -147,7 +147,9 @@ std::unique_ptr<Module> Registry::build(const std::string& type, DeviceType devi
                   type.c_str(), DeviceName(device), provider.c_str());
         return nullptr;
     }
-    return it->second();
+    auto m = it->second();
+    m->setProvider(provider);
+    return m;
 }
 std::vector<std::string> Registry::listAvailableModules(const std::string& type) const {
     std::vector<std::string> out;

@@ -64,6 +64,8 @@ class Module {
     virtual const Tensor* state(const std::string&) const { return nullptr; }
 
     const std::string& name() const { return name_; }
+    const std::string& provider() const { return provider_; }
+    void setProvider(const std::string& p) { provider_ = p; }
     DeviceType device() const { return DeviceType::HIP; }
     const Config& config() const { return config_; }
     const std::map<std::string, Tensor>& inputs() const { return inputs_; }
@@ -79,6 +81,7 @@ class Module {
     void produced(const std::string& port, const Tensor& t) { outputs_[port] = t; }
 
     std::string name_;
+    std::string provider_ = "generic";
     Config config_;
     std::map<std::string, Tensor> inputs_;
     std::map<std::string, Tensor> outputs_;

@@ -190,4 +190,28 @@ __device__ __forceinline__ float range_f32(float v, float scale, float offset) {
     return 0.5f + 0.5f * libm_tanhf(4.0f * (normalized - 0.5f));
 }
 
+
+// ---- "fast" provider variants ----------------------------------------------------------------
+// Registered as provider "fast" (the registry's 4th key exists to select alternative
+// implementations, src/registry.cc:608-613).  They use the gfx950 transcendental unit directly
+// (v_sqrt_f32, v_exp_f32, v_rcp_f32: ~1 ulp each) instead of restating libm bit for bit:
+// amplitude stays within 2e-6 dB and range within 3e-7 absolute of the reference CPU path
+// (tests/test_gpu_fast_provider.py), well inside BASELINE.json's 1e-5 tolerance for float
+// spectra, for ~1/8 of the instructions.
+__device__ __forceinline__ float amplitude_cf32_fast(f2 v, float coeff) {
+    const float mag = __builtin_amdgcn_sqrtf((v.x * v.x) + (v.y * v.y));
+    return (mag == 0.0f) ? -__builtin_inff() : 20.0f * approx_log10(mag) + coeff;
+}
+__device__ __forceinline__ float tanhf_fast(float a) {
+    const float ax = __builtin_fabsf(a);
+    const float e = __builtin_amdgcn_exp2f(ax * -2.885390081777927f);  // exp(-2|a|)
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    return __builtin_copysignf(t, a);  // NaN in -> NaN out; +-inf -> +-1
+}
+__device__ __forceinline__ float range_f32_fast(float v, float scale, float offset) {
+    if (scale == 0.0f) return 0.5f;
+    const float normalized = v * scale + offset;
+    return 0.5f + 0.5f * tanhf_fast(4.0f * (normalized - 0.5f));
+}
+
 }  // namespace jst::dev

@@ -90,6 +90,14 @@ struct AmpCF32 {
     float coeff;
     __device__ float operator()(uint64_t, float2 v) const { return amplitude_cf32(v, coeff); }
 };
+struct AmpCF32Fast {
+    float coeff;
+    __device__ float operator()(uint64_t, float2 v) const { return amplitude_cf32_fast(v, coeff); }
+};
+struct RangeF32Fast {
+    float scale, offset;
+    __device__ float operator()(uint64_t, float v) const { return range_f32_fast(v, scale, offset); }
+};
 struct AmpF32 {
     float coeff;
     __device__ float operator()(uint64_t, float v) const { return amplitude_f32(v, coeff); }
@@ -152,7 +160,8 @@ hipError_t launch_multiply_f32(const EwLayout& L, float* c, const float* a, cons
     return run_binary(L, c, a, b, MulF32{}, s);
 }
 hipError_t launch_amplitude_cf32(const EwLayout& L, float* out, const float2* in, float coeff,
-                                 hipStream_t s) {
+                                 bool fast, hipStream_t s) {
+    if (fast) return run_unary(L, out, in, AmpCF32Fast{coeff}, s);
     return run_unary(L, out, in, AmpCF32{coeff}, s);
 }
 hipError_t launch_amplitude_f32(const EwLayout& L, float* out, const float* in, float coeff,
@@ -160,7 +169,8 @@ hipError_t launch_amplitude_f32(const EwLayout& L, float* out, const float* in, 
     return run_unary(L, out, in, AmpF32{coeff}, s);
 }
 hipError_t launch_range_f32(const EwLayout& L, float* out, const float* in, float scale,
-                            float offset, hipStream_t s) {
+                            float offset, bool fast, hipStream_t s) {
+    if (fast) return run_unary(L, out, in, RangeF32Fast{scale, offset}, s);
     return run_unary(L, out, in, RangeF32{scale, offset}, s);
 }
 hipError_t launch_multiply_constant_cf32(const EwLayout& L, float2* out, const float2* in,

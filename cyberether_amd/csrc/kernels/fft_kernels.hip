@@ -102,14 +102,19 @@ hipError_t launch_fft_c2c(uint64_t n, bool forward, const FftLayout& L, const fl
 hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W,
                                  const float2* in, const float2* window, int64_t window_stride,
                                  float* out, float amp_coeff, bool with_range, float range_scale,
-                                 float range_offset, hipStream_t stream) {
+                                 float range_offset, bool fast, hipStream_t stream) {
     const LoadCF32TimesWindow pro{in, window, window_stride};
     if (with_range) {
-        const StoreAmplitudeRange epi{out, amp_coeff, range_scale, range_offset};
-        return dispatch_fused_n(n, L, W, pro, epi, stream);
+        if (fast)
+            return dispatch_fused_n(n, L, W, pro,
+                                    StoreAmplitudeRangeT<true>{out, amp_coeff, range_scale, range_offset},
+                                    stream);
+        return dispatch_fused_n(n, L, W, pro,
+                                StoreAmplitudeRangeT<false>{out, amp_coeff, range_scale, range_offset},
+                                stream);
     }
-    const StoreAmplitude epi{out, amp_coeff};
-    return dispatch_fused_n(n, L, W, pro, epi, stream);
+    if (fast) return dispatch_fused_n(n, L, W, pro, StoreAmplitudeT<true>{out, amp_coeff}, stream);
+    return dispatch_fused_n(n, L, W, pro, StoreAmplitudeT<false>{out, amp_coeff}, stream);
 }
 
 }  // namespace jst::kernels

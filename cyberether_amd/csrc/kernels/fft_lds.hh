@@ -112,28 +112,34 @@ struct StoreCF32 {
         else out[base + (int64_t)pos * axis_stride] = v;
     }
 };
-struct StoreAmplitude {  // Amplitude module fused (amplitude/module_impl_native_cpu.cc:73-86)
+template <bool FAST>
+struct StoreAmplitudeT {  // Amplitude module fused (amplitude/module_impl_native_cpu.cc:73-86)
     float* out;
     float coeff;
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
                                           float2 v) const {
-        const float r = amplitude_cf32(v, coeff);
+        const float r = FAST ? amplitude_cf32_fast(v, coeff) : amplitude_cf32(v, coeff);
         if constexpr (CONTIG) (out + base)[(unsigned)pos] = r;
         else out[base + (int64_t)pos * axis_stride] = r;
     }
 };
-struct StoreAmplitudeRange {  // Amplitude -> Range fused (range/module_impl_native_cpu.cc:67-82)
+template <bool FAST>
+struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_native_cpu.cc:67-82)
     float* out;
     float coeff, scale, offset;
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
                                           float2 v) const {
-        const float r = range_f32(amplitude_cf32(v, coeff), scale, offset);
+        const float r = FAST ? range_f32_fast(amplitude_cf32_fast(v, coeff), scale, offset)
+                             : range_f32(amplitude_cf32(v, coeff), scale, offset);
         if constexpr (CONTIG) (out + base)[(unsigned)pos] = r;
         else out[base + (int64_t)pos * axis_stride] = r;
     }
 };
+
+using StoreAmplitude = StoreAmplitudeT<false>;
+using StoreAmplitudeRange = StoreAmplitudeRangeT<false>;
 
 constexpr int cphys(int q) { return q + (q >> 3); }
 

@@ -53,7 +53,7 @@ hipError_t launch_fft_c2c(uint64_t n, bool forward, const FftLayout& L, const fl
 hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W,
                                  const float2* in, const float2* window, int64_t window_stride,
                                  float* out, float amp_coeff, bool with_range, float range_scale,
-                                 float range_offset, hipStream_t stream);
+                                 float range_offset, bool fast, hipStream_t stream);
 
 // ---- elementwise modules (elementwise.hip) -----------------------------------------------------
 hipError_t launch_multiply_cf32(const EwLayout& L, float2* c, const float2* a, const float2* b,
@@ -61,11 +61,11 @@ hipError_t launch_multiply_cf32(const EwLayout& L, float2* c, const float2* a, c
 hipError_t launch_multiply_f32(const EwLayout& L, float* c, const float* a, const float* b,
                                hipStream_t stream);
 hipError_t launch_amplitude_cf32(const EwLayout& L, float* out, const float2* in, float coeff,
-                                 hipStream_t stream);
+                                 bool fast, hipStream_t stream);
 hipError_t launch_amplitude_f32(const EwLayout& L, float* out, const float* in, float coeff,
                                 hipStream_t stream);
 hipError_t launch_range_f32(const EwLayout& L, float* out, const float* in, float scale,
-                            float offset, hipStream_t stream);
+                            float offset, bool fast, hipStream_t stream);
 hipError_t launch_multiply_constant_cf32(const EwLayout& L, float2* out, const float2* in,
                                          float constant, hipStream_t stream);
 hipError_t launch_multiply_constant_f32(const EwLayout& L, float* out, const float* in,

@@ -556,7 +556,7 @@ Result Amplitude::computeSubmit(hipStream_t stream) {
     if (input.dtype() == DataType::CF32)
         return hip_result(kernels::launch_amplitude_cf32(L, ptr<float>(output),
                                                          ptr<const float2>(input), scalingCoeff,
-                                                         stream),
+                                                         provider() == "fast", stream),
                           "amplitude kernel");
     return hip_result(kernels::launch_amplitude_f32(L, ptr<float>(output), ptr<const float>(input),
                                                     scalingCoeff, stream),
@@ -603,7 +603,8 @@ Result Range::computeSubmit(hipStream_t stream) {
     EwLayout L;
     if (!MakeEwLayout(output, &input, nullptr, L)) return Result::ERROR;
     return hip_result(kernels::launch_range_f32(L, ptr<float>(output), ptr<const float>(input),
-                                                scalingCoeff, offsetCoeff, stream),
+                                                scalingCoeff, offsetCoeff, provider() == "fast",
+                                                stream),
                       "range kernel");
 }
 
@@ -782,6 +783,9 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     if (amp->normalizationSize != n) return false;
     if (sig.rank() - 1 > (Index)dev::kMaxOuterRank) return false;
 
+    // one arithmetic flavour per fused kernel: both "generic" (libm-exact) or both "fast"
+    const bool fast = amp->provider() == "fast";
+    if (rng && (rng->provider() == "fast") != fast) return false;
     Tensor final_out = rng ? rng->output : amp->output;
     if (!final_out.contiguous()) return false;
 
@@ -791,7 +795,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     name = "spectrum_fused(" + mul->name() + "+" + fft->name() + "+" + amp->name() +
            (rng ? "+" + rng->name() : "") + ")";
 
-    submit = [mul, fft, amp, rng, axis, n](hipStream_t stream) -> Result {
+    submit = [mul, fft, amp, rng, axis, n, fast](hipStream_t stream) -> Result {
         const Tensor& sig = mul->a;
         const Tensor& win = mul->b;
         const Tensor& out = rng ? rng->output : amp->output;
@@ -817,7 +821,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                 n, L, fft->twiddles, static_cast<const float2*>(sig.data()),
                 static_cast<const float2*>(win.data()) + win.offset(), (int64_t)win.stride(axis),
                 static_cast<float*>(out.data()), amp->scalingCoeff, rng != nullptr,
-                rng ? rng->scalingCoeff : 0.0f, rng ? rng->offsetCoeff : 0.0f, stream),
+                rng ? rng->scalingCoeff : 0.0f, rng ? rng->offsetCoeff : 0.0f, fast, stream),
             "fused spectrum kernel");
     };
     return true;
@@ -834,6 +838,11 @@ JST_REGISTER_MODULE(MultiplyConstant, "multiply_constant", DeviceType::HIP, Runt
 JST_REGISTER_MODULE(Fft, "fft", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Amplitude, "amplitude", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Range, "range", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+// provider "fast": same modules, hardware-transcendental arithmetic (device_math.hh)
+using AmplitudeFast = Amplitude;
+using RangeFast = Range;
+JST_REGISTER_MODULE(AmplitudeFast, "amplitude", DeviceType::HIP, RuntimeType::NATIVE, "fast");
+JST_REGISTER_MODULE(RangeFast, "range", DeviceType::HIP, RuntimeType::NATIVE, "fast");
 JST_REGISTER_MODULE(Spectrogram, "spectrogram", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Waterfall, "waterfall", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(RingSource, "ring_source", DeviceType::HIP, RuntimeType::NATIVE, "generic");

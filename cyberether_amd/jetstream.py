@@ -428,7 +428,9 @@ class SpectrumEngine:
     (AGC branch omitted: enableAgc defaults to false, spectrum_engine/block.hh:9)."""
 
     def __init__(self, buffer: Tensor, enable_scale: bool = True, range_min: float = -100.0,
-                 range_max: float = 0.0, name: str = "spectrum"):
+                 range_max: float = 0.0, name: str = "spectrum", provider: str = "generic"):
+        """provider: registry key of the amplitude/range implementations -- "generic" restates the
+        reference's libm arithmetic bit for bit, "fast" uses the hardware transcendentals."""
         axes = buffer.axes
         rank = len(buffer.shape)
         axis = axes["sample"] if axes["sample"] is not None else (0 if rank == 1 else None)
@@ -449,11 +451,12 @@ class SpectrumEngine:
         self.fft = Module("fft", {"forward": True}, {"signal": self.multiply.output("product")},
                           p + "fft")
         self.amplitude = Module("amplitude", {}, {"signal": self.fft.output("signal")},
-                                p + "amplitude")
+                                p + "amplitude", provider=provider)
         self.range = None
         if enable_scale:
             self.range = Module("range", {"min": range_min, "max": range_max},
-                                {"signal": self.amplitude.output("signal")}, p + "range")
+                                {"signal": self.amplitude.output("signal")}, p + "range",
+                                provider=provider)
             self.buffer = self.range.output("signal")
         else:
             self.buffer = self.amplitude.output("signal")
