@@ -390,6 +390,7 @@ double jst_runtime_unit_mean_ms(jst_runtime r, const char* prefix) {
         if (name.compare(0, std::strlen(prefix), prefix) == 0) return r->rt.unitMeanMs(name);
     return -1.0;
 }
+double jst_runtime_event_overhead_ms(jst_runtime r) { return r ? r->rt.eventPairOverheadMs() : -1.0; }
 jst_result jst_runtime_reset_timing(jst_runtime r) {
     JST_ARG(r, "null runtime");
     r->rt.resetTiming();

@@ -237,14 +237,25 @@ Result Runtime::planUnits() {
         u.modules = {m};
         u.submit = [m](hipStream_t s) { return m->computeSubmit(s); };
         u.is_static = is_static[i];
+        u.has_kernels = m->launchesKernels();
         units_.push_back(std::move(u));
         ++i;
+    }
+    // Event pairs go around the units that launch kernels, plus ONE kernel-less dynamic unit
+    // whose (empty) pair measures what the pair itself costs on this stream.
+    calibration_unit_.clear();
+    for (auto& u : units_) {
+        u.timed = u.has_kernels;
+        if (!u.has_kernels && !u.is_static && calibration_unit_.empty()) {
+            calibration_unit_ = u.name;
+            u.timed = true;
+        }
     }
     unit_names_.clear();
     for (auto& u : units_) {
         unit_names_.push_back(u.name);
         u.span.name = u.name;
-        if (flags_ & TIMING) {
+        if ((flags_ & TIMING) && u.timed) {
             u.span.begin.assign(period_, nullptr);
             u.span.end.assign(period_, nullptr);
             u.span.recorded.assign(period_, false);
@@ -457,6 +468,10 @@ F64 Runtime::unitMeanMs(const std::string& name) {
     for (auto& u : units_)
         if (u.name == name && u.span.count) return u.span.totalMs / (F64)u.span.count;
     return -1.0;
+}
+
+F64 Runtime::eventPairOverheadMs() {
+    return calibration_unit_.empty() ? -1.0 : unitMeanMs(calibration_unit_);
 }
 
 void Runtime::resetTiming() {

@@ -60,6 +60,8 @@ class Module {
     // Number of consecutive cycles after which this module's host-side state repeats (a ring
     // source with R slots: R).  The runtime captures that many cycles into one hipGraph.
     virtual U64 cyclePeriod() const { return 1; }
+    // False for view/bookkeeping modules whose computeSubmit enqueues nothing on the stream.
+    virtual bool launchesKernels() const { return true; }
     // Named internal state tensors (spectrogram/waterfall "frequencyBins"), for read-back.
     virtual const Tensor* state(const std::string&) const { return nullptr; }
 
@@ -153,6 +155,9 @@ class Runtime {
     bool graphActive() const { return graph_exec_ != nullptr; }
     // Mean device time (ms) of the named unit over the cycles run with TIMING; <0 if unknown.
     F64 unitMeanMs(const std::string& name);
+    // Mean duration of an EMPTY event pair recorded in the same graph/stream (one kernel-less
+    // unit keeps its pair for this purpose): the cost of the measurement itself.
+    F64 eventPairOverheadMs();
     void resetTiming();
 
  private:
@@ -161,6 +166,8 @@ class Runtime {
         std::vector<Module*> modules;      // 1 module, or the fused chain
         std::function<Result(hipStream_t)> submit;
         bool is_static = false;            // STATIC_OUTPUT with settled inputs: runs once
+        bool has_kernels = true;           // false: nothing reaches the stream
+        bool timed = true;                 // carries an event pair
         bool settled = false;
         KernelSpan span;
     };
@@ -181,6 +188,7 @@ class Runtime {
     U64 cycles_ = 0;
     U64 period_ = 1;
     U64 capture_phase_ = 0;
+    std::string calibration_unit_;
     bool timing_pending_ = false;
     bool created_ = false;
 };

@@ -2,18 +2,63 @@
 #include "fft_lds.hh"
 #include "kernels.hh"
 
+#include <cstdlib>
+
 namespace jst::kernels {
 
 using namespace jst::dev;
 
 namespace {
 
+// JST_FFT_KERNEL=slot selects the non-pipelined kernel (A/B comparisons, tests run both).
+inline bool use_pipe_kernel() {
+    const char* e = getenv("JST_FFT_KERNEL");
+    return !(e && e[0] == 's');
+}
 inline bool window_contig(const LoadCF32&) { return true; }
 inline bool window_contig(const LoadCF32TimesWindow& p) { return p.wstride == 1; }
+
+int compute_units() {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    return cus;
+}
+
+template <int N, bool FWD, class Pro, class Epi>
+hipError_t launch_pipe(const FftLayout& L, const float2* W, const Pro& pro, const Epi& epi,
+                       hipStream_t stream) {
+    constexpr size_t lds = fft_pipe_lds_bytes(N);
+    const bool contig = L.in_axis_stride == 1 && L.out_axis_stride == 1 && window_contig(pro);
+    auto kernel = contig ? fft_pipe_kernel<N, FWD, true, Pro, Epi> : fft_pipe_kernel<N, FWD, false, Pro, Epi>;
+    static bool raised[2] = {false, false};
+    if (lds > 64 * 1024 && !raised[contig]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised[contig] = true;
+    }
+    if (L.transforms == 0) return hipSuccess;
+    // Resident workgroups: LDS allows floor(160 KiB / lds) per CU.  Give every resident
+    // workgroup at least two transforms when there are enough (so the prefetch pipeline fills).
+    uint64_t per_cu = (160 * 1024) / lds > 0 ? (160 * 1024) / lds : 1;
+    if (per_cu > 2048 / (N / 8)) per_cu = 2048 / (N / 8);  // 32 waves per CU
+    const uint64_t resident = per_cu * (uint64_t)compute_units();
+    const uint64_t blocks = L.transforms < resident ? L.transforms : resident;
+    (void)hipGetLastError();  // drop any stale error: only this launch is judged
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(N / 8), lds, stream, L, W, pro, epi);
+    return hipGetLastError();
+}
 
 template <int N, bool FWD, class Pro, class Epi>
 hipError_t launch_one(const FftLayout& L, const float2* W, const Pro& pro, const Epi& epi,
                       hipStream_t stream) {
+    if constexpr (fft_pipe_supported(N)) {
+        if (use_pipe_kernel()) return launch_pipe<N, FWD, Pro, Epi>(L, W, pro, epi, stream);
+    }
     constexpr int TPB = fft_transforms_per_block(N);
     constexpr size_t lds = fft_lds_bytes(N);
     const bool contig = L.in_axis_stride == 1 && L.out_axis_stride == 1 && window_contig(pro);

@@ -67,10 +67,42 @@ constexpr Plan make_plan(int n) {
     return p;
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a full workgroup fence:
+// hipcc emits s_waitcnt vmcnt(0) in front of s_barrier, which would drain the in-flight
+// prefetch of the next transform (and the previous transform's output stores) at every
+// exchange.  The passes only communicate through LDS, so release/acquire on the local address
+// space is all that is needed: s_waitcnt lgkmcnt(0) + s_barrier.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // LDS physical index: one pad element per 8 keeps the stride-8 / stride-64 read patterns of the
 // ido = 1 and ido = 8 passes on distinct banks (see header comment).
 __device__ __forceinline__ int phys(int p) { return p + (p >> 3); }
 constexpr int lds_elems(int n) { return n + (n >> 3); }
+
+// Buffer-descriptor addressing for the dense (CONTIG) case: one 128-bit descriptor in SGPRs per
+// tensor row, a single 32-bit per-lane byte offset shared by all of a thread's accesses and a
+// wave-uniform (SGPR/immediate) offset per access.  With flat addressing hipcc materialises a
+// 64-bit VGPR address pair per access and carries them through the transform loop.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float2 buf_load_f2(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff_bytes, soff_bytes, 0));
+    return mk(v.x, v.y);
+}
+__device__ __forceinline__ void buf_store_f2(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, float2 v) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(v2u{f2u(v.x), f2u(v.y)}, r, voff_bytes, soff_bytes, 0);
+}
+__device__ __forceinline__ void buf_store_f1(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(f2u(v), r, voff_bytes, soff_bytes, 0);
+}
 
 // ---- prologues (how pass 0 obtains CC(i,b,k)) -------------------------------------------------
 // operator()(base, axis_stride, pos): element 'pos' along the transform axis of the transform
@@ -83,6 +115,19 @@ struct LoadCF32 {
         if constexpr (CONTIG) return (in + base)[(unsigned)pos];
         else return in[base + (int64_t)pos * axis_stride];
     }
+    // pipelined kernel: raw load (prefetchable), per-position operand (none), apply (identity)
+    // position = upos (wave-uniform) + lpos (per lane)
+    __device__ __forceinline__ const void* row(int64_t base) const { return in + base; }
+    __device__ __forceinline__ const void* operand_row() const { return in; }
+    template <bool CONTIG>
+    __device__ __forceinline__ float2 load_raw(int64_t base, int64_t axis_stride, int upos,
+                                               int lpos) const {
+        return in[base + (int64_t)(upos + lpos) * axis_stride];
+    }
+    static constexpr bool kHasOperand = false;
+    template <bool CONTIG>
+    __device__ __forceinline__ float2 load_operand(int, int) const { return mk(0.0f, 0.0f); }
+    __device__ __forceinline__ float2 apply(float2 v, float2) const { return v; }
 };
 // Multiply fused in: signal[...,n] * window[n] with the Multiply module's arithmetic
 // (core/multiply/module_impl_native_cpu.cc:94-100); window broadcast over every outer axis
@@ -100,11 +145,30 @@ struct LoadCF32TimesWindow {
                              window[(int64_t)pos * wstride]);
         }
     }
+    // pipelined kernel: raw load (prefetchable), then the window multiply (taps from L1/L2)
+    __device__ __forceinline__ const void* row(int64_t base) const { return in + base; }
+    __device__ __forceinline__ const void* operand_row() const { return window; }
+    template <bool CONTIG>
+    __device__ __forceinline__ float2 load_raw(int64_t base, int64_t axis_stride, int upos,
+                                               int lpos) const {
+        return in[base + (int64_t)(upos + lpos) * axis_stride];
+    }
+    static constexpr bool kHasOperand = true;
+    template <bool CONTIG>
+    __device__ __forceinline__ float2 load_operand(int upos, int lpos) const {
+        return window[(int64_t)(upos + lpos) * wstride];
+    }
+    __device__ __forceinline__ float2 apply(float2 v, float2 w) const { return cmul_full(v, w); }
 };
 
 // ---- epilogues (what happens to CH of the last pass) ------------------------------------------
 struct StoreCF32 {
     float2* out;
+    static constexpr uint32_t kElemBytes = 8;
+    __device__ __forceinline__ const void* row(int64_t base) const { return out + base; }
+    __device__ __forceinline__ void store_buf(rsrc_t r, uint32_t voff, uint32_t soff, float2 v) const {
+        buf_store_f2(r, voff, soff, v);
+    }
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
                                           float2 v) const {
@@ -116,6 +180,11 @@ template <bool FAST>
 struct StoreAmplitudeT {  // Amplitude module fused (amplitude/module_impl_native_cpu.cc:73-86)
     float* out;
     float coeff;
+    static constexpr uint32_t kElemBytes = 4;
+    __device__ __forceinline__ const void* row(int64_t base) const { return out + base; }
+    __device__ __forceinline__ void store_buf(rsrc_t r, uint32_t voff, uint32_t soff, float2 v) const {
+        buf_store_f1(r, voff, soff, FAST ? amplitude_cf32_fast(v, coeff) : amplitude_cf32(v, coeff));
+    }
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
                                           float2 v) const {
@@ -128,6 +197,13 @@ template <bool FAST>
 struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_native_cpu.cc:67-82)
     float* out;
     float coeff, scale, offset;
+    static constexpr uint32_t kElemBytes = 4;
+    __device__ __forceinline__ const void* row(int64_t base) const { return out + base; }
+    __device__ __forceinline__ void store_buf(rsrc_t r, uint32_t voff, uint32_t soff, float2 v) const {
+        buf_store_f1(r, voff, soff,
+                     FAST ? range_f32_fast(amplitude_cf32_fast(v, coeff), scale, offset)
+                          : range_f32(amplitude_cf32(v, coeff), scale, offset));
+    }
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
                                           float2 v) const {
@@ -180,7 +256,7 @@ __device__ __forceinline__ void run_passes(float2* lds, const float2* __restrict
             for (int b = 0; b < IP; ++b) x[j][b] = rd[cphys(IDO * b)];
         }
     }
-    if constexpr (!FIRST && !LAST) __syncthreads();  // all reads done before anyone overwrites
+    if constexpr (!FIRST && !LAST) lds_barrier();  // all reads done before anyone overwrites
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int u = tid + j * T;
@@ -210,9 +286,275 @@ __device__ __forceinline__ void run_passes(float2* lds, const float2* __restrict
         }
     }
     if constexpr (!LAST) {
-        __syncthreads();  // writes visible before the next pass reads
+        lds_barrier();  // writes visible before the next pass reads
         run_passes<N, T, FWD, CONTIG, P + 1, Pro, Epi>(lds, W, tid, active, in_base, in_as,
                                                        out_base, out_as, pro, epi);
+    }
+}
+
+// =============================================================================================
+// Pipelined variant (512 <= N <= 8192): one transform per workgroup at a time, T = N/8 threads
+// (4096-pt: 512 threads = 8 wavefronts, ONE radix-8 butterfly per thread per pass), persistent
+// over the transforms blockIdx.x, blockIdx.x + gridDim.x, ...
+//   * the raw input of the NEXT transform is prefetched into registers while the current one is
+//     computed (HBM latency and the whole load phase hide behind VALU work from the second
+//     transform on);
+//   * twiddles of every pass and the window taps of this thread's pass-0 positions are loaded
+//     once per workgroup and stay in VGPRs across transforms;
+//   * passes exchange through TWO LDS buffers used alternately: one barrier per exchange (the
+//     buffer being written is never the one other waves may still be reading), 3 barriers per
+//     4096-pt transform instead of 6;
+//   * 2 x 36 KiB LDS, <=128 VGPR -> 2 workgroups = 16 waves per CU.
+// Same arithmetic, same order as the slot kernel above (bit-identical results).
+// Timeline instrumentation for tools/ubench/fft_timeline.hip only (never defined in the product).
+#ifdef JST_FFT_TIMELINE
+__device__ unsigned long long* jst_tl_base;
+#define JST_STAMP(slot)                                                                   \
+    do {                                                                                  \
+        if (threadIdx.x == 0) jst_tl_base[blockIdx.x * 64 + tl_it * 16 + (slot)] = clock64(); \
+    } while (0)
+#define JST_TL_ARG , int tl_it
+#define JST_TL_PASS , tl_it
+#else
+#define JST_STAMP(slot) do {} while (0)
+#define JST_TL_ARG
+#define JST_TL_PASS
+#endif
+
+// Where pass P's twiddles live in the pipelined kernel: a pass whose table IDO*(IP-1) is small
+// (<= 512 entries: every pass but the first one or two) reads it from an LDS copy shared by the
+// workgroup; the large, lane-unique tables of the early passes are held in VGPRs.
+struct TwPlan {
+    int reg_off[8];   // first register slot of pass p (or -1)
+    int lds_off[8];   // first LDS table entry of pass p (or -1)
+    int regs;         // float2 registers per thread
+    int lds_entries;  // float2 entries in the LDS table
+};
+constexpr TwPlan make_twplan(int n) {
+    const Plan plan = make_plan(n);
+    TwPlan t{};
+    for (int p = 0; p < 8; ++p) t.reg_off[p] = t.lds_off[p] = -1;
+    for (int p = 0; p < plan.nf; ++p) {
+        if (plan.ido[p] <= 1) continue;
+        const int entries = plan.ido[p] * (plan.ip[p] - 1);
+        if (entries <= 512) {
+            t.lds_off[p] = t.lds_entries;
+            t.lds_entries += entries;
+        } else {
+            t.reg_off[p] = t.regs;
+            t.regs += (8 / plan.ip[p]) * (plan.ip[p] - 1);
+        }
+    }
+    return t;
+}
+
+template <int N, int T, bool FWD, bool CONTIG, int P, class Pro, class Epi>
+__device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2* buf1,
+                                            const float2 (&twr)[make_twplan(N).regs + 1],
+                                            const float2* twl, int tid, int64_t out_base,
+                                            int64_t out_as, const Epi& epi, const Pro& pro,
+                                            float2 (&opnd)[8], bool more, rsrc_t r_out,
+                                            rsrc_t r_opnd JST_TL_ARG) {
+    constexpr Plan plan = make_plan(N);
+    constexpr TwPlan tp = make_twplan(N);
+    constexpr int IP = plan.ip[P], IDO = plan.ido[P];
+    constexpr int BUT = N / IP;
+    constexpr int NB = 8 / IP;  // butterflies per thread (8 points per thread)
+    constexpr bool LAST = (P == plan.nf - 1);
+    static_assert(BUT == NB * T, "T must be N/8");
+    if constexpr (LAST && Pro::kHasOperand) {
+        // The per-position operand of the prologue (window taps) is not kept live across the
+        // passes: it is re-requested from L2 here and lands during the epilogue.
+        if (more) {
+            constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int u0 = tid + (e / IP0) * T;
+                const int l0 = (u0 & (IDO0 - 1)) + IDO0 * IP0 * (u0 / IDO0);
+                if constexpr (CONTIG)
+                    opnd[e] = buf_load_f2(r_opnd, (uint32_t)l0 * 8u, (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                else
+                    opnd[e] = pro.template load_operand<CONTIG>(IDO0 * (e % IP0), l0);
+            }
+        }
+    }
+    // x[] holds CC(i,b,k) for butterfly j at x[j*IP + b]
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int u = tid + j * T;
+        const unsigned i = (unsigned)(u & (IDO - 1));
+        float2 y[IP];
+#pragma unroll
+        for (int b = 0; b < IP; ++b) y[b] = x[j * IP + b];
+        butterfly<IP, FWD>(y);
+        if constexpr (IDO > 1) {
+#pragma unroll
+            for (int c = 1; c < IP; ++c) {
+                float2 w;
+                if constexpr (tp.reg_off[P] >= 0) w = twr[tp.reg_off[P] + j * (IP - 1) + (c - 1)];
+                else w = twl[tp.lds_off[P] + i * (IP - 1) + (c - 1)];
+                const float2 z = special_mul<FWD>(y[c], w);
+                y[c] = (i != 0u) ? z : y[c];
+            }
+        }
+        if constexpr (LAST) {
+#pragma unroll
+            for (int c = 0; c < IP; ++c) {
+                if constexpr (CONTIG)
+                    epi.store_buf(r_out, (uint32_t)u * Epi::kElemBytes,
+                                  (uint32_t)(c * BUT) * Epi::kElemBytes, y[c]);
+                else
+                    epi.template store<CONTIG>(out_base, out_as, u + c * BUT, y[c]);
+                // keep at most two epilogues in flight: interleaving all eight costs ~40 VGPRs
+                // of temporaries and pushes the prefetch registers into scratch
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            float2* wr = buf0 + phys(u);
+#pragma unroll
+            for (int c = 0; c < IP; ++c) wr[cphys(c * BUT)] = y[c];
+        }
+    }
+    JST_STAMP(2 + 2 * P);  // pass P computed, results issued to LDS / HBM
+    if constexpr (!LAST) {
+        lds_barrier();
+        JST_STAMP(3 + 2 * P);  // barrier passed
+        constexpr int IP2 = plan.ip[P + 1], IDO2 = plan.ido[P + 1];
+        constexpr int NB2 = 8 / IP2;
+#pragma unroll
+        for (int j = 0; j < NB2; ++j) {
+            const int u = tid + j * T;
+            const int i = u & (IDO2 - 1), k = u / IDO2;
+            const float2* rd = buf0 + phys(i + IDO2 * IP2 * k);
+#pragma unroll
+            for (int b = 0; b < IP2; ++b) x[j * IP2 + b] = rd[cphys(IDO2 * b)];
+        }
+        pipe_passes<N, T, FWD, CONTIG, P + 1, Pro, Epi>(x, buf1, buf0, twr, twl, tid, out_base,
+                                                        out_as, epi, pro, opnd, more, r_out,
+                                                        r_opnd JST_TL_PASS);
+    }
+}
+
+constexpr bool fft_pipe_supported(int n) { return n >= 512 && n <= 8192; }
+constexpr size_t fft_pipe_lds_bytes(int n) {
+    return (2 * (size_t)lds_elems(n) + (size_t)make_twplan(n).lds_entries) * sizeof(float2);
+}
+
+template <int N, bool FWD, bool CONTIG, class Pro, class Epi>
+__global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 256) void fft_pipe_kernel(
+    const FftLayout L, const float2* __restrict__ W, const Pro pro, const Epi epi) {
+    constexpr int T = N / 8;
+    constexpr Plan plan = make_plan(N);
+    constexpr TwPlan tp = make_twplan(N);
+    constexpr int NEX = plan.nf - 1;  // LDS exchanges per transform
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* bufA = reinterpret_cast<float2*>(smem_raw);
+    float2* bufB = bufA + lds_elems(N);
+    float2* twl = bufB + lds_elems(N);
+    const int tid = threadIdx.x;
+
+    // ---- per-workgroup constants ------------------------------------------------------------
+    float2 twr[tp.regs + 1];
+#pragma unroll
+    for (int p = 0; p < plan.nf; ++p) {
+        if (plan.ido[p] <= 1) continue;
+        if (tp.reg_off[p] >= 0) {
+#pragma unroll
+            for (int j = 0; j < 8 / plan.ip[p]; ++j) {
+                const unsigned i = (unsigned)((tid + j * T) & (plan.ido[p] - 1));
+#pragma unroll
+                for (int c = 1; c < plan.ip[p]; ++c)
+                    twr[tp.reg_off[p] + j * (plan.ip[p] - 1) + (c - 1)] =
+                        W[(unsigned)(c * plan.l1[p]) * i];
+            }
+        } else {
+            const int entries = plan.ido[p] * (plan.ip[p] - 1);
+            for (int e = tid; e < entries; e += T) {
+                const unsigned i = (unsigned)(e / (plan.ip[p] - 1)), c = (unsigned)(e % (plan.ip[p] - 1)) + 1u;
+                twl[tp.lds_off[p] + e] = W[c * (unsigned)plan.l1[p] * i];
+            }
+        }
+    }
+    if constexpr (tp.lds_entries > 0) lds_barrier();
+
+    // pass-0 element positions of this thread: pos0[j] + IDO0*b
+    constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0], NB0 = 8 / IP0;
+    int pos0[NB0];
+#pragma unroll
+    for (int j = 0; j < NB0; ++j) {
+        const int u = tid + j * T;
+        pos0[j] = (u & (IDO0 - 1)) + IDO0 * IP0 * (u / IDO0);
+    }
+
+    uint64_t t = blockIdx.x;
+    if (t >= L.transforms) return;
+    int64_t in_base, out_base;
+    fft_bases(L, t, in_base, out_base);
+    float2 raw[8], opnd[8];
+    const rsrc_t r_opnd = make_rsrc(pro.operand_row(), (uint32_t)N * 8u);
+    {
+        const rsrc_t r_in = make_rsrc(pro.row(in_base), (uint32_t)N * 8u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if constexpr (CONTIG) {
+                if constexpr (Pro::kHasOperand)
+                    opnd[e] = buf_load_f2(r_opnd, (uint32_t)pos0[e / IP0] * 8u,
+                                          (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                raw[e] = buf_load_f2(r_in, (uint32_t)pos0[e / IP0] * 8u,
+                                     (uint32_t)(IDO0 * (e % IP0)) * 8u);
+            } else {
+                opnd[e] = pro.template load_operand<CONTIG>(IDO0 * (e % IP0), pos0[e / IP0]);
+                raw[e] = pro.template load_raw<CONTIG>(in_base, L.in_axis_stride,
+                                                       IDO0 * (e % IP0), pos0[e / IP0]);
+            }
+        }
+    }
+
+    bool flip = false;
+#ifdef JST_FFT_TIMELINE
+    int tl_it = 0;
+    if (threadIdx.x == 0) jst_tl_base[blockIdx.x * 64 + 62] = wall_clock64();
+#endif
+    while (true) {
+        JST_STAMP(0);  // iteration start
+        float2 x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = pro.apply(raw[e], opnd[e]);
+        JST_STAMP(1);  // input arrived + prologue applied
+        // prefetch the next transform of this workgroup while this one is computed
+        const uint64_t tn = t + gridDim.x;
+        const bool more = tn < L.transforms;
+        int64_t nin = 0, nout = 0;
+        if (more) {
+            fft_bases(L, tn, nin, nout);
+            const rsrc_t r_in = make_rsrc(pro.row(nin), (uint32_t)N * 8u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if constexpr (CONTIG)
+                    raw[e] = buf_load_f2(r_in, (uint32_t)pos0[e / IP0] * 8u,
+                                         (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                else
+                    raw[e] = pro.template load_raw<CONTIG>(nin, L.in_axis_stride,
+                                                           IDO0 * (e % IP0), pos0[e / IP0]);
+            }
+        }
+        const rsrc_t r_out = make_rsrc(epi.row(out_base), (uint32_t)N * Epi::kElemBytes);
+        if (flip)
+            pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufB, bufA, twr, twl, tid, out_base,
+                                                        L.out_axis_stride, epi, pro, opnd,
+                                                        more, r_out, r_opnd JST_TL_PASS);
+        else
+            pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
+                                                        L.out_axis_stride, epi, pro, opnd,
+                                                        more, r_out, r_opnd JST_TL_PASS);
+#ifdef JST_FFT_TIMELINE
+        ++tl_it;
+        if (threadIdx.x == 0) jst_tl_base[blockIdx.x * 64 + 63] = wall_clock64();
+#endif
+        if (!more) break;
+        if constexpr (NEX & 1) flip = !flip;  // next transform starts on the buffer written longest ago
+        t = tn;
+        out_base = nout;
     }
 }
 
@@ -264,7 +606,7 @@ __global__ __launch_bounds__(fft_block_threads(N), 4) void fft_lds_kernel(
             run_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(lds, W, tid, active, in_base,
                                                        L.in_axis_stride, out_base,
                                                        L.out_axis_stride, pro, epi);
-            __syncthreads();  // LDS reuse by the next transform of this slot
+            lds_barrier();  // LDS reuse by the next transform of this slot
         }
     }
 }

@@ -44,26 +44,46 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     if (x < width) {
         const float* col = in + in_offset + (int64_t)x * elem_stride;
         constexpr uint32_t rows_per_iter = kThreads / TW;
-        for (uint32_t b = tid / TW; b < batches; b += rows_per_iter) {
-            const float f = col[(int64_t)b * batch_stride] * fh;
-            if (f >= 1.0f && f < fh) atomicAdd(&hist[(uint32_t)f * TW + c], 1u);
+        constexpr uint32_t kDepth = 16;  // loads in flight per thread: the reads are latency bound
+        for (uint32_t b0 = tid / TW; b0 < batches; b0 += rows_per_iter * kDepth) {
+            float v[kDepth];
+#pragma unroll
+            for (uint32_t j = 0; j < kDepth; ++j) {
+                const uint32_t b = b0 + j * rows_per_iter;
+                v[j] = (b < batches) ? col[(int64_t)b * batch_stride] : 0.0f;  // 0 never hits
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < kDepth; ++j) {
+                const float f = v[j] * fh;
+                if (f >= 1.0f && f < fh) atomicAdd(&hist[(uint32_t)f * TW + c], 1u);
+            }
         }
     }
     __syncthreads();
 
-    for (uint32_t e = tid; e < cells; e += kThreads) {
-        const uint32_t idx = e / TW;
-        const uint32_t xx = blockIdx.x * TW + (e % TW);
-        if (xx >= width) continue;
-        float* cell = bins + (uint64_t)idx * width + xx;
-        float v = *cell * decay;
-        uint32_t k = hist[e];
-        k = k < 64u ? k : 64u;  // 0.02 * 51 > 1: the value is pinned at 1.0f long before 64 hits
-        for (uint32_t n = 0; n < k; ++n) {
-            const float t = v + 0.02f;
-            v = (1.0f < t) ? 1.0f : t;  // std::min(val + 0.02f, 1.0f)
+    constexpr uint32_t kCells = 4;  // state cells in flight per thread
+    for (uint32_t e0 = tid; e0 < cells; e0 += kThreads * kCells) {
+        float v[kCells];
+        float* cell[kCells];
+#pragma unroll
+        for (uint32_t j = 0; j < kCells; ++j) {
+            const uint32_t e = e0 + j * kThreads;
+            const uint32_t xx = blockIdx.x * TW + (e % TW);
+            cell[j] = (e < cells && xx < width) ? bins + (uint64_t)(e / TW) * width + xx : nullptr;
+            v[j] = cell[j] ? *cell[j] : 0.0f;
         }
-        *cell = v;
+#pragma unroll
+        for (uint32_t j = 0; j < kCells; ++j) {
+            if (!cell[j]) continue;
+            float w = v[j] * decay;
+            uint32_t k = hist[e0 + j * kThreads];
+            k = k < 64u ? k : 64u;  // 0.02 * 51 > 1: the value is pinned at 1.0f long before 64 hits
+            for (uint32_t n = 0; n < k; ++n) {
+                const float t = w + 0.02f;
+                w = (1.0f < t) ? 1.0f : t;  // std::min(val + 0.02f, 1.0f)
+            }
+            *cell[j] = w;
+        }
     }
 }
 

@@ -54,6 +54,7 @@ class Reshape : public Module {
     Result define() override;
     Result create() override;
     Result computeSubmit(hipStream_t) override { return Result::SUCCESS; }
+    bool launchesKernels() const override { return false; }
     Shape target;
 };
 
@@ -65,6 +66,7 @@ class Cast : public Module {
     Result define() override;
     Result create() override;
     Result computeSubmit(hipStream_t) override { return Result::SUCCESS; }
+    bool launchesKernels() const override { return false; }
 };
 
 // src/domains/core/multiply/{module_impl.cc:10-132, module_impl_native_cpu.cc:86-100}
@@ -182,6 +184,7 @@ class RingSource : public Module {
     Result create() override;
     Result computeSubmit(hipStream_t stream) override;
     U64 cyclePeriod() const override { return slots; }
+    bool launchesKernels() const override { return false; }
     Tensor output;
     U64 batches = 8, samples = 2048, slots = 1, cursor = 0;
     bool first = true;

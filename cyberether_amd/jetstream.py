@@ -122,6 +122,7 @@ _sig("jst_runtime_graph_active", C.c_int, _h)
 _sig("jst_runtime_order", C.c_size_t, _h, C.c_char_p, C.c_size_t)
 _sig("jst_runtime_units", C.c_size_t, _h, C.c_char_p, C.c_size_t)
 _sig("jst_runtime_unit_mean_ms", C.c_double, _h, C.c_char_p)
+_sig("jst_runtime_event_overhead_ms", C.c_double, _h)
 _sig("jst_runtime_reset_timing", R, _h)
 _sig("jst_fft_twiddles", R, C.c_uint64, C.POINTER(C.c_float))
 _sig("jst_probe_tanhf", R, C.c_void_p, C.c_void_p, C.c_uint64)
@@ -417,6 +418,9 @@ class Runtime:
 
     def unit_mean_ms(self, prefix: str) -> float:
         return float(_lib.jst_runtime_unit_mean_ms(self._h, prefix.encode()))
+
+    def event_overhead_ms(self) -> float:
+        return float(_lib.jst_runtime_event_overhead_ms(self._h))
 
     def reset_timing(self):
         _check(_lib.jst_runtime_reset_timing(self._h))

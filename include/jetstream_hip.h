@@ -162,6 +162,9 @@ size_t jst_runtime_order(jst_runtime r, char* buffer, size_t capacity);
 size_t jst_runtime_units(jst_runtime r, char* buffer, size_t capacity);
 /* mean device milliseconds of a unit (prefix match on its name), JST_RUNTIME_TIMING only */
 double jst_runtime_unit_mean_ms(jst_runtime r, const char* unit_prefix);
+/* mean duration of an EMPTY hipEvent pair recorded in the same graph (cost of the measurement
+ * itself; < 0 when the runtime has no kernel-less dynamic unit to carry it) */
+double jst_runtime_event_overhead_ms(jst_runtime r);
 jst_result jst_runtime_reset_timing(jst_runtime r);
 
 /* ---- test/bench probes -------------------------------------------------------------------- */

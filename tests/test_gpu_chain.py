@@ -9,6 +9,13 @@ from util import assert_bit_equal, csignal
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["pipe", "slot"])
+def fft_kernel_variant(request, monkeypatch):
+    """Every test here runs against both FFT kernel variants (pipelined / slot), same bits."""
+    monkeypatch.setenv("JST_FFT_KERNEL", request.param)
+    yield
+
+
 def tone_batch(oracle, b, n, seed, sigma=1e-3):
     """SURVEY 8(d) C2 input: row r = CW tone at bin 100.25 + r (signal_generator arithmetic) +
     complex AWGN sigma from default_rng(seed)."""

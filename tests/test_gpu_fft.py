@@ -9,6 +9,13 @@ from util import assert_bit_equal, csignal, run_module
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["pipe", "slot"])
+def fft_kernel_variant(request, monkeypatch):
+    """Every test here runs against both FFT kernel variants (pipelined / slot), same bits."""
+    monkeypatch.setenv("JST_FFT_KERNEL", request.param)
+    yield
+
+
 @pytest.mark.parametrize("m", range(0, 15))
 @pytest.mark.parametrize("forward", [True, False])
 def test_c2c_bit_exact_all_sizes(js, oracle, m, forward):
