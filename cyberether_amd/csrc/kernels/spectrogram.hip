@@ -26,7 +26,12 @@ namespace {
 
 constexpr int kThreads = 1024;
 
-template <int TW>
+// COPIES: private copies of the tile histogram, one per group of 16 lanes of a wavefront.  The 64
+// lanes of one LDS-atomic instruction cover 4 consecutive batches x 16 columns, and a spectrum's
+// neighbouring batches tend to land in the SAME bin of a column (noise floor): with one copy
+// that is a 4-way same-address collision on nearly every instruction.  Copies are offset by 8
+// words so the four lanes of a column fall on different banks.
+template <int TW, int COPIES>
 __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     float* __restrict__ bins, const float* __restrict__ in, uint64_t in_offset, uint32_t batches,
     uint32_t width, uint32_t height, int64_t batch_stride, int64_t elem_stride, float decay) {
@@ -35,12 +40,28 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
 
     const uint32_t tid = threadIdx.x;
     const uint32_t cells = height * TW;
-    for (uint32_t e = tid; e < cells; e += kThreads) hist[e] = 0u;
+    const uint32_t copy_stride = cells + 8u;
+
+    // The state tile does not depend on this cycle's hits: request it first so that its HBM/L2
+    // round trip overlaps the whole accumulate phase (tiles up to kCells*1024 cells; larger
+    // tiles fetch the remainder late).
+    constexpr uint32_t kCells = 4;
+    float state[kCells];
+    float* cell[kCells];
+#pragma unroll
+    for (uint32_t j = 0; j < kCells; ++j) {
+        const uint32_t e = tid + j * kThreads;
+        const uint32_t xx = blockIdx.x * TW + (e % TW);
+        cell[j] = (e < cells && xx < width) ? bins + (uint64_t)(e / TW) * width + xx : nullptr;
+        state[j] = cell[j] ? *cell[j] : 0.0f;
+    }
+    for (uint32_t e = tid; e < copy_stride * COPIES; e += kThreads) hist[e] = 0u;
     __syncthreads();
 
     const uint32_t c = tid % TW;
     const uint32_t x = blockIdx.x * TW + c;
     const float fh = (float)height;
+    uint32_t* my_hist = hist + ((tid / TW) % COPIES) * copy_stride;
     if (x < width) {
         const float* col = in + in_offset + (int64_t)x * elem_stride;
         constexpr uint32_t rows_per_iter = kThreads / TW;
@@ -55,43 +76,44 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
 #pragma unroll
             for (uint32_t j = 0; j < kDepth; ++j) {
                 const float f = v[j] * fh;
-                if (f >= 1.0f && f < fh) atomicAdd(&hist[(uint32_t)f * TW + c], 1u);
+                if (f >= 1.0f && f < fh) atomicAdd(&my_hist[(uint32_t)f * TW + c], 1u);
             }
         }
     }
     __syncthreads();
 
-    constexpr uint32_t kCells = 4;  // state cells in flight per thread
-    for (uint32_t e0 = tid; e0 < cells; e0 += kThreads * kCells) {
-        float v[kCells];
-        float* cell[kCells];
+    auto apply = [&](float w, uint32_t e) {
+        w *= decay;
+        uint32_t k = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < kCells; ++j) {
-            const uint32_t e = e0 + j * kThreads;
-            const uint32_t xx = blockIdx.x * TW + (e % TW);
-            cell[j] = (e < cells && xx < width) ? bins + (uint64_t)(e / TW) * width + xx : nullptr;
-            v[j] = cell[j] ? *cell[j] : 0.0f;
+        for (int cp = 0; cp < COPIES; ++cp) k += hist[cp * copy_stride + e];
+        k = k < 64u ? k : 64u;  // 0.02 * 51 > 1: the value is pinned at 1.0f long before 64 hits
+        for (uint32_t n = 0; n < k; ++n) {
+            const float t = w + 0.02f;
+            w = (1.0f < t) ? 1.0f : t;  // std::min(val + 0.02f, 1.0f)
         }
+        return w;
+    };
 #pragma unroll
-        for (uint32_t j = 0; j < kCells; ++j) {
-            if (!cell[j]) continue;
-            float w = v[j] * decay;
-            uint32_t k = hist[e0 + j * kThreads];
-            k = k < 64u ? k : 64u;  // 0.02 * 51 > 1: the value is pinned at 1.0f long before 64 hits
-            for (uint32_t n = 0; n < k; ++n) {
-                const float t = w + 0.02f;
-                w = (1.0f < t) ? 1.0f : t;  // std::min(val + 0.02f, 1.0f)
-            }
-            *cell[j] = w;
-        }
+    for (uint32_t j = 0; j < kCells; ++j)
+        if (cell[j]) *cell[j] = apply(state[j], tid + j * kThreads);
+    for (uint32_t e = tid + kCells * kThreads; e < cells; e += kThreads) {  // height > 256
+        const uint32_t xx = blockIdx.x * TW + (e % TW);
+        if (xx >= width) continue;
+        float* p = bins + (uint64_t)(e / TW) * width + xx;
+        *p = apply(*p, e);
     }
 }
 
 }  // namespace
 
+namespace {
+int spectrogram_copies(uint64_t height) { return height <= 256 ? 4 : (height <= 512 ? 2 : 1); }
+}  // namespace
+
 size_t spectrogram_lds_bytes(uint64_t height) {
     const int tw = height <= 1024 ? 16 : 8;
-    return (size_t)height * tw * sizeof(uint32_t);
+    return ((size_t)height * tw + 8) * spectrogram_copies(height) * sizeof(uint32_t);
 }
 
 hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, uint64_t batches,
@@ -101,19 +123,27 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
     if (height > 2048 || batches > 0xffffffffull || width > 0xffffffffull)
         return hipErrorInvalidValue;
     const size_t lds = spectrogram_lds_bytes(height);
-    if (height <= 1024) {
-        const unsigned tiles = (unsigned)((width + 15) / 16);
-        (void)hipGetLastError();  // drop any stale error: only this launch is judged
-    hipLaunchKernelGGL(spectrogram_kernel<16>, dim3(tiles), dim3(kThreads), lds, stream, bins,
-                           in, in_offset, (uint32_t)batches, (uint32_t)width, (uint32_t)height,
-                           batch_stride, elem_stride, decay);
-    } else {
-        const unsigned tiles = (unsigned)((width + 7) / 8);
-        (void)hipGetLastError();  // drop any stale error: only this launch is judged
-    hipLaunchKernelGGL(spectrogram_kernel<8>, dim3(tiles), dim3(kThreads), lds, stream, bins,
-                           in, in_offset, (uint32_t)batches, (uint32_t)width, (uint32_t)height,
-                           batch_stride, elem_stride, decay);
-    }
+    const unsigned tiles16 = (unsigned)((width + 15) / 16), tiles8 = (unsigned)((width + 7) / 8);
+    (void)hipGetLastError();  // drop any stale error: only this launch is judged
+#define JST_SPEC_LAUNCH(TW, COPIES, TILES)                                                        \
+    do {                                                                                          \
+        static bool raised = false;                                                               \
+        if (!raised) { /* the padded copies can exceed the 64 KiB default by a few words */       \
+            const hipError_t e = hipFuncSetAttribute(                                             \
+                reinterpret_cast<const void*>(spectrogram_kernel<TW, COPIES>),                    \
+                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                           \
+            if (e != hipSuccess) return e;                                                        \
+            raised = true;                                                                        \
+        }                                                                                         \
+        hipLaunchKernelGGL((spectrogram_kernel<TW, COPIES>), dim3(TILES), dim3(kThreads), lds,    \
+                           stream, bins, in, in_offset, (uint32_t)batches, (uint32_t)width,       \
+                           (uint32_t)height, batch_stride, elem_stride, decay);                   \
+    } while (0)
+    if (height <= 256) JST_SPEC_LAUNCH(16, 4, tiles16);
+    else if (height <= 512) JST_SPEC_LAUNCH(16, 2, tiles16);
+    else if (height <= 1024) JST_SPEC_LAUNCH(16, 1, tiles16);
+    else JST_SPEC_LAUNCH(8, 1, tiles8);
+#undef JST_SPEC_LAUNCH
     return hipGetLastError();
 }
 
