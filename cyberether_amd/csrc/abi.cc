@@ -221,6 +221,16 @@ jst_result jst_tensor_set_attribute_f64(jst_tensor t, const char* key, double va
     JST_ARG(t && key, "null argument");
     return R(t->t.setAttribute(key, AttrValue{F64{value}}));
 }
+jst_result jst_tensor_set_attribute_u64v(jst_tensor t, const char* key, const uint64_t* values,
+                                         uint64_t count) {
+    JST_ARG(t && key && (values || count == 0), "null argument");
+    return R(t->t.setAttribute(key, AttrValue{std::vector<U64>(values, values + count)}));
+}
+jst_result jst_tensor_set_attribute_f64v(jst_tensor t, const char* key, const double* values,
+                                         uint64_t count) {
+    JST_ARG(t && key && (values || count == 0), "null argument");
+    return R(t->t.setAttribute(key, AttrValue{std::vector<F64>(values, values + count)}));
+}
 jst_result jst_tensor_remove_attribute(jst_tensor t, const char* key) {
     JST_ARG(t && key, "null argument");
     return R(t->t.removeAttribute(key));

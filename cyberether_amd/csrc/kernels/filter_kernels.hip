@@ -1,0 +1,515 @@
+// filter_kernels.hip -- the modules of the Filter (FFT overlap-add) and FM side chains that are not
+// plain elementwise maps: Pad, Unpad, Fold, OverlapAdd, PhaseCorrection, FilterTaps, Arithmetic
+// (axis reduction) and FM.  The reference has CPU implementations only for all of them
+// (SURVEY 2b); every kernel restates the CPU arithmetic in the CPU's order (F64 where the CPU
+// uses F64) so results are bit-identical, except FM whose libm atan2f/sinf/cosf are replaced by
+// the device's (tolerance stated in the tests; the reference's own FM tests use 1e-2).
+#include "device_math.hh"
+#include "kernels.hh"
+
+namespace jst::kernels {
+
+using namespace jst::dev;
+
+namespace {
+constexpr int kBlock = 256;
+inline unsigned grid_for(uint64_t n) {
+    const uint64_t need = (n + kBlock - 1) / kBlock;
+    return (unsigned)(need < 4096 ? (need ? need : 1) : 4096);
+}
+#define JST_GRID_STRIDE(i, n)                                               \
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < (n); \
+         i += (uint64_t)gridDim.x * kBlock)
+
+// ---- Pad / Unpad (core/pad/module_impl_native_cpu.cc:75-140, core/unpad/...:66-135) ----------
+// dense [outer, axis, inner]; T is float (F32) or float2 (CF32)
+template <class T>
+__global__ __launch_bounds__(kBlock) void pad_kernel(T* __restrict__ out, const T* __restrict__ in,
+                                                     uint64_t outer, uint64_t in_axis,
+                                                     uint64_t out_axis, uint64_t inner) {
+    const uint64_t total = outer * out_axis * inner;
+    JST_GRID_STRIDE(e, total) {
+        const uint64_t i = e % inner, a = (e / inner) % out_axis, o = e / (inner * out_axis);
+        T v{};
+        if (a < in_axis) v = in[(o * in_axis + a) * inner + i];
+        out[e] = v;
+    }
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void unpad_kernel(T* __restrict__ body, T* __restrict__ tail,
+                                                       const T* __restrict__ in, uint64_t outer,
+                                                       uint64_t in_axis, uint64_t body_axis,
+                                                       uint64_t inner) {
+    const uint64_t total = outer * in_axis * inner, tail_axis = in_axis - body_axis;
+    JST_GRID_STRIDE(e, total) {
+        const uint64_t i = e % inner, a = (e / inner) % in_axis, o = e / (inner * in_axis);
+        if (a < body_axis) body[(o * body_axis + a) * inner + i] = in[e];
+        else tail[(o * tail_axis + (a - body_axis)) * inner + i] = in[e];
+    }
+}
+
+// ---- Fold (dsp/fold/module_impl_native_cpu.cc:103-172) ---------------------------------------
+// dense [outer, axis, inner]; channel coordinate = (flat / chan_inner) % chan_count of the OUTPUT.
+template <bool COMPLEX>
+__global__ __launch_bounds__(kBlock) void fold_kernel(float* __restrict__ out,
+                                                      const float* __restrict__ in, uint64_t outer,
+                                                      uint64_t axis_size, uint64_t fold_size,
+                                                      uint64_t inner, uint64_t scalar_offset,
+                                                      const uint64_t* __restrict__ chan_offsets,
+                                                      uint64_t chan_count, uint64_t chan_inner) {
+    const uint64_t decim = axis_size / fold_size, total = outer * fold_size * inner;
+    const double divisor = (double)decim;
+    JST_GRID_STRIDE(e, total) {
+        const uint64_t i = e % inner, k = (e / inner) % fold_size, o = e / (inner * fold_size);
+        const uint64_t off = chan_offsets ? chan_offsets[(e / chan_inner) % chan_count] % axis_size
+                                          : scalar_offset;
+        double sr = 0.0, si = 0.0;
+        for (uint64_t g = 0; g < decim; ++g) {
+            const uint64_t shifted = k + g * fold_size;
+            const uint64_t ia = shifted >= off ? shifted - off : axis_size - (off - shifted);
+            const uint64_t idx = (o * axis_size + ia) * inner + i;
+            if constexpr (COMPLEX) {
+                sr += (double)in[2 * idx];
+                si += (double)in[2 * idx + 1];
+            } else {
+                sr += (double)in[idx];
+            }
+        }
+        if constexpr (COMPLEX) {
+            out[2 * e] = (float)(sr / divisor);
+            out[2 * e + 1] = (float)(si / divisor);
+        } else {
+            out[e] = (float)(sr / divisor);
+        }
+    }
+}
+
+// ---- OverlapAdd (dsp/overlap_add/module_impl_native_cpu.cc:121-202) --------------------------
+struct OlaLayout {
+    uint32_t rank;
+    int32_t batch_axis;  // -1: none
+    uint64_t buf_shape[kMaxRank], ovl_shape[kMaxRank];
+};
+template <class T>
+__device__ __forceinline__ T add_t(T a, T b) {
+    if constexpr (sizeof(T) == 8) return mk(a.x + b.x, a.y + b.y);
+    else return a + b;
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void overlap_add_kernel(T* __restrict__ out,
+                                                             const T* __restrict__ buf,
+                                                             const T* __restrict__ ovl,
+                                                             const T* __restrict__ prev,
+                                                             const OlaLayout L, uint64_t total) {
+    JST_GRID_STRIDE(e, total) {
+        uint64_t c[kMaxRank], rem = e;  // coordinates of e in the buffer
+        for (int d = (int)L.rank - 1; d >= 0; --d) {
+            c[d] = rem % L.buf_shape[d];
+            rem /= L.buf_shape[d];
+        }
+        T v = buf[e];
+        bool inside = true;
+        for (uint32_t d = 0; d < L.rank; ++d) inside = inside && (c[d] < L.ovl_shape[d]);
+        if (inside) {
+            const bool first = L.batch_axis < 0 || c[L.batch_axis] == 0;
+            uint64_t idx = 0;
+            if (first) {  // previous-overlap state: overlap shape with batch extent 1
+                for (uint32_t d = 0; d < L.rank; ++d) {
+                    const bool is_batch = (int)d == L.batch_axis;
+                    idx = idx * (is_batch ? 1 : L.ovl_shape[d]) + (is_batch ? 0 : c[d]);
+                }
+                v = add_t(v, prev[idx]);
+            } else {
+                for (uint32_t d = 0; d < L.rank; ++d)
+                    idx = idx * L.ovl_shape[d] + (((int)d == L.batch_axis) ? c[d] - 1 : c[d]);
+                v = add_t(v, ovl[idx]);
+            }
+        }
+        out[e] = v;
+    }
+}
+template <class T>
+__global__ __launch_bounds__(kBlock) void overlap_state_kernel(T* __restrict__ prev,
+                                                               const T* __restrict__ ovl,
+                                                               const OlaLayout L, uint64_t total) {
+    JST_GRID_STRIDE(e, total) {  // e indexes prev (overlap shape with batch extent 1)
+        uint64_t c[kMaxRank], rem = e;
+        for (int d = (int)L.rank - 1; d >= 0; --d) {
+            const uint64_t ext = (d == L.batch_axis) ? 1 : L.ovl_shape[d];
+            c[d] = rem % ext;
+            rem /= ext;
+        }
+        if (L.batch_axis >= 0) c[L.batch_axis] = L.ovl_shape[L.batch_axis] - 1;
+        uint64_t idx = 0;
+        for (uint32_t d = 0; d < L.rank; ++d) idx = idx * L.ovl_shape[d] + c[d];
+        prev[e] = ovl[idx];
+    }
+}
+
+// ---- PhaseCorrection (dsp/phase_correction/module_impl_native_cpu.cc:60-115) -----------------
+__global__ void phase_table_kernel(float2* __restrict__ corr, double* __restrict__ phases,
+                                   const double* __restrict__ increments, uint64_t channels,
+                                   uint64_t batches) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= channels) return;
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    const double wrapped = remainder(increments[c], two_pi);
+    const double ph0 = phases[c];
+    for (uint64_t b = 0; b < batches; ++b) {
+        const double ph = ph0 + wrapped * (double)b;
+        corr[c * batches + b] = mk((float)cos(ph), (float)sin(ph));
+    }
+    phases[c] = remainder(ph0 + wrapped * (double)batches, two_pi);
+}
+__global__ __launch_bounds__(kBlock) void phase_mul_kernel(const EwLayout L, float2* __restrict__ out,
+                                                           const float2* __restrict__ in,
+                                                           const float2* __restrict__ corr,
+                                                           uint64_t batches, uint64_t batch_inner,
+                                                           uint64_t channels, uint64_t channel_inner) {
+    JST_GRID_STRIDE(idx, L.size) {
+        int64_t o0 = (int64_t)L.offset[0], o1 = (int64_t)L.offset[1];
+        if (L.contiguous) {
+            o0 += (int64_t)idx;
+            o1 += (int64_t)idx;
+        } else {
+            uint64_t rem = idx;
+            for (int a = L.rank - 1; a >= 0; --a) {
+                const uint64_t c = rem % L.shape[a];
+                rem /= L.shape[a];
+                o0 += (int64_t)c * L.stride[0][a];
+                o1 += (int64_t)c * L.stride[1][a];
+            }
+        }
+        const uint64_t b = batches == 1 ? 0 : (idx / batch_inner) % batches;
+        const uint64_t c = channels == 1 ? 0 : (idx / channel_inner) % channels;
+        out[o0] = cmul_full(in[o1], corr[c * batches + b]);
+    }
+}
+
+// ---- FilterTaps (dsp/filter_taps/module_impl_native_cpu.cc:46-80) ----------------------------
+__global__ void filter_taps_kernel(float2* __restrict__ out, double sample_rate, double bandwidth,
+                                   const double* __restrict__ center, uint64_t heads,
+                                   uint64_t taps) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= heads * taps) return;
+    const double pi = 3.14159265358979323846;
+    const uint64_t c = e / taps, i = e % taps;
+    const double filter_width = (bandwidth / sample_rate) / 2.0;
+    const double filter_offset = center[c] / sample_rate;
+    const double fi = (double)i, half = (double)(taps - 1) / 2.0, n = fi - half;
+    const double sinc =
+        (n == 0.0) ? (2.0 * filter_width) : sin(2.0 * pi * filter_width * n) / (pi * n);
+    const double win = (taps == 1) ? 1.0
+                                   : 0.42 - 0.50 * cos(2.0 * pi * fi / (double)(taps - 1)) +
+                                         0.08 * cos(4.0 * pi * fi / (double)(taps - 1));
+    const double theta = ((2.0 * pi) * n) * filter_offset;
+    const double sw = sinc * win;
+    out[e] = mk((float)(sw * cos(theta)), (float)(sw * sin(theta)));
+}
+
+// ---- Arithmetic (core/arithmetic/module_impl_native_cpu.cc:98-146) ---------------------------
+// L: operand 0 = output, operand 1 = input, both indexed over the OUTPUT shape (reduced axis has
+// extent 1); the reduced axis is walked with (r, r_stride) in increasing order from +0.
+template <class T, int OP>
+__global__ __launch_bounds__(kBlock) void arithmetic_kernel(const EwLayout L, T* __restrict__ out,
+                                                            const T* __restrict__ in, uint64_t r,
+                                                            int64_t r_stride) {
+    JST_GRID_STRIDE(idx, L.size) {
+        int64_t o0 = (int64_t)L.offset[0], o1 = (int64_t)L.offset[1];
+        uint64_t rem = idx;
+        for (int a = L.rank - 1; a >= 0; --a) {
+            const uint64_t c = rem % L.shape[a];
+            rem /= L.shape[a];
+            o0 += (int64_t)c * L.stride[0][a];
+            o1 += (int64_t)c * L.stride[1][a];
+        }
+        T acc{};  // zeroKernel(): the output starts at +0
+        for (uint64_t k = 0; k < r; ++k) {
+            const T v = in[o1 + (int64_t)k * r_stride];
+            if constexpr (sizeof(T) == 8) {
+                if (OP == 0) acc = mk(acc.x + v.x, acc.y + v.y);
+                else if (OP == 1) acc = mk(acc.x - v.x, acc.y - v.y);
+                else acc = cmul_full(acc, v);
+            } else {
+                if (OP == 0) acc = acc + v;
+                else if (OP == 1) acc = acc - v;
+                else if (OP == 2) acc = acc * v;
+                else acc = acc / v;
+            }
+        }
+        out[o0] = acc;
+    }
+}
+
+// ---- FM (dsp/fm/module_impl_native_cpu.cc:43-174) ---------------------------------------------
+// One thread per lane walks its batches x samples in order (the stereo decoder and the
+// de-emphasis are recursive filters: the lane is the only parallel dimension the reference's
+// algorithm offers).  Narrow FM without de-emphasis has no recursion: one thread per SAMPLE.
+struct FmState {
+    float prev_re, prev_im;
+    int has_prev;
+    float narrow_deemph;
+    float pilot_phase, pilot_cos_stage, pilot_sin_stage, pilot_cos, pilot_sin, left_de, right_de;
+    float sum_notch[2], diff_notch[2], sum_filter[3][2], diff_filter[3][2];
+};
+__device__ __forceinline__ float fm_biquad(float x, const float* c /*b0 b1 b2 a1 a2*/, float* s) {
+    const float y = c[0] * x + s[0];
+    s[0] = c[1] * x - c[3] * y + s[1];
+    s[1] = c[2] * x - c[4] * y;
+    return y;
+}
+__device__ __forceinline__ float fm_lowpass(float x, const FmCoeffs& k, float (*s)[2]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x = fm_biquad(x, k.lp[i], s[i]);
+    return x;
+}
+__device__ __forceinline__ void fm_lane_offsets(const FmLayout& L, uint64_t lane, int64_t& in_off,
+                                                int64_t& out_off) {
+    in_off = (int64_t)L.in_offset;
+    out_off = (int64_t)L.out_offset;
+    for (int a = L.lane_rank - 1; a >= 0; --a) {
+        const uint64_t c = lane % L.lane_shape[a];
+        lane /= L.lane_shape[a];
+        in_off += (int64_t)c * L.in_lane_stride[a];
+        out_off += (int64_t)c * L.out_lane_stride[a];
+    }
+}
+__device__ __forceinline__ float fm_discriminate(float2 prev, float2 cur, bool has, float ref) {
+    const bool fin = __builtin_isfinite(cur.x) && __builtin_isfinite(cur.y) &&
+                     __builtin_isfinite(prev.x) && __builtin_isfinite(prev.y);
+    if (!has) return 0.0f;
+    if (!fin) return __builtin_nanf("");
+    const float2 p = cmul_full(mk(prev.x, -prev.y), cur);  // conj(previous) * current
+    return atan2f(p.y, p.x) * ref;
+}
+__global__ __launch_bounds__(64) void fm_kernel(float* __restrict__ out, const float2* __restrict__ in,
+                                                FmState* __restrict__ states, const FmCoeffs k,
+                                                const FmLayout L) {
+    const uint64_t lane = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (lane >= L.lanes) return;
+    int64_t in_off, out_off;
+    fm_lane_offsets(L, lane, in_off, out_off);
+    FmState st = states[lane];
+    const double two_pi = 2.0f * 3.14159265358979323846;  // F32 op F64 like the reference
+    float2 prev = mk(st.prev_re, st.prev_im);
+    bool has = st.has_prev != 0;
+    for (uint64_t b = 0; b < L.batches; ++b) {
+        for (uint64_t s = 0; s < L.samples; ++s) {
+            const float2 cur =
+                in[in_off + (int64_t)b * L.in_batch_stride + (int64_t)s * L.in_sample_stride];
+            const int64_t oo =
+                out_off + (int64_t)b * L.out_batch_stride + (int64_t)s * L.out_sample_stride;
+            const float d = fm_discriminate(prev, cur, has, k.ref);
+            if (!__builtin_isfinite(d)) {
+                out[oo] = d;
+                if (k.wide) {
+                    out[oo + L.out_channel_stride] = d;
+                    st.pilot_phase += k.pilot_inc;
+                    if ((double)st.pilot_phase >= two_pi)
+                        st.pilot_phase = (float)((double)st.pilot_phase - two_pi);
+                }
+            } else if (!k.wide) {
+                if (!k.deemph_enabled) out[oo] = d;
+                else {
+                    st.narrow_deemph += k.deemph_alpha * (d - st.narrow_deemph);
+                    out[oo] = st.narrow_deemph;
+                }
+            } else {
+                const float pc = cosf(st.pilot_phase), ps = sinf(st.pilot_phase);
+                st.pilot_cos_stage += k.pilot_alpha * (d * pc - st.pilot_cos_stage);
+                st.pilot_sin_stage += k.pilot_alpha * (d * ps - st.pilot_sin_stage);
+                st.pilot_cos += k.pilot_alpha * (st.pilot_cos_stage - st.pilot_cos);
+                st.pilot_sin += k.pilot_alpha * (st.pilot_sin_stage - st.pilot_sin);
+                const float sum = fm_lowpass(fm_biquad(d, k.notch, st.sum_notch), k, st.sum_filter);
+                const float po = atan2f(st.pilot_cos, st.pilot_sin);
+                const float carrier = sinf(2.0f * (st.pilot_phase + po));
+                const float diff = fm_lowpass(
+                    fm_biquad(2.0f * d * carrier, k.notch, st.diff_notch), k, st.diff_filter);
+                float left = sum + diff, right = sum - diff;
+                if (k.deemph_enabled) {
+                    st.left_de += k.deemph_alpha * (left - st.left_de);
+                    st.right_de += k.deemph_alpha * (right - st.right_de);
+                    left = st.left_de;
+                    right = st.right_de;
+                }
+                out[oo] = left;
+                out[oo + L.out_channel_stride] = right;
+                st.pilot_phase += k.pilot_inc;
+                if ((double)st.pilot_phase >= two_pi)
+                    st.pilot_phase = (float)((double)st.pilot_phase - two_pi);
+            }
+            prev = cur;
+            has = true;
+        }
+    }
+    st.prev_re = prev.x;
+    st.prev_im = prev.y;
+    st.has_prev = 1;
+    states[lane] = st;
+}
+__global__ __launch_bounds__(kBlock) void fm_narrow_parallel_kernel(
+    float* __restrict__ out, const float2* __restrict__ in, const FmState* __restrict__ states,
+    const FmCoeffs k, const FmLayout L) {
+    const uint64_t per_lane = L.batches * L.samples, total = L.lanes * per_lane;
+    JST_GRID_STRIDE(e, total) {
+        const uint64_t lane = e / per_lane, n = e % per_lane, b = n / L.samples, s = n % L.samples;
+        int64_t in_off, out_off;
+        fm_lane_offsets(L, lane, in_off, out_off);
+        const float2 cur =
+            in[in_off + (int64_t)b * L.in_batch_stride + (int64_t)s * L.in_sample_stride];
+        float2 prev;
+        bool has = true;
+        if (n == 0) {
+            prev = mk(states[lane].prev_re, states[lane].prev_im);
+            has = states[lane].has_prev != 0;
+        } else {
+            const uint64_t pb = (n - 1) / L.samples, ps = (n - 1) % L.samples;
+            prev = in[in_off + (int64_t)pb * L.in_batch_stride + (int64_t)ps * L.in_sample_stride];
+        }
+        out[out_off + (int64_t)b * L.out_batch_stride + (int64_t)s * L.out_sample_stride] =
+            fm_discriminate(prev, cur, has, k.ref);
+    }
+}
+__global__ void fm_narrow_state_kernel(const float2* __restrict__ in, FmState* __restrict__ states,
+                                       const FmLayout L) {
+    const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= L.lanes) return;
+    int64_t in_off, out_off;
+    fm_lane_offsets(L, lane, in_off, out_off);
+    const float2 last = in[in_off + (int64_t)(L.batches - 1) * L.in_batch_stride +
+                           (int64_t)(L.samples - 1) * L.in_sample_stride];
+    states[lane].prev_re = last.x;
+    states[lane].prev_im = last.y;
+    states[lane].has_prev = 1;
+}
+
+}  // namespace
+
+size_t fm_state_bytes() { return sizeof(FmState); }
+
+hipError_t launch_pad(void* out, const void* in, bool complex, uint64_t outer, uint64_t in_axis,
+                      uint64_t out_axis, uint64_t inner, hipStream_t s) {
+    const uint64_t total = outer * out_axis * inner;
+    (void)hipGetLastError();
+    if (complex)
+        hipLaunchKernelGGL(pad_kernel<float2>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                           (float2*)out, (const float2*)in, outer, in_axis, out_axis, inner);
+    else
+        hipLaunchKernelGGL(pad_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                           (float*)out, (const float*)in, outer, in_axis, out_axis, inner);
+    return hipGetLastError();
+}
+hipError_t launch_unpad(void* body, void* tail, const void* in, bool complex, uint64_t outer,
+                        uint64_t in_axis, uint64_t body_axis, uint64_t inner, hipStream_t s) {
+    const uint64_t total = outer * in_axis * inner;
+    (void)hipGetLastError();
+    if (complex)
+        hipLaunchKernelGGL(unpad_kernel<float2>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                           (float2*)body, (float2*)tail, (const float2*)in, outer, in_axis,
+                           body_axis, inner);
+    else
+        hipLaunchKernelGGL(unpad_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                           (float*)body, (float*)tail, (const float*)in, outer, in_axis, body_axis,
+                           inner);
+    return hipGetLastError();
+}
+hipError_t launch_fold(float* out, const float* in, bool complex, uint64_t outer, uint64_t axis_size,
+                       uint64_t fold_size, uint64_t inner, uint64_t scalar_offset,
+                       const uint64_t* chan_offsets, uint64_t chan_count, uint64_t chan_inner,
+                       hipStream_t s) {
+    const uint64_t total = outer * fold_size * inner;
+    (void)hipGetLastError();
+    if (complex)
+        hipLaunchKernelGGL(fold_kernel<true>, dim3(grid_for(total)), dim3(kBlock), 0, s, out, in,
+                           outer, axis_size, fold_size, inner, scalar_offset, chan_offsets,
+                           chan_count, chan_inner);
+    else
+        hipLaunchKernelGGL(fold_kernel<false>, dim3(grid_for(total)), dim3(kBlock), 0, s, out, in,
+                           outer, axis_size, fold_size, inner, scalar_offset, chan_offsets,
+                           chan_count, chan_inner);
+    return hipGetLastError();
+}
+hipError_t launch_overlap_add(void* out, const void* buf, const void* ovl, void* prev, bool complex,
+                              uint32_t rank, int32_t batch_axis, const uint64_t* buf_shape,
+                              const uint64_t* ovl_shape, hipStream_t s) {
+    OlaLayout L{};
+    L.rank = rank;
+    L.batch_axis = batch_axis;
+    uint64_t total = 1, prev_total = 1;
+    for (uint32_t d = 0; d < rank; ++d) {
+        L.buf_shape[d] = buf_shape[d];
+        L.ovl_shape[d] = ovl_shape[d];
+        total *= buf_shape[d];
+        prev_total *= ((int32_t)d == batch_axis) ? 1 : ovl_shape[d];
+    }
+    (void)hipGetLastError();
+    if (complex) {
+        hipLaunchKernelGGL(overlap_add_kernel<float2>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                           (float2*)out, (const float2*)buf, (const float2*)ovl,
+                           (const float2*)prev, L, total);
+        hipLaunchKernelGGL(overlap_state_kernel<float2>, dim3(grid_for(prev_total)), dim3(kBlock),
+                           0, s, (float2*)prev, (const float2*)ovl, L, prev_total);
+    } else {
+        hipLaunchKernelGGL(overlap_add_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                           (float*)out, (const float*)buf, (const float*)ovl, (const float*)prev, L,
+                           total);
+        hipLaunchKernelGGL(overlap_state_kernel<float>, dim3(grid_for(prev_total)), dim3(kBlock), 0,
+                           s, (float*)prev, (const float*)ovl, L, prev_total);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_phase_correction(const EwLayout& L, float2* out, const float2* in, float2* corr,
+                                   double* phases, const double* increments, uint64_t batches,
+                                   uint64_t batch_inner, uint64_t channels, uint64_t channel_inner,
+                                   hipStream_t s) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((channels + 63) / 64)), dim3(64), 0, s,
+                       corr, phases, increments, channels, batches);
+    hipLaunchKernelGGL(phase_mul_kernel, dim3(grid_for(L.size)), dim3(kBlock), 0, s, L, out, in,
+                       (const float2*)corr, batches, batch_inner, channels, channel_inner);
+    return hipGetLastError();
+}
+hipError_t launch_filter_taps(float2* out, double sample_rate, double bandwidth, const double* center,
+                              uint64_t heads, uint64_t taps, hipStream_t s) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(filter_taps_kernel, dim3((unsigned)((heads * taps + 255) / 256)), dim3(256),
+                       0, s, out, sample_rate, bandwidth, center, heads, taps);
+    return hipGetLastError();
+}
+hipError_t launch_arithmetic(const EwLayout& L, void* out, const void* in, bool complex, int op,
+                             uint64_t r, int64_t r_stride, hipStream_t s) {
+    (void)hipGetLastError();
+#define JST_ARITH(T, OP)                                                                       \
+    hipLaunchKernelGGL((arithmetic_kernel<T, OP>), dim3(grid_for(L.size)), dim3(kBlock), 0, s, \
+                       L, (T*)out, (const T*)in, r, r_stride)
+    if (complex) {
+        if (op == 0) JST_ARITH(float2, 0);
+        else if (op == 1) JST_ARITH(float2, 1);
+        else if (op == 2) JST_ARITH(float2, 2);
+        else return hipErrorInvalidValue;
+    } else {
+        if (op == 0) JST_ARITH(float, 0);
+        else if (op == 1) JST_ARITH(float, 1);
+        else if (op == 2) JST_ARITH(float, 2);
+        else JST_ARITH(float, 3);
+    }
+#undef JST_ARITH
+    return hipGetLastError();
+}
+hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
+                     hipStream_t s) {
+    (void)hipGetLastError();
+    if (!k.wide && !k.deemph_enabled) {
+        const uint64_t total = L.lanes * L.batches * L.samples;
+        hipLaunchKernelGGL(fm_narrow_parallel_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, out,
+                           in, (const FmState*)states, k, L);
+        hipLaunchKernelGGL(fm_narrow_state_kernel, dim3((unsigned)((L.lanes + 63) / 64)), dim3(64),
+                           0, s, in, (FmState*)states, L);
+    } else {
+        hipLaunchKernelGGL(fm_kernel, dim3((unsigned)((L.lanes + 63) / 64)), dim3(64), 0, s, out, in,
+                           (FmState*)states, k, L);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace jst::kernels

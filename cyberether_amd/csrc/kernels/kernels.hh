@@ -37,9 +37,29 @@ struct EwLayout {
     uint64_t offset[3];
 };
 
+// FM demodulator coefficients (dsp/fm/module_impl.cc:108-172) and lane addressing.
+struct FmCoeffs {
+    float ref, pilot_inc, pilot_alpha, deemph_alpha;
+    float notch[5];  // b0 b1 b2 a1 a2
+    float lp[3][5];
+    int wide, deemph_enabled;
+};
+struct FmLayout {
+    uint64_t lanes, batches, samples;
+    int32_t lane_rank;
+    uint64_t lane_shape[kMaxRank];
+    int64_t in_lane_stride[kMaxRank], out_lane_stride[kMaxRank];
+    int64_t in_batch_stride, in_sample_stride, out_batch_stride, out_sample_stride,
+        out_channel_stride;
+    uint64_t in_offset, out_offset;
+};
+
 }  // namespace jst::dev
 
 namespace jst::kernels {
+
+using jst::dev::FmCoeffs;
+using jst::dev::FmLayout;
 
 using jst::dev::EwLayout;
 using jst::dev::FftLayout;
@@ -95,5 +115,31 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
 hipError_t launch_waterfall(float* ring, uint64_t* state, const float* in, uint64_t in_offset,
                             uint64_t batches, uint64_t width, uint64_t height,
                             int64_t batch_stride, int64_t elem_stride, hipStream_t stream);
+
+// ---- Filter / FM side chains (filter_kernels.hip) ----------------------------------------------
+hipError_t launch_pad(void* out, const void* in, bool complex, uint64_t outer, uint64_t in_axis,
+                      uint64_t out_axis, uint64_t inner, hipStream_t s);
+hipError_t launch_unpad(void* body, void* tail, const void* in, bool complex, uint64_t outer,
+                        uint64_t in_axis, uint64_t body_axis, uint64_t inner, hipStream_t s);
+hipError_t launch_fold(float* out, const float* in, bool complex, uint64_t outer, uint64_t axis_size,
+                       uint64_t fold_size, uint64_t inner, uint64_t scalar_offset,
+                       const uint64_t* chan_offsets, uint64_t chan_count, uint64_t chan_inner,
+                       hipStream_t s);
+hipError_t launch_overlap_add(void* out, const void* buf, const void* ovl, void* prev, bool complex,
+                              uint32_t rank, int32_t batch_axis, const uint64_t* buf_shape,
+                              const uint64_t* ovl_shape, hipStream_t s);
+hipError_t launch_phase_correction(const EwLayout& L, float2* out, const float2* in, float2* corr,
+                                   double* phases, const double* increments, uint64_t batches,
+                                   uint64_t batch_inner, uint64_t channels, uint64_t channel_inner,
+                                   hipStream_t s);
+hipError_t launch_filter_taps(float2* out, double sample_rate, double bandwidth, const double* center,
+                              uint64_t heads, uint64_t taps, hipStream_t s);
+// op: 0 add, 1 sub, 2 mul, 3 div; L: operand 0 = output, operand 1 = input indexed over the OUTPUT
+// shape (reduced axis extent 1); (r, r_stride) walk the reduced axis
+hipError_t launch_arithmetic(const EwLayout& L, void* out, const void* in, bool complex, int op,
+                             uint64_t r, int64_t r_stride, hipStream_t s);
+size_t fm_state_bytes();
+hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
+                     hipStream_t s);
 
 }  // namespace jst::kernels

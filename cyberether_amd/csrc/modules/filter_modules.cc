@@ -1,0 +1,930 @@
+// filter_modules.cc -- host side of the Filter (FFT overlap-add) and FM side-chain modules:
+// pad, unpad, fold, overlap_add, phase_correction, filter_taps, arithmetic, expand_dims,
+// squeeze_dims, duplicate, fm.  Same contract as modules.cc; kernels in kernels/filter_kernels.hip.
+#include <cmath>
+#include <cstring>
+
+#include "modules.hh"
+
+namespace jst::modules {
+
+using dev::EwLayout;
+
+namespace {
+
+template <class T>
+T* ptr(const Tensor& t) {
+    return static_cast<T*>(t.data());
+}
+Result hip_result(hipError_t e, const char* what) {
+    if (e == hipSuccess) return Result::SUCCESS;
+    JST_ERROR("[HIP] %s failed: %s", what, hipGetErrorString(e));
+    return Result::ERROR;
+}
+// src/memory/axis.cc:196-212 (ResolveAxis): negative axes count from the end.
+std::optional<Index> resolve_axis(I64 axis, Index rank) {
+    if (rank == 0) return std::nullopt;
+    const I64 r = (I64)rank, a = axis < 0 ? r + axis : axis;
+    if (a < 0 || a >= r) return std::nullopt;
+    return (Index)a;
+}
+I64 config_i64(const Config& c, const std::string& key, I64 fallback, bool* ok) {
+    *ok = true;
+    auto it = c.find(key);
+    if (it == c.end()) return fallback;
+    char* end = nullptr;
+    const long long v = std::strtoll(it->second.c_str(), &end, 10);
+    if (end == it->second.c_str() || *end != '\0') *ok = false;
+    return v;
+}
+bool parse_f64_list(const std::string& s, std::vector<F64>& out) {
+    out.clear();
+    std::string body = s;
+    if (!body.empty() && body.front() == '[') {
+        if (body.back() != ']') return false;
+        body = body.substr(1, body.size() - 2);
+    }
+    size_t pos = 0;
+    while (pos < body.size()) {
+        while (pos < body.size() && (std::isspace((unsigned char)body[pos]) || body[pos] == ',')) ++pos;
+        if (pos >= body.size()) break;
+        char* end = nullptr;
+        const double v = std::strtod(body.c_str() + pos, &end);
+        if (end == body.c_str() + pos) return false;
+        out.push_back(v);
+        pos = (size_t)(end - body.c_str());
+    }
+    return true;
+}
+void split_axis(const Tensor& t, Index axis, U64& outer, U64& inner) {
+    outer = inner = 1;
+    for (Index i = 0; i < axis; ++i) outer *= t.shape(i);
+    for (Index i = axis + 1; i < t.rank(); ++i) inner *= t.shape(i);
+}
+bool is_f32_or_cf32(const Tensor& t) { return t.dtype() == DataType::F32 || t.dtype() == DataType::CF32; }
+
+}  // namespace
+
+// ---- Pad (core/pad/module_impl.cc, module_impl_native_cpu.cc:75-140) ---------------------------
+class Pad : public Module {
+ public:
+    const char* type() const override { return "pad"; }
+    Result validate() override {
+        bool ok1, ok2;
+        size = ConfigU64(config_, "size", 0, &ok1);
+        const I64 axis = config_i64(config_, "axis", -1, &ok2);
+        if (!ok1 || !ok2) {
+            JST_ERROR("[MODULE_PAD] Invalid size/axis.");
+            return Result::ERROR;
+        }
+        if (!inputs_.count("unpadded")) return Result::SUCCESS;
+        const Tensor& in = inputs_.at("unpadded");
+        if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+        const auto a = resolve_axis(axis, in.rank());
+        if (!a) {
+            JST_ERROR("[MODULE_PAD] Axis %lld out of range for tensor with %llu dimensions.",
+                      (long long)axis, (unsigned long long)in.rank());
+            return Result::ERROR;
+        }
+        if (!is_f32_or_cf32(in)) {
+            JST_ERROR("[MODULE_PAD_NATIVE_HIP] Unsupported data type '%s'.", DataTypeName(in.dtype()));
+            return Result::ERROR;
+        }
+        resolvedAxis = *a;
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineTaint(STATELESS));
+        JST_CHECK(defineInterfaceInput("unpadded"));
+        return defineInterfaceOutput("padded");
+    }
+    Result create() override {
+        input = inputs_.at("unpadded");
+        Shape os = input.shape();
+        os[resolvedAxis] += size;
+        JST_CHECK(output.create(device(), input.dtype(), os));
+        JST_CHECK(output.propagateAttributes(input));
+        produced("padded", output);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        U64 outer, inner;
+        split_axis(input, resolvedAxis, outer, inner);
+        const bool cx = input.dtype() == DataType::CF32;
+        return hip_result(kernels::launch_pad(ptr<char>(output) + output.offsetBytes(),
+                                              ptr<char>(input) + input.offsetBytes(), cx, outer,
+                                              input.shape(resolvedAxis), output.shape(resolvedAxis),
+                                              inner, s),
+                          "pad kernel");
+    }
+    Tensor input, output;
+    U64 size = 0;
+    Index resolvedAxis = 0;
+};
+
+// ---- Unpad (core/unpad/module_impl.cc, module_impl_native_cpu.cc:66-135) -----------------------
+class Unpad : public Module {
+ public:
+    const char* type() const override { return "unpad"; }
+    Result validate() override {
+        bool ok1, ok2;
+        size = ConfigU64(config_, "size", 0, &ok1);
+        const I64 axis = config_i64(config_, "axis", -1, &ok2);
+        if (!ok1 || !ok2) {
+            JST_ERROR("[MODULE_UNPAD] Invalid size/axis.");
+            return Result::ERROR;
+        }
+        if (!inputs_.count("padded")) return Result::SUCCESS;
+        const Tensor& in = inputs_.at("padded");
+        if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+        const auto a = resolve_axis(axis, in.rank());
+        if (!a) {
+            JST_ERROR("[MODULE_UNPAD] Axis %lld out of range for tensor with %llu dimensions.",
+                      (long long)axis, (unsigned long long)in.rank());
+            return Result::ERROR;
+        }
+        if (size > in.shape(*a)) {
+            JST_ERROR("[MODULE_UNPAD] Size %llu exceeds axis dimension %llu.",
+                      (unsigned long long)size, (unsigned long long)in.shape(*a));
+            return Result::ERROR;
+        }
+        if (!is_f32_or_cf32(in)) {
+            JST_ERROR("[MODULE_UNPAD_NATIVE_HIP] Unsupported data type '%s'.", DataTypeName(in.dtype()));
+            return Result::ERROR;
+        }
+        resolvedAxis = *a;
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineTaint(STATELESS));
+        JST_CHECK(defineInterfaceInput("padded"));
+        JST_CHECK(defineInterfaceOutput("unpadded"));
+        return defineInterfaceOutput("pad");
+    }
+    Result create() override {
+        input = inputs_.at("padded");
+        Shape bs = input.shape(), ts = input.shape();
+        bs[resolvedAxis] = input.shape(resolvedAxis) - size;
+        ts[resolvedAxis] = size;
+        JST_CHECK(body.create(device(), input.dtype(), bs));
+        JST_CHECK(tail.create(device(), input.dtype(), ts));
+        JST_CHECK(body.propagateAttributes(input));
+        JST_CHECK(tail.propagateAttributes(input));
+        produced("unpadded", body);
+        produced("pad", tail);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        U64 outer, inner;
+        split_axis(input, resolvedAxis, outer, inner);
+        return hip_result(kernels::launch_unpad(ptr<char>(body) + body.offsetBytes(),
+                                                ptr<char>(tail) + tail.offsetBytes(),
+                                                ptr<char>(input) + input.offsetBytes(),
+                                                input.dtype() == DataType::CF32, outer,
+                                                input.shape(resolvedAxis), body.shape(resolvedAxis),
+                                                inner, s),
+                          "unpad kernel");
+    }
+    Tensor input, body, tail;
+    U64 size = 0;
+    Index resolvedAxis = 0;
+};
+
+// ---- Fold (dsp/fold/module_impl.cc:16-172 region, module_impl_native_cpu.cc:103-172) -----------
+class Fold : public Module {
+ public:
+    const char* type() const override { return "fold"; }
+    Result validate() override {
+        bool ok1, ok2;
+        offset = ConfigU64(config_, "offset", 0, &ok1);
+        size = ConfigU64(config_, "size", 0, &ok2);
+        if (!ok1 || !ok2 || size == 0) {
+            JST_ERROR("[MODULE_FOLD] Size cannot be zero.");
+            return Result::ERROR;
+        }
+        channelOffsets.clear();
+        channelAxis.reset();
+        if (!inputs_.count("buffer")) return Result::SUCCESS;
+        const Tensor& in = inputs_.at("buffer");
+        if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+        SignalAxes axes;
+        if (ResolveSignalAxes(in, axes) != Result::SUCCESS) {
+            JST_ERROR("[MODULE_FOLD] Input must contain valid signal axis metadata.");
+            return Result::ERROR;
+        }
+        const U64 axisSize = in.shape(*axes.sample);
+        if (axisSize % size != 0) {
+            JST_ERROR("[MODULE_FOLD] Size (%llu) is not a divisor of the input shape (%llu) along "
+                      "axis (%llu).",
+                      (unsigned long long)size, (unsigned long long)axisSize,
+                      (unsigned long long)*axes.sample);
+            return Result::ERROR;
+        }
+        if (const AttrValue* v = in.attribute("channelOffsets")) {
+            const auto* offs = std::get_if<std::vector<U64>>(v);
+            if (!offs) {
+                JST_ERROR("[MODULE_FOLD] Input channelOffsets metadata must have type vector<U64>.");
+                return Result::ERROR;
+            }
+            if (offs->empty()) {
+                JST_ERROR("[MODULE_FOLD] Input channelOffsets metadata cannot be empty.");
+                return Result::ERROR;
+            }
+            channelOffsets = *offs;
+        }
+        if (channelOffsets.empty()) {
+            if (axisSize < offset) {
+                JST_ERROR("[MODULE_FOLD] Offset (%llu) is greater than the input shape (%llu) along "
+                          "axis (%llu).",
+                          (unsigned long long)offset, (unsigned long long)axisSize,
+                          (unsigned long long)*axes.sample);
+                return Result::ERROR;
+            }
+        } else {
+            if (!axes.channel || channelOffsets.size() != in.shape(*axes.channel)) {
+                JST_ERROR("[MODULE_FOLD] Channel offsets must match channelAxis extent.");
+                return Result::ERROR;
+            }
+            for (size_t c = 0; c < channelOffsets.size(); ++c)
+                if (axisSize < channelOffsets[c]) {
+                    JST_ERROR("[MODULE_FOLD] Channel offset #%zu (%llu) is greater than the input "
+                              "shape (%llu) along axis (%llu).",
+                              c, (unsigned long long)channelOffsets[c],
+                              (unsigned long long)axisSize, (unsigned long long)*axes.sample);
+                    return Result::ERROR;
+                }
+            channelAxis = axes.channel;
+        }
+        if (!is_f32_or_cf32(in)) {
+            JST_ERROR("[MODULE_FOLD_NATIVE_HIP] Unsupported data type '%s'.", DataTypeName(in.dtype()));
+            return Result::ERROR;
+        }
+        resolvedAxis = *axes.sample;
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineTaint(STATELESS));
+        JST_CHECK(defineInterfaceInput("buffer"));
+        return defineInterfaceOutput("buffer");
+    }
+    Result create() override {
+        input = inputs_.at("buffer");
+        Shape os = input.shape();
+        os[resolvedAxis] = size;
+        JST_CHECK(output.create(device(), input.dtype(), os));
+        JST_CHECK(output.propagateAttributes(input));
+        output.removeAttribute("channelOffsets");
+        if (!channelOffsets.empty()) {
+            JST_CHECK(devOffsets.create(device(), DataType::U64, {(U64)channelOffsets.size()}));
+            JST_CHECK(devOffsets.copyFromHost(channelOffsets.data(),
+                                              channelOffsets.size() * sizeof(U64), nullptr));
+            JST_HIP_CHECK(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
+        }
+        produced("buffer", output);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        U64 outer, inner;
+        split_axis(input, resolvedAxis, outer, inner);
+        U64 chanCount = 1, chanInner = 1;
+        if (channelAxis) {
+            chanCount = output.shape(*channelAxis);
+            for (Index i = *channelAxis + 1; i < output.rank(); ++i) chanInner *= output.shape(i);
+        }
+        return hip_result(
+            kernels::launch_fold(ptr<float>(output), ptr<const float>(input),
+                                 input.dtype() == DataType::CF32, outer, input.shape(resolvedAxis),
+                                 size, inner, offset % input.shape(resolvedAxis),
+                                 channelAxis ? ptr<const uint64_t>(devOffsets) : nullptr, chanCount,
+                                 chanInner, s),
+            "fold kernel");
+    }
+    Tensor input, output, devOffsets;
+    U64 offset = 0, size = 0;
+    Index resolvedAxis = 0;
+    std::optional<Index> channelAxis;
+    std::vector<U64> channelOffsets;
+};
+
+// ---- OverlapAdd (dsp/overlap_add/module_impl.cc:15-140, module_impl_native_cpu.cc:121-202) -----
+class OverlapAdd : public Module {
+ public:
+    const char* type() const override { return "overlap_add"; }
+    Result validate() override {
+        if (!inputs_.count("buffer") || !inputs_.count("overlap")) return Result::SUCCESS;
+        const Tensor& b = inputs_.at("buffer");
+        const Tensor& o = inputs_.at("overlap");
+        if (!b.validShape() || !o.validShape() || b.size() == 0 || o.size() == 0)
+            return Result::SUCCESS;
+        if (b.rank() != o.rank()) {
+            JST_ERROR("[MODULE_OVERLAP_ADD] Buffer rank (%llu) does not match overlap rank (%llu).",
+                      (unsigned long long)b.rank(), (unsigned long long)o.rank());
+            return Result::ERROR;
+        }
+        SignalAxes ba, oa;
+        if (ResolveSignalAxes(b, ba) != Result::SUCCESS || ResolveSignalAxes(o, oa) != Result::SUCCESS) {
+            JST_ERROR("[MODULE_OVERLAP_ADD] Input signal axis metadata is invalid.");
+            return Result::ERROR;
+        }
+        if (ba.sample != oa.sample || ba.batch != oa.batch || ba.channel != oa.channel) {
+            JST_ERROR("[MODULE_OVERLAP_ADD] Buffer and overlap sample, batch, and channel axes must "
+                      "match.");
+            return Result::ERROR;
+        }
+        if (b.shape(*ba.sample) < o.shape(*oa.sample)) {
+            JST_ERROR("[MODULE_OVERLAP_ADD] Overlap size (%llu) is larger than buffer size (%llu) "
+                      "along axis (%llu).",
+                      (unsigned long long)o.shape(*oa.sample), (unsigned long long)b.shape(*ba.sample),
+                      (unsigned long long)*ba.sample);
+            return Result::ERROR;
+        }
+        for (Index d = 0; d < b.rank(); ++d) {
+            if (d == *ba.sample) continue;
+            if (b.shape(d) != o.shape(d)) {
+                JST_ERROR("[MODULE_OVERLAP_ADD] Shape mismatch on axis (%llu): buffer has %llu, "
+                          "overlap has %llu. Non-overlap axes must match exactly.",
+                          (unsigned long long)d, (unsigned long long)b.shape(d),
+                          (unsigned long long)o.shape(d));
+                return Result::ERROR;
+            }
+        }
+        if (b.dtype() != o.dtype() || !is_f32_or_cf32(b)) {
+            JST_ERROR("[MODULE_OVERLAP_ADD_NATIVE_HIP] Unsupported data types.");
+            return Result::ERROR;
+        }
+        if (b.rank() > (Index)dev::kMaxRank) {
+            JST_ERROR("[MODULE_OVERLAP_ADD] Rank exceeds the supported layout range.");
+            return Result::ERROR;
+        }
+        batchAxis = ba.batch;
+        return Result::SUCCESS;
+    }
+    Result define() override {  // no taint: contiguous inputs, stateful
+        JST_CHECK(defineInterfaceInput("buffer"));
+        JST_CHECK(defineInterfaceInput("overlap"));
+        return defineInterfaceOutput("buffer");
+    }
+    Result create() override {
+        buffer = inputs_.at("buffer");
+        overlap = inputs_.at("overlap");
+        JST_CHECK(output.create(device(), buffer.dtype(), buffer.shape()));
+        JST_CHECK(output.propagateAttributes(buffer));
+        Shape ps = overlap.shape();
+        if (batchAxis) ps[*batchAxis] = 1;
+        JST_CHECK(previousOverlap.create(device(), buffer.dtype(), ps));  // zeroed
+        produced("buffer", output);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        return hip_result(
+            kernels::launch_overlap_add(
+                ptr<char>(output), ptr<char>(buffer) + buffer.offsetBytes(),
+                ptr<char>(overlap) + overlap.offsetBytes(), ptr<char>(previousOverlap),
+                buffer.dtype() == DataType::CF32, (uint32_t)buffer.rank(),
+                batchAxis ? (int32_t)*batchAxis : -1, buffer.shape().data(), overlap.shape().data(), s),
+            "overlap_add kernel");
+    }
+    const Tensor* state(const std::string& key) const override {
+        return key == "previousOverlap" ? &previousOverlap : nullptr;
+    }
+    Tensor buffer, overlap, output, previousOverlap;
+    std::optional<Index> batchAxis;
+};
+
+// ---- PhaseCorrection (dsp/phase_correction/module_impl.cc, module_impl_native_cpu.cc:36-115) ---
+class PhaseCorrection : public Module {
+ public:
+    const char* type() const override { return "phase_correction"; }
+    Result validate() override {
+        bool ok;
+        phaseIncrement = ConfigF64(config_, "phaseIncrement", 0.0, &ok);
+        if (!ok || !std::isfinite(phaseIncrement)) {
+            JST_ERROR("[MODULE_PHASE_CORRECTION] Phase increment must be finite.");
+            return Result::ERROR;
+        }
+        increments.clear();
+        channelAxis.reset();
+        if (!inputs_.count("signal")) return Result::SUCCESS;
+        const Tensor& in = inputs_.at("signal");
+        if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+        if (const AttrValue* v = in.attribute("channelPhaseIncrements")) {
+            const auto* inc = std::get_if<std::vector<F64>>(v);
+            if (!inc) {
+                JST_ERROR("[MODULE_PHASE_CORRECTION] Input channelPhaseIncrements metadata must "
+                          "have type vector<F64>.");
+                return Result::ERROR;
+            }
+            if (inc->empty()) {
+                JST_ERROR("[MODULE_PHASE_CORRECTION] Input channelPhaseIncrements metadata cannot "
+                          "be empty.");
+                return Result::ERROR;
+            }
+            increments = *inc;
+        }
+        SignalAxes axes;
+        if (ResolveSignalAxes(in, axes) != Result::SUCCESS) {
+            JST_ERROR("[MODULE_PHASE_CORRECTION] Input signal axis metadata is invalid.");
+            return Result::ERROR;
+        }
+        batchAxis = axes.batch;
+        if (!increments.empty()) {
+            if (!axes.channel || increments.size() != in.shape(*axes.channel)) {
+                JST_ERROR("[MODULE_PHASE_CORRECTION] Channel phase increments must match "
+                          "channelAxis extent.");
+                return Result::ERROR;
+            }
+            for (size_t c = 0; c < increments.size(); ++c)
+                if (!std::isfinite(increments[c])) {
+                    JST_ERROR("[MODULE_PHASE_CORRECTION] Channel phase increment #%zu must be "
+                              "finite.", c);
+                    return Result::ERROR;
+                }
+            channelAxis = axes.channel;
+        }
+        if (in.dtype() != DataType::CF32) {
+            JST_ERROR("[MODULE_PHASE_CORRECTION_NATIVE_HIP] Input must be CF32.");
+            return Result::ERROR;
+        }
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineTaint(DISCONTIGUOUS));
+        JST_CHECK(defineInterfaceInput("signal"));
+        return defineInterfaceOutput("signal");
+    }
+    Result create() override {
+        input = inputs_.at("signal");
+        JST_CHECK(output.create(device(), input.dtype(), input.shape()));
+        JST_CHECK(output.propagateAttributes(input));
+        output.removeAttribute("channelPhaseIncrements");
+        // module_impl_native_cpu.cc:36-70: counts and inner sizes from the (row-major) shape
+        batchCount = batchAxis ? input.shape(*batchAxis) : 1;
+        channelCount = channelAxis ? input.shape(*channelAxis) : 1;
+        batchInner = channelInner = 1;
+        if (batchAxis)
+            for (Index i = *batchAxis + 1; i < input.rank(); ++i) batchInner *= input.shape(i);
+        if (channelAxis)
+            for (Index i = *channelAxis + 1; i < input.rank(); ++i) channelInner *= input.shape(i);
+        std::vector<F64> inc(channelCount, phaseIncrement);
+        if (!increments.empty()) inc = increments;
+        JST_CHECK(devIncrements.create(device(), DataType::F64, {channelCount}));
+        JST_CHECK(devIncrements.copyFromHost(inc.data(), inc.size() * sizeof(F64), nullptr));
+        JST_HIP_CHECK(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
+        JST_CHECK(phases.create(device(), DataType::F64, {channelCount}));  // zero
+        JST_CHECK(corrections.create(device(), DataType::CF32, {channelCount, batchCount}));
+        produced("signal", output);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        EwLayout L;
+        if (!MakeEwLayout(output, &input, nullptr, L)) return Result::ERROR;
+        return hip_result(
+            kernels::launch_phase_correction(L, ptr<float2>(output), ptr<const float2>(input),
+                                             ptr<float2>(corrections), ptr<double>(phases),
+                                             ptr<const double>(devIncrements), batchCount, batchInner,
+                                             channelCount, channelInner, s),
+            "phase_correction kernel");
+    }
+    const Tensor* state(const std::string& key) const override {
+        return key == "phases" ? &phases : nullptr;
+    }
+    Tensor input, output, phases, corrections, devIncrements;
+    F64 phaseIncrement = 0.0;
+    std::vector<F64> increments;
+    std::optional<Index> batchAxis, channelAxis;
+    U64 batchCount = 1, channelCount = 1, batchInner = 1, channelInner = 1;
+};
+
+// ---- FilterTaps (dsp/filter_taps/module_impl.cc:15-175, module_impl_native_cpu.cc:46-80) -------
+class FilterTaps : public Module {
+ public:
+    const char* type() const override { return "filter_taps"; }
+    Result validate() override {
+        bool ok1, ok2, ok3;
+        sampleRate = ConfigF64(config_, "sampleRate", 2.0e6, &ok1);
+        bandwidth = ConfigF64(config_, "bandwidth", 1.0e6, &ok2);
+        taps = ConfigU64(config_, "taps", 101, &ok3);
+        if (!parse_f64_list(ConfigStr(config_, "center", "[0.0]"), center)) ok1 = false;
+        if (!ok1 || !std::isfinite(sampleRate) || sampleRate <= 0.0) {
+            JST_ERROR("[MODULE_FILTER_TAPS] Sample rate must be positive (%g).", sampleRate);
+            return Result::ERROR;
+        }
+        if (!ok2 || !std::isfinite(bandwidth) || bandwidth <= 0.0 || bandwidth > sampleRate) {
+            JST_ERROR("[MODULE_FILTER_TAPS] Bandwidth (%.2f MHz) must be between 0 and sample rate "
+                      "(%.2f MHz).", bandwidth / 1e6, sampleRate / 1e6);
+            return Result::ERROR;
+        }
+        if (!ok3 || taps == 0) {
+            JST_ERROR("[MODULE_FILTER_TAPS] Number of taps cannot be zero.");
+            return Result::ERROR;
+        }
+        if ((taps % 2) == 0) {
+            JST_ERROR("[MODULE_FILTER_TAPS] Number of taps must be odd (%llu).",
+                      (unsigned long long)taps);
+            return Result::ERROR;
+        }
+        if (center.empty()) {
+            JST_ERROR("[MODULE_FILTER_TAPS] At least one center frequency is required.");
+            return Result::ERROR;
+        }
+        const F64 half = sampleRate / 2.0;
+        for (size_t i = 0; i < center.size(); ++i)
+            if (!std::isfinite(center[i]) || center[i] > half || center[i] < -half) {
+                JST_ERROR("[MODULE_FILTER_TAPS] Center frequency #%zu (%.2f MHz) must be between "
+                          "%.2f MHz and %.2f MHz.", i, center[i] / 1e6, -half / 1e6, half / 1e6);
+                return Result::ERROR;
+            }
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineTaint(STATIC_OUTPUT));
+        return defineInterfaceOutput("coeffs");
+    }
+    Result create() override {
+        const U64 heads = center.size();
+        JST_CHECK(coeffs.create(device(), DataType::CF32, {heads, taps}));
+        JST_CHECK(SetSignalAxes(coeffs, {.sample = Index{1}, .channel = Index{0}}));
+        coeffs.setAttribute("sampleRate", AttrValue{(F64)(F32)sampleRate});
+        coeffs.setAttribute("bandwidth", AttrValue{(F64)(F32)bandwidth});
+        std::vector<F64> narrowed(center.size());
+        for (size_t i = 0; i < center.size(); ++i) narrowed[i] = (F64)(F32)center[i];
+        if (narrowed.size() == 1) coeffs.setAttribute("center", AttrValue{narrowed[0]});
+        else coeffs.setAttribute("center", AttrValue{narrowed});
+        JST_CHECK(devCenter.create(device(), DataType::F64, {heads}));
+        JST_CHECK(devCenter.copyFromHost(center.data(), heads * sizeof(F64), nullptr));
+        JST_HIP_CHECK(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
+        produced("coeffs", coeffs);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        return hip_result(kernels::launch_filter_taps(ptr<float2>(coeffs), sampleRate, bandwidth,
+                                                      ptr<const double>(devCenter), center.size(),
+                                                      taps, s),
+                          "filter_taps kernel");
+    }
+    Tensor coeffs, devCenter;
+    F64 sampleRate = 2.0e6, bandwidth = 1.0e6;
+    std::vector<F64> center;
+    U64 taps = 101;
+};
+
+// ---- Arithmetic (core/arithmetic/module_impl.cc:10-120, module_impl_native_cpu.cc:98-146) ------
+class Arithmetic : public Module {
+ public:
+    const char* type() const override { return "arithmetic"; }
+    Result validate() override {
+        operation = ConfigStr(config_, "operation", "add");
+        if (operation != "add" && operation != "sub" && operation != "mul" && operation != "div") {
+            JST_ERROR("[MODULE_ARITHMETIC] Invalid operation '%s'.", operation.c_str());
+            return Result::ERROR;
+        }
+        bool ok1, ok2;
+        const I64 axis = config_i64(config_, "axis", -1, &ok1);
+        squeeze = ConfigBool(config_, "squeeze", false, &ok2);
+        if (!ok1 || !ok2) {
+            JST_ERROR("[MODULE_ARITHMETIC] Invalid axis/squeeze.");
+            return Result::ERROR;
+        }
+        if (!inputs_.count("buffer")) return Result::SUCCESS;
+        const Tensor& in = inputs_.at("buffer");
+        SignalAxes axes;
+        JST_CHECK(MapSignalAxes(in, axes));
+        if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+        const auto a = resolve_axis(axis, in.rank());
+        if (!a) {
+            JST_ERROR("[MODULE_ARITHMETIC] Axis %lld out of range for input buffer rank %llu.",
+                      (long long)axis, (unsigned long long)in.rank());
+            return Result::ERROR;
+        }
+        if (!is_f32_or_cf32(in) || (in.dtype() == DataType::CF32 && operation == "div")) {
+            JST_ERROR("[MODULE_ARITHMETIC_NATIVE_HIP] Unsupported data type / operation.");
+            return Result::ERROR;
+        }
+        resolvedAxis = *a;
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+        JST_CHECK(defineInterfaceInput("buffer"));
+        return defineInterfaceOutput("buffer");
+    }
+    Result create() override {
+        input = inputs_.at("buffer");
+        Shape os = input.shape();
+        os[resolvedAxis] = 1;
+        JST_CHECK(output.create(device(), input.dtype(), os));
+        unsqueezed = output.clone();
+        if (squeeze) JST_CHECK(output.squeezeDims(resolvedAxis));
+        JST_CHECK(output.propagateAttributes(input));
+        SignalAxes in_axes, out_axes;
+        JST_CHECK(MapSignalAxes(input, in_axes));
+        auto remap = [&](const std::optional<Index>& a) -> std::optional<Index> {
+            if (!a) return std::nullopt;
+            if (!squeeze || *a < resolvedAxis) return *a;
+            if (*a > resolvedAxis) return *a - 1;
+            return std::nullopt;  // the reduced axis disappears
+        };
+        out_axes.sample = remap(in_axes.sample);
+        out_axes.batch = remap(in_axes.batch);
+        out_axes.channel = remap(in_axes.channel);
+        JST_CHECK(SetSignalAxes(output, out_axes));
+        produced("buffer", output);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        // index space = output shape with the reduced axis kept at extent 1
+        Tensor in_view = input.clone();
+        in_view.slice(resolvedAxis, 0, 1, 1);
+        EwLayout L;
+        if (!MakeEwLayout(unsqueezed, &in_view, nullptr, L)) return Result::ERROR;
+        L.contiguous = 0;
+        const int op = operation == "add" ? 0 : operation == "sub" ? 1 : operation == "mul" ? 2 : 3;
+        return hip_result(kernels::launch_arithmetic(L, unsqueezed.data(), input.data(),
+                                                     input.dtype() == DataType::CF32, op,
+                                                     input.shape(resolvedAxis),
+                                                     (int64_t)input.stride(resolvedAxis), s),
+                          "arithmetic kernel");
+    }
+    Tensor input, output, unsqueezed;
+    std::string operation = "add";
+    bool squeeze = false;
+    Index resolvedAxis = 0;
+};
+
+// ---- view modules: expand_dims, squeeze_dims (core/{expand_dims,squeeze_dims}) -----------------
+class ExpandDims : public Module {
+ public:
+    const char* type() const override { return "expand_dims"; }
+    Result validate() override {
+        bool ok;
+        axis = config_i64(config_, "axis", 0, &ok);
+        if (!ok) {
+            JST_ERROR("[MODULE_EXPAND_DIMS] Invalid axis.");
+            return Result::ERROR;
+        }
+        if (!inputs_.count("buffer")) return Result::SUCCESS;
+        const I64 r = (I64)inputs_.at("buffer").rank();
+        const I64 a = axis < 0 ? r + 1 + axis : axis;  // axis.cc ResolveInsertionAxis
+        if (a < 0 || a > r) {
+            JST_ERROR("[MODULE_EXPAND_DIMS] Axis %lld out of range.", (long long)axis);
+            return Result::ERROR;
+        }
+        resolved = (Index)a;
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+        JST_CHECK(defineInterfaceInput("buffer"));
+        return defineInterfaceOutput("buffer");
+    }
+    Result create() override {
+        Tensor view = inputs_.at("buffer").clone();
+        SignalAxes axes;
+        JST_CHECK(MapSignalAxes(view, axes));
+        JST_CHECK(view.expandDims(resolved));
+        auto shift = [&](std::optional<Index>& a) { if (a && *a >= resolved) a = *a + 1; };
+        shift(axes.sample);
+        shift(axes.batch);
+        shift(axes.channel);
+        JST_CHECK(SetSignalAxes(view, axes));
+        produced("buffer", view);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t) override { return Result::SUCCESS; }
+    bool launchesKernels() const override { return false; }
+    I64 axis = 0;
+    Index resolved = 0;
+};
+
+class SqueezeDims : public Module {
+ public:
+    const char* type() const override { return "squeeze_dims"; }
+    Result validate() override {
+        bool ok;
+        axis = config_i64(config_, "axis", 0, &ok);
+        if (!ok) {
+            JST_ERROR("[MODULE_SQUEEZE_DIMS] Invalid axis.");
+            return Result::ERROR;
+        }
+        if (!inputs_.count("buffer")) return Result::SUCCESS;
+        const Tensor& in = inputs_.at("buffer");
+        const auto a = resolve_axis(axis, in.rank());
+        if (!a || in.shape(*a) != 1) {
+            JST_ERROR("[MODULE_SQUEEZE_DIMS] Axis %lld is not a size-1 axis.", (long long)axis);
+            return Result::ERROR;
+        }
+        resolved = *a;
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+        JST_CHECK(defineInterfaceInput("buffer"));
+        return defineInterfaceOutput("buffer");
+    }
+    Result create() override {
+        Tensor view = inputs_.at("buffer").clone();
+        SignalAxes axes;
+        JST_CHECK(MapSignalAxes(view, axes));
+        JST_CHECK(view.squeezeDims(resolved));
+        auto shift = [&](std::optional<Index>& a) {
+            if (!a) return;
+            if (*a == resolved) a.reset();
+            else if (*a > resolved) a = *a - 1;
+        };
+        shift(axes.sample);
+        shift(axes.batch);
+        shift(axes.channel);
+        JST_CHECK(SetSignalAxes(view, axes));
+        produced("buffer", view);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t) override { return Result::SUCCESS; }
+    bool launchesKernels() const override { return false; }
+    I64 axis = 0;
+    Index resolved = 0;
+};
+
+// ---- FM (dsp/fm/module_impl.cc:20-172, module_impl_native_cpu.cc:30-174) -----------------------
+class Fm : public Module {
+ public:
+    const char* type() const override { return "fm"; }
+    Result validate() override {
+        mode = ConfigStr(config_, "mode", "narrow");
+        deemphasis = ConfigStr(config_, "deemphasis", "none");
+        bool ok;
+        sampleRate = (F32)ConfigF64(config_, "sampleRate", 240e3, &ok);
+        if (mode != "narrow" && mode != "wide") {
+            JST_ERROR("[MODULE_FM] Mode must be 'narrow' or 'wide'.");
+            return Result::ERROR;
+        }
+        if (deemphasis != "none" && deemphasis != "50us" && deemphasis != "75us") {
+            JST_ERROR("[MODULE_FM] De-emphasis must be 'none', '50us', or '75us'.");
+            return Result::ERROR;
+        }
+        if (!ok || !std::isfinite(sampleRate) || sampleRate <= 0.0f) {
+            JST_ERROR("[MODULE_FM] Sample rate must be finite and positive.");
+            return Result::ERROR;
+        }
+        if (sampleRate > 20e6f) {
+            JST_ERROR("[MODULE_FM] Sample rate must not exceed 20 MHz.");
+            return Result::ERROR;
+        }
+        if (mode == "wide" && sampleRate < 200e3f) {
+            JST_ERROR("[MODULE_FM] Wideband mode requires a sample rate of at least 200 kHz.");
+            return Result::ERROR;
+        }
+        if (!inputs_.count("signal")) return Result::SUCCESS;
+        const Tensor& in = inputs_.at("signal");
+        if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+        if (ResolveSignalAxes(in, axes) != Result::SUCCESS) {
+            JST_ERROR("[MODULE_FM] Input must contain valid signal axis metadata.");
+            return Result::ERROR;
+        }
+        if (mode == "wide" && axes.channel) {
+            JST_ERROR("[MODULE_FM] Wideband mode does not support channelized input.");
+            return Result::ERROR;
+        }
+        if (in.dtype() != DataType::CF32) {
+            JST_ERROR("[MODULE_FM_NATIVE_HIP] Input must be complex (CF32).");
+            return Result::ERROR;
+        }
+        laneCount = in.size() / in.shape(*axes.sample);
+        if (axes.batch) laneCount /= in.shape(*axes.batch);
+        return Result::SUCCESS;
+    }
+    Result define() override {  // no taint: contiguous input, stateful
+        JST_CHECK(defineInterfaceInput("signal"));
+        return defineInterfaceOutput("signal");
+    }
+    Result create() override {
+        input = inputs_.at("signal");
+        const bool wide = mode == "wide";
+        // FmImpl::updateCoefficients (fm/module_impl.cc:108-157)
+        const double pi = 3.14159265358979323846;
+        const F32 deviation = wide ? 75e3f : 100e3f;
+        const F32 kf = deviation / sampleRate;
+        std::memset(&k, 0, sizeof(k));
+        k.wide = wide;
+        k.deemph_enabled = deemphasis != "none";
+        k.ref = (F32)(1.0f / (2.0f * pi * kf));
+        k.pilot_inc = (F32)(2.0f * pi * 19e3f / sampleRate);
+        const F64 sr = sampleRate;
+        k.pilot_alpha = (F32)(1.0 - std::exp(-2.0 * pi * 200.0 / sr));
+        k.deemph_alpha = deemphasis == "none"
+                             ? 1.0f
+                             : (F32)(1.0 - std::exp(-1.0 / (sr * (deemphasis == "50us" ? 50e-6 : 75e-6))));
+        const F64 pw = 2.0 * pi * 19e3 / sr, pc = std::cos(pw), ps = std::sin(pw);
+        const F64 na = ps / (2.0 * 20.0), na0 = 1.0 + na;
+        k.notch[0] = (F32)(1.0 / na0);
+        k.notch[1] = (F32)(-2.0 * pc / na0);
+        k.notch[2] = k.notch[0];
+        k.notch[3] = k.notch[1];
+        k.notch[4] = (F32)((1.0 - na) / na0);
+        const F64 q[3] = {0.51763809, 0.70710678, 1.93185165};
+        const F64 w = 2.0 * pi * 15e3 / sr, co = std::cos(w), si = std::sin(w);
+        for (int s = 0; s < 3; ++s) {
+            const F64 al = si / (2.0 * q[s]), a0 = 1.0 + al;
+            k.lp[s][0] = (F32)((1.0 - co) * 0.5 / a0);
+            k.lp[s][1] = (F32)((1.0 - co) / a0);
+            k.lp[s][2] = k.lp[s][0];
+            k.lp[s][3] = (F32)(-2.0 * co / a0);
+            k.lp[s][4] = (F32)((1.0 - al) / a0);
+        }
+        Shape os = input.shape();
+        SignalAxes out_axes = axes;
+        if (wide) {
+            out_axes.channel = os.size();
+            os.push_back(2);
+        }
+        JST_CHECK(output.create(device(), DataType::F32, os));
+        JST_CHECK(output.propagateAttributes(input));
+        JST_CHECK(SetSignalAxes(output, out_axes));
+        output.setAttribute("frequency", AttrValue{F64{0.0}});
+        JST_CHECK(states.create(device(), DataType::U8, {laneCount * (U64)kernels::fm_state_bytes()}));
+        produced("signal", output);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        dev::FmLayout L;
+        std::memset(&L, 0, sizeof(L));
+        L.lanes = laneCount;
+        L.samples = input.shape(*axes.sample);
+        L.batches = axes.batch ? input.shape(*axes.batch) : 1;
+        L.in_sample_stride = (int64_t)input.stride(*axes.sample);
+        L.out_sample_stride = (int64_t)output.stride(*axes.sample);
+        L.in_batch_stride = axes.batch ? (int64_t)input.stride(*axes.batch) : 0;
+        L.out_batch_stride = axes.batch ? (int64_t)output.stride(*axes.batch) : 0;
+        L.out_channel_stride = k.wide ? (int64_t)output.stride(input.rank()) : 0;
+        int r = 0;
+        for (Index ax = 0; ax < input.rank(); ++ax) {
+            if (ax == *axes.sample || (axes.batch && ax == *axes.batch)) continue;
+            L.lane_shape[r] = input.shape(ax);
+            L.in_lane_stride[r] = (int64_t)input.stride(ax);
+            L.out_lane_stride[r] = (int64_t)output.stride(ax);
+            ++r;
+        }
+        L.lane_rank = r;
+        L.in_offset = input.offset();
+        L.out_offset = output.offset();
+        return hip_result(kernels::launch_fm(ptr<float>(output), ptr<const float2>(input),
+                                             states.data(), k, L, s),
+                          "fm kernel");
+    }
+    Tensor input, output, states;
+    std::string mode = "narrow", deemphasis = "none";
+    F32 sampleRate = 240e3f;
+    SignalAxes axes;
+    U64 laneCount = 0;
+    dev::FmCoeffs k;
+};
+
+// ---- Duplicate (core/duplicate/module_impl_native_cuda.cc:15-151): dense device copy -----------
+class Duplicate : public Module {
+ public:
+    const char* type() const override { return "duplicate"; }
+    Result define() override {
+        JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
+        JST_CHECK(defineInterfaceInput("buffer"));
+        return defineInterfaceOutput("buffer");
+    }
+    Result validate() override {
+        if (inputs_.count("buffer") && !is_f32_or_cf32(inputs_.at("buffer"))) {
+            JST_ERROR("[MODULE_DUPLICATE_NATIVE_HIP] Unsupported data type.");
+            return Result::ERROR;
+        }
+        return Result::SUCCESS;
+    }
+    Result create() override {
+        input = inputs_.at("buffer");
+        JST_CHECK(output.create(device(), input.dtype(), input.shape()));
+        JST_CHECK(output.propagateAttributes(input));
+        produced("buffer", output);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {  // strided gather = multiply by 1 in the
+        EwLayout L;                                 // elementwise engine (exact)
+        if (!MakeEwLayout(output, &input, nullptr, L)) return Result::ERROR;
+        if (input.dtype() == DataType::CF32)
+            return hip_result(kernels::launch_multiply_constant_cf32(
+                                  L, ptr<float2>(output), ptr<const float2>(input), 1.0f, s),
+                              "duplicate kernel");
+        return hip_result(kernels::launch_multiply_constant_f32(L, ptr<float>(output),
+                                                                ptr<const float>(input), 1.0f, s),
+                          "duplicate kernel");
+    }
+    Tensor input, output;
+};
+
+JST_REGISTER_MODULE(Pad, "pad", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Unpad, "unpad", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Fold, "fold", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(OverlapAdd, "overlap_add", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(PhaseCorrection, "phase_correction", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(FilterTaps, "filter_taps", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Arithmetic, "arithmetic", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(ExpandDims, "expand_dims", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(SqueezeDims, "squeeze_dims", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Fm, "fm", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Duplicate, "duplicate", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+
+}  // namespace jst::modules

@@ -98,6 +98,8 @@ _sig("jst_tensor_permute", R, _h, C.c_uint32, _u64p)
 _sig("jst_tensor_broadcast_to", R, _h, C.c_uint32, _u64p)
 _sig("jst_tensor_set_attribute_u64", R, _h, C.c_char_p, C.c_uint64)
 _sig("jst_tensor_set_attribute_f64", R, _h, C.c_char_p, C.c_double)
+_sig("jst_tensor_set_attribute_u64v", R, _h, C.c_char_p, _u64p, C.c_uint64)
+_sig("jst_tensor_set_attribute_f64v", R, _h, C.c_char_p, C.POINTER(C.c_double), C.c_uint64)
 _sig("jst_tensor_remove_attribute", R, _h, C.c_char_p)
 _sig("jst_tensor_copy_from_host", R, _h, C.c_void_p, C.c_size_t)
 _sig("jst_tensor_copy_to_host", R, _h, C.c_void_p, C.c_size_t)
@@ -286,6 +288,14 @@ class Tensor:
         return self
 
     def set_attribute(self, key: str, value):
+        if isinstance(value, (list, tuple, np.ndarray)):
+            if all(isinstance(v, (int, np.integer)) for v in value):
+                arr = (C.c_uint64 * len(value))(*[int(v) for v in value])
+                _check(_lib.jst_tensor_set_attribute_u64v(self._h, key.encode(), arr, len(value)))
+            else:
+                arr = (C.c_double * len(value))(*[float(v) for v in value])
+                _check(_lib.jst_tensor_set_attribute_f64v(self._h, key.encode(), arr, len(value)))
+            return self
         if isinstance(value, (int, np.integer)):
             _check(_lib.jst_tensor_set_attribute_u64(self._h, key.encode(), int(value)))
         else:
@@ -359,7 +369,7 @@ def _cfg_value(v) -> str:
     if isinstance(v, float):
         return repr(v)
     if isinstance(v, (list, tuple)):
-        return "[" + ", ".join(str(int(x)) for x in v) + "]"
+        return "[" + ", ".join(repr(float(x)) if isinstance(x, float) else str(int(x)) for x in v) + "]"
     return str(v)
 
 

@@ -120,6 +120,11 @@ jst_result jst_tensor_broadcast_to(jst_tensor t, uint32_t rank, const uint64_t* 
 /* attributes: "sampleAxis" | "batchAxis" | "channelAxis" (Index), "sampleRate", ... (F64) */
 jst_result jst_tensor_set_attribute_u64(jst_tensor t, const char* key, uint64_t value);
 jst_result jst_tensor_set_attribute_f64(jst_tensor t, const char* key, double value);
+/* vector attributes: "channelOffsets" (vector<U64>), "channelPhaseIncrements" / "center" (vector<F64>) */
+jst_result jst_tensor_set_attribute_u64v(jst_tensor t, const char* key, const uint64_t* values,
+                                         uint64_t count);
+jst_result jst_tensor_set_attribute_f64v(jst_tensor t, const char* key, const double* values,
+                                         uint64_t count);
 jst_result jst_tensor_remove_attribute(jst_tensor t, const char* key);
 /* dense copies, synchronous on return (tensor.cc:882-963) */
 jst_result jst_tensor_copy_from_host(jst_tensor t, const void* src, size_t bytes);

@@ -760,3 +760,241 @@ void jst_oracle_signal_cosine_cf32(float* out, uint64_t count, double amplitude,
     }
     *phase = ph;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Fold (spectral decimation).  src/domains/dsp/fold/module_impl_native_cpu.cc:103-172.
+ * Dense tensors; 'axis' is the fold axis; out[k] = (1/D) * sum_g in[(k + g*size - offset) mod axis]
+ * accumulated in F64.  channel_offsets (optional, per coordinate of channel_axis) replace offset.
+ * ---------------------------------------------------------------------------------------- */
+void jst_oracle_fold_cf32(const float* in, float* out, uint32_t rank, const uint64_t* in_shape,
+                          uint64_t fold_axis, uint64_t fold_offset, uint64_t fold_size,
+                          int64_t channel_axis, const uint64_t* channel_offsets) {
+    uint64_t out_shape[ORACLE_MAX_RANK], in_str[ORACLE_MAX_RANK], out_str[ORACLE_MAX_RANK];
+    const uint64_t axis_size = in_shape[fold_axis], decim = axis_size / fold_size;
+    uint64_t total_out = 1;
+    for (uint32_t d = 0; d < rank; ++d) out_shape[d] = (d == fold_axis) ? fold_size : in_shape[d];
+    for (uint32_t d = rank; d-- > 0;) {
+        in_str[d] = (d == rank - 1) ? 1 : in_str[d + 1] * in_shape[d + 1];
+        out_str[d] = (d == rank - 1) ? 1 : out_str[d + 1] * out_shape[d + 1];
+        total_out *= out_shape[d];
+    }
+    const double divisor = (double)decim;
+    const uint64_t scalar_offset = fold_offset % axis_size;
+    uint64_t coords[ORACLE_MAX_RANK];
+    for (uint64_t oi = 0; oi < total_out; ++oi) {
+        uint64_t rem = oi, base = 0;
+        for (uint32_t d = 0; d < rank; ++d) {
+            coords[d] = rem / out_str[d];
+            rem %= out_str[d];
+        }
+        const uint64_t off = channel_axis < 0 ? scalar_offset
+                                              : channel_offsets[coords[channel_axis]] % axis_size;
+        for (uint32_t d = 0; d < rank; ++d)
+            if (d != fold_axis) base += coords[d] * in_str[d];
+        double sr = 0.0, si = 0.0;
+        for (uint64_t g = 0; g < decim; ++g) {
+            const uint64_t shifted = coords[fold_axis] + g * fold_size;
+            const uint64_t ia = shifted >= off ? shifted - off : axis_size - (off - shifted);
+            const uint64_t idx = base + ia * in_str[fold_axis];
+            sr += (double)in[2 * idx];
+            si += (double)in[2 * idx + 1];
+        }
+        sr /= divisor;
+        si /= divisor;
+        out[2 * oi] = (float)sr;
+        out[2 * oi + 1] = (float)si;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Arithmetic, reduction by "add" along one axis: out zeroed, then out += in in row-major input
+ * order (src/domains/core/arithmetic/module_impl_native_cpu.cc:98-146): a left-to-right F32 sum
+ * starting from +0.  in: dense [outer, r, inner]; out: [outer, inner].  'complex' doubles lanes.
+ * ---------------------------------------------------------------------------------------- */
+void jst_oracle_arithmetic_add_f32(const float* in, float* out, uint64_t outer, uint64_t r,
+                                   uint64_t inner) {
+    for (uint64_t o = 0; o < outer; ++o)
+        for (uint64_t i = 0; i < inner; ++i) {
+            float acc = 0.0f;
+            for (uint64_t k = 0; k < r; ++k) acc += in[(o * r + k) * inner + i];
+            out[o * inner + i] = acc;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Filter taps.  src/domains/dsp/filter_taps/module_impl_native_cpu.cc:46-80.
+ * out: CF32 [heads][taps].  std::exp(j*2*pi*n*offset) has real part exactly 0*..., so it is
+ * (cos(theta), sin(theta)) with theta = ((2.0*pi)*n)*offset (left-to-right products).
+ * ---------------------------------------------------------------------------------------- */
+void jst_oracle_filter_taps(float* out, double sample_rate, double bandwidth,
+                            const double* center, uint64_t heads, uint64_t taps) {
+    const double filter_width = (bandwidth / sample_rate) / 2.0;
+    for (uint64_t c = 0; c < heads; ++c) {
+        const double filter_offset = center[c] / sample_rate;
+        for (uint64_t i = 0; i < taps; ++i) {
+            const double fi = (double)i, half = (double)(taps - 1) / 2.0, n = fi - half;
+            const double sinc = (n == 0.0) ? (2.0 * filter_width)
+                                           : sin(2.0 * JST_PI * filter_width * n) / (JST_PI * n);
+            const double win = (taps == 1) ? 1.0
+                                           : 0.42 - 0.50 * cos(2.0 * JST_PI * fi / (taps - 1)) +
+                                                 0.08 * cos(4.0 * JST_PI * fi / (taps - 1));
+            const double theta = ((2.0 * JST_PI) * n) * filter_offset;
+            const double sw = sinc * win;
+            out[2 * (c * taps + i)] = (float)(sw * cos(theta));
+            out[2 * (c * taps + i) + 1] = (float)(sw * sin(theta));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Phase correction.  src/domains/dsp/phase_correction/module_impl_native_cpu.cc:60-115.
+ * Dense CF32; batch/channel coordinates from the flat index; phases[C] (F64) carried across calls.
+ * ---------------------------------------------------------------------------------------- */
+void jst_oracle_phase_correction(const float* in, float* out, uint64_t count, uint64_t batch_count,
+                                 uint64_t batch_inner, uint64_t channel_count,
+                                 uint64_t channel_inner, const double* increments, double* phases) {
+    float* corr = (float*)malloc(2 * channel_count * batch_count * sizeof(float));
+    double* wrapped = (double*)malloc(channel_count * sizeof(double));
+    for (uint64_t c = 0; c < channel_count; ++c) wrapped[c] = remainder(increments[c], 2.0 * JST_PI);
+    for (uint64_t c = 0; c < channel_count; ++c)
+        for (uint64_t b = 0; b < batch_count; ++b) {
+            const double ph = phases[c] + wrapped[c] * (double)b;
+            corr[2 * (c * batch_count + b)] = (float)cos(ph);
+            corr[2 * (c * batch_count + b) + 1] = (float)sin(ph);
+        }
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint64_t b = batch_count == 1 ? 0 : (i / batch_inner) % batch_count;
+        const uint64_t c = channel_count == 1 ? 0 : (i / channel_inner) % channel_count;
+        const float* k = &corr[2 * (c * batch_count + b)];
+        cmul_f32(in[2 * i], in[2 * i + 1], k[0], k[1], &out[2 * i], &out[2 * i + 1]);
+    }
+    for (uint64_t c = 0; c < channel_count; ++c)
+        phases[c] = remainder(phases[c] + wrapped[c] * (double)batch_count, 2.0 * JST_PI);
+    free(corr);
+    free(wrapped);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * FM demodulator.  src/domains/dsp/fm/module_impl.cc:108-172 (coefficients, biquads) and
+ * module_impl_native_cpu.cc:43-174 (compute).  One lane: 'batches' x 'samples' consecutive
+ * samples (batch-major), state carried in fm_state_t across calls.  mode: 0 narrow, 1 wide.
+ * Output: narrow F32[batches*samples]; wide F32[batches*samples*2] interleaved (left, right).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { float b0, b1, b2, a1, a2; } fm_biquad_t;
+typedef struct { float z1, z2; } fm_bqstate_t;
+typedef struct {
+    float prev_re, prev_im;
+    int has_prev;
+    float narrow_deemph;
+    float pilot_phase, pilot_cos_stage, pilot_sin_stage, pilot_cos, pilot_sin, left_de, right_de;
+    fm_bqstate_t sum_notch, diff_notch, sum_filter[3], diff_filter[3];
+} fm_state_t;
+typedef struct {
+    float ref, pilot_inc, pilot_alpha, deemph_alpha;
+    fm_biquad_t notch, lp[3];
+    int wide, deemph_enabled;
+} fm_coeffs_t;
+
+void jst_oracle_fm_coeffs(fm_coeffs_t* k, int wide, int deemph /*0 none,1 50us,2 75us*/, float sample_rate) {
+    const float deviation = wide ? 75e3f : 100e3f;
+    const float kf = deviation / sample_rate;
+    k->wide = wide;
+    k->deemph_enabled = deemph != 0;
+    k->ref = 1.0f / (2.0f * JST_PI * kf);                 /* F32 * F64 -> F64, then to F32 */
+    k->pilot_inc = 2.0f * JST_PI * 19e3f / sample_rate;
+    const double sr = sample_rate;
+    k->pilot_alpha = (float)(1.0 - exp(-2.0 * JST_PI * 200.0 / sr));
+    if (deemph == 0) k->deemph_alpha = 1.0f;
+    else k->deemph_alpha = (float)(1.0 - exp(-1.0 / (sr * (deemph == 1 ? 50e-6 : 75e-6))));
+    const double pw = 2.0 * JST_PI * 19e3 / sr, pc = cos(pw), ps = sin(pw);
+    const double na = ps / (2.0 * 20.0), na0 = 1.0 + na;
+    k->notch.b0 = (float)(1.0 / na0);
+    k->notch.b1 = (float)(-2.0 * pc / na0);
+    k->notch.b2 = k->notch.b0;
+    k->notch.a1 = k->notch.b1;
+    k->notch.a2 = (float)((1.0 - na) / na0);
+    const double q[3] = {0.51763809, 0.70710678, 1.93185165};
+    const double w = 2.0 * JST_PI * 15e3 / sr, co = cos(w), si = sin(w);
+    for (int s = 0; s < 3; ++s) {
+        const double al = si / (2.0 * q[s]), a0 = 1.0 + al;
+        k->lp[s].b0 = (float)((1.0 - co) * 0.5 / a0);
+        k->lp[s].b1 = (float)((1.0 - co) / a0);
+        k->lp[s].b2 = k->lp[s].b0;
+        k->lp[s].a1 = (float)(-2.0 * co / a0);
+        k->lp[s].a2 = (float)((1.0 - al) / a0);
+    }
+}
+
+static float fm_biquad(float x, const fm_biquad_t* c, fm_bqstate_t* s) {
+    const float y = c->b0 * x + s->z1;
+    s->z1 = c->b1 * x - c->a1 * y + s->z2;
+    s->z2 = c->b2 * x - c->a2 * y;
+    return y;
+}
+static float fm_lowpass(float x, const fm_coeffs_t* k, fm_bqstate_t* s) {
+    for (int i = 0; i < 3; ++i) x = fm_biquad(x, &k->lp[i], &s[i]);
+    return x;
+}
+
+void jst_oracle_fm_lane(const float* in, float* out, uint64_t count, const fm_coeffs_t* k,
+                        fm_state_t* st) {
+    const double two_pi = 2.0f * JST_PI; /* the reference compares/subtracts in F64 (F32 op F64) */
+    float pr = st->prev_re, pi_ = st->prev_im;
+    int has = st->has_prev;
+    for (uint64_t n = 0; n < count; ++n) {
+        const float cr = in[2 * n], ci = in[2 * n + 1];
+        const int fin = isfinite(cr) && isfinite(ci) && isfinite(pr) && isfinite(pi_);
+        float d;
+        if (!has) d = 0.0f;
+        else if (fin) {
+            float re, im; /* conj(previous) * current */
+            cmul_f32(pr, -pi_, cr, ci, &re, &im);
+            d = atan2f(im, re) * k->ref;
+        } else d = NAN;
+        if (!isfinite(d)) {
+            if (!k->wide) out[n] = d;
+            else {
+                out[2 * n] = d;
+                out[2 * n + 1] = d;
+                st->pilot_phase += k->pilot_inc;
+                if ((double)st->pilot_phase >= two_pi) st->pilot_phase = (float)((double)st->pilot_phase - two_pi);
+            }
+        } else if (!k->wide) {
+            if (!k->deemph_enabled) out[n] = d;
+            else {
+                st->narrow_deemph += k->deemph_alpha * (d - st->narrow_deemph);
+                out[n] = st->narrow_deemph;
+            }
+        } else {
+            const float pc = cosf(st->pilot_phase), ps = sinf(st->pilot_phase);
+            st->pilot_cos_stage += k->pilot_alpha * (d * pc - st->pilot_cos_stage);
+            st->pilot_sin_stage += k->pilot_alpha * (d * ps - st->pilot_sin_stage);
+            st->pilot_cos += k->pilot_alpha * (st->pilot_cos_stage - st->pilot_cos);
+            st->pilot_sin += k->pilot_alpha * (st->pilot_sin_stage - st->pilot_sin);
+            const float sum = fm_lowpass(fm_biquad(d, &k->notch, &st->sum_notch), k, st->sum_filter);
+            const float po = atan2f(st->pilot_cos, st->pilot_sin);
+            const float carrier = sinf(2.0f * (st->pilot_phase + po));
+            const float diff = fm_lowpass(fm_biquad(2.0f * d * carrier, &k->notch, &st->diff_notch),
+                                          k, st->diff_filter);
+            float left = sum + diff, right = sum - diff;
+            if (k->deemph_enabled) {
+                st->left_de += k->deemph_alpha * (left - st->left_de);
+                st->right_de += k->deemph_alpha * (right - st->right_de);
+                left = st->left_de;
+                right = st->right_de;
+            }
+            out[2 * n] = left;
+            out[2 * n + 1] = right;
+            st->pilot_phase += k->pilot_inc;
+            if ((double)st->pilot_phase >= two_pi) st->pilot_phase = (float)((double)st->pilot_phase - two_pi);
+        }
+        pr = cr;
+        pi_ = ci;
+        has = 1;
+    }
+    st->prev_re = pr;
+    st->prev_im = pi_;
+    st->has_prev = 1;
+}
+uint64_t jst_oracle_fm_state_size(void) { return sizeof(fm_state_t); }
+uint64_t jst_oracle_fm_coeffs_size(void) { return sizeof(fm_coeffs_t); }

@@ -51,6 +51,8 @@ def lib() -> C.CDLL:
         _lib.jst_oracle_cast_u64.restype = C.c_uint64
         _lib.jst_oracle_cast_u64.argtypes = [C.c_float]
         _lib.jst_oracle_fft_c2c.restype = C.c_int
+        _lib.jst_oracle_fm_state_size.restype = C.c_uint64
+        _lib.jst_oracle_fm_coeffs_size.restype = C.c_uint64
     return _lib
 
 
@@ -291,3 +293,106 @@ def spectrum_chain(x: np.ndarray, range_min=None, range_max=None):
     if range_min is not None:
         out["range"] = range_(amp, range_min, range_max)
     return out
+
+
+# ------------------------------------------------------------- filter / FM side chains
+def pad(x: np.ndarray, size: int, axis: int = -1) -> np.ndarray:
+    """core/pad/module_impl_native_cpu.cc:75-140: zeros appended along axis."""
+    shape = list(x.shape)
+    shape[axis] = size
+    return np.concatenate([x, np.zeros(shape, x.dtype)], axis=axis)
+
+
+def unpad(x: np.ndarray, size: int, axis: int = -1):
+    """core/unpad/module_impl_native_cpu.cc:66-135: (body, tail) split along axis."""
+    n = x.shape[axis] - size
+    body, tail = np.split(x, [n], axis=axis)
+    return np.ascontiguousarray(body), np.ascontiguousarray(tail)
+
+
+def fold(x: np.ndarray, axis: int, size: int, offset: int = 0, channel_axis=None,
+         channel_offsets=None) -> np.ndarray:
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    oshape = list(x.shape)
+    oshape[axis] = size
+    out = np.empty(oshape, np.complex64)
+    co = _u64(channel_offsets) if channel_offsets is not None else None
+    lib().jst_oracle_fold_cf32(_p(x), _p(out), C.c_uint32(x.ndim), _p(_u64(x.shape), _u64p),
+                               C.c_uint64(axis), C.c_uint64(offset), C.c_uint64(size),
+                               C.c_int64(-1 if co is None else channel_axis),
+                               _p(co, _u64p) if co is not None else None)
+    return out
+
+
+def arithmetic_add(x: np.ndarray, axis: int) -> np.ndarray:
+    """Left-to-right F32 sum from +0 along axis (keepdims), components summed independently."""
+    x = np.ascontiguousarray(x)
+    axis %= x.ndim
+    outer = int(np.prod(x.shape[:axis], dtype=np.uint64))
+    r = x.shape[axis]
+    inner = int(np.prod(x.shape[axis + 1:], dtype=np.uint64))
+    lanes = 2 if x.dtype == np.complex64 else 1
+    flat = x.view(np.float32).reshape(outer, r, inner * lanes)
+    out = np.empty((outer, inner * lanes), np.float32)
+    lib().jst_oracle_arithmetic_add_f32(_p(np.ascontiguousarray(flat)), _p(out), C.c_uint64(outer),
+                                        C.c_uint64(r), C.c_uint64(inner * lanes))
+    oshape = list(x.shape)
+    oshape[axis] = 1
+    return out.view(x.dtype).reshape(oshape)
+
+
+def filter_taps(sample_rate: float, bandwidth: float, center, taps: int) -> np.ndarray:
+    center = np.ascontiguousarray(np.atleast_1d(center), dtype=np.float64)
+    out = np.empty((center.size, taps), np.complex64)
+    lib().jst_oracle_filter_taps(_p(out), C.c_double(sample_rate), C.c_double(bandwidth),
+                                 center.ctypes.data_as(C.POINTER(C.c_double)),
+                                 C.c_uint64(center.size), C.c_uint64(taps))
+    return out
+
+
+def overlap_add(buf: np.ndarray, ovl: np.ndarray, prev: np.ndarray, batch_axis=None):
+    """dsp/overlap_add/module_impl_native_cpu.cc:121-202.  Returns (out, new_prev); the overlap
+    region is the leading corner of the buffer (same coordinates)."""
+    out = buf.copy()
+    sl = tuple(slice(0, s) for s in ovl.shape)
+    if batch_axis is None:
+        out[sl] = out[sl] + prev
+        return out, ovl.copy()
+    shifted = np.concatenate([prev, np.delete(ovl, -1, axis=batch_axis)], axis=batch_axis)
+    out[sl] = out[sl] + shifted
+    return out, np.take(ovl, [ovl.shape[batch_axis] - 1], axis=batch_axis).copy()
+
+
+def phase_correction(x: np.ndarray, increments, phases: np.ndarray, batch_axis=None,
+                     channel_axis=None):
+    """phases (F64[channels]) is updated in place, like the module's state."""
+    x = np.ascontiguousarray(x, dtype=np.complex64)
+    bc = x.shape[batch_axis] if batch_axis is not None else 1
+    cc = x.shape[channel_axis] if channel_axis is not None else 1
+    binner = int(np.prod(x.shape[batch_axis + 1:], dtype=np.uint64)) if batch_axis is not None else 1
+    cinner = int(np.prod(x.shape[channel_axis + 1:], dtype=np.uint64)) if channel_axis is not None else 1
+    inc = np.ascontiguousarray(np.broadcast_to(np.asarray(increments, np.float64), (cc,)))
+    out = np.empty_like(x)
+    dp = C.POINTER(C.c_double)
+    lib().jst_oracle_phase_correction(_p(x), _p(out), C.c_uint64(x.size), C.c_uint64(bc),
+                                      C.c_uint64(binner), C.c_uint64(cc), C.c_uint64(cinner),
+                                      inc.ctypes.data_as(dp), phases.ctypes.data_as(dp))
+    return out
+
+
+class FmLane:
+    """One lane of the FM demodulator with its carried state (oracle/jst_oracle.c fm_*)."""
+
+    def __init__(self, mode="narrow", deemphasis="none", sample_rate=240e3):
+        self._k = C.create_string_buffer(int(lib().jst_oracle_fm_coeffs_size()))
+        self._st = C.create_string_buffer(int(lib().jst_oracle_fm_state_size()))
+        self.wide = mode == "wide"
+        lib().jst_oracle_fm_coeffs(self._k, C.c_int(self.wide),
+                                   C.c_int({"none": 0, "50us": 1, "75us": 2}[deemphasis]),
+                                   C.c_float(sample_rate))
+
+    def __call__(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x.reshape(-1), dtype=np.complex64)
+        out = np.empty(x.size * (2 if self.wide else 1), np.float32)
+        lib().jst_oracle_fm_lane(_p(x), _p(out), C.c_uint64(x.size), self._k, self._st)
+        return out.reshape(-1, 2) if self.wide else out
