@@ -69,6 +69,14 @@ bool fft_lds_supported(uint64_t n);
 bool fft_fused_supported(uint64_t n);
 hipError_t launch_fft_c2c(uint64_t n, bool forward, const FftLayout& L, const float2* W,
                           const float2* in, float2* out, hipStream_t stream);
+// General lengths (factors 2,3,4,5,8; any size): one Stockham pass per launch through HBM
+// (fft_global.hip).  scratch_a/b: dense CF32[transforms * n] each (b may be null when the plan
+// has at most two passes).
+int fft_plan_factors(uint64_t n, uint32_t* factors /*[64]*/);
+bool fft_global_supported(uint64_t n);
+hipError_t launch_fft_c2c_global(uint64_t n, bool forward, const FftLayout& L, const float2* W,
+                                 const float2* in, float2* out, float2* scratch_a,
+                                 float2* scratch_b, hipStream_t stream);
 // Multiply(window) -> FFT(forward) -> Amplitude [-> Range] in one pass over HBM.
 hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W,
                                  const float2* in, const float2* window, int64_t window_stride,

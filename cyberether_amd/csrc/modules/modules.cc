@@ -462,9 +462,9 @@ Result Fft::validate() {
         return Result::ERROR;
     }
     const U64 n = in.shape(*axes.sample);
-    if (!kernels::fft_lds_supported(n)) {
+    if (!kernels::fft_lds_supported(n) && !kernels::fft_global_supported(n)) {
         JST_ERROR("[MODULE_FFT_NATIVE_HIP] Transform length %llu is not implemented on the HIP "
-                  "device (powers of two up to 16384).",
+                  "device (lengths whose prime factors are 2, 3 and 5).",
                   (unsigned long long)n);
         return Result::ERROR;
     }
@@ -487,7 +487,23 @@ Result Fft::create() {
     produced("signal", output);
     return Result::SUCCESS;
 }
-Result Fft::computeInitialize() { return GetTwiddles(input.shape(resolvedAxis), &twiddles); }
+Result Fft::computeInitialize() {
+    const U64 n = input.shape(resolvedAxis);
+    JST_CHECK(GetTwiddles(n, &twiddles));
+    useGlobalPasses = !kernels::fft_lds_supported(n);
+    if (useGlobalPasses) {  // ping-pong scratch for the pass-per-launch path
+        uint32_t fact[64];
+        const int nf = kernels::fft_plan_factors(n, fact);
+        if (nf >= 2) JST_CHECK(scratchA.create(device(), DataType::CF32, {input.size()}));
+        if (nf >= 3) JST_CHECK(scratchB.create(device(), DataType::CF32, {input.size()}));
+    }
+    return Result::SUCCESS;
+}
+Result Fft::computeDeinitialize() {
+    scratchA = Tensor();
+    scratchB = Tensor();
+    return Result::SUCCESS;
+}
 Result Fft::layout(FftLayout& L) const {
     std::memset(&L, 0, sizeof(L));
     L.transforms = 1;
@@ -510,6 +526,12 @@ Result Fft::layout(FftLayout& L) const {
 Result Fft::computeSubmit(hipStream_t stream) {
     FftLayout L;
     JST_CHECK(layout(L));
+    if (useGlobalPasses)
+        return hip_result(
+            kernels::launch_fft_c2c_global(input.shape(resolvedAxis), forward, L, twiddles,
+                                           ptr<const float2>(input), ptr<float2>(output),
+                                           ptr<float2>(scratchA), ptr<float2>(scratchB), stream),
+            "fft (global passes) kernel");
     return hip_result(kernels::launch_fft_c2c(input.shape(resolvedAxis), forward, L, twiddles,
                                               ptr<const float2>(input), ptr<float2>(output), stream),
                       "fft kernel");

@@ -102,9 +102,11 @@ class Fft : public Module {
     Result define() override;
     Result create() override;
     Result computeInitialize() override;
+    Result computeDeinitialize() override;
     Result computeSubmit(hipStream_t stream) override;
     Result layout(dev::FftLayout& L) const;
-    Tensor input, output;
+    Tensor input, output, scratchA, scratchB;
+    bool useGlobalPasses = false;
     bool forward = true, complexOutput = false;
     Index resolvedAxis = 0;
     const float2* twiddles = nullptr;

@@ -216,9 +216,11 @@ void jst_oracle_multiply_f32(uint32_t rank, const uint64_t* shape, const float* 
  *   sincos_2pibyn :296-372    -> twiddles from two F64 tables multiplied in F64, cast to F32
  *   pass_all      :1420-1468  -> Stockham passes ping-ponging between c and ch
  *   pass2/4/8     :843-872, :929-975, :1141-1223 with special_mul<fwd> (:266-272, conj for fwd)
- * This restatement covers exactly those lengths (n = 2^m, m >= 0); other lengths are checked
- * against oracle/_ref only.  It is verified BIT-EXACT against oracle/_ref for every m in
- * 0..16, both directions (tests/test_oracle_fft.py).
+ * plus pass3 :873-923 and pass5 :976-1050 for lengths with factors 3 and 5 (the Filter block's
+ * convolution sizes, e.g. 160000 = 8*8*4*5*5*5*5).  Lengths with any other prime factor (pass7,
+ * pass11, passg, Bluestein) are checked against oracle/_ref only.  Verified BIT-EXACT against
+ * oracle/_ref for every 2^m, m in 0..16, and a sweep of 2^a 3^b 5^c lengths, both directions
+ * (tests/test_oracle_fft.py).
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     double r, i;
@@ -334,7 +336,9 @@ void jst_oracle_fft_twiddles(float* tw, uint64_t n) {
     sincos_free(&s);
 }
 
-/* Factor list for n = 2^m (pocketfft.hh:1476-1497).  Returns count. */
+/* Factor list (pocketfft.hh:1476-1497): 8s, 4s, one 2 moved to the FRONT, then odd divisors in
+ * increasing order.  Returns the count, or -1 when a factor other than 2,3,4,5,8 appears (those
+ * lengths use pass7/pass11/passg or Bluestein in the reference and are not restated). */
 int jst_oracle_fft_factors(uint64_t n, uint32_t* fact) {
     int nf = 0;
     uint64_t len = n;
@@ -354,7 +358,15 @@ int jst_oracle_fft_factors(uint64_t n, uint32_t* fact) {
         fact[0] = fact[nf - 1];
         fact[nf - 1] = t;
     }
-    return (len == 1) ? nf : -1; /* -1: not a power of two -> not restated */
+    for (uint64_t divisor = 3; divisor * divisor <= len; divisor += 2)
+        while ((len % divisor) == 0) {
+            fact[nf++] = (uint32_t)divisor;
+            len /= divisor;
+        }
+    if (len > 1) fact[nf++] = (uint32_t)len;
+    for (int i = 0; i < nf; ++i)
+        if (fact[i] != 2 && fact[i] != 3 && fact[i] != 4 && fact[i] != 5 && fact[i] != 8) return -1;
+    return nf;
 }
 
 static inline c32 cadd(c32 a, c32 b) {
@@ -517,6 +529,63 @@ static void pass8(uint64_t ido, uint64_t l1, const c32* cc, c32* ch, const c32* 
         }
     }
 }
+static void pass3(uint64_t ido, uint64_t l1, const c32* cc, c32* ch, const c32* wa, int fwd) {
+    const uint64_t ip = 3; /* pocketfft.hh:873-923 */
+    const float tw1r = -0.5f;
+    const float tw1i = (fwd ? -1 : 1) * (float)0.8660254037844386467637231707529362L;
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 0; i < ido; ++i) {
+            const c32 t0 = CC(i, 0, k);
+            const c32 t1 = cadd(CC(i, 1, k), CC(i, 2, k)), t2 = csub(CC(i, 1, k), CC(i, 2, k));
+            CH(i, k, 0) = cadd(t0, t1);
+            c32 ca = {t0.r + t1.r * tw1r, t0.i + t1.i * tw1r};
+            c32 cb = {-t2.i * tw1i, t2.r * tw1i};
+            if (i == 0) {
+                CH(0, k, 1) = cadd(ca, cb);
+                CH(0, k, 2) = csub(ca, cb);
+            } else {
+                CH(i, k, 1) = special_mul(cadd(ca, cb), WA(0, i), fwd);
+                CH(i, k, 2) = special_mul(csub(ca, cb), WA(1, i), fwd);
+            }
+        }
+}
+
+static void pass5(uint64_t ido, uint64_t l1, const c32* cc, c32* ch, const c32* wa, int fwd) {
+    const uint64_t ip = 5; /* pocketfft.hh:976-1050 */
+    const float tw1r = (float)0.3090169943749474241022934171828191L;
+    const float tw1i = (fwd ? -1 : 1) * (float)0.9510565162951535721164393333793821L;
+    const float tw2r = (float)-0.8090169943749474241022934171828191L;
+    const float tw2i = (fwd ? -1 : 1) * (float)0.5877852522924731291687059546390728L;
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 0; i < ido; ++i) {
+            const c32 t0 = CC(i, 0, k);
+            const c32 t1 = cadd(CC(i, 1, k), CC(i, 4, k)), t4 = csub(CC(i, 1, k), CC(i, 4, k));
+            const c32 t2 = cadd(CC(i, 2, k), CC(i, 3, k)), t3 = csub(CC(i, 2, k), CC(i, 3, k));
+            c32 o0 = {t0.r + t1.r + t2.r, t0.i + t1.i + t2.i};
+            CH(i, k, 0) = o0;
+            /* PARTSTEP5(1,4, tw1r,tw2r,+tw1i,+tw2i) */
+            c32 ca = {t0.r + tw1r * t1.r + tw2r * t2.r, t0.i + tw1r * t1.i + tw2r * t2.i};
+            c32 cb;
+            cb.i = +tw1i * t4.r + tw2i * t3.r;
+            cb.r = -(+tw1i * t4.i + tw2i * t3.i);
+            /* PARTSTEP5(2,3, tw2r,tw1r,+tw2i,-tw1i) */
+            c32 da = {t0.r + tw2r * t1.r + tw1r * t2.r, t0.i + tw2r * t1.i + tw1r * t2.i};
+            c32 db;
+            db.i = +tw2i * t4.r - tw1i * t3.r;
+            db.r = -(+tw2i * t4.i - tw1i * t3.i);
+            if (i == 0) {
+                CH(0, k, 1) = cadd(ca, cb);
+                CH(0, k, 4) = csub(ca, cb);
+                CH(0, k, 2) = cadd(da, db);
+                CH(0, k, 3) = csub(da, db);
+            } else {
+                CH(i, k, 1) = special_mul(cadd(ca, cb), WA(0, i), fwd);
+                CH(i, k, 4) = special_mul(csub(ca, cb), WA(3, i), fwd);
+                CH(i, k, 2) = special_mul(cadd(da, db), WA(1, i), fwd);
+                CH(i, k, 3) = special_mul(csub(da, db), WA(2, i), fwd);
+            }
+        }
+}
 #undef CC
 #undef CH
 #undef WA
@@ -559,6 +628,10 @@ int jst_oracle_fft_c2c(const float* in, float* out, uint64_t n, uint64_t batch, 
                 pass8(ido, l1, p1, p2, tw[k], forward);
             else if (ip == 4)
                 pass4(ido, l1, p1, p2, tw[k], forward);
+            else if (ip == 5)
+                pass5(ido, l1, p1, p2, tw[k], forward);
+            else if (ip == 3)
+                pass3(ido, l1, p1, p2, tw[k], forward);
             else
                 pass2(ido, l1, p1, p2, tw[k], forward);
             c32* t = p1;

@@ -138,7 +138,7 @@ def fft_twiddles(n: int) -> np.ndarray:
 
 
 def fft_c2c(x: np.ndarray, forward: bool = True) -> np.ndarray:
-    """Restated pocketfft c2c over the LAST axis (power-of-two lengths only)."""
+    """Restated pocketfft c2c over the LAST axis (lengths with prime factors 2, 3, 5)."""
     x = np.ascontiguousarray(x, dtype=np.complex64)
     n = x.shape[-1]
     batch = x.size // n if n else 0
@@ -146,7 +146,7 @@ def fft_c2c(x: np.ndarray, forward: bool = True) -> np.ndarray:
     rc = lib().jst_oracle_fft_c2c(_p(x), _p(out), C.c_uint64(n), C.c_uint64(batch),
                                   C.c_int(1 if forward else 0))
     if rc != 0:
-        raise ValueError(f"oracle restatement covers power-of-two lengths only (n={n})")
+        raise ValueError(f"oracle restatement covers lengths with factors 2, 3, 5 only (n={n})")
     return out
 
 

@@ -103,8 +103,33 @@ def test_special_values_propagate_like_the_cpu(js, oracle):
     assert np.array_equal(got.view(np.uint32)[fin], ref.view(np.uint32)[fin])
 
 
+@pytest.mark.parametrize("n", [3, 5, 6, 12, 15, 60, 100, 243, 625, 1000, 2000, 6000, 32768, 65536, 160000])
+def test_general_lengths_bit_exact(js, oracle, n):
+    """Lengths with factors 3 and 5 and lengths beyond LDS: pass-per-launch path (fft_global.hip)."""
+    rng = np.random.default_rng(n)
+    batch = 3 if n < 10000 else 2
+    x = csignal(rng, (batch, n))
+    for forward in (True, False):
+        _, out = run_module(js, "fft", {"forward": forward},
+                            {"signal": js.Tensor.from_numpy(x, sample=1, batch=0)})
+        assert_bit_equal(out["signal"], oracle.fft_c2c(x, forward), f"n={n} fwd={forward}")
+
+
+def test_general_length_strided(js, oracle):
+    rng = np.random.default_rng(77)
+    store = csignal(rng, (4, 3, 300))
+    t = js.Tensor.from_numpy(store)
+    t.slice(2, 0, 300, 2).permute((1, 0, 2)).set_axes(sample=2)   # n = 150 = 2*3*5*5
+    host = np.ascontiguousarray(store[:, :, ::2].transpose(1, 0, 2))
+    _, out = run_module(js, "fft", {}, {"signal": t})
+    assert_bit_equal(out["signal"], oracle.fft_c2c(host))
+    lead = csignal(rng, (45, 4))                                  # transform along axis 0
+    _, out = run_module(js, "fft", {}, {"signal": js.Tensor.from_numpy(lead, sample=0, batch=1)})
+    assert_bit_equal(out["signal"], np.ascontiguousarray(oracle.fft_c2c(np.ascontiguousarray(lead.T)).T))
+
+
 def test_unsupported_cases_fail_loudly(js):
-    x = np.zeros((2, 12), np.complex64)
+    x = np.zeros((2, 14), np.complex64)   # prime factor 7: pass7 is not implemented
     with pytest.raises(js.JetstreamError, match="not implemented"):
         js.Module("fft", {}, {"signal": js.Tensor.from_numpy(x, sample=1, batch=0)})
     r = np.zeros((2, 16), np.float32)

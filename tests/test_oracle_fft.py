@@ -23,6 +23,19 @@ def test_restatement_bit_exact_vs_reference_pocketfft(oracle, m):
         assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), (n, forward)
 
 
+@pytest.mark.parametrize("n", [3, 5, 6, 9, 10, 12, 15, 20, 25, 30, 45, 60, 75, 100, 125, 243, 250, 360,
+                               625, 1000, 2000, 3125, 6000, 10000, 160000])
+def test_radix_3_5_restatement_bit_exact_vs_reference_pocketfft(oracle, n):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    rng = np.random.default_rng(n)
+    x = _signal(rng, (3 if n < 10000 else 1, n))
+    for forward in (True, False):
+        mine = oracle.fft_c2c(x, forward)
+        ref = oracle.ref_fft_c2c(x, axis=1, forward=forward)
+        assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), (n, forward)
+
+
 def test_twiddles_match_reference_usage(oracle):
     # exp(+2 pi j k / n) to float accuracy, and exactly symmetric the way pocketfft builds it
     for n in (8, 64, 4096, 65536):
@@ -37,4 +50,7 @@ def test_factor_order(oracle):
     assert oracle.fft_factors(8192) == [2, 8, 8, 8, 8]
     assert oracle.fft_factors(2048) == [8, 8, 8, 4]
     assert oracle.fft_factors(65536) == [2, 8, 8, 8, 8, 8]
-    assert oracle.fft_factors(12) is None
+    assert oracle.fft_factors(12) == [4, 3]
+    assert oracle.fft_factors(160000) == [8, 8, 4, 5, 5, 5, 5]
+    assert oracle.fft_factors(10) == [2, 5]
+    assert oracle.fft_factors(14) is None  # pass7 is not restated
