@@ -482,3 +482,162 @@ class SpectrumEngine:
         if self.range is not None:
             ms.append(self.range)
         return ms
+
+
+def filter_plan(sample_rate: float, bandwidth: float, center: Sequence[float], taps: int,
+                heads: int, signal_size: int) -> dict:
+    """CalculateCandidatePlan (src/domains/dsp/filter/block_impl.cc:40-168): convolution size,
+    whether the block resamples (fold), per-head fold offsets (integers), pad size."""
+    import math
+    sr = float(np.float32(sample_rate))  # the block config holds F32 (filter/block.hh)
+    bw = float(np.float32(bandwidth))
+    plan = {"padSize": taps - 1, "convolutionSize": taps + signal_size - 1, "resample": False,
+            "resamplerOffsets": [], "resamplerSize": 0, "resampledSampleRate": 0.0}
+    conv = plan["convolutionSize"]
+    ratio = sr / bw
+    if not math.isfinite(ratio) or ratio <= 0 or ratio >= 2.0 ** 64 or ratio != math.floor(ratio):
+        return plan
+    r = int(ratio)
+    if plan["padSize"] % r != 0 or conv % r != 0:
+        return plan
+    offsets = [0] * heads
+    per_bin = sr / float(conv)
+    for head in range(heads):
+        ct = float(np.float32(center[head])) if head < len(center) else 0.0
+        if ct == 0.0:
+            continue
+        center_bin = ct / per_bin
+        rounded = float(np.round(center_bin))  # std::round: half away from zero
+        if abs(center_bin - math.trunc(center_bin)) == 0.5:
+            rounded = math.trunc(center_bin) + math.copysign(1.0, center_bin)
+        fold_offset_bin = -rounded
+        if fold_offset_bin < 0.0:
+            rem = int(-fold_offset_bin) % conv
+            offsets[head] = 0 if rem == 0 else conv - rem
+        else:
+            offsets[head] = int(math.fmod(fold_offset_bin, float(conv)))
+    plan.update(resamplerOffsets=offsets, resamplerSize=conv // r, padSize=plan["padSize"] // r,
+                resampledSampleRate=float(np.float32(sr / float(r))), resample=True)
+    return plan
+
+
+class Filter:
+    """The filter BLOCK: filter_taps -> pad -> fft -> multiply -> [fold] -> ifft -> normalize ->
+    [phase_correction] -> unpad -> overlap_add, wired as src/domains/dsp/filter/block_impl.cc:350-582."""
+
+    def __init__(self, signal: Tensor, sample_rate: float = 2.0e6, bandwidth: float = 1.0e6,
+                 center: Sequence[float] = (0.0,), taps: int = 101, heads: int = 1,
+                 name: str = "filter"):
+        import math
+        axes = signal.axes
+        rank = len(signal.shape)
+        s_axis = axes["sample"] if axes["sample"] is not None else (0 if rank == 1 else None)
+        if s_axis is None:
+            raise JetstreamError(1, "[BLOCK_FILTER] Input validation plan is unavailable.")
+        head_axis, sample_axis = s_axis, s_axis + 1
+        signal_size = signal.shape[s_axis]
+        self.plan = plan = filter_plan(sample_rate, bandwidth, center, taps, heads, signal_size)
+        batch = axes["batch"]
+        out_axes = {"sample": sample_axis, "channel": head_axis,
+                    "batch": None if batch is None else (batch + 1 if batch >= head_axis else batch)}
+        p = name + "."
+        sr, bw = float(np.float32(sample_rate)), float(np.float32(bandwidth))
+        ctr = [float(np.float32(c)) for c in list(center)[:heads]] + [0.0] * max(0, heads - len(center))
+        self.filter_taps = Module("filter_taps", {"sampleRate": sr, "bandwidth": bw, "center": ctr,
+                                                  "taps": taps}, {}, p + "filter_taps")
+        filt = self.filter_taps.output("coeffs").set_axes(sample=1, channel=0)
+        self.cast_signal = Module("cast", {"outputType": "CF32"}, {"buffer": signal}, p + "cast_signal")
+        self.expand_signal = Module("expand_dims", {"axis": head_axis},
+                                    {"buffer": self.cast_signal.output("buffer")}, p + "expand_signal")
+        sig_in = self.expand_signal.output("buffer").set_axes(**out_axes)
+        self.pad_signal = Module("pad", {"size": taps - 1, "axis": sample_axis}, {"unpadded": sig_in},
+                                 p + "padSignal")
+        self.pad_filter = Module("pad", {"size": signal_size - 1, "axis": 1}, {"unpadded": filt},
+                                 p + "padFilter")
+        self.fft_signal = Module("fft", {"forward": True},
+                                 {"signal": self.pad_signal.output("padded")}, p + "fftSignal")
+        self.fft_filter = Module("fft", {"forward": True},
+                                 {"signal": self.pad_filter.output("padded")}, p + "fftFilter")
+        spec_shape = [1] * (rank + 1)
+        spec_shape[head_axis] = heads
+        spec_shape[sample_axis] = plan["convolutionSize"]
+        self.reshape_filter = Module("reshape", {"shape": spec_shape},
+                                     {"buffer": self.fft_filter.output("signal")}, p + "reshape_filter")
+        aligned = self.reshape_filter.output("buffer").set_axes(sample=sample_axis, channel=head_axis)
+        self.multiply = Module("multiply", {}, {"a": self.fft_signal.output("signal"), "b": aligned},
+                               p + "multiply")
+        product = self.multiply.output("product").set_axes(**out_axes)
+        ifft_in = product
+        self.fold = None
+        if plan["resample"]:
+            product.set_attribute("channelOffsets", [int(o) for o in plan["resamplerOffsets"]])
+            self.fold = Module("fold", {"offset": 0, "size": plan["resamplerSize"]},
+                               {"buffer": product}, p + "fold")
+            ifft_in = self.fold.output("buffer")
+        self.ifft = Module("fft", {"forward": False}, {"signal": ifft_in}, p + "ifft")
+        ifft_out = self.ifft.output("signal")
+        n_ifft = ifft_out.shape[sample_axis]
+        self.normalize = Module("multiply_constant", {"constant": float(np.float32(1.0) / np.float32(n_ifft))},
+                                {"factor": ifft_out}, p + "normalize")
+        normalized = self.normalize.output("product")
+        self.phase_correction = None
+        if plan["resample"] and any(o != 0 for o in plan["resamplerOffsets"]):
+            inc = [math.remainder(2.0 * math.pi * float(o) * float(signal_size) /
+                                  float(plan["convolutionSize"]), 2.0 * math.pi)
+                   for o in plan["resamplerOffsets"]]
+            normalized.set_attribute("channelPhaseIncrements", inc)
+            self.phase_correction = Module("phase_correction", {"phaseIncrement": 0.0},
+                                           {"signal": normalized}, p + "phase_correction")
+            normalized = self.phase_correction.output("signal")
+        self.unpad = self.overlap = None
+        if plan["padSize"] == 0:
+            self.buffer = normalized
+        else:
+            self.unpad = Module("unpad", {"size": plan["padSize"], "axis": sample_axis},
+                                {"padded": normalized}, p + "unpad")
+            self.overlap = Module("overlap_add", {}, {"buffer": self.unpad.output("unpadded"),
+                                                      "overlap": self.unpad.output("pad")}, p + "overlap")
+            self.buffer = self.overlap.output("buffer")
+        self.buffer.set_axes(**out_axes)
+        if plan["resample"]:
+            self.buffer.set_attribute("sampleRate", plan["resampledSampleRate"])
+
+    @property
+    def modules(self) -> List[Module]:
+        ms = [self.filter_taps, self.cast_signal, self.expand_signal, self.pad_signal, self.pad_filter,
+              self.fft_signal, self.fft_filter, self.reshape_filter, self.multiply, self.fold, self.ifft,
+              self.normalize, self.phase_correction, self.unpad, self.overlap]
+        return [m for m in ms if m is not None]
+
+
+class Decimator:
+    """The decimator BLOCK: reshape [.., S/r, r] -> arithmetic(add, ratio axis) -> squeeze_dims ->
+    duplicate (src/domains/dsp/decimator/block_impl.cc:140-207): integrate-and-dump, no divide."""
+
+    def __init__(self, buffer: Tensor, ratio: int = 4, name: str = "decimator"):
+        axes = buffer.axes
+        shape = list(buffer.shape)
+        s_axis = axes["sample"] if axes["sample"] is not None else (0 if len(shape) == 1 else None)
+        if s_axis is None or ratio == 0 or shape[s_axis] % ratio != 0:
+            raise JetstreamError(1, "[BLOCK_DECIMATOR] Input validation plan is unavailable.")
+        child = s_axis + 1
+        new_shape = shape[:s_axis] + [shape[s_axis] // ratio, ratio] + shape[s_axis + 1:]
+        bump = lambda a: None if a is None else (a + 1 if a > s_axis else a)
+        reshaped_axes = {k: bump(v) for k, v in axes.items()}
+        reshaped_axes["sample"] = s_axis
+        p = name + "."
+        self.reshape = Module("reshape", {"shape": new_shape}, {"buffer": buffer}, p + "reshape")
+        reshaped = self.reshape.output("buffer").set_axes(**reshaped_axes)
+        self.arithmetic = Module("arithmetic", {"operation": "add", "axis": child},
+                                 {"buffer": reshaped}, p + "arithmetic")
+        self.squeeze = Module("squeeze_dims", {"axis": child},
+                              {"buffer": self.arithmetic.output("buffer")}, p + "squeeze_dims")
+        squeezed = self.squeeze.output("buffer").set_axes(sample=s_axis, batch=axes["batch"],
+                                                          channel=axes["channel"])
+        self.duplicate = Module("duplicate", {}, {"buffer": squeezed}, p + "duplicate")
+        self.buffer = self.duplicate.output("buffer").set_axes(sample=s_axis, batch=axes["batch"],
+                                                               channel=axes["channel"])
+
+    @property
+    def modules(self) -> List[Module]:
+        return [self.reshape, self.arithmetic, self.squeeze, self.duplicate]

@@ -396,3 +396,40 @@ class FmLane:
         out = np.empty(x.size * (2 if self.wide else 1), np.float32)
         lib().jst_oracle_fm_lane(_p(x), _p(out), C.c_uint64(x.size), self._k, self._st)
         return out.reshape(-1, 2) if self.wide else out
+
+
+def filter_block(x: np.ndarray, plan: dict, sample_rate: float, bandwidth: float, center,
+                 taps: int, state: dict) -> np.ndarray:
+    """The Filter block's module chain on the CPU oracle (filter/block_impl.cc:350-582) for a
+    signal [batch, samples] (batchAxis 0, sampleAxis 1) -> [batch, heads, out].  `state` carries
+    the overlap and phase state across calls ({} to start)."""
+    import math
+    heads = len(center)
+    b, s = x.shape
+    conv = plan["convolutionSize"]
+    sr, bw = float(np.float32(sample_rate)), float(np.float32(bandwidth))
+    ctr = [float(np.float32(c)) for c in center]
+    tapsv = filter_taps(sr, bw, ctr, taps)                          # [heads, taps]
+    sig = pad(x.reshape(b, 1, s).astype(np.complex64), taps - 1, 2)  # [b, 1, conv]
+    fsig = fft_c2c(sig, True)
+    ffil = fft_c2c(pad(tapsv, s - 1, 1), True).reshape(1, heads, conv)
+    prod = multiply(fsig, ffil)                                      # [b, heads, conv]
+    spec = prod
+    if plan["resample"]:
+        spec = fold(prod, 2, plan["resamplerSize"], 0, 1, plan["resamplerOffsets"])
+    time = fft_c2c(spec, False)
+    c = np.float32(1.0) / np.float32(time.shape[2])
+    norm = (time.real * c + 1j * (time.imag * c)).astype(np.complex64)
+    if plan["resample"] and any(o != 0 for o in plan["resamplerOffsets"]):
+        inc = [math.remainder(2.0 * math.pi * float(o) * float(s) / float(conv), 2.0 * math.pi)
+               for o in plan["resamplerOffsets"]]
+        phases = state.setdefault("phases", np.zeros(heads, np.float64))
+        norm = phase_correction(norm, inc, phases, batch_axis=0, channel_axis=1)
+    if plan["padSize"] == 0:
+        return norm
+    body, tail = unpad(norm, plan["padSize"], 2)
+    prev = state.get("prev")
+    if prev is None:
+        prev = np.zeros((1,) + tail.shape[1:], np.complex64)
+    out, state["prev"] = overlap_add(body, tail, prev, batch_axis=0)
+    return out
