@@ -124,6 +124,11 @@ hipError_t launch_waterfall(float* ring, uint64_t* state, const float* in, uint6
                             uint64_t batches, uint64_t width, uint64_t height,
                             int64_t batch_stride, int64_t elem_stride, hipStream_t stream);
 
+hipError_t launch_lineplot(float* points, float* average, const float* in, uint64_t in_offset,
+                           uint64_t batches, uint64_t elements, int64_t batch_stride,
+                           int64_t elem_stride, uint64_t decimation, float normalization,
+                           float averaging, hipStream_t stream);
+
 // ---- Filter / FM side chains (filter_kernels.hip) ----------------------------------------------
 hipError_t launch_pad(void* out, const void* in, bool complex, uint64_t outer, uint64_t in_axis,
                       uint64_t out_axis, uint64_t inner, hipStream_t s);

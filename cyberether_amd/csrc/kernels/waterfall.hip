@@ -71,4 +71,43 @@ hipError_t launch_waterfall(float* ring, uint64_t* state, const float* in, uint6
     return hipGetLastError();
 }
 
+// ---- Lineplot compute (visualization/lineplot/module_impl_native_cpu.cc:80-118; CUDA analogue
+// module_impl_native_cuda.cc:21-49): per-bin batch sum (left to right from +0), normalisation to
+// [-1, 1], then the moving average  avg -= avg/averaging; avg += amplitude/averaging.
+// The averaged trace is the reference's only "averaged spectrum": it is what the optional
+// cross-GPU all-reduce of BASELINE config 5 averages (cyberether_amd/distributed.py).
+namespace {
+__global__ __launch_bounds__(256) void lineplot_kernel(float* __restrict__ points,
+                                                       float* __restrict__ average,
+                                                       const float* __restrict__ in,
+                                                       uint64_t in_offset, uint64_t batches,
+                                                       uint64_t elements, int64_t batch_stride,
+                                                       int64_t elem_stride, uint64_t decimation,
+                                                       float normalization, float averaging) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elements) return;
+    float sum = 0.0f;
+    for (uint64_t b = 0; b < batches; ++b)
+        sum += in[in_offset + (int64_t)b * batch_stride + (int64_t)(i * decimation) * elem_stride];
+    const float amplitude = fminf(fmaxf((sum * normalization) - 1.0f, -1.0f), 1.0f);
+    float avg = average[i];
+    avg -= avg / averaging;
+    avg += amplitude / averaging;
+    average[i] = avg;
+    points[(i * 2) + 1] = avg;
+}
+}  // namespace
+
+hipError_t launch_lineplot(float* points, float* average, const float* in, uint64_t in_offset,
+                           uint64_t batches, uint64_t elements, int64_t batch_stride,
+                           int64_t elem_stride, uint64_t decimation, float normalization,
+                           float averaging, hipStream_t stream) {
+    if (elements == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(lineplot_kernel, dim3((unsigned)((elements + 255) / 256)), dim3(256), 0,
+                       stream, points, average, in, in_offset, batches, elements, batch_stride,
+                       elem_stride, decimation, normalization, averaging);
+    return hipGetLastError();
+}
+
 }  // namespace jst::kernels

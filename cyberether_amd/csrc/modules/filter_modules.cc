@@ -915,6 +915,91 @@ class Duplicate : public Module {
     Tensor input, output;
 };
 
+// ---- Lineplot, compute part (visualization/lineplot/module_impl.cc:30-215,
+// module_impl_native_cpu.cc:80-118) ------------------------------------------------------------
+class Lineplot : public Module {
+ public:
+    const char* type() const override { return "lineplot"; }
+    Result validate() override {
+        bool ok1, ok2;
+        averaging = ConfigU64(config_, "averaging", 1, &ok1);
+        decimation = ConfigU64(config_, "decimation", 1, &ok2);
+        if (!ok1 || averaging == 0) {
+            JST_ERROR("[MODULE_LINEPLOT] Averaging must be greater than zero.");
+            return Result::ERROR;
+        }
+        if (!ok2 || decimation == 0) {
+            JST_ERROR("[MODULE_LINEPLOT] Decimation must be greater than zero.");
+            return Result::ERROR;
+        }
+        if (!inputs_.count("signal")) return Result::SUCCESS;
+        const Tensor& in = inputs_.at("signal");
+        if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+        SignalAxes axes;
+        if (MapSignalAxes(in, axes) != Result::SUCCESS) {
+            JST_ERROR("[MODULE_LINEPLOT] Input must contain valid signal axis metadata.");
+            return Result::ERROR;
+        }
+        if (axes.sample && axes.channel) {
+            JST_ERROR("[MODULE_LINEPLOT] Input cannot contain both sampleAxis and channelAxis.");
+            return Result::ERROR;
+        }
+        const auto element = axes.sample ? axes.sample : axes.channel;
+        if (!element) {
+            JST_ERROR("[MODULE_LINEPLOT] Input must contain sampleAxis or channelAxis.");
+            return Result::ERROR;
+        }
+        for (Index ax = 0; ax < in.rank(); ++ax)
+            if (ax != *element && (!axes.batch || ax != *axes.batch)) {
+                JST_ERROR("[MODULE_LINEPLOT] Unsupported auxiliary input axis %llu.",
+                          (unsigned long long)ax);
+                return Result::ERROR;
+            }
+        if (in.dtype() != DataType::F32) {
+            JST_ERROR("[MODULE_LINEPLOT] Input must be F32.");
+            return Result::ERROR;
+        }
+        numberOfElements = in.shape(*element) / decimation;
+        if (numberOfElements < 2) {
+            JST_ERROR("[MODULE_LINEPLOT] Decimated input must keep at least two elements.");
+            return Result::ERROR;
+        }
+        numberOfBatches = axes.batch ? in.shape(*axes.batch) : 1;
+        elementStride = in.stride(*element);
+        batchStride = axes.batch ? in.stride(*axes.batch) : 0;
+        normalizationFactor = 1.0f / (0.5f * static_cast<F32>(numberOfBatches));
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineTaint(SURFACE));
+        return defineInterfaceInput("signal");
+    }
+    Result create() override {
+        input = inputs_.at("signal");
+        JST_CHECK(signalPoints.create(device(), DataType::F32, {numberOfElements, 2}));
+        JST_CHECK(averagingBuffer.create(device(), DataType::F32, {numberOfElements}));
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        return hip_result(
+            kernels::launch_lineplot(ptr<float>(signalPoints), ptr<float>(averagingBuffer),
+                                     ptr<const float>(input), input.offset(), numberOfBatches,
+                                     numberOfElements, (int64_t)batchStride, (int64_t)elementStride,
+                                     decimation, normalizationFactor, static_cast<F32>(averaging), s),
+            "lineplot kernel");
+    }
+    const Tensor* state(const std::string& key) const override {
+        if (key == "signalPoints") return &signalPoints;
+        if (key == "averagingBuffer") return &averagingBuffer;
+        return nullptr;
+    }
+    Tensor input, signalPoints, averagingBuffer;
+    U64 averaging = 1, decimation = 1, numberOfElements = 0, numberOfBatches = 0;
+    U64 elementStride = 0, batchStride = 0;
+    F32 normalizationFactor = 1.0f;
+};
+
+JST_REGISTER_MODULE(Lineplot, "lineplot", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Pad, "pad", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Unpad, "unpad", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Fold, "fold", DeviceType::HIP, RuntimeType::NATIVE, "generic");

@@ -1071,3 +1071,21 @@ void jst_oracle_fm_lane(const float* in, float* out, uint64_t count, const fm_co
 }
 uint64_t jst_oracle_fm_state_size(void) { return sizeof(fm_state_t); }
 uint64_t jst_oracle_fm_coeffs_size(void) { return sizeof(fm_coeffs_t); }
+
+/* ------------------------------------------------------------------------------------------
+ * Lineplot compute.  src/domains/visualization/lineplot/module_impl_native_cpu.cc:80-118,
+ * normalisation module_impl.cc:91.  avg[] (F32[elements]) is the carried state.
+ * ---------------------------------------------------------------------------------------- */
+void jst_oracle_lineplot(float* avg, const float* in, uint64_t batches, uint64_t elements,
+                         uint64_t batch_stride, uint64_t elem_stride, uint64_t decimation,
+                         uint64_t averaging) {
+    const float norm = 1.0f / (0.5f * (float)batches);
+    const float av = (float)averaging;
+    for (uint64_t i = 0; i < elements; ++i) {
+        float sum = 0.0f;
+        for (uint64_t b = 0; b < batches; ++b) sum += in[b * batch_stride + i * decimation * elem_stride];
+        const float amplitude = fminf(fmaxf((sum * norm) - 1.0f, -1.0f), 1.0f);
+        avg[i] -= avg[i] / av;
+        avg[i] += amplitude / av;
+    }
+}

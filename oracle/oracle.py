@@ -433,3 +433,11 @@ def filter_block(x: np.ndarray, plan: dict, sample_rate: float, bandwidth: float
         prev = np.zeros((1,) + tail.shape[1:], np.complex64)
     out, state["prev"] = overlap_add(body, tail, prev, batch_axis=0)
     return out
+
+
+def lineplot(avg: np.ndarray, x: np.ndarray, averaging: int = 1, decimation: int = 1) -> None:
+    """In-place update of the averaged trace avg (F32[width // decimation]); x: F32 [batches, width]."""
+    assert x.dtype == np.float32 and x.ndim == 2 and avg.dtype == np.float32
+    lib().jst_oracle_lineplot(_p(avg), _p(x), C.c_uint64(x.shape[0]), C.c_uint64(avg.size),
+                              C.c_uint64(x.strides[0] // 4), C.c_uint64(x.strides[1] // 4),
+                              C.c_uint64(decimation), C.c_uint64(averaging))

@@ -127,3 +127,20 @@ def test_waterfall_cursor_advances_under_graph_replay(js, oracle, graph):
         assert_bit_equal(m.state("frequencyBins").numpy(), ring, f"cycle {cycle}")
     assert int(m.state("ringState").numpy()[0]) == state[0] == (9 * batches) % height
     assert rt.graph_active == graph
+
+
+def test_lineplot_compute_and_averaging(js, oracle):
+    rng = np.random.default_rng(21)
+    x = rng.uniform(0, 1, (7, 512)).astype(np.float32)
+    for averaging, decimation in ((1, 1), (4, 2)):
+        t = js.Tensor.from_numpy(x, sample=1, batch=0)
+        m = js.Module("lineplot", {"averaging": averaging, "decimation": decimation}, {"signal": t})
+        rt = js.Runtime([m], graph=True)
+        avg = np.zeros(512 // decimation, np.float32)
+        for cycle in range(3):
+            rt.compute()
+            oracle.lineplot(avg, x, averaging, decimation)
+            assert_bit_equal(m.state("averagingBuffer").numpy(), avg, f"cycle {cycle}")
+            assert_bit_equal(m.state("signalPoints").numpy()[:, 1], avg)
+    with pytest.raises(js.JetstreamError, match="Averaging must be greater than zero"):
+        js.Module("lineplot", {"averaging": 0}, {"signal": t})
