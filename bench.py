@@ -83,6 +83,8 @@ def main() -> None:
     ap.add_argument("--no-fuse", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="no hipEvent nodes in the graph")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="spectrogram strictly after the spectrum kernel of the same cycle")
     ap.add_argument("--provider", default="generic", choices=["generic", "fast"],
                     help="amplitude/range arithmetic: generic = bit-identical to the reference CPU "
                          "path; fast = hardware transcendentals (within 3e-7 of it)")
@@ -117,7 +119,8 @@ def main() -> None:
     spectrogram = js.Module("spectrogram", {"height": HEIGHT}, {"signal": engine.buffer},
                             "spectrogram")
     rt = js.Runtime([source] + engine.modules + [spectrogram], graph=not args.no_graph,
-                    fuse=not args.no_fuse, timing=not args.no_timing)
+                    fuse=not args.no_fuse, timing=not args.no_timing,
+                    pipeline=not args.no_pipeline)
 
     def barrier():
         if world > 1:
@@ -175,7 +178,7 @@ def main() -> None:
                                    "1024 batches cf32 per step, hipGraph capture",
                        "batches": BATCHES, "fft_size": N_FFT, "ring_slots": args.slots,
                        "graph": rt.graph_active, "fused": not args.no_fuse,
-                       "provider": args.provider,
+                       "provider": args.provider, "pipelined": not args.no_pipeline,
                        "units_ms": {u.split("(")[0]: rt.unit_mean_ms(u) for u in rt.units
                                     if rt.unit_mean_ms(u) > 0},
                        "sharding": "independent batches per GPU, no data-path collective"},

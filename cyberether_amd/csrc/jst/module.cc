@@ -301,8 +301,101 @@ Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
         period_ = period_ / a * (m->cyclePeriod() ? m->cyclePeriod() : 1);
     }
     JST_CHECK(planUnits());
+    if ((flags_ & PIPELINE) && (flags_ & GRAPH)) JST_CHECK(planPipeline());
     cycles_ = 0;
     created_ = true;
+    return Result::SUCCESS;
+}
+
+// PIPELINE planning: SURFACE units (spectrogram, waterfall, lineplot: pure consumers with their
+// own state) move to a side stream so that cycle c's surfaces overlap cycle c+1's producers.
+// Every tensor they read from a dynamic producer becomes a 2-slot ring (cycle c uses slot c%2);
+// a producer of cycle c+2 waits for the surfaces of cycle c before it overwrites the slot.
+Result Runtime::planPipeline() {
+    std::vector<size_t> surfaces;
+    for (size_t i = 0; i < units_.size(); ++i) {
+        bool all_surface = !units_[i].is_static;
+        for (Module* mod : units_[i].modules)
+            all_surface &= (mod->taint() & SURFACE) != 0 && mod->outputs().empty();
+        if (all_surface) surfaces.push_back(i);
+    }
+    if (surfaces.empty()) return Result::SUCCESS;
+    std::vector<Tensor> ring;
+    std::set<const void*> seen;
+    for (size_t si : surfaces)
+        for (Module* mod : units_[si].modules)
+            for (const auto& kv : mod->inputs()) {
+                for (size_t ui = 0; ui < units_.size(); ++ui) {
+                    if (units_[ui].is_static || ui == si) continue;
+                    for (Module* prod : units_[ui].modules)
+                        for (const auto& out : prod->outputs())
+                            if (out.second.storageId() == kv.second.storageId() &&
+                                prod->launchesKernels() && seen.insert(kv.second.storageId()).second)
+                                ring.push_back(kv.second);
+                }
+            }
+    if (ring.empty()) return Result::SUCCESS;
+    for (Tensor& t : ring)
+        if (t.ringSlots() != 1) return Result::SUCCESS;  // already a ring (a source): leave as is
+    for (Tensor& t : ring) JST_CHECK(t.promoteToRing(2));
+    pipelined_ = ring;
+    for (size_t si : surfaces) units_[si].lane = 1;
+    if (period_ % 2) period_ *= 2;
+    JST_HIP_CHECK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking), "hipStreamCreate");
+    lane_events_.assign(2 * period_ + 1, nullptr);
+    for (auto& e : lane_events_)
+        JST_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+    // timing events were sized for the old period
+    for (auto& u : units_) {
+        if (!((flags_ & TIMING) && u.timed)) continue;
+        while (u.span.begin.size() < period_) {
+            hipEvent_t b = nullptr, e = nullptr;
+            JST_HIP_CHECK(hipEventCreate(&b), "hipEventCreate");
+            JST_HIP_CHECK(hipEventCreate(&e), "hipEventCreate");
+            u.span.begin.push_back(b);
+            u.span.end.push_back(e);
+            u.span.recorded.push_back(false);
+        }
+    }
+    return Result::SUCCESS;
+}
+
+Result Runtime::capturePipelined(bool timing) {
+    auto submit_lane = [&](int lane, hipStream_t s, U64 slot) -> Result {
+        for (auto& u : units_) {
+            if (u.lane != lane || (u.is_static && u.settled)) continue;
+            const bool rec = timing && slot < u.span.begin.size();
+            if (rec) JST_HIP_CHECK(hipEventRecord(u.span.begin[slot], s), "hipEventRecord");
+            const Result r = u.submit(s);
+            if (r != Result::SUCCESS && r != Result::RELOAD) {
+                JST_ERROR("[RUNTIME] computeSubmit failed in '%s' (%s): %s", u.name.c_str(),
+                          ResultName(r), last_error());
+                return r;
+            }
+            if (rec) {
+                JST_HIP_CHECK(hipEventRecord(u.span.end[slot], s), "hipEventRecord");
+                u.span.recorded[slot] = true;
+            }
+        }
+        return Result::SUCCESS;
+    };
+    hipEvent_t fork = lane_events_[2 * period_];
+    JST_HIP_CHECK(hipEventRecord(fork, stream_), "hipEventRecord");
+    JST_HIP_CHECK(hipStreamWaitEvent(side_stream_, fork, 0), "hipStreamWaitEvent");
+    for (U64 c = 0; c < period_; ++c) {
+        for (Tensor& t : pipelined_) JST_CHECK(t.ringSelect((cycles_ + c) % 2));
+        if (c >= 2)  // the slot is free once the surfaces of two cycles ago have read it
+            JST_HIP_CHECK(hipStreamWaitEvent(stream_, lane_events_[2 * (c - 2) + 1], 0),
+                          "hipStreamWaitEvent");
+        JST_CHECK(submit_lane(0, stream_, c));
+        JST_HIP_CHECK(hipEventRecord(lane_events_[2 * c], stream_), "hipEventRecord");
+        JST_HIP_CHECK(hipStreamWaitEvent(side_stream_, lane_events_[2 * c], 0), "hipStreamWaitEvent");
+        JST_CHECK(submit_lane(1, side_stream_, c));
+        JST_HIP_CHECK(hipEventRecord(lane_events_[2 * c + 1], side_stream_), "hipEventRecord");
+    }
+    // join: the origin stream ends after the last two surface cycles
+    for (U64 c = (period_ >= 2 ? period_ - 2 : 0); c < period_; ++c)
+        JST_HIP_CHECK(hipStreamWaitEvent(stream_, lane_events_[2 * c + 1], 0), "hipStreamWaitEvent");
     return Result::SUCCESS;
 }
 
@@ -310,6 +403,15 @@ Result Runtime::destroy() {
     if (!created_) return Result::SUCCESS;
     created_ = false;
     (void)hipStreamSynchronize(stream_);
+    if (side_stream_) {
+        (void)hipStreamSynchronize(side_stream_);
+        (void)hipStreamDestroy(side_stream_);
+        side_stream_ = nullptr;
+    }
+    for (hipEvent_t e : lane_events_)
+        if (e) (void)hipEventDestroy(e);
+    lane_events_.clear();
+    pipelined_.clear();
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
     if (graph_) (void)hipGraphDestroy(graph_);
     graph_exec_ = nullptr;
@@ -382,6 +484,7 @@ Result Runtime::eagerCycle(bool& needs_sync) {
             JST_CHECK(harvestTiming());
         }
     }
+    for (Tensor& t : pipelined_) JST_CHECK(t.ringSelect(cycles_ % 2));
     JST_CHECK(submitAll(timing, slot, true));
     timing_pending_ = timing_pending_ || timing;
     ++cycles_;
@@ -418,7 +521,10 @@ Result Runtime::compute(U64 cycles, bool sync) {
                 JST_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal),
                               "hipStreamBeginCapture");
                 Result r = Result::SUCCESS;
-                for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c) r = submitAll(timing, c, false);
+                if (pipelined()) r = capturePipelined(timing);
+                else
+                    for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c)
+                        r = submitAll(timing, c, false);
                 hipGraph_t g = nullptr;
                 const hipError_t e = hipStreamEndCapture(stream_, &g);
                 if (r != Result::SUCCESS) {

@@ -131,7 +131,7 @@ struct KernelSpan {  // hipEvent pairs around one execution unit, for live per-k
 
 class Runtime {
  public:
-    enum Flags : U32 { NONE = 0, GRAPH = 1 << 0, FUSE = 1 << 1, TIMING = 1 << 2 };
+    enum Flags : U32 { NONE = 0, GRAPH = 1 << 0, FUSE = 1 << 1, TIMING = 1 << 2, PIPELINE = 1 << 3 };
 
     Runtime();
     ~Runtime();
@@ -168,6 +168,7 @@ class Runtime {
         bool is_static = false;            // STATIC_OUTPUT with settled inputs: runs once
         bool has_kernels = true;           // false: nothing reaches the stream
         bool timed = true;                 // carries an event pair
+        int lane = 0;                      // PIPELINE: 1 = surface lane (runs beside the next cycle)
         bool settled = false;
         KernelSpan span;
     };
@@ -189,6 +190,13 @@ class Runtime {
     U64 period_ = 1;
     U64 capture_phase_ = 0;
     std::string calibration_unit_;
+    // PIPELINE: a second captured stream for SURFACE units and double-buffered intermediates
+    hipStream_t side_stream_ = nullptr;
+    std::vector<Tensor> pipelined_;        // producer->surface tensors, promoted to 2-slot rings
+    std::vector<hipEvent_t> lane_events_;  // [2*period]: lane-0 done / lane-1 done per cycle
+    bool pipelined() const { return !pipelined_.empty(); }
+    Result planPipeline();
+    Result capturePipelined(bool timing);
     bool timing_pending_ = false;
     bool created_ = false;
 };

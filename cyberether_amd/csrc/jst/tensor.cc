@@ -128,6 +128,25 @@ Result Tensor::ringSelect(U64 slot) {
     return Result::SUCCESS;
 }
 
+Result Tensor::promoteToRing(U64 slots) {
+    if (!buffer_ || !buffer_->owned || buffer_->device != DeviceType::HIP || buffer_->slots != 1 ||
+        slots < 2) {
+        JST_ERROR("[MEMORY] Only an owned single-slot HBM buffer can be promoted to a ring.");
+        return Result::ERROR;
+    }
+    const size_t slot_bytes = buffer_->bytes;
+    void* fresh = nullptr;
+    JST_HIP_CHECK(hipMalloc(&fresh, slot_bytes * slots), "hipMalloc");
+    JST_HIP_CHECK(hipMemset(fresh, 0, slot_bytes * slots), "hipMemset");
+    (void)hipFree(buffer_->ptr);
+    buffer_->ptr = fresh;
+    buffer_->bytes = slot_bytes * slots;
+    buffer_->slot_bytes = slot_bytes;
+    buffer_->slots = slots;
+    buffer_->slot = 0;
+    return Result::SUCCESS;
+}
+
 Result Tensor::createRing(DeviceType device, DataType dtype, const Shape& shape, U64 slots) {
     if (slots == 0) {
         JST_ERROR("[MEMORY] A ring needs at least one slot.");

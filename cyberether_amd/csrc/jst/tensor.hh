@@ -43,6 +43,10 @@ class Tensor {
     // Ring of 'slots' tensors of this shape in one allocation; ringSelect() moves every view.
     Result createRing(DeviceType device, DataType dtype, const Shape& shape, U64 slots);
     Result ringSelect(U64 slot);
+    // Re-allocate an owned, single-slot HBM buffer as a ring of 'slots' (contents are dropped,
+    // every view of the storage follows).  Used by the runtime to double-buffer an intermediate
+    // tensor between a producer kernel and a consumer that runs concurrently with the NEXT cycle.
+    Result promoteToRing(U64 slots);
     U64 ringSlots() const { return buffer_ ? buffer_->slots : 0; }
     U64 ringSlot() const { return buffer_ ? buffer_->slot : 0; }
     // Borrow external memory (no ownership): stride empty = dense row-major.

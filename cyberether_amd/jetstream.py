@@ -43,7 +43,7 @@ DTYPE_OF_NP = {np.dtype(np.float32): 1, np.dtype(np.complex64): 2, np.dtype(np.f
 RESULT_NAMES = ["SUCCESS", "ERROR", "WARNING", "FATAL", "SKIP", "YIELD", "RELOAD", "RECREATE",
                 "TIMEOUT", "INCOMPLETE"]
 
-RUNTIME_GRAPH, RUNTIME_FUSE, RUNTIME_TIMING = 1, 2, 4
+RUNTIME_GRAPH, RUNTIME_FUSE, RUNTIME_TIMING, RUNTIME_PIPELINE = 1, 2, 4, 8
 
 TAINT = {"IN_PLACE": 1, "DISCONTIGUOUS": 2, "SURFACE": 4, "CROSS_DEVICE": 16,
          "STATIC_OUTPUT": 64, "STATELESS": 128}
@@ -377,10 +377,10 @@ class Runtime:
     """One device segment: ordered modules on one HIP stream, optionally as a hipGraph."""
 
     def __init__(self, modules: Iterable[Module], graph: bool = False, fuse: bool = False,
-                 timing: bool = False):
+                 timing: bool = False, pipeline: bool = False):
         self.modules = list(modules)
         flags = (RUNTIME_GRAPH if graph else 0) | (RUNTIME_FUSE if fuse else 0) | \
-                (RUNTIME_TIMING if timing else 0)
+                (RUNTIME_TIMING if timing else 0) | (RUNTIME_PIPELINE if pipeline else 0)
         arr = (C.c_void_p * max(len(self.modules), 1))(*[m._h for m in self.modules])
         out = C.c_void_p()
         self._h = None

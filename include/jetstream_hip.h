@@ -57,7 +57,10 @@ enum { JST_DTYPE_F32 = 1, JST_DTYPE_CF32 = 2, JST_DTYPE_F64 = 3, JST_DTYPE_U64 =
 enum {
     JST_RUNTIME_GRAPH = 1 << 0,  /* capture the steady-state cycle(s) into a hipGraph */
     JST_RUNTIME_FUSE = 1 << 1,   /* submit Multiply->FFT->Amplitude[->Range] as one kernel */
-    JST_RUNTIME_TIMING = 1 << 2  /* hipEvent pair around every execution unit */
+    JST_RUNTIME_TIMING = 1 << 2, /* hipEvent pair around every execution unit */
+    JST_RUNTIME_PIPELINE = 1 << 3 /* with GRAPH: SURFACE units (spectrogram, waterfall, lineplot) run on
+                                     a second captured stream beside the NEXT cycle's producers; the
+                                     tensors they read are double-buffered */
 };
 
 typedef struct jst_tensor_s* jst_tensor;

@@ -28,11 +28,11 @@ def tone_batch(oracle, b, n, seed, sigma=1e-3):
     return (x + (noise[..., 0] + 1j * noise[..., 1])).astype(np.complex64)
 
 
-def build(js, x, h=256, fuse=True, graph=True, scale=True, timing=False):
+def build(js, x, h=256, fuse=True, graph=True, scale=True, timing=False, pipeline=False):
     src = js.Tensor.from_numpy(x, sample=x.ndim - 1, **({"batch": 0} if x.ndim > 1 else {}))
     eng = js.SpectrumEngine(src, enable_scale=scale, range_min=-100.0, range_max=0.0)
     spec = js.Module("spectrogram", {"height": h}, {"signal": eng.buffer}, "spectrogram")
-    rt = js.Runtime(eng.modules + [spec], graph=graph, fuse=fuse, timing=timing)
+    rt = js.Runtime(eng.modules + [spec], graph=graph, fuse=fuse, timing=timing, pipeline=pipeline)
     return src, eng, spec, rt
 
 
@@ -62,10 +62,11 @@ def test_fused_equals_oracle_and_unfused(js, oracle, n, b, scale):
     assert_bit_equal(eng.buffer.numpy(), ref["range" if scale else "amplitude"], "fused output")
 
 
-def test_spectrogram_state_over_cycles_with_graph(js, oracle):
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_spectrogram_state_over_cycles_with_graph(js, oracle, pipeline):
     n, b, h = 4096, 32, 256
     x = tone_batch(oracle, b, n, 1234)
-    src, eng, spec, rt = build(js, x, h=h, fuse=True, graph=True)
+    src, eng, spec, rt = build(js, x, h=h, fuse=True, graph=True, pipeline=pipeline)
     ref_out = oracle.spectrum_chain(x, -100.0, 0.0)["range"]
     ref_bins = np.zeros(n * h, np.float32)
     for cycle in range(1, 5):
@@ -86,7 +87,8 @@ def test_spectrogram_state_over_cycles_with_graph(js, oracle):
     assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), ref_bins, "bins after new input")
 
 
-def test_ring_source_period_and_graph(js, oracle):
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_ring_source_period_and_graph(js, oracle, pipeline):
     n, b, h, slots = 1024, 8, 64, 4
     src = js.Module("ring_source", {"batches": b, "samples": n, "slots": slots}, {}, "source")
     out = src.output("buffer")
@@ -97,8 +99,10 @@ def test_ring_source_period_and_graph(js, oracle):
     assert out.axes == {"sample": 1, "batch": 0, "channel": None}  # soapy/module_impl.cc:197-201
     eng = js.SpectrumEngine(out)
     spec = js.Module("spectrogram", {"height": h}, {"signal": eng.buffer}, "spectrogram")
-    rt = js.Runtime([src] + eng.modules + [spec], graph=True, fuse=True)
+    water = js.Module("waterfall", {"height": 16}, {"signal": eng.buffer}, "waterfall")
+    rt = js.Runtime([src] + eng.modules + [spec, water], graph=True, fuse=True, pipeline=pipeline)
     assert rt.period == slots
+    ring, wstate = np.zeros((16, n), np.float32), (0, 0)
     refs = [oracle.spectrum_chain(d, -100.0, 0.0)["range"] for d in data]
     bins = np.zeros(n * h, np.float32)
     total = 0
@@ -106,7 +110,9 @@ def test_ring_source_period_and_graph(js, oracle):
         rt.compute(chunk)
         for _ in range(chunk):
             oracle.spectrogram(bins, refs[total % slots], h)
+            wstate = oracle.waterfall(ring, wstate, refs[total % slots], 16)
             total += 1
+        assert_bit_equal(water.state("frequencyBins").numpy(), ring, f"waterfall after {total}")
         assert_bit_equal(eng.buffer.numpy(), refs[(total - 1) % slots], f"after {total} cycles")
         assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins, f"bins after {total}")
     assert rt.graph_active
