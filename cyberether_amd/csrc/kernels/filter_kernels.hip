@@ -383,7 +383,51 @@ __global__ void fm_narrow_state_kernel(const float2* __restrict__ in, FmState* _
     states[lane].has_prev = 1;
 }
 
+// ---- SignalGenerator, cosine / sine (dsp/signal_generator/module_impl_native_cpu.cc:20-23,
+// 159-163, 200-231).  The phase is a serial F64 recurrence with an fmod wrap per sample; to keep
+// every bit, ONE thread walks it (it is the synthetic INPUT generator of the benchmark configs,
+// not a hot kernel), then all threads evaluate cos/sin in parallel.
+__global__ void siggen_phase_kernel(double* __restrict__ phases, double* __restrict__ state,
+                                    uint64_t count, double frequency, double sample_rate) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const double period = 2.0 * 3.14159265358979323846;
+    double ph = state[0];
+    for (uint64_t i = 0; i < count; ++i) {
+        phases[i] = ph;
+        const double w = fmod(ph + 2.0 * 3.14159265358979323846 * frequency / sample_rate, period);
+        ph = w < 0.0 ? w + period : w;
+    }
+    state[0] = ph;
+}
+__global__ __launch_bounds__(kBlock) void siggen_eval_kernel(float* __restrict__ out,
+                                                             const double* __restrict__ phases,
+                                                             uint64_t count, int complex_out,
+                                                             int sine, double amplitude,
+                                                             double dc_offset) {
+    JST_GRID_STRIDE(i, count) {
+        const double ph = phases[i];
+        if (complex_out) {  // kernelCosineCF32 :222-231 (sine CF32 swaps the roles of cos and sin)
+            const double a = sine ? sin(ph) : cos(ph), b = sine ? -cos(ph) : sin(ph);
+            out[2 * i] = (float)(amplitude * a + dc_offset);
+            out[2 * i + 1] = (float)(amplitude * b);
+        } else {
+            out[i] = (float)(amplitude * (sine ? sin(ph) : cos(ph)) + dc_offset);
+        }
+    }
+}
+
 }  // namespace
+
+hipError_t launch_signal_cosine(float* out, double* phases, double* state, uint64_t count,
+                                bool complex_out, double amplitude, double frequency,
+                                double sample_rate, double dc_offset, hipStream_t s) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(siggen_phase_kernel, dim3(1), dim3(64), 0, s, phases, state, count, frequency,
+                       sample_rate);
+    hipLaunchKernelGGL(siggen_eval_kernel, dim3(grid_for(count)), dim3(kBlock), 0, s, out,
+                       (const double*)phases, count, complex_out ? 1 : 0, 0, amplitude, dc_offset);
+    return hipGetLastError();
+}
 
 size_t fm_state_bytes() { return sizeof(FmState); }
 

@@ -151,6 +151,10 @@ hipError_t launch_filter_taps(float2* out, double sample_rate, double bandwidth,
 // shape (reduced axis extent 1); (r, r_stride) walk the reduced axis
 hipError_t launch_arithmetic(const EwLayout& L, void* out, const void* in, bool complex, int op,
                              uint64_t r, int64_t r_stride, hipStream_t s);
+// cosine oscillator: phases = F64 scratch [count], state = F64[1] carried phase
+hipError_t launch_signal_cosine(float* out, double* phases, double* state, uint64_t count,
+                                bool complex_out, double amplitude, double frequency,
+                                double sample_rate, double dc_offset, hipStream_t s);
 size_t fm_state_bytes();
 hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
                      hipStream_t s);

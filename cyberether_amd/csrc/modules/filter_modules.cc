@@ -999,6 +999,77 @@ class Lineplot : public Module {
     F32 normalizationFactor = 1.0f;
 };
 
+// ---- SignalGenerator (dsp/signal_generator/module_impl.cc:16-170, module_impl_native_cpu.cc) ---
+// Only the cosine oscillator (the CW tone of the BASELINE configs) is implemented on the device.
+class SignalGenerator : public Module {
+ public:
+    const char* type() const override { return "signal_generator"; }
+    Result validate() override {
+        signalType = ConfigStr(config_, "signalType", "cosine");
+        dataType = ConfigStr(config_, "signalDataType", "F32");
+        bool o1, o2, o3, o4, o5, o6;
+        sampleRate = ConfigF64(config_, "sampleRate", 1.0e6, &o1);
+        frequency = ConfigF64(config_, "frequency", 1000.0, &o2);
+        amplitude = ConfigF64(config_, "amplitude", 1.0, &o3);
+        phase = ConfigF64(config_, "phase", 0.0, &o4);
+        dcOffset = ConfigF64(config_, "dcOffset", 0.0, &o5);
+        bufferSize = ConfigU64(config_, "bufferSize", 8192, &o6);
+        static const char* kTypes[] = {"sine", "cosine", "square", "triangle", "sawtooth", "noise", "dc", "chirp"};
+        bool known = false;
+        for (const char* t : kTypes) known |= signalType == t;
+        if (!known) {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Invalid signal type '%s'.", signalType.c_str());
+            return Result::ERROR;
+        }
+        if (dataType != "F32" && dataType != "CF32") {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Invalid signal data type '%s'.", dataType.c_str());
+            return Result::ERROR;
+        }
+        if (!(o1 && o2 && o3 && o4 && o5 && o6) || !std::isfinite(sampleRate) || sampleRate <= 0.0) {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Sample rate must be positive.");
+            return Result::ERROR;
+        }
+        if (bufferSize == 0) {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Buffer size cannot be zero.");
+            return Result::ERROR;
+        }
+        if (signalType != "cosine") {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR_NATIVE_HIP] Signal type '%s' is not implemented on the "
+                      "HIP device (cosine only).", signalType.c_str());
+            return Result::ERROR;
+        }
+        return Result::SUCCESS;
+    }
+    Result define() override { return defineInterfaceOutput("signal"); }
+    Result create() override {
+        const bool cx = dataType == "CF32";
+        JST_CHECK(signal.create(device(), cx ? DataType::CF32 : DataType::F32, {bufferSize}));
+        JST_CHECK(SetSignalAxes(signal, {.sample = Index{0}}));
+        signal.setAttribute("sampleRate", AttrValue{(F64)(F32)sampleRate});
+        JST_CHECK(phases.create(device(), DataType::F64, {bufferSize}));
+        JST_CHECK(oscillator.create(device(), DataType::F64, {1}));
+        const F64 period = 2.0 * 3.14159265358979323846;
+        F64 w = std::fmod(phase, period);
+        if (w < 0.0) w += period;
+        JST_CHECK(oscillator.copyFromHost(&w, sizeof(w), nullptr));
+        JST_HIP_CHECK(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
+        produced("signal", signal);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        return hip_result(kernels::launch_signal_cosine(ptr<float>(signal), ptr<double>(phases),
+                                                        ptr<double>(oscillator), bufferSize,
+                                                        dataType == "CF32", amplitude, frequency,
+                                                        sampleRate, dcOffset, s),
+                          "signal_generator kernel");
+    }
+    Tensor signal, phases, oscillator;
+    std::string signalType = "cosine", dataType = "F32";
+    F64 sampleRate = 1.0e6, frequency = 1000.0, amplitude = 1.0, phase = 0.0, dcOffset = 0.0;
+    U64 bufferSize = 8192;
+};
+
+JST_REGISTER_MODULE(SignalGenerator, "signal_generator", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Lineplot, "lineplot", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Pad, "pad", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Unpad, "unpad", DeviceType::HIP, RuntimeType::NATIVE, "generic");

@@ -192,3 +192,25 @@ def test_fm_reference_kats(js):
     assert out["signal"][0] == 0 and np.max(np.abs(out["signal"][1:] - dphi * ref)) < 1e-2
     with pytest.raises(js.JetstreamError, match="at least 200 kHz"):
         js.Module("fm", {"mode": "wide", "sampleRate": 100e3}, {"signal": js.Tensor.from_numpy(ramp)})
+
+
+def test_signal_generator_cosine_continuity(js, oracle):
+    """CW tone generator (the input of BASELINE config 1): bit-exact vs the oracle, phase carried
+    across submissions (signal_generator/module_impl_native_cpu.cc:159-163,222-231)."""
+    n, fs = 4096, 2.0e6
+    f0 = 100.25 * fs / n
+    for dtype in ("CF32", "F32"):
+        m = js.Module("signal_generator", {"signalType": "cosine", "signalDataType": dtype,
+                                           "sampleRate": fs, "frequency": f0, "amplitude": 0.75,
+                                           "dcOffset": 0.1, "phase": 7.0, "bufferSize": n}, {})
+        rt = js.Runtime([m], graph=True)
+        ph = 7.0
+        for cycle in range(3):
+            rt.compute()
+            ref, ph = oracle.signal_cosine(n, 0.75, f0, fs, 0.1, ph)
+            got = m.output("signal").numpy()
+            if dtype == "F32":
+                ref = np.ascontiguousarray(ref.real)
+            assert_bit_equal(got, ref, f"{dtype} cycle {cycle}")
+    with pytest.raises(js.JetstreamError, match="not implemented on the HIP device"):
+        js.Module("signal_generator", {"signalType": "chirp"}, {})

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Secondary benchmark lines for the other BASELINE.json configs (1 GPU, device-resident inputs):
+  C1  signal_generator -> Window -> 4096-pt FFT -> Amplitude, 1 batch (latency of one cycle)
+  C3  Filter block: 251-tap band-pass + /10 resampling on CF32[100, 159750] (16 MS per cycle)
+  C4  WBFM chain: Filter(20 MS/s -> 200 kS/s) -> FM(wide) -> Decimator(/4)
+  C5  65536-pt Window -> FFT -> Amplitude -> Range -> Lineplot average, 16 batches (one stream)
+Prints one JSON line per config (informational; bench.py is the contract benchmark)."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(rt, cycles, warmup):
+    import torch
+    rt.compute(warmup, sync=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rt.compute(cycles, sync=False)
+    rt.synchronize()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / cycles
+
+
+def main():
+    import torch
+    torch.cuda.set_device(0)
+    import cyberether_amd.jetstream as js
+    rng = np.random.default_rng(1235)
+    out = []
+
+    # ---- C1 ------------------------------------------------------------------------------------
+    n, fs = 4096, 2.0e6
+    gen = js.Module("signal_generator", {"signalType": "cosine", "signalDataType": "CF32",
+                                         "sampleRate": fs, "frequency": 100.25 * fs / n,
+                                         "bufferSize": n}, {}, "cw")
+    eng = js.SpectrumEngine(gen.output("signal"), enable_scale=False)
+    rt = js.Runtime([gen] + eng.modules, graph=True, fuse=True)
+    dt = timed(rt, 200, 20)
+    out.append({"config": "C1: CW tone -> Window -> 4096-pt FFT -> Amplitude, 1 batch", "us_per_cycle": dt * 1e6,
+                "MS_per_s": n / dt / 1e6, "note": "latency bound (one transform); includes the serial tone generator"})
+    rt.destroy()
+
+    # ---- C3 ------------------------------------------------------------------------------------
+    b, s, taps, sr, bw = 100, 159750, 251, 20e6, 2e6
+    t = np.arange(b * s) / sr
+    x = (np.exp(2j * np.pi * 0.3e6 * t) + np.exp(2j * np.pi * 4.0e6 * t)).astype(np.complex64)
+    x += (0.01 * (rng.standard_normal(b * s) + 1j * rng.standard_normal(b * s))).astype(np.complex64)
+    src = js.Tensor.from_numpy(x.reshape(b, s), batch=0, sample=1)
+    blk = js.Filter(src, sr, bw, [0.0], taps, 1)
+    rt = js.Runtime(blk.modules, graph=True)
+    dt = timed(rt, 20, 3)
+    out.append({"config": "C3: Filter block 251 taps, /10, CF32[100,159750] (conv 160000 = 8*8*4*5^4)",
+                "ms_per_cycle": dt * 1e3, "MS_per_s_in": b * s / dt / 1e6, "plan": blk.plan,
+                "note": "FFT overlap-add through pass-per-launch 160000-pt FFTs (HBM bound, 7 passes)"})
+    rt.destroy()
+
+    # ---- C4 ------------------------------------------------------------------------------------
+    b, s, taps, sr, bw = 10, 199900, 101, 20e6, 200e3
+    tt = np.arange(b * s) / sr
+    audio = np.sin(2 * np.pi * 1e3 * tt) * 0.45 + 0.1 * np.sin(2 * np.pi * 19e3 * tt)
+    x = np.exp(2j * np.pi * 75e3 * np.cumsum(audio) / sr).astype(np.complex64)
+    src = js.Tensor.from_numpy(x.reshape(b, s), batch=0, sample=1)
+    filt = js.Filter(src, sr, bw, [0.0], taps, 1)
+    squeeze = js.Module("squeeze_dims", {"axis": 1}, {"buffer": filt.buffer}, "squeeze_head")
+    iq = squeeze.output("buffer").set_axes(batch=0, sample=1)
+    fm = js.Module("fm", {"mode": "wide", "deemphasis": "75us", "sampleRate": 200e3}, {"signal": iq}, "fm")
+    audio_lr = fm.output("signal")
+    dec_in = audio_lr.clone().permute((0, 2, 1)).set_axes(batch=0, channel=1, sample=2)
+    dup = js.Module("duplicate", {}, {"buffer": dec_in}, "to_planar")
+    dec = js.Decimator(dup.output("buffer").set_axes(batch=0, channel=1, sample=2), 4)
+    rt = js.Runtime(filt.modules + [squeeze, fm, dup] + dec.modules, graph=True)
+    dt = timed(rt, 20, 3)
+    out.append({"config": "C4: WBFM 20 MS/s -> Filter(/100) -> FM wide 75us -> Decimator(/4)",
+                "ms_per_cycle": dt * 1e3, "MS_per_s_in": b * s / dt / 1e6,
+                "audio_shape": list(dec.buffer.shape),
+                "note": "FM stereo decode is a serial recursion per lane (1 lane here): latency bound"})
+    rt.destroy()
+
+    # ---- C5 (one stream on one GPU) ------------------------------------------------------------
+    n, b = 65536, 16
+    x = (rng.standard_normal((b, n)) + 1j * rng.standard_normal((b, n))).astype(np.complex64)
+    src = js.Tensor.from_numpy(x, batch=0, sample=1)
+    eng = js.SpectrumEngine(src, enable_scale=True)
+    lp = js.Module("lineplot", {"averaging": 8}, {"signal": eng.buffer}, "psd")
+    rt = js.Runtime(eng.modules + [lp], graph=True, fuse=True)
+    dt = timed(rt, 50, 5)
+    out.append({"config": "C5 (per GPU): Window -> 65536-pt FFT -> Amplitude -> Range -> Lineplot avg, 16 batches",
+                "us_per_cycle": dt * 1e6, "MS_per_s": b * n / dt / 1e6, "units": rt.units,
+                "note": "65536-pt FFT = 6 Stockham passes through HBM (not fused); PSD all-reduce is one "
+                        "256 KiB RCCL all-reduce per reporting interval (cyberether_amd/distributed.py)"})
+    rt.destroy()
+
+    for line in out:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
