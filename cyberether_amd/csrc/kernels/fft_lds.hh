@@ -362,22 +362,6 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
     constexpr int NB = 8 / IP;  // butterflies per thread (8 points per thread)
     constexpr bool LAST = (P == plan.nf - 1);
     static_assert(BUT == NB * T, "T must be N/8");
-    if constexpr (LAST && Pro::kHasOperand) {
-        // The per-position operand of the prologue (window taps) is not kept live across the
-        // passes: it is re-requested from L2 here and lands during the epilogue.
-        if (more) {
-            constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int u0 = tid + (e / IP0) * T;
-                const int l0 = (u0 & (IDO0 - 1)) + IDO0 * IP0 * (u0 / IDO0);
-                if constexpr (CONTIG)
-                    opnd[e] = buf_load_f2(r_opnd, (uint32_t)l0 * 8u, (uint32_t)(IDO0 * (e % IP0)) * 8u);
-                else
-                    opnd[e] = pro.template load_operand<CONTIG>(IDO0 * (e % IP0), l0);
-            }
-        }
-    }
     // x[] holds CC(i,b,k) for butterfly j at x[j*IP + b]
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -408,6 +392,23 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                 // keep at most two epilogues in flight: interleaving all eight costs ~40 VGPRs
                 // of temporaries and pushes the prefetch registers into scratch
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (Pro::kHasOperand) {
+                    // The per-position operand of the prologue (window taps) is not kept live
+                    // across the passes: element e is re-requested from L2 as soon as output e
+                    // has retired, into the registers that output just freed.
+                    if (more) {
+                        constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
+                        const int e = j * IP + c;  // constant after unrolling
+                        const int u0 = tid + (e / IP0) * T;
+                        const int l0 = (u0 & (IDO0 - 1)) + IDO0 * IP0 * (u0 / IDO0);
+                        if constexpr (CONTIG)
+                            opnd[e] = buf_load_f2(r_opnd, (uint32_t)l0 * 8u,
+                                                  (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                        else
+                            opnd[e] = pro.template load_operand<CONTIG>(IDO0 * (e % IP0), l0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
         } else {
             float2* wr = buf0 + phys(u);

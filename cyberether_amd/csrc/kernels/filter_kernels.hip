@@ -391,10 +391,30 @@ __global__ void siggen_phase_kernel(double* __restrict__ phases, double* __restr
                                     uint64_t count, double frequency, double sample_rate) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     const double period = 2.0 * 3.14159265358979323846;
+    const double step = 2.0 * 3.14159265358979323846 * frequency / sample_rate;
     double ph = state[0];
-    for (uint64_t i = 0; i < count; ++i) {
+    uint64_t i = 0;
+    // fmod is exact, so for 0 <= ph < period and |step| < period the wrapped sum is one of
+    // x, x - period (Sterbenz) or x + period: a short select chain instead of a libm call.
+    // Anything outside that window (first sample of a non-canonical phase, steps beyond one
+    // turn, non-finite values) takes the general path below.
+    if (step >= 0.0 && step < period) {
+        for (; i < count && ph >= 0.0 && ph < period; ++i) {
+            phases[i] = ph;
+            const double x = ph + step, y = x - period;
+            if (!(x < 2.0 * period)) break;  // rounding carried x to 2*period: general path
+            ph = x < period ? x : y;
+        }
+    } else if (step < 0.0 && step > -period) {
+        for (; i < count && ph >= 0.0 && ph < period; ++i) {
+            phases[i] = ph;
+            const double x = ph + step;  // in (-period, period): fmod(x) == x
+            ph = x < 0.0 ? x + period : x;
+        }
+    }
+    for (; i < count; ++i) {
         phases[i] = ph;
-        const double w = fmod(ph + 2.0 * 3.14159265358979323846 * frequency / sample_rate, period);
+        const double w = fmod(ph + step, period);
         ph = w < 0.0 ? w + period : w;
     }
     state[0] = ph;
