@@ -59,7 +59,10 @@ DataType to_dtype(uint8_t d) {
         case JST_DTYPE_CF32: return DataType::CF32;
         case JST_DTYPE_F64: return DataType::F64;
         case JST_DTYPE_U64: return DataType::U64;
-        default: return DataType::None;
+        default:
+            // the integer sample formats share their numeric value with jst::DataType
+            if (d >= JST_DTYPE_I8 && d <= JST_DTYPE_CU32) return static_cast<DataType>(d);
+            return DataType::None;
     }
 }
 DeviceType to_device(uint8_t d) {

@@ -21,8 +21,20 @@ const char* DataTypeName(DataType t) {
         case DataType::CI8: return "CI8";
         case DataType::I16: return "I16";
         case DataType::CI16: return "CI16";
+        case DataType::CU8: return "CU8";
+        case DataType::U16: return "U16";
+        case DataType::CU16: return "CU16";
+        case DataType::I32: return "I32";
+        case DataType::CI32: return "CI32";
+        case DataType::U32: return "U32";
+        case DataType::CU32: return "CU32";
         default: return "None";
     }
+}
+DataType NameToDataType(const std::string& name) {
+    for (uint8_t v = 1; v <= static_cast<uint8_t>(DataType::CU32); ++v)
+        if (name == DataTypeName(static_cast<DataType>(v))) return static_cast<DataType>(v);
+    return DataType::None;
 }
 const char* DeviceName(DeviceType d) {
     switch (d) {

@@ -46,7 +46,10 @@ enum class DeviceType : uint8_t {
 
 enum class RuntimeType : uint8_t { NATIVE = 0 };
 
-enum class DataType : uint8_t { None = 0, F32 = 1, CF32 = 2, F64 = 3, U64 = 4, I8 = 5, CI8 = 6, I16 = 7, CI16 = 8, U8 = 9 };
+enum class DataType : uint8_t {
+    None = 0, F32 = 1, CF32 = 2, F64 = 3, U64 = 4, I8 = 5, CI8 = 6, I16 = 7, CI16 = 8, U8 = 9,
+    CU8 = 10, U16 = 11, CU16 = 12, I32 = 13, CI32 = 14, U32 = 15, CU32 = 16
+};
 
 inline size_t DataTypeSize(DataType t) {
     switch (t) {
@@ -59,10 +62,18 @@ inline size_t DataTypeSize(DataType t) {
         case DataType::CI8: return 2;
         case DataType::I16: return 2;
         case DataType::CI16: return 4;
+        case DataType::CU8: return 2;
+        case DataType::U16: return 2;
+        case DataType::CU16: return 4;
+        case DataType::I32: return 4;
+        case DataType::CI32: return 8;
+        case DataType::U32: return 4;
+        case DataType::CU32: return 8;
         default: return 0;
     }
 }
 const char* DataTypeName(DataType t);
+DataType NameToDataType(const std::string& name);  // "CF32" -> CF32, unknown -> None
 const char* DeviceName(DeviceType d);
 DeviceType StringToDevice(const std::string& s);  // "hip" | "cpu" | ... case-insensitive
 const char* ResultName(Result r);

@@ -1,0 +1,167 @@
+// agc.hip -- tiled RMS automatic gain control (dsp/agc/module_impl_native_cpu.cc:20-160).
+//
+// Reference arithmetic, kept operation for operation (all in F64):
+//   power(tile)  = sum over the tile, in sample order, of re*re + im*im          (:24-33,116-121)
+//   raw(tile)    = clamp(reference / sqrt(power / len + epsilon), minGain, maxGain)  (:123-126)
+//   start(0)     = raw(0); end(t) = t+1 < tiles ? LimitGainChange(raw(t+1), start(t)) : start(t);
+//   start(t+1)   = end(t)                                                            (:128-150)
+//   out[s]       = ApplyGain(in[s], start + (end-start)/len * s_in_tile)             (:41-64,136-147)
+//
+// The F64 tile sum is order dependent, so it stays sequential: one workgroup per (lane, tile)
+// stages the per-sample powers in LDS with coalesced loads and lane 0 adds them in order.  The
+// tile chain (LimitGainChange) is one thread per lane; the gain application is one thread per
+// sample.  Three launches; all state is recomputed every call (the module is STATELESS).
+#include "device_math.hh"
+#include "kernels.hh"
+
+namespace jst::kernels {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kChunk = 2048;  // F64 powers staged per step: 16 KiB of LDS
+
+__device__ __forceinline__ void lane_bases(const AgcParams& p, uint64_t lane, int64_t& in_base,
+                                           int64_t& out_base) {
+    in_base = (int64_t)p.in_offset;
+    out_base = (int64_t)p.out_offset;
+    for (int a = p.lane_rank - 1; a >= 0; --a) {
+        const uint64_t c = lane % p.lane_shape[a];
+        lane /= p.lane_shape[a];
+        in_base += (int64_t)c * p.in_lane_stride[a];
+        out_base += (int64_t)c * p.out_lane_stride[a];
+    }
+}
+
+__device__ __forceinline__ double sample_power(float v) {
+    const double x = v;
+    return x * x;
+}
+__device__ __forceinline__ double sample_power(float2 v) {
+    const double re = v.x, im = v.y;
+    return re * re + im * im;
+}
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) {
+    return (v < lo) ? lo : ((hi < v) ? hi : v);  // std::clamp
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void agc_power_kernel(const AgcParams p,
+                                                           const T* __restrict__ in,
+                                                           double* __restrict__ gains) {
+    __shared__ double powers[kChunk];
+    const uint64_t lane = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
+    int64_t in_base, out_base;
+    lane_bases(p, lane, in_base, out_base);
+    const uint64_t start = tile * p.tile;
+    const uint64_t len = (p.tile < p.samples - start) ? p.tile : (p.samples - start);
+    double sum = 0.0;
+    for (uint64_t c0 = 0; c0 < len; c0 += kChunk) {
+        const uint64_t n = (len - c0 < (uint64_t)kChunk) ? (len - c0) : (uint64_t)kChunk;
+        for (uint64_t i = threadIdx.x; i < n; i += kBlock)
+            powers[i] = sample_power(in[in_base + (int64_t)(start + c0 + i) * p.in_sample_stride]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll 8
+            for (uint64_t i = 0; i < n; ++i) sum += powers[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = sum / (double)len;
+        gains[(lane * p.tiles + tile) * 2] =
+            clampd(p.reference / sqrt(mean + p.epsilon), p.min_gain, p.max_gain);
+    }
+}
+
+// LimitGainChange (:66-77) walked along the tiles of one lane; rewrites gains[][0..1] in place
+// as (start, end) of every tile.
+__global__ __launch_bounds__(kBlock) void agc_chain_kernel(const AgcParams p,
+                                                           double* __restrict__ gains) {
+    const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (lane >= p.lanes) return;
+    double* g = gains + lane * p.tiles * 2;
+    double start = g[0];
+    for (uint64_t t = 0; t < p.tiles; ++t) {
+        double end = start;
+        if (t + 1 < p.tiles) {
+            const double raw = g[(t + 1) * 2];
+            const double q = start / p.max_gain_change;
+            const double lo = (p.min_gain < q) ? q : p.min_gain;  // std::max(minGain, q)
+            const double hi =
+                (start > p.max_gain / p.max_gain_change) ? p.max_gain : start * p.max_gain_change;
+            end = clampd(raw, lo, hi);
+        }
+        g[t * 2] = start;
+        g[t * 2 + 1] = end;
+        start = end;
+    }
+}
+
+__device__ __forceinline__ double limit_gain(double magnitude, double gain, double limit) {
+    return (magnitude > limit / gain) ? nextafter(limit / magnitude, 0.0) : gain;  // :35-41
+}
+__device__ __forceinline__ float clamp_to_f32(double v) {
+    const double m = 3.40282346638528859811704183484516925e+38;  // numeric_limits<F32>::max()
+    return (float)clampd(v, -m, m);
+}
+__device__ __forceinline__ float apply_gain(float v, double gain) {
+    const double x = v;
+    const double g = limit_gain(fabs(x), gain, 3.40282346638528859811704183484516925e+38);
+    return clamp_to_f32(x * g);
+}
+__device__ __forceinline__ float2 apply_gain(float2 v, double gain) {
+    const double re = v.x, im = v.y;
+    // kMaxSafeCF32Magnitude = (F64)nextafterf(FLT_MAX, 0) (:20-21)
+    const double g = limit_gain(hypot(re, im), gain, 3.40282326356119256160033759537265639e+38);
+    return jst::dev::mk(clamp_to_f32(re * g), clamp_to_f32(im * g));
+}
+
+template <class T>
+__global__ __launch_bounds__(kBlock) void agc_apply_kernel(const AgcParams p, T* __restrict__ out,
+                                                           const T* __restrict__ in,
+                                                           const double* __restrict__ gains) {
+    const uint64_t total = p.lanes * p.samples;
+    for (uint64_t idx = (uint64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t lane = idx / p.samples, s = idx % p.samples;
+        int64_t in_base, out_base;
+        lane_bases(p, lane, in_base, out_base);
+        const uint64_t tile = s / p.tile, k = s % p.tile;
+        const uint64_t start = tile * p.tile;
+        const uint64_t len = (p.tile < p.samples - start) ? p.tile : (p.samples - start);
+        const double g0 = gains[(lane * p.tiles + tile) * 2], g1 = gains[(lane * p.tiles + tile) * 2 + 1];
+        const double step = (g1 - g0) / (double)len;
+        const double gain = g0 + step * (double)k;
+        out[out_base + (int64_t)s * p.out_sample_stride] =
+            apply_gain(in[in_base + (int64_t)s * p.in_sample_stride], gain);
+    }
+}
+
+template <class T>
+hipError_t run(T* out, const T* in, double* gains, const AgcParams& p, hipStream_t s) {
+    if (p.lanes == 0 || p.samples == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((agc_power_kernel<T>), dim3((unsigned)(p.lanes * p.tiles)), dim3(kBlock), 0,
+                       s, p, in, gains);
+    hipLaunchKernelGGL(agc_chain_kernel, dim3((unsigned)((p.lanes + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, s, p, gains);
+    const uint64_t total = p.lanes * p.samples;
+    uint64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 256ull * 16ull) blocks = 256ull * 16ull;
+    hipLaunchKernelGGL((agc_apply_kernel<T>), dim3((unsigned)blocks), dim3(kBlock), 0, s, p, out,
+                       in, (const double*)gains);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_agc(void* out, const void* in, bool complex, double* gains, const AgcParams& p,
+                      hipStream_t s) {
+    if (p.lanes * p.tiles > 0x7fffffffull) return hipErrorInvalidValue;
+    if (complex) return run(static_cast<float2*>(out), static_cast<const float2*>(in), gains, p, s);
+    return run(static_cast<float*>(out), static_cast<const float*>(in), gains, p, s);
+}
+
+}  // namespace jst::kernels

@@ -115,6 +115,35 @@ struct MulConstF32 {
     float c;
     __device__ float operator()(uint64_t, float v) const { return v * c; }
 };
+// add/module_impl_native_cpu.cc:83-98: c = a + b (complex: component-wise).
+struct AddCF32 {
+    __device__ float2 operator()(uint64_t, float2 a, float2 b) const { return cadd(a, b); }
+};
+struct AddF32 {
+    __device__ float operator()(uint64_t, float a, float b) const { return a + b; }
+};
+// cast/module_impl_native_cpu.cc:137-283: out = static_cast<F32>(in) / scaler per component
+// (the scaler is a power of two: the division is exact; the int -> float conversion rounds to
+// nearest even like x86 cvtsi2ss).  No offset is removed from unsigned formats, as in the reference.
+template <class TI>
+struct CastRealOp {
+    float s;
+    __device__ float operator()(uint64_t, TI v) const { return static_cast<float>(v) / s; }
+};
+template <class TI>
+struct IntPair {
+    TI re, im;
+};
+template <class TI>
+struct CastComplexOp {
+    float s;
+    __device__ float2 operator()(uint64_t, IntPair<TI> v) const {
+        return mk(static_cast<float>(v.re) / s, static_cast<float>(v.im) / s);
+    }
+};
+struct CastF32ToCF32 {
+    __device__ float2 operator()(uint64_t, float v) const { return mk(v, 0.0f); }
+};
 struct TanhProbe {
     __device__ float operator()(uint64_t, float v) const { return libm_tanhf(v); }
 };
@@ -193,6 +222,42 @@ hipError_t launch_window(float2* out, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(window_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        s, out, n);
     return hipGetLastError();
+}
+hipError_t launch_add_cf32(const EwLayout& L, float2* c, const float2* a, const float2* b,
+                           hipStream_t s) {
+    return run_binary(L, c, a, b, AddCF32{}, s);
+}
+hipError_t launch_add_f32(const EwLayout& L, float* c, const float* a, const float* b,
+                          hipStream_t s) {
+    return run_binary(L, c, a, b, AddF32{}, s);
+}
+hipError_t launch_cast(const EwLayout& L, void* out, const void* in, CastKind kind, float scaler,
+                       hipStream_t s) {
+#define JST_CAST_REAL(T) \
+    return run_unary(L, static_cast<float*>(out), static_cast<const T*>(in), CastRealOp<T>{scaler}, s)
+#define JST_CAST_CPLX(T)                                                                       \
+    return run_unary(L, static_cast<float2*>(out), static_cast<const IntPair<T>*>(in),         \
+                     CastComplexOp<T>{scaler}, s)
+    switch (kind) {
+        case CastKind::I8: JST_CAST_REAL(int8_t);
+        case CastKind::U8: JST_CAST_REAL(uint8_t);
+        case CastKind::I16: JST_CAST_REAL(int16_t);
+        case CastKind::U16: JST_CAST_REAL(uint16_t);
+        case CastKind::I32: JST_CAST_REAL(int32_t);
+        case CastKind::U32: JST_CAST_REAL(uint32_t);
+        case CastKind::CI8: JST_CAST_CPLX(int8_t);
+        case CastKind::CU8: JST_CAST_CPLX(uint8_t);
+        case CastKind::CI16: JST_CAST_CPLX(int16_t);
+        case CastKind::CU16: JST_CAST_CPLX(uint16_t);
+        case CastKind::CI32: JST_CAST_CPLX(int32_t);
+        case CastKind::CU32: JST_CAST_CPLX(uint32_t);
+        case CastKind::F32_TO_CF32:
+            return run_unary(L, static_cast<float2*>(out), static_cast<const float*>(in),
+                             CastF32ToCF32{}, s);
+    }
+#undef JST_CAST_REAL
+#undef JST_CAST_CPLX
+    return hipErrorInvalidValue;
 }
 hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipStream_t s) {
     EwLayout L{};

@@ -102,6 +102,29 @@ hipError_t launch_multiply_constant_f32(const EwLayout& L, float* out, const flo
 // (invert/module_impl_native_cpu.cc:79-103).  Output always CF32.
 hipError_t launch_invert(const EwLayout& L, float2* out, const void* in, bool in_is_complex,
                          uint64_t inner, uint64_t length, hipStream_t stream);
+// Add (core/add/module_impl_native_cpu.cc:83-98), broadcast like multiply.
+hipError_t launch_add_cf32(const EwLayout& L, float2* c, const float2* a, const float2* b,
+                           hipStream_t stream);
+hipError_t launch_add_f32(const EwLayout& L, float* c, const float* a, const float* b,
+                          hipStream_t stream);
+// Cast (core/cast/module_impl_native_cpu.cc:137-283): integer sample formats -> F32 / CF32 with
+// the reference's scalers (128, 32768, 2^31), and F32 -> CF32 (imag = 0).
+enum class CastKind { I8, U8, I16, U16, I32, U32, CI8, CU8, CI16, CU16, CI32, CU32, F32_TO_CF32 };
+hipError_t launch_cast(const EwLayout& L, void* out, const void* in, CastKind kind, float scaler,
+                       hipStream_t stream);
+// AGC (dsp/agc/module_impl_native_cpu.cc:20-160): tiled RMS gain with linear interpolation
+// between tiles, all gain arithmetic in F64.  gains: F64 [lanes][tiles][2] scratch (start, end).
+struct AgcParams {
+    uint64_t lanes, samples, tile, tiles;
+    int32_t lane_rank;
+    uint64_t lane_shape[jst::dev::kMaxRank];
+    int64_t in_lane_stride[jst::dev::kMaxRank], out_lane_stride[jst::dev::kMaxRank];
+    int64_t in_sample_stride, out_sample_stride;
+    uint64_t in_offset, out_offset;
+    double reference, epsilon, min_gain, max_gain, max_gain_change;
+};
+hipError_t launch_agc(void* out, const void* in, bool complex, double* gains, const AgcParams& p,
+                      hipStream_t stream);
 // Window: Blackman taps evaluated in F64 (window/module_impl_native_cpu.cc:20-37).
 hipError_t launch_window(float2* out, uint64_t n, hipStream_t stream);
 // libm-faithful tanhf sweep helper for the parity tests (out[i] = libm_tanhf(in[i])).

@@ -279,12 +279,40 @@ Result Reshape::create() {
 }
 
 Result Cast::validate() {
-    if (!inputs_.count("buffer")) return Result::SUCCESS;
     const std::string want = ConfigStr(config_, "outputType", "CF32");
-    if (want != DataTypeName(inputs_.at("buffer").dtype())) {
-        JST_ERROR("[MODULE_CAST_NATIVE_HIP] Only same-type passthrough (%s) is implemented, "
-                  "requested '%s'.",
-                  DataTypeName(inputs_.at("buffer").dtype()), want.c_str());
+    outputDtype = NameToDataType(want);
+    if (outputDtype == DataType::None) {
+        JST_ERROR("[MODULE_CAST] Invalid output type '%s'.", want.c_str());
+        return Result::ERROR;
+    }
+    bypass = false;
+    scaler = 1.0f;
+    if (!inputs_.count("buffer")) return Result::SUCCESS;
+    const Tensor& in = inputs_.at("buffer");
+    bypass = in.dtype() == outputDtype;
+    if (!in.validShape() || in.size() == 0 || bypass) return Result::SUCCESS;
+    switch (in.dtype()) {  // cast/module_impl.cc:47-70
+        case DataType::I8: case DataType::CI8: case DataType::U8: case DataType::CU8:
+            scaler = 128.0f;
+            break;
+        case DataType::I16: case DataType::CI16: case DataType::U16: case DataType::CU16:
+            scaler = 32768.0f;
+            break;
+        case DataType::I32: case DataType::CI32: case DataType::U32: case DataType::CU32:
+            scaler = 2147483648.0f;
+            break;
+        default: break;
+    }
+    const DataType d = in.dtype();
+    const bool real_int = d == DataType::I8 || d == DataType::U8 || d == DataType::I16 ||
+                          d == DataType::U16 || d == DataType::I32 || d == DataType::U32;
+    const bool cplx_int = d == DataType::CI8 || d == DataType::CU8 || d == DataType::CI16 ||
+                          d == DataType::CU16 || d == DataType::CI32 || d == DataType::CU32;
+    const bool ok = (outputDtype == DataType::F32 && real_int) ||
+                    (outputDtype == DataType::CF32 && (d == DataType::F32 || cplx_int));
+    if (!ok) {
+        JST_ERROR("[MODULE_CAST_NATIVE_HIP] Unsupported conversion '%s' -> '%s'.", DataTypeName(d),
+                  DataTypeName(outputDtype));
         return Result::ERROR;
     }
     return Result::SUCCESS;
@@ -295,8 +323,42 @@ Result Cast::define() {
     return defineInterfaceOutput("buffer");
 }
 Result Cast::create() {
-    produced("buffer", inputs_.at("buffer"));  // output aliases input (cast/module_impl.cc:99)
+    input = inputs_.at("buffer");
+    if (bypass) {
+        produced("buffer", input);  // output aliases input (cast/module_impl.cc:96-100)
+        return Result::SUCCESS;
+    }
+    JST_CHECK(output.create(device(), outputDtype, input.shape()));
+    JST_CHECK(output.propagateAttributes(input));
+    produced("buffer", output);
     return Result::SUCCESS;
+}
+Result Cast::computeSubmit(hipStream_t stream) {
+    if (bypass) return Result::SUCCESS;
+    EwLayout L;
+    if (!MakeEwLayout(output, &input, nullptr, L)) {
+        JST_ERROR("[MODULE_CAST] Unsupported tensor rank.");
+        return Result::ERROR;
+    }
+    using kernels::CastKind;
+    CastKind kind = CastKind::F32_TO_CF32;
+    switch (input.dtype()) {
+        case DataType::I8: kind = CastKind::I8; break;
+        case DataType::U8: kind = CastKind::U8; break;
+        case DataType::I16: kind = CastKind::I16; break;
+        case DataType::U16: kind = CastKind::U16; break;
+        case DataType::I32: kind = CastKind::I32; break;
+        case DataType::U32: kind = CastKind::U32; break;
+        case DataType::CI8: kind = CastKind::CI8; break;
+        case DataType::CU8: kind = CastKind::CU8; break;
+        case DataType::CI16: kind = CastKind::CI16; break;
+        case DataType::CU16: kind = CastKind::CU16; break;
+        case DataType::CI32: kind = CastKind::CI32; break;
+        case DataType::CU32: kind = CastKind::CU32; break;
+        default: break;
+    }
+    return hip_result(kernels::launch_cast(L, output.data(), input.data(), kind, scaler, stream),
+                      "cast kernel");
 }
 
 // ---- Multiply ----------------------------------------------------------------------------------
@@ -342,7 +404,7 @@ Result Multiply::validate() {
     if (!ta.validShape() || !tb.validShape() || ta.size() == 0 || tb.size() == 0)
         return Result::SUCCESS;
     if (ta.dtype() != tb.dtype() || (ta.dtype() != DataType::F32 && ta.dtype() != DataType::CF32)) {
-        JST_ERROR("[MODULE_MULTIPLY_NATIVE_HIP] Unsupported data types '%s' x '%s'.",
+        JST_ERROR("[MODULE_%s_NATIVE_HIP] Unsupported data types '%s' x '%s'.", tag(),
                   DataTypeName(ta.dtype()), DataTypeName(tb.dtype()));
         return Result::ERROR;
     }
@@ -352,7 +414,7 @@ Result Multiply::validate() {
         const U64 da = ra > i ? ta.shape(ra - 1 - i) : 1;
         const U64 db = rb > i ? tb.shape(rb - 1 - i) : 1;
         if (da != db && da != 1 && db != 1) {
-            JST_ERROR("[MODULE_MULTIPLY] Input shapes %s and %s are not broadcastable.",
+            JST_ERROR("[MODULE_%s] Input shapes %s and %s are not broadcastable.", tag(),
                       ShapeToString(ta.shape()).c_str(), ShapeToString(tb.shape()).c_str());
             return Result::ERROR;
         }
@@ -360,7 +422,7 @@ Result Multiply::validate() {
     }
     Tensor ba = ta.clone(), bb = tb.clone();
     if (ba.broadcastTo(os) != Result::SUCCESS || bb.broadcastTo(os) != Result::SUCCESS) {
-        JST_ERROR("[MODULE_MULTIPLY] Failed to construct validated broadcast views.");
+        JST_ERROR("[MODULE_%s] Failed to construct validated broadcast views.", tag());
         return Result::ERROR;
     }
     a = ba;
@@ -378,7 +440,7 @@ Result Multiply::create() {
     JST_CHECK(c.create(device(), a.dtype(), outputShape));
     JST_CHECK(c.propagateAttributes(inputs_.at("a")));
     JST_CHECK(merge_broadcast_axes(inputs_.at("a"), inputs_.at("b"), c));
-    produced("product", c);
+    produced(outputPort(), c);
     return Result::SUCCESS;
 }
 Result Multiply::computeSubmit(hipStream_t stream) {
@@ -395,6 +457,53 @@ Result Multiply::computeSubmit(hipStream_t stream) {
                                                    ptr<const float>(b), stream),
                       "multiply kernel");
 }
+
+// ---- Add (core/add/{module_impl.cc:9-146, module_impl_native_cpu.cc:24-98}) ---------------------
+// Same broadcast planning as Multiply; DISCONTIGUOUS only (not STATELESS), output port "sum", and
+// the sampleRate / frequency attributes follow the "a unless a is unset" rule of :108-135.
+class Add : public Multiply {
+ public:
+    const char* type() const override { return "add"; }
+    const char* tag() const override { return "ADD"; }
+    const char* outputPort() const override { return "sum"; }
+    Result define() override {
+        JST_CHECK(defineTaint(DISCONTIGUOUS));
+        JST_CHECK(defineInterfaceOutput("sum"));
+        JST_CHECK(defineInterfaceInput("a"));
+        return defineInterfaceInput("b");
+    }
+    Result create() override {
+        JST_CHECK(Multiply::create());
+        for (const char* key : {"sampleRate", "frequency"}) {
+            const auto read = [&](const Tensor& t) -> F64 {
+                const AttrValue* v = t.attribute(key);
+                if (!v) return 0.0;
+                if (const F64* f = std::get_if<F64>(v)) return (F64)(F32)*f;
+                if (const U64* u = std::get_if<U64>(v)) return (F64)(F32)*u;
+                return 0.0;
+            };
+            const F64 va = read(inputs_.at("a")), vb = read(inputs_.at("b"));
+            const F64 merged = (va == vb || vb == 0.0) ? va : (va == 0.0 ? vb : va);
+            if (inputs_.at("a").hasAttribute(key) || inputs_.at("b").hasAttribute(key))
+                c.setAttribute(key, AttrValue{merged});
+        }
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t stream) override {
+        EwLayout L;
+        if (!MakeEwLayout(c, &a, &b, L)) {
+            JST_ERROR("[MODULE_ADD] Unsupported tensor rank.");
+            return Result::ERROR;
+        }
+        if (a.dtype() == DataType::CF32)
+            return hip_result(kernels::launch_add_cf32(L, ptr<float2>(c), ptr<const float2>(a),
+                                                       ptr<const float2>(b), stream),
+                              "add kernel");
+        return hip_result(kernels::launch_add_f32(L, ptr<float>(c), ptr<const float>(a),
+                                                  ptr<const float>(b), stream),
+                          "add kernel");
+    }
+};
 
 // ---- MultiplyConstant --------------------------------------------------------------------------
 Result MultiplyConstant::validate() {
@@ -770,7 +879,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     auto* mul = dynamic_cast<Multiply*>(ordered[at]);
     auto* fft = dynamic_cast<Fft*>(ordered[at + 1]);
     auto* amp = dynamic_cast<Amplitude*>(ordered[at + 2]);
-    if (!mul || !fft || !amp) return false;
+    if (!mul || !fft || !amp || std::string(mul->type()) != "multiply") return false;
     Range* rng = at + 3 < ordered.size() ? dynamic_cast<Range*>(ordered[at + 3]) : nullptr;
 
     // dataflow: mul.c -> fft.input, fft.output -> amp.input [, amp.output -> rng.input]
@@ -854,6 +963,7 @@ JST_REGISTER_MODULE(Window, "window", DeviceType::HIP, RuntimeType::NATIVE, "gen
 JST_REGISTER_MODULE(Invert, "invert", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Reshape, "reshape", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Cast, "cast", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Add, "add", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Multiply, "multiply", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(MultiplyConstant, "multiply_constant", DeviceType::HIP, RuntimeType::NATIVE,
                     "generic");

@@ -58,21 +58,29 @@ class Reshape : public Module {
     Shape target;
 };
 
-// src/domains/core/cast -- same-dtype passthrough only (cast/module_impl.cc:99)
+// src/domains/core/cast/{module_impl.cc:8-113, module_impl_native_cpu.cc:42-283}: integer sample
+// formats -> F32 / CF32 (scalers 128, 32768, 2^31), F32 -> CF32, same-dtype bypass (alias).
 class Cast : public Module {
  public:
     const char* type() const override { return "cast"; }
     Result validate() override;
     Result define() override;
     Result create() override;
-    Result computeSubmit(hipStream_t) override { return Result::SUCCESS; }
-    bool launchesKernels() const override { return false; }
+    Result computeSubmit(hipStream_t stream) override;
+    bool launchesKernels() const override { return !bypass; }
+    Tensor input, output;
+    DataType outputDtype = DataType::None;
+    F32 scaler = 1.0f;
+    bool bypass = false;
 };
 
 // src/domains/core/multiply/{module_impl.cc:10-132, module_impl_native_cpu.cc:86-100}
 class Multiply : public Module {
  public:
     const char* type() const override { return "multiply"; }
+    // Add (core/add) shares the broadcast planning; only names, taint and the op differ.
+    virtual const char* tag() const { return "MULTIPLY"; }
+    virtual const char* outputPort() const { return "product"; }
     Result validate() override;
     Result define() override;
     Result create() override;

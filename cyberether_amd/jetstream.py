@@ -36,10 +36,13 @@ _lib = C.CDLL(LIB_PATH)
 MAX_RANK = 8
 DEVICE = {"none": 1, "cpu": 2, "hip": 64}
 DEVICE_NAME = {v: k for k, v in DEVICE.items()}
-DTYPE = {"F32": 1, "CF32": 2, "F64": 3, "U64": 4}
-NP_DTYPE = {1: np.float32, 2: np.complex64, 3: np.float64, 4: np.uint64}
-DTYPE_OF_NP = {np.dtype(np.float32): 1, np.dtype(np.complex64): 2, np.dtype(np.float64): 3,
-               np.dtype(np.uint64): 4}
+DTYPE = {"F32": 1, "CF32": 2, "F64": 3, "U64": 4, "I8": 5, "CI8": 6, "I16": 7, "CI16": 8, "U8": 9,
+         "CU8": 10, "U16": 11, "CU16": 12, "I32": 13, "CI32": 14, "U32": 15, "CU32": 16}
+# complex integer formats are interleaved (re, im) pairs: numpy sees them as a trailing axis of 2
+_CINT = {6: np.int8, 8: np.int16, 10: np.uint8, 12: np.uint16, 14: np.int32, 16: np.uint32}
+NP_DTYPE = {1: np.float32, 2: np.complex64, 3: np.float64, 4: np.uint64, 5: np.int8, 7: np.int16,
+            9: np.uint8, 11: np.uint16, 13: np.int32, 15: np.uint32}
+DTYPE_OF_NP = {np.dtype(v): k for k, v in NP_DTYPE.items()}
 RESULT_NAMES = ["SUCCESS", "ERROR", "WARNING", "FATAL", "SKIP", "YIELD", "RELOAD", "RECREATE",
                 "TIMEOUT", "INCOMPLETE"]
 
@@ -183,10 +186,16 @@ class Tensor:
         return Tensor(out.value)
 
     @staticmethod
-    def from_numpy(array: np.ndarray, device: str = "hip", **axes) -> "Tensor":
+    def from_numpy(array: np.ndarray, device: str = "hip", dtype: Optional[str] = None,
+                   **axes) -> "Tensor":
+        """dtype: only needed for the complex integer sample formats ("CI8", "CI16", ...), which
+        numpy has no type for: pass an integer array whose last axis holds (re, im)."""
         array = np.ascontiguousarray(array)
-        t = Tensor.create(device, {v: k for k, v in DTYPE.items()}[DTYPE_OF_NP[array.dtype]],
-                          array.shape)
+        if dtype is not None and DTYPE[dtype] in _CINT:
+            t = Tensor.create(device, dtype, array.shape[:-1])
+        else:
+            t = Tensor.create(device, {v: k for k, v in DTYPE.items()}[DTYPE_OF_NP[array.dtype]],
+                              array.shape)
         t.copy_from(array)
         if axes:
             t.set_axes(**axes)
@@ -304,13 +313,23 @@ class Tensor:
 
     # -- data movement (dense only) -------------------------------------------------------------
     def copy_from(self, array: np.ndarray, asynchronous: bool = False):
-        array = np.ascontiguousarray(array, dtype=NP_DTYPE[self._desc().dtype])
+        code = self._desc().dtype
+        if code in _CINT:  # interleaved (re, im) integer pairs: array[..., 2]
+            array = np.ascontiguousarray(array, dtype=_CINT[code])
+            if tuple(array.shape) != tuple(self.shape) + (2,):
+                raise ValueError("complex integer tensors take an array with a trailing axis of 2")
+        else:
+            array = np.ascontiguousarray(array, dtype=NP_DTYPE[code])
         fn = _lib.jst_tensor_copy_from_host_async if asynchronous else _lib.jst_tensor_copy_from_host
         _check(fn(self._h, array.ctypes.data_as(C.c_void_p), array.nbytes))
         return self
 
     def numpy(self) -> np.ndarray:
-        out = np.empty(self.shape, dtype=NP_DTYPE[self._desc().dtype])
+        code = self._desc().dtype
+        if code in _CINT:
+            out = np.empty(tuple(self.shape) + (2,), dtype=_CINT[code])
+        else:
+            out = np.empty(self.shape, dtype=NP_DTYPE[code])
         _check(_lib.jst_tensor_copy_to_host(self._h, out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
@@ -438,11 +457,13 @@ class Runtime:
 
 class SpectrumEngine:
     """The spectrum_engine BLOCK: cast -> window -> invert -> reshape -> multiply -> fft ->
-    amplitude -> [range], wired exactly as src/domains/dsp/spectrum_engine/block_impl.cc:120-217
-    (AGC branch omitted: enableAgc defaults to false, spectrum_engine/block.hh:9)."""
+    [agc] -> amplitude -> [range], wired exactly as
+    src/domains/dsp/spectrum_engine/block_impl.cc:120-217 (enableAgc defaults to false,
+    spectrum_engine/block.hh:9; with it the chain is not fused: agc sits between fft and amplitude)."""
 
     def __init__(self, buffer: Tensor, enable_scale: bool = True, range_min: float = -100.0,
-                 range_max: float = 0.0, name: str = "spectrum", provider: str = "generic"):
+                 range_max: float = 0.0, name: str = "spectrum", provider: str = "generic",
+                 enable_agc: bool = False):
         """provider: registry key of the amplitude/range implementations -- "generic" restates the
         reference's libm arithmetic bit for bit, "fast" uses the hardware transcendentals."""
         axes = buffer.axes
@@ -464,7 +485,12 @@ class SpectrumEngine:
         self.multiply = Module("multiply", {}, {"a": complex_input, "b": reshaped}, p + "multiply")
         self.fft = Module("fft", {"forward": True}, {"signal": self.multiply.output("product")},
                           p + "fft")
-        self.amplitude = Module("amplitude", {}, {"signal": self.fft.output("signal")},
+        self.agc = None
+        spectrum = self.fft.output("signal")
+        if enable_agc:  # one RMS tile per spectrum keeps the relative bin levels (:186-190)
+            self.agc = Module("agc", {"tileSize": n}, {"signal": spectrum}, p + "agc")
+            spectrum = self.agc.output("signal")
+        self.amplitude = Module("amplitude", {}, {"signal": spectrum},
                                 p + "amplitude", provider=provider)
         self.range = None
         if enable_scale:
@@ -477,8 +503,10 @@ class SpectrumEngine:
 
     @property
     def modules(self) -> List[Module]:
-        ms = [self.cast, self.window, self.invert, self.reshape, self.multiply, self.fft,
-              self.amplitude]
+        ms = [self.cast, self.window, self.invert, self.reshape, self.multiply, self.fft]
+        if self.agc is not None:
+            ms.append(self.agc)
+        ms.append(self.amplitude)
         if self.range is not None:
             ms.append(self.range)
         return ms

@@ -51,7 +51,13 @@ enum {
 /* include/jetstream/memory/types.hh:22-29; HIP uses the free bit 1<<6. */
 enum { JST_DEVICE_NONE = 1 << 0, JST_DEVICE_CPU = 1 << 1, JST_DEVICE_HIP = 1 << 6 };
 
-enum { JST_DTYPE_F32 = 1, JST_DTYPE_CF32 = 2, JST_DTYPE_F64 = 3, JST_DTYPE_U64 = 4 };
+/* include/jetstream/memory/types.hh (DataType); the integer sample formats feed `cast`. */
+enum {
+    JST_DTYPE_F32 = 1, JST_DTYPE_CF32 = 2, JST_DTYPE_F64 = 3, JST_DTYPE_U64 = 4,
+    JST_DTYPE_I8 = 5, JST_DTYPE_CI8 = 6, JST_DTYPE_I16 = 7, JST_DTYPE_CI16 = 8, JST_DTYPE_U8 = 9,
+    JST_DTYPE_CU8 = 10, JST_DTYPE_U16 = 11, JST_DTYPE_CU16 = 12, JST_DTYPE_I32 = 13,
+    JST_DTYPE_CI32 = 14, JST_DTYPE_U32 = 15, JST_DTYPE_CU32 = 16
+};
 
 /* Runtime flags. */
 enum {

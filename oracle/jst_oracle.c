@@ -15,6 +15,7 @@
  *   (2) oracle/_ref/libref_pocketfft.so -- the reference's vendored pocketfft.hh compiled
  *       in place from /root/reference (bit-exact comparison of the FFT restatement).
  */
+#include <float.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1087,5 +1088,78 @@ void jst_oracle_lineplot(float* avg, const float* in, uint64_t batches, uint64_t
         const float amplitude = fminf(fmaxf((sum * norm) - 1.0f, -1.0f), 1.0f);
         avg[i] -= avg[i] / av;
         avg[i] += amplitude / av;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * AGC: tiled RMS gain with interpolation.  src/domains/dsp/agc/module_impl_native_cpu.cc:20-160
+ * (SamplePower :24-33, LimitGainToFiniteRange :35-41, ClampToF32 :43-45, ApplyGain :47-64,
+ * LimitGainChange :66-77, ApplyTiledRmsAgc :79-152).  Dense [lanes][samples] arrays.
+ * ---------------------------------------------------------------------------------------- */
+static double agc_clamp(double v, double lo, double hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }
+static double agc_limit_gain(double magnitude, double gain, double limit) {
+    return magnitude > limit / gain ? nextafter(limit / magnitude, 0.0) : gain;
+}
+static float agc_clamp_f32(double v) { return (float)agc_clamp(v, -(double)FLT_MAX, (double)FLT_MAX); }
+static double agc_limit_change(double gain, double prev, double min_gain, double max_gain,
+                               double max_change) {
+    const double q = prev / max_change;
+    const double lo = (min_gain < q) ? q : min_gain;
+    const double hi = prev > max_gain / max_change ? max_gain : prev * max_change;
+    return agc_clamp(gain, lo, hi);
+}
+static double agc_tile_gain(const float* in, int complex_in, uint64_t start, uint64_t len,
+                            double reference, double epsilon, double min_gain, double max_gain) {
+    double sum = 0.0;
+    for (uint64_t s = 0; s < len; ++s) {
+        if (complex_in) {
+            const double re = in[2 * (start + s)], im = in[2 * (start + s) + 1];
+            sum += re * re + im * im;
+        } else {
+            const double v = in[start + s];
+            sum += v * v;
+        }
+    }
+    const double mean = sum / (double)len;
+    return agc_clamp(reference / sqrt(mean + epsilon), min_gain, max_gain);
+}
+void jst_oracle_agc(const float* in, float* out, int complex_in, uint64_t lanes, uint64_t samples,
+                    uint64_t tile, double reference, double epsilon, double min_gain,
+                    double max_gain, double max_change) {
+    const double max_safe_c = (double)nextafterf(FLT_MAX, 0.0f);
+    const uint64_t tiles = 1 + (samples - 1) / tile;
+    const uint64_t w = complex_in ? 2 : 1;
+    for (uint64_t lane = 0; lane < lanes; ++lane) {
+        const float* li = in + lane * samples * w;
+        float* lo = out + lane * samples * w;
+        double start_gain = agc_tile_gain(li, complex_in, 0, samples < tile ? samples : tile,
+                                          reference, epsilon, min_gain, max_gain);
+        for (uint64_t t = 0; t < tiles; ++t) {
+            const uint64_t ts = t * tile;
+            const uint64_t len = tile < samples - ts ? tile : samples - ts;
+            double end_gain = start_gain;
+            if (t + 1 < tiles) {
+                const uint64_t ns = (t + 1) * tile;
+                const uint64_t nl = tile < samples - ns ? tile : samples - ns;
+                end_gain = agc_limit_change(agc_tile_gain(li, complex_in, ns, nl, reference, epsilon,
+                                                          min_gain, max_gain),
+                                            start_gain, min_gain, max_gain, max_change);
+            }
+            const double step = (end_gain - start_gain) / (double)len;
+            for (uint64_t s = 0; s < len; ++s) {
+                const double gain = start_gain + step * (double)s;
+                if (complex_in) {
+                    const double re = li[2 * (ts + s)], im = li[2 * (ts + s) + 1];
+                    const double g = agc_limit_gain(hypot(re, im), gain, max_safe_c);
+                    lo[2 * (ts + s)] = agc_clamp_f32(re * g);
+                    lo[2 * (ts + s) + 1] = agc_clamp_f32(im * g);
+                } else {
+                    const double v = li[ts + s];
+                    const double g = agc_limit_gain(fabs(v), gain, (double)FLT_MAX);
+                    lo[ts + s] = agc_clamp_f32(v * g);
+                }
+            }
+            start_gain = end_gain;
+        }
     }
 }

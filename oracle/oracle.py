@@ -441,3 +441,43 @@ def lineplot(avg: np.ndarray, x: np.ndarray, averaging: int = 1, decimation: int
     lib().jst_oracle_lineplot(_p(avg), _p(x), C.c_uint64(x.shape[0]), C.c_uint64(avg.size),
                               C.c_uint64(x.strides[0] // 4), C.c_uint64(x.strides[1] // 4),
                               C.c_uint64(decimation), C.c_uint64(averaging))
+
+
+def agc(x: np.ndarray, axis: int = -1, tile: int = 1024, reference: float = 1.0,
+        epsilon: float = 1e-12, min_gain: float = 0.01, max_gain: float = 100.0,
+        max_gain_change: float = 4.0) -> np.ndarray:
+    """Tiled RMS AGC along `axis` (every other coordinate is an independent lane)."""
+    assert x.dtype in (np.float32, np.complex64)
+    moved = np.ascontiguousarray(np.moveaxis(x, axis, -1))
+    out = np.empty_like(moved)
+    samples = moved.shape[-1]
+    lanes = moved.size // samples
+    lib().jst_oracle_agc(_p(moved.view(np.float32)), _p(out.view(np.float32)),
+                         C.c_int(1 if x.dtype == np.complex64 else 0), C.c_uint64(lanes),
+                         C.c_uint64(samples), C.c_uint64(tile), C.c_double(reference),
+                         C.c_double(epsilon), C.c_double(min_gain), C.c_double(max_gain),
+                         C.c_double(max_gain_change))
+    return np.moveaxis(out, -1, axis)
+
+
+_CAST_SCALER = {np.dtype(np.int8): 128.0, np.dtype(np.uint8): 128.0, np.dtype(np.int16): 32768.0,
+                np.dtype(np.uint16): 32768.0, np.dtype(np.int32): 2147483648.0,
+                np.dtype(np.uint32): 2147483648.0}
+
+
+def cast(x: np.ndarray, complex_pairs: bool = False) -> np.ndarray:
+    """core/cast/module_impl_native_cpu.cc:137-283: F32(in) / scaler (128, 32768, 2^31);
+    complex_pairs: the last axis holds (re, im) -> CF32.  F32 input -> CF32 with imag 0."""
+    if x.dtype == np.float32:
+        return x.astype(np.complex64)
+    s = np.float32(_CAST_SCALER[x.dtype])
+    y = x.astype(np.float32) / s  # int -> F32 rounds to nearest even, the division is exact
+    if complex_pairs:
+        return np.ascontiguousarray(y).view(np.complex64)[..., 0]
+    return y
+
+
+def add(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """core/add/module_impl_native_cpu.cc:83-98 (broadcasting like multiply)."""
+    assert a.dtype == b.dtype and a.dtype in (np.float32, np.complex64)
+    return (a + b).astype(a.dtype)

@@ -142,3 +142,64 @@ def test_range_and_invert_and_multiply(oracle):
     a = (np.arange(6, dtype=np.float32).reshape(2, 3) + 1j).astype(np.complex64)
     b = np.array([1 + 1j, 2, 3j], np.complex64).reshape(1, 3)
     assert np.allclose(oracle.multiply(a, b), a * b)
+
+
+def _agc_case(fn, case):
+    """Runs one AGC KAT of tests/golden/reference_kats.json through `fn(x, axis, **config)`."""
+    cfgmap = {"tileSize": "tile", "reference": "reference", "epsilon": "epsilon", "minGain": "min_gain",
+              "maxGain": "max_gain", "maxGainChange": "max_gain_change"}
+    kw = {cfgmap[k]: v for k, v in case["config"].items()}
+    axis = case.get("sample_axis", -1)
+    if "generate" in case:
+        amp = (1 + np.arange(1024) % 16).astype(np.float32)
+        x = np.stack([amp, amp, 2 * amp, 2 * amp]).astype(np.float32)
+    elif case["dtype"] == "CF32":
+        raw = np.array(case["input"], np.float64)
+        x = (raw[..., 0].astype(np.float32) + 1j * raw[..., 1].astype(np.float32)).astype(np.complex64)
+    else:
+        x = np.array(case["input"], np.float32)
+    y = fn(x, axis, **kw)
+    assert y.shape == x.shape and y.dtype == x.dtype
+    if "expect" in case:
+        e = np.array(case["expect"], np.float64)
+        if case["dtype"] == "CF32":
+            e = e[..., 0] + 1j * e[..., 1]
+        assert np.max(np.abs(y - e)) <= case["abs_tol"], case["name"]
+    if "expect_rows" in case:
+        assert np.max(np.abs(y - np.array(case["expect_rows"])[:, None])) <= case["abs_tol"]
+    if "expect_abs" in case:
+        assert np.all(np.isfinite(y.view(np.float32)))
+        assert abs(abs(complex(y[0])) - case["expect_abs"]) <= case["abs_tol"]
+    if "expect_signs" in case:
+        assert np.all(np.isfinite(y)) and np.array_equal(np.sign(y), np.array(case["expect_signs"], np.float32))
+        assert y[0] == 0.0
+    if "expect_exact" in case:
+        assert np.array_equal(y, np.array(case["expect_exact"], np.float64).astype(np.float32)), case["name"]
+    if "expect_ratio" in case:
+        s = complex(y[1])
+        assert np.isfinite(abs(s)) and s.real > 0 and s.imag < 0
+        assert abs(s.imag / s.real - case["expect_ratio"]) <= case["abs_tol"]
+    if "expect_rel" in case:
+        e = np.array(case["expect_rel"], np.float64)
+        assert np.allclose(y.real, e[..., 0], rtol=case["rel_tol"]) and np.allclose(y.imag, e[..., 1], rtol=case["rel_tol"])
+
+
+def test_agc_kats(oracle):
+    for case in KATS["agc"]:
+        _agc_case(lambda x, axis, **kw: oracle.agc(x, axis, **kw), case)
+
+
+def test_cast_scalers(oracle):
+    s = KATS["cast"][0]["scalers"]
+    for name, npdt in (("I8", np.int8), ("U8", np.uint8), ("I16", np.int16), ("U16", np.uint16),
+                       ("I32", np.int32), ("U32", np.uint32)):
+        info = np.iinfo(npdt)
+        x = np.array([info.min, -1 if info.min < 0 else 1, 0, 1, info.max], npdt)
+        y = oracle.cast(x)
+        assert y.dtype == np.float32
+        assert np.array_equal(y, x.astype(np.float32) / np.float32(s[name]))
+        pairs = np.stack([x, x[::-1]], axis=-1)
+        z = oracle.cast(pairs, complex_pairs=True)
+        assert z.dtype == np.complex64 and z.shape == x.shape
+        assert np.array_equal(z.real, y) and np.array_equal(z.imag, y[::-1])
+    assert s["CI8"] == 128.0 and s["CI16"] == 32768.0 and s["CU32"] == 2147483648.0
