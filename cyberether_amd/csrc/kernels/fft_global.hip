@@ -1,11 +1,14 @@
 // fft_global.hip -- general-length FFT: one Stockham pass per launch, through HBM.
 //
-// Covers what the LDS-resident kernels (fft_lds.hh) do not: lengths above 16384 points and
-// lengths with factors 3 and 5 (the Filter block's convolution size S + taps - 1 is rarely a power
-// of two: 160000 = 8*8*4*5*5*5*5 for BASELINE config 3).  Same plan, butterflies and twiddle table
-// as pocketfft's cfftp (factor order pocketfft.hh:1476-1497; pass2/3/4/5/8 :843-1223), so results
-// are bit-identical to the reference CPU path; the passes ping-pong between two dense scratch
+// Covers what the LDS-resident kernels (fft_lds.hh) do not: lengths above 16384 points and every
+// length that is not a power of two (the Filter block's convolution size S + taps - 1 rarely is:
+// 160000 = 8*8*4*5*5*5*5 for BASELINE config 3, 8050 = 2*5*5*7*23 in the overlap-add example).
+// Same plan, butterflies and twiddle table as pocketfft's cfftp (factor order pocketfft.hh:
+// 1476-1497; pass2/3/4/5/7/8/11 :843-1312, generic odd radix passg :1314-1421), so results are
+// bit-identical to the reference CPU path; the passes ping-pong between two dense scratch
 // tensors, the first reading the (strided) input and the last writing the (strided) output.
+// Lengths for which pocketfft_c picks Bluestein (:2472-2489) are composed from these passes by the
+// Fft module with the three elementwise kernels at the end of this file (fftblue, :2362-2432).
 // One thread per butterfly: writes are fully coalesced (u + c*N/ip), reads are contiguous runs of
 // ido elements.  Traffic is nf x 16 B per sample -- correctness-first; a fused LDS multi-pass
 // version for 65536 points is future work.
@@ -56,10 +59,80 @@ __device__ __forceinline__ void butterfly5(float2 (&x)[5]) {
     x[2] = cadd(da, db);
     x[3] = csub(da, db);
 }
+// pocketfft pass7 (pocketfft.hh:1047-1122) without the output twiddles
+template <bool FWD>
+__device__ __forceinline__ void butterfly7(float2 (&x)[7]) {
+    constexpr float sg = FWD ? -1.0f : 1.0f;
+    constexpr float tw1r = 0.6234898018587335305250048840042398f,
+                    tw1i = sg * 0.7818314824680298087084445266740578f,
+                    tw2r = -0.2225209339563144042889025644967948f,
+                    tw2i = sg * 0.9749279121818236070181316829939312f,
+                    tw3r = -0.9009688679024191262361023195074451f,
+                    tw3i = sg * 0.433883739117558120475768332848359f;
+    const float2 t1 = x[0];
+    const float2 t2 = cadd(x[1], x[6]), t7 = csub(x[1], x[6]);
+    const float2 t3 = cadd(x[2], x[5]), t6 = csub(x[2], x[5]);
+    const float2 t4 = cadd(x[3], x[4]), t5 = csub(x[3], x[4]);
+    x[0] = mk(t1.x + t2.x + t3.x + t4.x, t1.y + t2.y + t3.y + t4.y);
+#define JST_STEP7(u1, u2, x1, x2, x3, y1, y2, y3)                            \
+    {                                                                        \
+        float2 ca, cb;                                                       \
+        ca.x = t1.x + x1 * t2.x + x2 * t3.x + x3 * t4.x;                     \
+        ca.y = t1.y + x1 * t2.y + x2 * t3.y + x3 * t4.y;                     \
+        cb.y = y1 * t7.x y2 * t6.x y3 * t5.x;                                \
+        cb.x = -(y1 * t7.y y2 * t6.y y3 * t5.y);                             \
+        x[u1] = cadd(ca, cb);                                                \
+        x[u2] = csub(ca, cb);                                                \
+    }
+    JST_STEP7(1, 6, tw1r, tw2r, tw3r, +tw1i, +tw2i, +tw3i)
+    JST_STEP7(2, 5, tw2r, tw3r, tw1r, +tw2i, -tw3i, -tw1i)
+    JST_STEP7(3, 4, tw3r, tw1r, tw2r, +tw3i, -tw1i, +tw2i)
+#undef JST_STEP7
+}
+// pocketfft pass11 (pocketfft.hh:1226-1312) without the output twiddles
+template <bool FWD>
+__device__ __forceinline__ void butterfly11(float2 (&x)[11]) {
+    constexpr float sg = FWD ? -1.0f : 1.0f;
+    constexpr float tw1r = 0.8412535328311811688618116489193677f,
+                    tw1i = sg * 0.5406408174555975821076359543186917f,
+                    tw2r = 0.4154150130018864255292741492296232f,
+                    tw2i = sg * 0.9096319953545183714117153830790285f,
+                    tw3r = -0.1423148382732851404437926686163697f,
+                    tw3i = sg * 0.9898214418809327323760920377767188f,
+                    tw4r = -0.6548607339452850640569250724662936f,
+                    tw4i = sg * 0.7557495743542582837740358439723444f,
+                    tw5r = -0.9594929736144973898903680570663277f,
+                    tw5i = sg * 0.2817325568414296977114179153466169f;
+    const float2 t1 = x[0];
+    const float2 t2 = cadd(x[1], x[10]), t11 = csub(x[1], x[10]);
+    const float2 t3 = cadd(x[2], x[9]), t10 = csub(x[2], x[9]);
+    const float2 t4 = cadd(x[3], x[8]), t9 = csub(x[3], x[8]);
+    const float2 t5 = cadd(x[4], x[7]), t8 = csub(x[4], x[7]);
+    const float2 t6 = cadd(x[5], x[6]), t7 = csub(x[5], x[6]);
+    x[0] = mk(t1.x + t2.x + t3.x + t4.x + t5.x + t6.x, t1.y + t2.y + t3.y + t4.y + t5.y + t6.y);
+#define JST_STEP11(u1, u2, x1, x2, x3, x4, x5, y1, y2, y3, y4, y5)                           \
+    {                                                                                        \
+        float2 ca, cb;                                                                       \
+        ca.x = t1.x + t2.x * x1 + t3.x * x2 + t4.x * x3 + t5.x * x4 + t6.x * x5;             \
+        ca.y = t1.y + t2.y * x1 + t3.y * x2 + t4.y * x3 + t5.y * x4 + t6.y * x5;             \
+        cb.y = y1 * t11.x y2 * t10.x y3 * t9.x y4 * t8.x y5 * t7.x;                          \
+        cb.x = -(y1 * t11.y y2 * t10.y y3 * t9.y y4 * t8.y y5 * t7.y);                       \
+        x[u1] = cadd(ca, cb);                                                                \
+        x[u2] = csub(ca, cb);                                                                \
+    }
+    JST_STEP11(1, 10, tw1r, tw2r, tw3r, tw4r, tw5r, +tw1i, +tw2i, +tw3i, +tw4i, +tw5i)
+    JST_STEP11(2, 9, tw2r, tw4r, tw5r, tw3r, tw1r, +tw2i, +tw4i, -tw5i, -tw3i, -tw1i)
+    JST_STEP11(3, 8, tw3r, tw5r, tw2r, tw1r, tw4r, +tw3i, -tw5i, -tw2i, +tw1i, +tw4i)
+    JST_STEP11(4, 7, tw4r, tw3r, tw1r, tw5r, tw2r, +tw4i, -tw3i, +tw1i, +tw5i, -tw2i)
+    JST_STEP11(5, 6, tw5r, tw1r, tw4r, tw2r, tw3r, +tw5i, -tw1i, +tw4i, -tw2i, +tw3i)
+#undef JST_STEP11
+}
 template <int IP, bool FWD>
 __device__ __forceinline__ void butterfly_any(float2 (&x)[IP]) {
     if constexpr (IP == 3) butterfly3<FWD>(x);
     else if constexpr (IP == 5) butterfly5<FWD>(x);
+    else if constexpr (IP == 7) butterfly7<FWD>(x);
+    else if constexpr (IP == 11) butterfly11<FWD>(x);
     else butterfly<IP, FWD>(x);
 }
 
@@ -123,11 +196,213 @@ hipError_t launch_pass(int ip, const FftLayout& L, const PassIo& io, const float
         case 3: JST_GPASS(3); break;
         case 4: JST_GPASS(4); break;
         case 5: JST_GPASS(5); break;
+        case 7: JST_GPASS(7); break;
         case 8: JST_GPASS(8); break;
+        case 11: JST_GPASS(11); break;
         default: return hipErrorInvalidValue;
     }
 #undef JST_GPASS
     return hipGetLastError();
+}
+
+// ---- generic odd radix (pocketfft passg, pocketfft.hh:1314-1421) ---------------------------------
+// Per butterfly (i,k) the reference computes, in this order:
+//   H[0] = CC0; H[j], H[ip-j] = CCj +/- CC(ip-j);  X[0] = H[0] + H[1] + ... + H[ipph-1]
+//   X[l], X[ip-l] from the wal[] sums (two terms at a time, then single terms);
+//   out[l], out[ip-l] = (X[l] +/- X[ip-l]) * twiddle.
+// Stage 1 writes H to a dense temp laid out [transform][j][butterfly] (coalesced), stage 2 is one
+// thread per (butterfly, l) pair.  wal[m] = W[m * n/ip] (comp_twiddle's csarr, :1526-1531).
+template <bool FWD>
+__global__ __launch_bounds__(kBlock) void fft_passg_prep_kernel(const FftLayout L, const PassIo io,
+                                                                float2* __restrict__ H,
+                                                                uint64_t n, uint64_t ip,
+                                                                uint64_t ido) {
+    const uint64_t but = n / ip, ipph = (ip + 1) / 2, total = L.transforms * but * ipph;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t u = g % but, j = (g / but) % ipph, t = g / (but * ipph);
+        const uint64_t i = u % ido, k = u / ido;
+        int64_t sbase = (int64_t)(t * n);
+        if (io.src_strided) {
+            sbase = (int64_t)L.in_offset;
+            uint64_t rem = t;
+            for (int a = L.outer_rank - 1; a >= 0; --a) {
+                sbase += (int64_t)(rem % L.outer_shape[a]) * L.in_outer_stride[a];
+                rem /= L.outer_shape[a];
+            }
+        }
+        float2* h = H + t * n + u;
+        if (j == 0) {
+            h[0] = io.src[sbase + (int64_t)(i + ido * (ip * k)) * io.src_stride];
+        } else {
+            const uint64_t jc = ip - j;
+            const float2 a = io.src[sbase + (int64_t)(i + ido * (j + ip * k)) * io.src_stride];
+            const float2 b = io.src[sbase + (int64_t)(i + ido * (jc + ip * k)) * io.src_stride];
+            h[j * but] = cadd(a, b);
+            h[jc * but] = csub(a, b);
+        }
+    }
+}
+template <bool FWD>
+__global__ __launch_bounds__(kBlock) void fft_passg_out_kernel(const FftLayout L, const PassIo io,
+                                                               const float2* __restrict__ H,
+                                                               const float2* __restrict__ W,
+                                                               uint64_t n, uint64_t ip, uint64_t l1,
+                                                               uint64_t ido) {
+    const uint64_t but = n / ip, ipph = (ip + 1) / 2, total = L.transforms * but * ipph;
+    const uint64_t wstep = n / ip;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t u = g % but, l = (g / but) % ipph, t = g / (but * ipph);
+        const uint64_t i = u % ido;
+        int64_t dbase = (int64_t)(t * n);
+        if (io.dst_strided) {
+            dbase = (int64_t)L.out_offset;
+            uint64_t rem = t;
+            for (int a = L.outer_rank - 1; a >= 0; --a) {
+                dbase += (int64_t)(rem % L.outer_shape[a]) * L.out_outer_stride[a];
+                rem /= L.outer_shape[a];
+            }
+        }
+        const float2* h = H + t * n + u;
+        if (l == 0) {
+            float2 tmp = h[0];
+            for (uint64_t j = 1; j < ipph; ++j) {
+                const float2 v = h[j * but];
+                tmp.x += v.x;
+                tmp.y += v.y;
+            }
+            io.dst[dbase + (int64_t)u * io.dst_stride] = tmp;
+            continue;
+        }
+        const uint64_t lc = ip - l;
+        auto wal = [&](uint64_t m) {
+            float2 w = W[m * wstep];
+            if (FWD) w.y = -w.y;
+            return w;
+        };
+        const float2 h0 = h[0], h1 = h[but], h2 = h[2 * but];
+        const float2 hm1 = h[(ip - 1) * but], hm2 = h[(ip - 2) * but];
+        const float2 w1 = wal(l), w2 = wal(2 * l);
+        float2 xl, xlc;
+        xl.x = h0.x + w1.x * h1.x + w2.x * h2.x;
+        xl.y = h0.y + w1.x * h1.y + w2.x * h2.y;
+        xlc.x = -w1.y * hm1.y - w2.y * hm2.y;
+        xlc.y = w1.y * hm1.x + w2.y * hm2.x;
+        uint64_t iwal = 2 * l;
+        uint64_t j = 3, jc = ip - 3;
+        for (; j < ipph - 1; j += 2, jc -= 2) {
+            iwal += l;
+            if (iwal > ip) iwal -= ip;
+            const float2 xw = wal(iwal);
+            iwal += l;
+            if (iwal > ip) iwal -= ip;
+            const float2 xw2 = wal(iwal);
+            const float2 a = h[j * but], b = h[(j + 1) * but];
+            const float2 c = h[jc * but], d = h[(jc - 1) * but];
+            xl.x += a.x * xw.x + b.x * xw2.x;
+            xl.y += a.y * xw.x + b.y * xw2.x;
+            xlc.x -= c.y * xw.y + d.y * xw2.y;
+            xlc.y += c.x * xw.y + d.x * xw2.y;
+        }
+        for (; j < ipph; ++j, --jc) {
+            iwal += l;
+            if (iwal > ip) iwal -= ip;
+            const float2 xw = wal(iwal);
+            const float2 a = h[j * but], c = h[jc * but];
+            xl.x += a.x * xw.x;
+            xl.y += a.y * xw.x;
+            xlc.x -= c.y * xw.y;
+            xlc.y += c.x * xw.y;
+        }
+        float2 s1 = cadd(xl, xlc), s2 = csub(xl, xlc);
+        if (i != 0) {
+            s1 = special_mul<FWD>(s1, W[l * l1 * i]);
+            s2 = special_mul<FWD>(s2, W[lc * l1 * i]);
+        }
+        io.dst[dbase + (int64_t)(u + l * but) * io.dst_stride] = s1;
+        io.dst[dbase + (int64_t)(u + lc * but) * io.dst_stride] = s2;
+    }
+}
+
+template <bool FWD>
+hipError_t launch_passg(const FftLayout& L, const PassIo& io, float2* H, const float2* W,
+                        uint64_t n, uint64_t ip, uint64_t l1, uint64_t ido, hipStream_t s) {
+    const uint64_t total = L.transforms * (n / ip) * ((ip + 1) / 2);
+    uint64_t blocks = (total + kBlock - 1) / kBlock;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks == 0) return hipSuccess;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((fft_passg_prep_kernel<FWD>), dim3((unsigned)blocks), dim3(kBlock), 0, s, L,
+                       io, H, n, ip, ido);
+    hipLaunchKernelGGL((fft_passg_out_kernel<FWD>), dim3((unsigned)blocks), dim3(kBlock), 0, s, L,
+                       io, (const float2*)H, W, n, ip, l1, ido);
+    return hipGetLastError();
+}
+
+// ---- Bluestein (pocketfft fftblue::fft, pocketfft.hh:2370-2399) ----------------------------------
+// a[m] = special_mul<fwd>(c[m], bk[m]) for m < n, then akf[0]*0 up to n2 (NaN and -0 propagate).
+template <bool FWD>
+__global__ __launch_bounds__(kBlock) void blue_pre_kernel(const FftLayout L, float2* __restrict__ akf,
+                                                          const float2* __restrict__ in,
+                                                          const float2* __restrict__ bk,
+                                                          uint64_t n, uint64_t n2) {
+    const uint64_t total = L.transforms * n2;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t t = g / n2, m = g % n2;
+        int64_t base = (int64_t)L.in_offset;
+        uint64_t rem = t;
+        for (int a = L.outer_rank - 1; a >= 0; --a) {
+            base += (int64_t)(rem % L.outer_shape[a]) * L.in_outer_stride[a];
+            rem /= L.outer_shape[a];
+        }
+        if (m < n) {
+            akf[g] = special_mul<FWD>(in[base + (int64_t)m * L.in_axis_stride], bk[m]);
+        } else {
+            const float2 a0 = special_mul<FWD>(in[base], bk[0]);
+            akf[g] = mk(a0.x * 0.0f, a0.y * 0.0f);
+        }
+    }
+}
+// akf[m] *= bkf[min(m, n2-m)] with special_mul<!fwd> (:2383-2391)
+template <bool FWD>
+__global__ __launch_bounds__(kBlock) void blue_mul_kernel(float2* __restrict__ akf,
+                                                          const float2* __restrict__ bkf,
+                                                          uint64_t transforms, uint64_t n2) {
+    const uint64_t total = transforms * n2;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t m = g % n2;
+        const uint64_t q = (2 * m <= n2) ? m : n2 - m;
+        akf[g] = special_mul<!FWD>(akf[g], bkf[q]);
+    }
+}
+// c[m] = special_mul<fwd>(akf[m], bk[m]) * fct, fct == 1 (:2396-2398)
+template <bool FWD>
+__global__ __launch_bounds__(kBlock) void blue_post_kernel(const FftLayout L, float2* __restrict__ out,
+                                                           const float2* __restrict__ akf,
+                                                           const float2* __restrict__ bk,
+                                                           uint64_t n, uint64_t n2) {
+    const uint64_t total = L.transforms * n;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t t = g / n, m = g % n;
+        int64_t base = (int64_t)L.out_offset;
+        uint64_t rem = t;
+        for (int a = L.outer_rank - 1; a >= 0; --a) {
+            base += (int64_t)(rem % L.outer_shape[a]) * L.out_outer_stride[a];
+            rem /= L.outer_shape[a];
+        }
+        const float2 v = special_mul<FWD>(akf[t * n2 + m], bk[m]);
+        out[base + (int64_t)m * L.out_axis_stride] = mk(v.x * 1.0f, v.y * 1.0f);
+    }
+}
+
+inline unsigned blocks_for(uint64_t total) {
+    uint64_t b = (total + kBlock - 1) / kBlock;
+    if (b > 16384) b = 16384;
+    return (unsigned)(b ? b : 1);
 }
 
 }  // namespace
@@ -152,20 +427,82 @@ int fft_plan_factors(uint64_t n, uint32_t* fact) {
             fact[nf++] = (uint32_t)d;
             len /= d;
         }
-    if (len > 1) fact[nf++] = (uint32_t)len;
-    for (int i = 0; i < nf; ++i)
-        if (fact[i] != 2 && fact[i] != 3 && fact[i] != 4 && fact[i] != 5 && fact[i] != 8) return -1;
+    if (len > 1) {
+        if (nf >= 60 || len > 0xffffffffull) return -1;
+        fact[nf++] = (uint32_t)len;
+    }
     return nf;
 }
 
 bool fft_global_supported(uint64_t n) {
     uint32_t fact[64];
-    return n >= 1 && n <= (1ull << 31) && fft_plan_factors(n, fact) >= 0;
+    return n >= 2 && n <= (1ull << 31) && fft_plan_factors(n, fact) >= 0;
+}
+bool fft_plan_has_generic_radix(uint64_t n) {
+    uint32_t fact[64];
+    const int nf = fft_plan_factors(n, fact);
+    for (int i = 0; i < nf; ++i)
+        if (fact[i] > 11) return true;
+    return false;
+}
+
+// pocketfft_c's plan choice (pocketfft.hh:372-428, 2472-2489), integer/double arithmetic restated.
+namespace {
+uint64_t largest_prime_factor(uint64_t n) {
+    uint64_t res = 1;
+    while ((n & 1) == 0) { res = 2; n >>= 1; }
+    for (uint64_t x = 3; x * x <= n; x += 2)
+        while ((n % x) == 0) { res = x; n /= x; }
+    if (n > 1) res = n;
+    return res;
+}
+double cost_guess(uint64_t n) {
+    constexpr double lfp = 1.1;  // penalty for non-hardcoded larger factors
+    const uint64_t ni = n;
+    double result = 0.;
+    while ((n & 1) == 0) { result += 2; n >>= 1; }
+    for (uint64_t x = 3; x * x <= n; x += 2)
+        while ((n % x) == 0) {
+            result += (x <= 5) ? double(x) : lfp * double(x);
+            n /= x;
+        }
+    if (n > 1) result += (n <= 5) ? double(n) : lfp * double(n);
+    return result * double(ni);
+}
+uint64_t good_size_cmplx(uint64_t n) {
+    if (n <= 12) return n;
+    uint64_t bestfac = 2 * n;
+    for (uint64_t f11 = 1; f11 < bestfac; f11 *= 11)
+        for (uint64_t f117 = f11; f117 < bestfac; f117 *= 7)
+            for (uint64_t f1175 = f117; f1175 < bestfac; f1175 *= 5) {
+                uint64_t x = f1175;
+                while (x < n) x *= 2;
+                for (;;) {
+                    if (x < n) x *= 3;
+                    else if (x > n) {
+                        if (x < bestfac) bestfac = x;
+                        if (x & 1) break;
+                        x >>= 1;
+                    } else
+                        return n;
+                }
+            }
+    return bestfac;
+}
+}  // namespace
+uint64_t fft_bluestein_size(uint64_t n) {
+    if (n == 0) return 0;
+    const uint64_t lpf = (n < 50) ? 0 : largest_prime_factor(n);
+    if (lpf * lpf <= n) return 0;
+    const double comp1 = cost_guess(n);
+    double comp2 = 2 * cost_guess(good_size_cmplx(2 * n - 1));
+    comp2 *= 1.5;  // the reference's fudge factor
+    return (comp2 < comp1) ? good_size_cmplx(2 * n - 1) : 0;
 }
 
 hipError_t launch_fft_c2c_global(uint64_t n, bool forward, const FftLayout& L, const float2* W,
                                  const float2* in, float2* out, float2* scratch_a,
-                                 float2* scratch_b, hipStream_t s) {
+                                 float2* scratch_b, float2* scratch_h, hipStream_t s) {
     uint32_t fact[64];
     const int nf = fft_plan_factors(n, fact);
     if (nf < 0) return hipErrorInvalidValue;
@@ -185,13 +522,54 @@ hipError_t launch_fft_c2c_global(uint64_t n, bool forward, const FftLayout& L, c
         io.dst_strided = last ? 1 : 0;
         io.src_stride = first ? L.in_axis_stride : 1;
         io.dst_stride = last ? L.out_axis_stride : 1;
-        const hipError_t e = forward ? launch_pass<true>((int)ip, L, io, W, n, l1, ido, s)
-                                     : launch_pass<false>((int)ip, L, io, W, n, l1, ido, s);
+        hipError_t e;
+        if (ip > 11) {
+            if (!scratch_h) return hipErrorInvalidValue;
+            e = forward ? launch_passg<true>(L, io, scratch_h, W, n, ip, l1, ido, s)
+                        : launch_passg<false>(L, io, scratch_h, W, n, ip, l1, ido, s);
+        } else {
+            e = forward ? launch_pass<true>((int)ip, L, io, W, n, l1, ido, s)
+                        : launch_pass<false>((int)ip, L, io, W, n, l1, ido, s);
+        }
         if (e != hipSuccess) return e;
         src = dst;
         l1 *= ip;
     }
     return hipSuccess;
+}
+
+hipError_t launch_bluestein_pre(bool forward, const FftLayout& L, float2* akf, const float2* in,
+                                const float2* bk, uint64_t n, uint64_t n2, hipStream_t s) {
+    (void)hipGetLastError();
+    if (forward)
+        hipLaunchKernelGGL((blue_pre_kernel<true>), dim3(blocks_for(L.transforms * n2)), dim3(kBlock),
+                           0, s, L, akf, in, bk, n, n2);
+    else
+        hipLaunchKernelGGL((blue_pre_kernel<false>), dim3(blocks_for(L.transforms * n2)),
+                           dim3(kBlock), 0, s, L, akf, in, bk, n, n2);
+    return hipGetLastError();
+}
+hipError_t launch_bluestein_mul(bool forward, float2* akf, const float2* bkf, uint64_t transforms,
+                                uint64_t n2, hipStream_t s) {
+    (void)hipGetLastError();
+    if (forward)
+        hipLaunchKernelGGL((blue_mul_kernel<true>), dim3(blocks_for(transforms * n2)), dim3(kBlock), 0,
+                           s, akf, bkf, transforms, n2);
+    else
+        hipLaunchKernelGGL((blue_mul_kernel<false>), dim3(blocks_for(transforms * n2)), dim3(kBlock),
+                           0, s, akf, bkf, transforms, n2);
+    return hipGetLastError();
+}
+hipError_t launch_bluestein_post(bool forward, const FftLayout& L, float2* out, const float2* akf,
+                                 const float2* bk, uint64_t n, uint64_t n2, hipStream_t s) {
+    (void)hipGetLastError();
+    if (forward)
+        hipLaunchKernelGGL((blue_post_kernel<true>), dim3(blocks_for(L.transforms * n)), dim3(kBlock),
+                           0, s, L, out, akf, bk, n, n2);
+    else
+        hipLaunchKernelGGL((blue_post_kernel<false>), dim3(blocks_for(L.transforms * n)),
+                           dim3(kBlock), 0, s, L, out, akf, bk, n, n2);
+    return hipGetLastError();
 }
 
 }  // namespace jst::kernels

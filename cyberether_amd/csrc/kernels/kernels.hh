@@ -69,14 +69,26 @@ bool fft_lds_supported(uint64_t n);
 bool fft_fused_supported(uint64_t n);
 hipError_t launch_fft_c2c(uint64_t n, bool forward, const FftLayout& L, const float2* W,
                           const float2* in, float2* out, hipStream_t stream);
-// General lengths (factors 2,3,4,5,8; any size): one Stockham pass per launch through HBM
-// (fft_global.hip).  scratch_a/b: dense CF32[transforms * n] each (b may be null when the plan
-// has at most two passes).
+// General lengths (pocketfft's cfftp for any n >= 2: radix 2/3/4/5/7/8/11 passes plus the generic
+// odd radix): one Stockham pass per launch through HBM (fft_global.hip).  scratch_a/b: dense
+// CF32[transforms * n] each (b may be null when the plan has at most two passes); scratch_h: one
+// more of the same size, needed only when fft_plan_has_generic_radix(n).
 int fft_plan_factors(uint64_t n, uint32_t* factors /*[64]*/);
 bool fft_global_supported(uint64_t n);
+bool fft_plan_has_generic_radix(uint64_t n);
 hipError_t launch_fft_c2c_global(uint64_t n, bool forward, const FftLayout& L, const float2* W,
                                  const float2* in, float2* out, float2* scratch_a,
-                                 float2* scratch_b, hipStream_t stream);
+                                 float2* scratch_b, float2* scratch_h, hipStream_t stream);
+// pocketfft_c's plan choice (pocketfft.hh:2472-2489): 0 = cfftp of n, else the Bluestein
+// convolution length n2 = good_size_cmplx(2n-1).  The three elementwise steps of fftblue::fft
+// (:2370-2399) around the two n2-point transforms; akf: dense CF32[transforms * n2].
+uint64_t fft_bluestein_size(uint64_t n);
+hipError_t launch_bluestein_pre(bool forward, const FftLayout& L, float2* akf, const float2* in,
+                                const float2* bk, uint64_t n, uint64_t n2, hipStream_t stream);
+hipError_t launch_bluestein_mul(bool forward, float2* akf, const float2* bkf, uint64_t transforms,
+                                uint64_t n2, hipStream_t stream);
+hipError_t launch_bluestein_post(bool forward, const FftLayout& L, float2* out, const float2* akf,
+                                 const float2* bk, uint64_t n, uint64_t n2, hipStream_t stream);
 // Multiply(window) -> FFT(forward) -> Amplitude [-> Range] in one pass over HBM.
 hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W,
                                  const float2* in, const float2* window, int64_t window_stride,

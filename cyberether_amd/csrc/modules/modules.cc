@@ -572,8 +572,7 @@ Result Fft::validate() {
     }
     const U64 n = in.shape(*axes.sample);
     if (!kernels::fft_lds_supported(n) && !kernels::fft_global_supported(n)) {
-        JST_ERROR("[MODULE_FFT_NATIVE_HIP] Transform length %llu is not implemented on the HIP "
-                  "device (lengths whose prime factors are 2, 3 and 5).",
+        JST_ERROR("[MODULE_FFT_NATIVE_HIP] Transform length %llu exceeds the supported range.",
                   (unsigned long long)n);
         return Result::ERROR;
     }
@@ -598,20 +597,82 @@ Result Fft::create() {
 }
 Result Fft::computeInitialize() {
     const U64 n = input.shape(resolvedAxis);
-    JST_CHECK(GetTwiddles(n, &twiddles));
-    useGlobalPasses = !kernels::fft_lds_supported(n);
+    const U64 transforms = input.size() / n;
+    bluesteinSize = kernels::fft_bluestein_size(n);
+    // the length the pass kernels actually run at: n, or the Bluestein convolution length
+    const U64 m = bluesteinSize ? bluesteinSize : n;
+    JST_CHECK(GetTwiddles(m, &twiddles));
+    useGlobalPasses = !kernels::fft_lds_supported(m);
     if (useGlobalPasses) {  // ping-pong scratch for the pass-per-launch path
         uint32_t fact[64];
-        const int nf = kernels::fft_plan_factors(n, fact);
-        if (nf >= 2) JST_CHECK(scratchA.create(device(), DataType::CF32, {input.size()}));
-        if (nf >= 3) JST_CHECK(scratchB.create(device(), DataType::CF32, {input.size()}));
+        const int nf = kernels::fft_plan_factors(m, fact);
+        if (nf >= 2) JST_CHECK(scratchA.create(device(), DataType::CF32, {transforms * m}));
+        if (nf >= 3) JST_CHECK(scratchB.create(device(), DataType::CF32, {transforms * m}));
+        if (kernels::fft_plan_has_generic_radix(m))
+            JST_CHECK(scratchH.create(device(), DataType::CF32, {transforms * m}));
     }
+    if (!bluesteinSize) return Result::SUCCESS;
+
+    // fftblue's constructor (pocketfft.hh:2402-2429): chirp b_k from the 2n-point table, and the
+    // transform of the zero-padded, 1/n2-scaled chirp -- computed with the same device passes.
+    const U64 n2 = bluesteinSize;
+    JST_CHECK(akf.create(device(), DataType::CF32, {transforms * n2}));
+    JST_CHECK(bk.create(device(), DataType::CF32, {n}));
+    JST_CHECK(bkf.create(device(), DataType::CF32, {n2 / 2 + 1}));
+    std::vector<float> table(4 * n), chirp(2 * n), padded(2 * n2, 0.0f);
+    ComputeTwiddles(2 * n, table.data());
+    chirp[0] = 1.0f;
+    chirp[1] = 0.0f;
+    U64 coeff = 0;
+    for (U64 k = 1; k < n; ++k) {
+        coeff += 2 * k - 1;
+        if (coeff >= 2 * n) coeff -= 2 * n;
+        chirp[2 * k] = table[2 * coeff];
+        chirp[2 * k + 1] = table[2 * coeff + 1];
+    }
+    const float xn2 = 1.0f / (float)n2;
+    padded[0] = chirp[0] * xn2;
+    padded[1] = chirp[1] * xn2;
+    for (U64 k = 1; k < n; ++k) {
+        const float re = chirp[2 * k] * xn2, im = chirp[2 * k + 1] * xn2;
+        padded[2 * k] = padded[2 * (n2 - k)] = re;
+        padded[2 * k + 1] = padded[2 * (n2 - k) + 1] = im;
+    }
+    JST_HIP_CHECK(hipMemcpy(bk.data(), chirp.data(), n * sizeof(float2), hipMemcpyHostToDevice),
+                  "hipMemcpy(bluestein chirp)");
+    JST_HIP_CHECK(hipMemcpy(akf.data(), padded.data(), n2 * sizeof(float2), hipMemcpyHostToDevice),
+                  "hipMemcpy(bluestein padded chirp)");
+    JST_CHECK(innerTransform(ptr<float2>(akf), n2, 1, true, nullptr));
+    JST_HIP_CHECK(hipStreamSynchronize(nullptr), "hipStreamSynchronize(bluestein setup)");
+    JST_HIP_CHECK(hipMemcpy(bkf.data(), akf.data(), (n2 / 2 + 1) * sizeof(float2),
+                            hipMemcpyDeviceToDevice),
+                  "hipMemcpy(bluestein kernel)");
     return Result::SUCCESS;
 }
 Result Fft::computeDeinitialize() {
     scratchA = Tensor();
     scratchB = Tensor();
+    scratchH = Tensor();
+    akf = Tensor();
+    bk = Tensor();
+    bkf = Tensor();
     return Result::SUCCESS;
+}
+Result Fft::innerTransform(float2* data, U64 length, U64 transforms, bool fwd, hipStream_t stream) {
+    FftLayout L;
+    std::memset(&L, 0, sizeof(L));
+    L.transforms = transforms;
+    L.outer_rank = 1;
+    L.outer_shape[0] = transforms;
+    L.in_outer_stride[0] = L.out_outer_stride[0] = (int64_t)length;
+    L.in_axis_stride = L.out_axis_stride = 1;
+    if (useGlobalPasses)
+        return hip_result(kernels::launch_fft_c2c_global(length, fwd, L, twiddles, data, data,
+                                                         ptr<float2>(scratchA), ptr<float2>(scratchB),
+                                                         ptr<float2>(scratchH), stream),
+                          "fft (global passes) kernel");
+    return hip_result(kernels::launch_fft_c2c(length, fwd, L, twiddles, data, data, stream),
+                      "fft kernel");
 }
 Result Fft::layout(FftLayout& L) const {
     std::memset(&L, 0, sizeof(L));
@@ -635,11 +696,29 @@ Result Fft::layout(FftLayout& L) const {
 Result Fft::computeSubmit(hipStream_t stream) {
     FftLayout L;
     JST_CHECK(layout(L));
+    if (bluesteinSize) {  // fftblue::fft (pocketfft.hh:2370-2399)
+        const U64 n = input.shape(resolvedAxis), n2 = bluesteinSize;
+        JST_CHECK(hip_result(kernels::launch_bluestein_pre(forward, L, ptr<float2>(akf),
+                                                           ptr<const float2>(input),
+                                                           ptr<const float2>(bk), n, n2, stream),
+                             "bluestein chirp kernel"));
+        JST_CHECK(innerTransform(ptr<float2>(akf), n2, L.transforms, true, stream));
+        JST_CHECK(hip_result(kernels::launch_bluestein_mul(forward, ptr<float2>(akf),
+                                                           ptr<const float2>(bkf), L.transforms,
+                                                           n2, stream),
+                             "bluestein convolution kernel"));
+        JST_CHECK(innerTransform(ptr<float2>(akf), n2, L.transforms, false, stream));
+        return hip_result(kernels::launch_bluestein_post(forward, L, ptr<float2>(output),
+                                                         ptr<const float2>(akf),
+                                                         ptr<const float2>(bk), n, n2, stream),
+                          "bluestein output kernel");
+    }
     if (useGlobalPasses)
         return hip_result(
             kernels::launch_fft_c2c_global(input.shape(resolvedAxis), forward, L, twiddles,
                                            ptr<const float2>(input), ptr<float2>(output),
-                                           ptr<float2>(scratchA), ptr<float2>(scratchB), stream),
+                                           ptr<float2>(scratchA), ptr<float2>(scratchB),
+                                           ptr<float2>(scratchH), stream),
             "fft (global passes) kernel");
     return hip_result(kernels::launch_fft_c2c(input.shape(resolvedAxis), forward, L, twiddles,
                                               ptr<const float2>(input), ptr<float2>(output), stream),

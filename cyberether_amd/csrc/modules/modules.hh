@@ -113,11 +113,17 @@ class Fft : public Module {
     Result computeDeinitialize() override;
     Result computeSubmit(hipStream_t stream) override;
     Result layout(dev::FftLayout& L) const;
-    Tensor input, output, scratchA, scratchB;
+    // one dense batch of `length`-point transforms, in place in `data` (the Bluestein inner FFTs)
+    Result innerTransform(float2* data, U64 length, U64 transforms, bool fwd, hipStream_t stream);
+    Tensor input, output, scratchA, scratchB, scratchH;
     bool useGlobalPasses = false;
     bool forward = true, complexOutput = false;
     Index resolvedAxis = 0;
     const float2* twiddles = nullptr;
+    // Bluestein plan (pocketfft fftblue, pocketfft.hh:2362-2432): chosen exactly when pocketfft_c
+    // would (kernels::fft_bluestein_size); bluesteinSize = n2, 0 otherwise.
+    U64 bluesteinSize = 0;
+    Tensor akf, bk, bkf;
 };
 
 // src/domains/dsp/amplitude/{module_impl.cc:8-60, module_impl_native_cpu.cc:73-99}

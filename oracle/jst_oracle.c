@@ -338,8 +338,8 @@ void jst_oracle_fft_twiddles(float* tw, uint64_t n) {
 }
 
 /* Factor list (pocketfft.hh:1476-1497): 8s, 4s, one 2 moved to the FRONT, then odd divisors in
- * increasing order.  Returns the count, or -1 when a factor other than 2,3,4,5,8 appears (those
- * lengths use pass7/pass11/passg or Bluestein in the reference and are not restated). */
+ * increasing order.  Returns the count (any prime may appear: 7 and 11 have dedicated passes,
+ * larger ones use passg).  Whether this plan or Bluestein is used: jst_oracle_fft_bluestein_size. */
 int jst_oracle_fft_factors(uint64_t n, uint32_t* fact) {
     int nf = 0;
     uint64_t len = n;
@@ -365,8 +365,6 @@ int jst_oracle_fft_factors(uint64_t n, uint32_t* fact) {
             len /= divisor;
         }
     if (len > 1) fact[nf++] = (uint32_t)len;
-    for (int i = 0; i < nf; ++i)
-        if (fact[i] != 2 && fact[i] != 3 && fact[i] != 4 && fact[i] != 5 && fact[i] != 8) return -1;
     return nf;
 }
 
@@ -587,65 +585,417 @@ static void pass5(uint64_t ido, uint64_t l1, const c32* cc, c32* ch, const c32* 
             }
         }
 }
+/* pass7 (pocketfft.hh:1047-1122).  Sums are left to right, exactly as the macros expand. */
+static void pass7(uint64_t ido, uint64_t l1, const c32* cc, c32* ch, const c32* wa, int fwd) {
+    const uint64_t ip = 7;
+    const float sg = fwd ? -1.0f : 1.0f;
+    const float tw1r = (float)0.6234898018587335305250048840042398L,
+                tw1i = sg * (float)0.7818314824680298087084445266740578L,
+                tw2r = (float)-0.2225209339563144042889025644967948L,
+                tw2i = sg * (float)0.9749279121818236070181316829939312L,
+                tw3r = (float)-0.9009688679024191262361023195074451L,
+                tw3i = sg * (float)0.433883739117558120475768332848359L;
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 0; i < ido; ++i) {
+            const c32 t1 = CC(i, 0, k);
+            const c32 t2 = cadd(CC(i, 1, k), CC(i, 6, k)), t7 = csub(CC(i, 1, k), CC(i, 6, k));
+            const c32 t3 = cadd(CC(i, 2, k), CC(i, 5, k)), t6 = csub(CC(i, 2, k), CC(i, 5, k));
+            const c32 t4 = cadd(CC(i, 3, k), CC(i, 4, k)), t5 = csub(CC(i, 3, k), CC(i, 4, k));
+            c32 o0 = {t1.r + t2.r + t3.r + t4.r, t1.i + t2.i + t3.i + t4.i};
+            CH(i, k, 0) = o0;
+#define JST_STEP7(u1, u2, x1, x2, x3, y1, y2, y3)                                            \
+    {                                                                                        \
+        c32 ca, cb;                                                                          \
+        ca.r = t1.r + x1 * t2.r + x2 * t3.r + x3 * t4.r;                                     \
+        ca.i = t1.i + x1 * t2.i + x2 * t3.i + x3 * t4.i;                                     \
+        cb.i = y1 * t7.r y2 * t6.r y3 * t5.r;                                                \
+        cb.r = -(y1 * t7.i y2 * t6.i y3 * t5.i);                                             \
+        if (i == 0) {                                                                        \
+            CH(0, k, u1) = cadd(ca, cb);                                                     \
+            CH(0, k, u2) = csub(ca, cb);                                                     \
+        } else {                                                                             \
+            CH(i, k, u1) = special_mul(cadd(ca, cb), WA(u1 - 1, i), fwd);                    \
+            CH(i, k, u2) = special_mul(csub(ca, cb), WA(u2 - 1, i), fwd);                    \
+        }                                                                                    \
+    }
+            JST_STEP7(1, 6, tw1r, tw2r, tw3r, +tw1i, +tw2i, +tw3i)
+            JST_STEP7(2, 5, tw2r, tw3r, tw1r, +tw2i, -tw3i, -tw1i)
+            JST_STEP7(3, 4, tw3r, tw1r, tw2r, +tw3i, -tw1i, +tw2i)
+#undef JST_STEP7
+        }
+}
+
+/* pass11 (pocketfft.hh:1226-1312). */
+static void pass11(uint64_t ido, uint64_t l1, const c32* cc, c32* ch, const c32* wa, int fwd) {
+    const uint64_t ip = 11;
+    const float sg = fwd ? -1.0f : 1.0f;
+    const float tw1r = (float)0.8412535328311811688618116489193677L,
+                tw1i = sg * (float)0.5406408174555975821076359543186917L,
+                tw2r = (float)0.4154150130018864255292741492296232L,
+                tw2i = sg * (float)0.9096319953545183714117153830790285L,
+                tw3r = (float)-0.1423148382732851404437926686163697L,
+                tw3i = sg * (float)0.9898214418809327323760920377767188L,
+                tw4r = (float)-0.6548607339452850640569250724662936L,
+                tw4i = sg * (float)0.7557495743542582837740358439723444L,
+                tw5r = (float)-0.9594929736144973898903680570663277L,
+                tw5i = sg * (float)0.2817325568414296977114179153466169L;
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 0; i < ido; ++i) {
+            const c32 t1 = CC(i, 0, k);
+            const c32 t2 = cadd(CC(i, 1, k), CC(i, 10, k)), t11 = csub(CC(i, 1, k), CC(i, 10, k));
+            const c32 t3 = cadd(CC(i, 2, k), CC(i, 9, k)), t10 = csub(CC(i, 2, k), CC(i, 9, k));
+            const c32 t4 = cadd(CC(i, 3, k), CC(i, 8, k)), t9 = csub(CC(i, 3, k), CC(i, 8, k));
+            const c32 t5 = cadd(CC(i, 4, k), CC(i, 7, k)), t8 = csub(CC(i, 4, k), CC(i, 7, k));
+            const c32 t6 = cadd(CC(i, 5, k), CC(i, 6, k)), t7 = csub(CC(i, 5, k), CC(i, 6, k));
+            c32 o0 = {t1.r + t2.r + t3.r + t4.r + t5.r + t6.r, t1.i + t2.i + t3.i + t4.i + t5.i + t6.i};
+            CH(i, k, 0) = o0;
+#define JST_STEP11(u1, u2, x1, x2, x3, x4, x5, y1, y2, y3, y4, y5)                            \
+    {                                                                                        \
+        c32 ca, cb;                                                                          \
+        ca.r = t1.r + t2.r * x1 + t3.r * x2 + t4.r * x3 + t5.r * x4 + t6.r * x5;             \
+        ca.i = t1.i + t2.i * x1 + t3.i * x2 + t4.i * x3 + t5.i * x4 + t6.i * x5;             \
+        cb.i = y1 * t11.r y2 * t10.r y3 * t9.r y4 * t8.r y5 * t7.r;                          \
+        cb.r = -(y1 * t11.i y2 * t10.i y3 * t9.i y4 * t8.i y5 * t7.i);                       \
+        if (i == 0) {                                                                        \
+            CH(0, k, u1) = cadd(ca, cb);                                                     \
+            CH(0, k, u2) = csub(ca, cb);                                                     \
+        } else {                                                                             \
+            CH(i, k, u1) = special_mul(cadd(ca, cb), WA(u1 - 1, i), fwd);                    \
+            CH(i, k, u2) = special_mul(csub(ca, cb), WA(u2 - 1, i), fwd);                    \
+        }                                                                                    \
+    }
+            JST_STEP11(1, 10, tw1r, tw2r, tw3r, tw4r, tw5r, +tw1i, +tw2i, +tw3i, +tw4i, +tw5i)
+            JST_STEP11(2, 9, tw2r, tw4r, tw5r, tw3r, tw1r, +tw2i, +tw4i, -tw5i, -tw3i, -tw1i)
+            JST_STEP11(3, 8, tw3r, tw5r, tw2r, tw1r, tw4r, +tw3i, -tw5i, -tw2i, +tw1i, +tw4i)
+            JST_STEP11(4, 7, tw4r, tw3r, tw1r, tw5r, tw2r, +tw4i, -tw3i, +tw1i, +tw5i, -tw2i)
+            JST_STEP11(5, 6, tw5r, tw1r, tw4r, tw2r, tw3r, +tw5i, -tw1i, +tw4i, -tw2i, +tw3i)
+#undef JST_STEP11
+        }
+}
 #undef CC
 #undef CH
 #undef WA
 
-/* in/out: interleaved CF32, 'batch' contiguous rows of n.  Returns 0, or -1 if n is not 2^m. */
-int jst_oracle_fft_c2c(const float* in, float* out, uint64_t n, uint64_t batch, int forward) {
+/* passg (pocketfft.hh:1314-1421): generic odd radix.  Per (i,k) the computation only touches
+ * CC(i,*,k), so it is restated butterfly by butterfly with the same expression grouping; the
+ * result is what the reference leaves in `cc` (it swaps once more afterwards), written here to
+ * `ch` in CH(i,k,j) order.  csarr[j] = twiddle[j*l1*ido] (comp_twiddle, :1526-1531). */
+static void passg(uint64_t ido, uint64_t ip, uint64_t l1, const c32* cc, c32* ch, const c32* wa,
+                  const c32* csarr, int fwd) {
+    const uint64_t ipph = (ip + 1) / 2;
+    c32* wal = (c32*)malloc(ip * sizeof(c32));
+    c32* h = (c32*)malloc(ip * sizeof(c32));
+    c32* x = (c32*)malloc(ip * sizeof(c32));
+    wal[0].r = 1.0f;
+    wal[0].i = 0.0f;
+    for (uint64_t i = 1; i < ip; ++i) {
+        wal[i].r = csarr[i].r;
+        wal[i].i = fwd ? -csarr[i].i : csarr[i].i;
+    }
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 0; i < ido; ++i) {
+            h[0] = cc[i + ido * (0 + ip * k)];
+            for (uint64_t j = 1, jc = ip - 1; j < ipph; ++j, --jc) {
+                const c32 a = cc[i + ido * (j + ip * k)], b = cc[i + ido * (jc + ip * k)];
+                h[j] = cadd(a, b);
+                h[jc] = csub(a, b);
+            }
+            c32 tmp = h[0];
+            for (uint64_t j = 1; j < ipph; ++j) {
+                tmp.r += h[j].r;
+                tmp.i += h[j].i;
+            }
+            x[0] = tmp;
+            for (uint64_t l = 1, lc = ip - 1; l < ipph; ++l, --lc) {
+                c32 xl, xlc;
+                xl.r = h[0].r + wal[l].r * h[1].r + wal[2 * l].r * h[2].r;
+                xl.i = h[0].i + wal[l].r * h[1].i + wal[2 * l].r * h[2].i;
+                xlc.r = -wal[l].i * h[ip - 1].i - wal[2 * l].i * h[ip - 2].i;
+                xlc.i = wal[l].i * h[ip - 1].r + wal[2 * l].i * h[ip - 2].r;
+                uint64_t iwal = 2 * l;
+                uint64_t j = 3, jc = ip - 3;
+                for (; j < ipph - 1; j += 2, jc -= 2) {
+                    iwal += l;
+                    if (iwal > ip) iwal -= ip;
+                    const c32 xwal = wal[iwal];
+                    iwal += l;
+                    if (iwal > ip) iwal -= ip;
+                    const c32 xwal2 = wal[iwal];
+                    xl.r += h[j].r * xwal.r + h[j + 1].r * xwal2.r;
+                    xl.i += h[j].i * xwal.r + h[j + 1].i * xwal2.r;
+                    xlc.r -= h[jc].i * xwal.i + h[jc - 1].i * xwal2.i;
+                    xlc.i += h[jc].r * xwal.i + h[jc - 1].r * xwal2.i;
+                }
+                for (; j < ipph; ++j, --jc) {
+                    iwal += l;
+                    if (iwal > ip) iwal -= ip;
+                    const c32 xwal = wal[iwal];
+                    xl.r += h[j].r * xwal.r;
+                    xl.i += h[j].i * xwal.r;
+                    xlc.r -= h[jc].i * xwal.i;
+                    xlc.i += h[jc].r * xwal.i;
+                }
+                x[l] = xl;
+                x[lc] = xlc;
+            }
+            ch[i + ido * (k + l1 * 0)] = x[0];
+            for (uint64_t j = 1, jc = ip - 1; j < ipph; ++j, --jc) {
+                const c32 s1 = cadd(x[j], x[jc]), s2 = csub(x[j], x[jc]);
+                if (i == 0) {
+                    ch[i + ido * (k + l1 * j)] = s1;
+                    ch[i + ido * (k + l1 * jc)] = s2;
+                } else {
+                    ch[i + ido * (k + l1 * j)] = special_mul(s1, wa[(j - 1) * (ido - 1) + i - 1], fwd);
+                    ch[i + ido * (k + l1 * jc)] = special_mul(s2, wa[(jc - 1) * (ido - 1) + i - 1], fwd);
+                }
+            }
+        }
+    free(wal);
+    free(h);
+    free(x);
+}
+
+/* cfftp plan (pocketfft.hh:1476-1547): factors + per-pass twiddles (+ csarr for ip > 11). */
+typedef struct {
+    uint64_t n;
+    int nf;
     uint32_t fact[64];
-    const int nf = jst_oracle_fft_factors(n, fact);
-    if (n == 0 || nf < 0) return -1;
+    c32* mem;
+    const c32* tw[64];
+    const c32* tws[64];
+} cfftp_t;
+
+static int cfftp_init(cfftp_t* p, uint64_t n) {
+    memset(p, 0, sizeof(*p));
+    p->n = n;
+    if (n == 0) return -1;
+    if (n == 1) return 0;
+    p->nf = jst_oracle_fft_factors(n, p->fact);
+    if (p->nf < 0) return -1;
+    uint64_t twsize = 0, l1 = 1;
+    for (int k = 0; k < p->nf; ++k) {
+        const uint64_t ip = p->fact[k], ido = n / (l1 * ip);
+        twsize += (ip - 1) * (ido - 1);
+        if (ip > 11) twsize += ip;
+        l1 *= ip;
+    }
+    sincos_t s;
+    sincos_init(&s, n);
+    p->mem = (c32*)malloc((twsize + 1) * sizeof(c32));
+    uint64_t memofs = 0;
+    l1 = 1;
+    for (int k = 0; k < p->nf; ++k) {
+        const uint64_t ip = p->fact[k], ido = n / (l1 * ip);
+        p->tw[k] = p->mem + memofs;
+        for (uint64_t j = 1; j < ip; ++j)
+            for (uint64_t i = 1; i < ido; ++i)
+                p->mem[memofs + (j - 1) * (ido - 1) + i - 1] = sincos_get(&s, j * l1 * i);
+        memofs += (ip - 1) * (ido - 1);
+        if (ip > 11) {
+            p->tws[k] = p->mem + memofs;
+            for (uint64_t j = 0; j < ip; ++j) p->mem[memofs + j] = sincos_get(&s, j * l1 * ido);
+            memofs += ip;
+        }
+        l1 *= ip;
+    }
+    sincos_free(&s);
+    return 0;
+}
+static void cfftp_free(cfftp_t* p) { free(p->mem); }
+
+/* pass_all with fct == 1 (pocketfft.hh:1423-1471): c is transformed in place, ch is scratch. */
+static void cfftp_exec(const cfftp_t* p, c32* c, c32* ch, int forward) {
+    const uint64_t n = p->n;
+    if (n == 1) return;
+    c32 *p1 = c, *p2 = ch;
+    uint64_t l1 = 1;
+    for (int k = 0; k < p->nf; ++k) {
+        const uint64_t ip = p->fact[k], l2 = ip * l1, ido = n / l2;
+        if (ip == 8) pass8(ido, l1, p1, p2, p->tw[k], forward);
+        else if (ip == 4) pass4(ido, l1, p1, p2, p->tw[k], forward);
+        else if (ip == 2) pass2(ido, l1, p1, p2, p->tw[k], forward);
+        else if (ip == 3) pass3(ido, l1, p1, p2, p->tw[k], forward);
+        else if (ip == 5) pass5(ido, l1, p1, p2, p->tw[k], forward);
+        else if (ip == 7) pass7(ido, l1, p1, p2, p->tw[k], forward);
+        else if (ip == 11) pass11(ido, l1, p1, p2, p->tw[k], forward);
+        else passg(ido, ip, l1, p1, p2, p->tw[k], p->tws[k], forward);
+        c32* t = p1;
+        p1 = p2;
+        p2 = t;
+        l1 = l2;
+    }
+    if (p1 != c) memcpy(c, p1, n * sizeof(c32));
+}
+
+/* util::largest_prime_factor / cost_guess / good_size_cmplx (pocketfft.hh:372-428). */
+static uint64_t largest_prime_factor(uint64_t n) {
+    uint64_t res = 1;
+    while ((n & 1) == 0) {
+        res = 2;
+        n >>= 1;
+    }
+    for (uint64_t x = 3; x * x <= n; x += 2)
+        while ((n % x) == 0) {
+            res = x;
+            n /= x;
+        }
+    if (n > 1) res = n;
+    return res;
+}
+static double cost_guess(uint64_t n) {
+    const double lfp = 1.1;
+    const uint64_t ni = n;
+    double result = 0.;
+    while ((n & 1) == 0) {
+        result += 2;
+        n >>= 1;
+    }
+    for (uint64_t x = 3; x * x <= n; x += 2)
+        while ((n % x) == 0) {
+            result += (x <= 5) ? (double)x : lfp * (double)x;
+            n /= x;
+        }
+    if (n > 1) result += (n <= 5) ? (double)n : lfp * (double)n;
+    return result * (double)ni;
+}
+static uint64_t good_size_cmplx(uint64_t n) {
+    if (n <= 12) return n;
+    uint64_t bestfac = 2 * n;
+    for (uint64_t f11 = 1; f11 < bestfac; f11 *= 11)
+        for (uint64_t f117 = f11; f117 < bestfac; f117 *= 7)
+            for (uint64_t f1175 = f117; f1175 < bestfac; f1175 *= 5) {
+                uint64_t x = f1175;
+                while (x < n) x *= 2;
+                for (;;) {
+                    if (x < n)
+                        x *= 3;
+                    else if (x > n) {
+                        if (x < bestfac) bestfac = x;
+                        if (x & 1) break;
+                        x >>= 1;
+                    } else
+                        return n;
+                }
+            }
+    return bestfac;
+}
+/* pocketfft_c's plan choice (pocketfft.hh:2472-2489): 0 = cfftp of n; otherwise the Bluestein
+ * convolution length n2. */
+uint64_t jst_oracle_fft_bluestein_size(uint64_t n) {
+    if (n == 0) return 0;
+    const uint64_t lpf = (n < 50) ? 0 : largest_prime_factor(n);
+    if (lpf * lpf <= n) return 0;
+    const double comp1 = cost_guess(n);
+    double comp2 = 2 * cost_guess(good_size_cmplx(2 * n - 1));
+    comp2 *= 1.5;
+    return (comp2 < comp1) ? good_size_cmplx(2 * n - 1) : 0;
+}
+
+/* fftblue (pocketfft.hh:2362-2432). */
+typedef struct {
+    uint64_t n, n2;
+    cfftp_t plan;
+    c32 *bk, *bkf;
+} fftblue_t;
+static int fftblue_init(fftblue_t* b, uint64_t n, uint64_t n2) {
+    b->n = n;
+    b->n2 = n2;
+    if (cfftp_init(&b->plan, n2) != 0) return -1;
+    b->bk = (c32*)malloc(n * sizeof(c32));
+    b->bkf = (c32*)malloc((n2 / 2 + 1) * sizeof(c32));
+    sincos_t tmp;
+    sincos_init(&tmp, 2 * n);
+    b->bk[0].r = 1.0f;
+    b->bk[0].i = 0.0f;
+    uint64_t coeff = 0;
+    for (uint64_t m = 1; m < n; ++m) {
+        coeff += 2 * m - 1;
+        if (coeff >= 2 * n) coeff -= 2 * n;
+        b->bk[m] = sincos_get(&tmp, coeff);
+    }
+    sincos_free(&tmp);
+    c32* tbkf = (c32*)malloc(n2 * sizeof(c32));
+    c32* scratch = (c32*)malloc(n2 * sizeof(c32));
+    const float xn2 = 1.0f / (float)n2;
+    tbkf[0].r = b->bk[0].r * xn2;
+    tbkf[0].i = b->bk[0].i * xn2;
+    for (uint64_t m = 1; m < n; ++m) {
+        c32 v = {b->bk[m].r * xn2, b->bk[m].i * xn2};
+        tbkf[m] = tbkf[n2 - m] = v;
+    }
+    for (uint64_t m = n; m <= (n2 - n); ++m) {
+        tbkf[m].r = 0.0f;
+        tbkf[m].i = 0.0f;
+    }
+    cfftp_exec(&b->plan, tbkf, scratch, 1);
+    for (uint64_t i = 0; i < n2 / 2 + 1; ++i) b->bkf[i] = tbkf[i];
+    free(tbkf);
+    free(scratch);
+    return 0;
+}
+static void fftblue_free(fftblue_t* b) {
+    cfftp_free(&b->plan);
+    free(b->bk);
+    free(b->bkf);
+}
+static void fftblue_exec(const fftblue_t* b, c32* c, c32* akf, c32* scratch, int fwd) {
+    const uint64_t n = b->n, n2 = b->n2;
+    for (uint64_t m = 0; m < n; ++m) akf[m] = special_mul(c[m], b->bk[m], fwd);
+    const c32 zero = {akf[0].r * 0.0f, akf[0].i * 0.0f}; /* akf[0]*T0(0): NaN/-0 propagate */
+    for (uint64_t m = n; m < n2; ++m) akf[m] = zero;
+    cfftp_exec(&b->plan, akf, scratch, 1);
+    akf[0] = special_mul(akf[0], b->bkf[0], !fwd);
+    for (uint64_t m = 1; m < (n2 + 1) / 2; ++m) {
+        akf[m] = special_mul(akf[m], b->bkf[m], !fwd);
+        akf[n2 - m] = special_mul(akf[n2 - m], b->bkf[m], !fwd);
+    }
+    if ((n2 & 1) == 0) akf[n2 / 2] = special_mul(akf[n2 / 2], b->bkf[n2 / 2], !fwd);
+    cfftp_exec(&b->plan, akf, scratch, 0);
+    for (uint64_t m = 0; m < n; ++m) {
+        const c32 v = special_mul(akf[m], b->bk[m], fwd);
+        c[m].r = v.r * 1.0f; /* *fct with fct == 1 */
+        c[m].i = v.i * 1.0f;
+    }
+}
+
+/* in/out: interleaved CF32, 'batch' contiguous rows of n; any n >= 1 (plan chosen like
+ * pocketfft_c).  Returns 0, or -1 for n == 0. */
+int jst_oracle_fft_c2c(const float* in, float* out, uint64_t n, uint64_t batch, int forward) {
+    if (n == 0) return -1;
     if (n == 1) {
         memcpy(out, in, batch * 2 * sizeof(float));
         return 0;
     }
-    /* twiddles, laid out per pass exactly like cfftp::mem (pocketfft.hh:1513-1535) */
-    sincos_t s;
-    sincos_init(&s, n);
-    c32* mem = (c32*)malloc((n + 64) * sizeof(c32));
-    const c32* tw[64];
-    {
-        uint64_t l1 = 1, memofs = 0;
-        for (int k = 0; k < nf; ++k) {
-            const uint64_t ip = fact[k], ido = n / (l1 * ip);
-            tw[k] = mem + memofs;
-            for (uint64_t j = 1; j < ip; ++j)
-                for (uint64_t i = 1; i < ido; ++i)
-                    mem[memofs + (j - 1) * (ido - 1) + i - 1] = sincos_get(&s, j * l1 * i);
-            memofs += (ip - 1) * (ido - 1);
-            l1 *= ip;
+    const uint64_t n2 = jst_oracle_fft_bluestein_size(n);
+    if (n2 != 0) {
+        fftblue_t b;
+        if (fftblue_init(&b, n, n2) != 0) return -1;
+        c32* c = (c32*)malloc(n * sizeof(c32));
+        c32* akf = (c32*)malloc(n2 * sizeof(c32));
+        c32* scratch = (c32*)malloc(n2 * sizeof(c32));
+        for (uint64_t r = 0; r < batch; ++r) {
+            memcpy(c, in + 2 * r * n, n * sizeof(c32));
+            fftblue_exec(&b, c, akf, scratch, forward);
+            memcpy(out + 2 * r * n, c, n * sizeof(c32));
         }
+        free(c);
+        free(akf);
+        free(scratch);
+        fftblue_free(&b);
+        return 0;
     }
+    cfftp_t p;
+    if (cfftp_init(&p, n) != 0) return -1;
     c32* c = (c32*)malloc(n * sizeof(c32));
     c32* ch = (c32*)malloc(n * sizeof(c32));
-    for (uint64_t b = 0; b < batch; ++b) {
-        memcpy(c, in + 2 * b * n, n * sizeof(c32));
-        c32 *p1 = c, *p2 = ch;
-        uint64_t l1 = 1;
-        for (int k = 0; k < nf; ++k) { /* pass_all, pocketfft.hh:1420-1468 */
-            const uint64_t ip = fact[k], l2 = ip * l1, ido = n / l2;
-            if (ip == 8)
-                pass8(ido, l1, p1, p2, tw[k], forward);
-            else if (ip == 4)
-                pass4(ido, l1, p1, p2, tw[k], forward);
-            else if (ip == 5)
-                pass5(ido, l1, p1, p2, tw[k], forward);
-            else if (ip == 3)
-                pass3(ido, l1, p1, p2, tw[k], forward);
-            else
-                pass2(ido, l1, p1, p2, tw[k], forward);
-            c32* t = p1;
-            p1 = p2;
-            p2 = t;
-            l1 = l2;
-        }
-        memcpy(out + 2 * b * n, p1, n * sizeof(c32)); /* fct == 1: plain copy */
+    for (uint64_t r = 0; r < batch; ++r) {
+        memcpy(c, in + 2 * r * n, n * sizeof(c32));
+        cfftp_exec(&p, c, ch, forward);
+        memcpy(out + 2 * r * n, c, n * sizeof(c32));
     }
     free(c);
     free(ch);
-    free(mem);
-    sincos_free(&s);
+    cfftp_free(&p);
     return 0;
 }
 

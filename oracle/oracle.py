@@ -138,7 +138,8 @@ def fft_twiddles(n: int) -> np.ndarray:
 
 
 def fft_c2c(x: np.ndarray, forward: bool = True) -> np.ndarray:
-    """Restated pocketfft c2c over the LAST axis (lengths with prime factors 2, 3, 5)."""
+    """Restated pocketfft c2c over the LAST axis: any length (radix 2/3/4/5/7/8/11 passes, the
+    generic odd-radix pass, and Bluestein when pocketfft_c would pick it)."""
     x = np.ascontiguousarray(x, dtype=np.complex64)
     n = x.shape[-1]
     batch = x.size // n if n else 0
@@ -146,8 +147,14 @@ def fft_c2c(x: np.ndarray, forward: bool = True) -> np.ndarray:
     rc = lib().jst_oracle_fft_c2c(_p(x), _p(out), C.c_uint64(n), C.c_uint64(batch),
                                   C.c_int(1 if forward else 0))
     if rc != 0:
-        raise ValueError(f"oracle restatement covers lengths with factors 2, 3, 5 only (n={n})")
+        raise ValueError(f"zero-length FFT requested (n={n})")
     return out
+
+
+def fft_bluestein_size(n: int) -> int:
+    """0 when pocketfft_c plans a cfftp of n, else the Bluestein convolution length n2."""
+    lib().jst_oracle_fft_bluestein_size.restype = C.c_uint64
+    return int(lib().jst_oracle_fft_bluestein_size(C.c_uint64(n)))
 
 
 def _ref_call(fn, x: np.ndarray, out: np.ndarray, axis: int, forward: bool) -> np.ndarray:

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/pocketfft_ref_vectors.npz from the REFERENCE's own pocketfft
+(oracle/_ref/libref_pocketfft.so, compiled in place from /root/reference): forward and backward
+c2c outputs for seeded inputs at lengths that exercise every plan kind of pocketfft_c (radix
+2/3/4/5/7/8/11 passes, the generic odd radix, Bluestein).  Inputs are regenerated from the seed by
+the tests, so only outputs are stored.  Run in the build container (needs /root/reference)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle  # noqa: E402
+
+LENGTHS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 21, 22, 23, 25, 26, 27, 29, 31, 32,
+           33, 35, 37, 39, 44, 46, 47, 49, 50, 51, 53, 55, 58, 59, 62, 64, 65, 74, 77, 82, 91, 94, 97, 98, 100,
+           89, 101, 106, 107, 118, 121, 122, 127, 128, 131, 143, 154, 169, 187, 202, 211, 212, 214, 221, 243, 254, 256, 257, 289, 299,
+           321, 323,
+           343, 360, 422, 512, 529, 539, 625, 810, 847, 1000, 1001, 1024, 1147, 2048, 2209, 2401]
+
+
+def signal(n: int) -> np.ndarray:
+    rng = np.random.default_rng(20260924 + n)
+    return (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(np.complex64)
+
+
+def main():
+    assert oracle.have_ref(), "oracle/_ref not built"
+    out = {"lengths": np.array(LENGTHS, np.int64)}
+    for n in LENGTHS:
+        x = signal(n)
+        out[f"fwd_{n}"] = oracle.ref_fft_c2c(x, 1, True)
+        out[f"bwd_{n}"] = oracle.ref_fft_c2c(x, 1, False)
+        out[f"blue_{n}"] = np.array(oracle.fft_bluestein_size(n), np.int64)
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pocketfft_ref_vectors.npz"), **out)
+    kinds = sum(1 for n in LENGTHS if oracle.fft_bluestein_size(n))
+    print(f"{len(LENGTHS)} lengths, {kinds} of them Bluestein")
+
+
+if __name__ == "__main__":
+    main()

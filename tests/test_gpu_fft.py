@@ -128,10 +128,38 @@ def test_general_length_strided(js, oracle):
     assert_bit_equal(out["signal"], np.ascontiguousarray(oracle.fft_c2c(np.ascontiguousarray(lead.T)).T))
 
 
+@pytest.mark.parametrize("n", [7, 11, 14, 49, 77, 121, 154, 1001, 2401, 8050,      # pass7 / pass11
+                               13, 17, 23, 26, 46, 97, 169, 299, 1147, 2209, 8170,  # generic radix (passg)
+                               53 * 4, 211 * 2, 4099, 8191, 8292, 10007])           # Bluestein
+def test_every_pocketfft_plan_bit_exact(js, oracle, n):
+    """Radix 7 / 11, the generic odd radix and Bluestein: whatever plan pocketfft_c picks for the
+    length (pocketfft.hh:2472-2489) is the plan the device runs, bit for bit."""
+    rng = np.random.default_rng(n)
+    x = csignal(rng, (3, n))
+    for forward in (True, False):
+        _, out = run_module(js, "fft", {"forward": forward},
+                            {"signal": js.Tensor.from_numpy(x, sample=1, batch=0)})
+        assert_bit_equal(out["signal"], oracle.fft_c2c(x, forward), f"n={n} fwd={forward}")
+
+
+def test_bluestein_strided_and_special_values(js, oracle):
+    rng = np.random.default_rng(5)
+    n = 422                                                # 2 * 211 -> Bluestein, n2 = 847 = 7*11*11 (odd)
+    assert oracle.fft_bluestein_size(n) == 847
+    lead = csignal(rng, (n, 5))                            # transform along axis 0 (strided both ways)
+    _, out = run_module(js, "fft", {}, {"signal": js.Tensor.from_numpy(lead, sample=0, batch=1)})
+    assert_bit_equal(out["signal"], np.ascontiguousarray(oracle.fft_c2c(np.ascontiguousarray(lead.T)).T))
+    x = csignal(rng, (2, n))
+    x[0, 0] = complex(np.inf, 0.0)                         # akf[0]*0 pads with NaN like the CPU path
+    _, out = run_module(js, "fft", {}, {"signal": js.Tensor.from_numpy(x, sample=1, batch=0)})
+    ref = oracle.fft_c2c(x)
+    got = out["signal"]
+    assert np.array_equal(np.isnan(got.view(np.float32)), np.isnan(ref.view(np.float32)))
+    fin = ~np.isnan(ref.view(np.float32))
+    assert np.array_equal(got.view(np.uint32)[fin], ref.view(np.uint32)[fin])
+
+
 def test_unsupported_cases_fail_loudly(js):
-    x = np.zeros((2, 14), np.complex64)   # prime factor 7: pass7 is not implemented
-    with pytest.raises(js.JetstreamError, match="not implemented"):
-        js.Module("fft", {}, {"signal": js.Tensor.from_numpy(x, sample=1, batch=0)})
     r = np.zeros((2, 16), np.float32)
     with pytest.raises(js.JetstreamError, match="not implemented"):
         js.Module("fft", {}, {"signal": js.Tensor.from_numpy(r, sample=1, batch=0)})

@@ -53,4 +53,51 @@ def test_factor_order(oracle):
     assert oracle.fft_factors(12) == [4, 3]
     assert oracle.fft_factors(160000) == [8, 8, 4, 5, 5, 5, 5]
     assert oracle.fft_factors(10) == [2, 5]
-    assert oracle.fft_factors(14) is None  # pass7 is not restated
+    assert oracle.fft_factors(14) == [2, 7]
+    assert oracle.fft_factors(8050) == [2, 5, 5, 7, 23]
+    assert oracle.fft_bluestein_size(8050) == 0 and oracle.fft_bluestein_size(8292) == 16632
+    assert oracle.fft_bluestein_size(97) == 0 and oracle.fft_bluestein_size(101) == 210
+
+
+@pytest.mark.parametrize("lo", [1, 100, 200, 300, 400])
+def test_every_length_bit_exact_vs_reference_pocketfft(oracle, lo):
+    """All lengths 1..499 -- radix 7 / 11 passes, the generic odd radix and Bluestein included."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    rng = np.random.default_rng(lo)
+    for n in range(lo, lo + 100):
+        x = _signal(rng, (2, n))
+        for forward in (True, False):
+            mine = oracle.fft_c2c(x, forward)
+            ref = oracle.ref_fft_c2c(x, axis=1, forward=forward)
+            assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32)), (n, forward)
+
+
+@pytest.mark.parametrize("n", [4099, 8050, 8191, 8292, 10007, 12345, 30030, 65521])
+def test_large_odd_plans_bit_exact_vs_reference_pocketfft(oracle, n):
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    x = _signal(np.random.default_rng(n), (1, n))
+    for forward in (True, False):
+        assert np.array_equal(oracle.fft_c2c(x, forward).view(np.uint32),
+                              oracle.ref_fft_c2c(x, axis=1, forward=forward).view(np.uint32)), (n, forward)
+
+
+def test_restatement_matches_committed_reference_vectors(oracle):
+    """Travels to the GPU box: outputs of the reference's own pocketfft, generated here by
+    tests/golden/make_pocketfft_golden.py, for every plan kind."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from make_pocketfft_golden import signal
+    gold = np.load(os.path.join(here, "golden", "pocketfft_ref_vectors.npz"))
+    blue = 0
+    for n in gold["lengths"]:
+        n = int(n)
+        x = signal(n)
+        assert oracle.fft_bluestein_size(n) == int(gold[f"blue_{n}"]), n
+        blue += int(gold[f"blue_{n}"]) != 0
+        for key, fwd in (("fwd", True), ("bwd", False)):
+            assert np.array_equal(oracle.fft_c2c(x, fwd).view(np.uint32), gold[f"{key}_{n}"].view(np.uint32)), (n, key)
+    assert blue >= 8
