@@ -79,6 +79,18 @@ bool fft_plan_has_generic_radix(uint64_t n);
 hipError_t launch_fft_c2c_global(uint64_t n, bool forward, const FftLayout& L, const float2* W,
                                  const float2* in, float2* out, float2* scratch_a,
                                  float2* scratch_b, float2* scratch_h, hipStream_t stream);
+// LDS-tiled mixed-radix path (fft_tiled.hip): plans with radices <= 11; one kernel when a
+// transform fits an LDS tile (n <= 8192), two kernels (columns, then blocks) up to 2^26 points.
+// scratch: dense CF32[transforms * n], needed when fft_tiled_needs_scratch(n).
+bool fft_tiled_supported(uint64_t n);
+bool fft_tiled_needs_scratch(uint64_t n);
+hipError_t launch_fft_c2c_tiled(uint64_t n, bool forward, const FftLayout& L, const float2* W,
+                                const float2* in, float2* out, float2* scratch, hipStream_t stream);
+hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const float2* W,
+                                       const float2* in, const float2* window,
+                                       int64_t window_stride, float* out, float amp_coeff,
+                                       bool with_range, float range_scale, float range_offset,
+                                       bool fast, float2* scratch, hipStream_t stream);
 // pocketfft_c's plan choice (pocketfft.hh:2472-2489): 0 = cfftp of n, else the Bluestein
 // convolution length n2 = good_size_cmplx(2n-1).  The three elementwise steps of fftblue::fft
 // (:2370-2399) around the two n2-point transforms; akf: dense CF32[transforms * n2].

@@ -602,7 +602,10 @@ Result Fft::computeInitialize() {
     // the length the pass kernels actually run at: n, or the Bluestein convolution length
     const U64 m = bluesteinSize ? bluesteinSize : n;
     JST_CHECK(GetTwiddles(m, &twiddles));
-    useGlobalPasses = !kernels::fft_lds_supported(m);
+    useTiled = !kernels::fft_lds_supported(m) && kernels::fft_tiled_supported(m);
+    useGlobalPasses = !kernels::fft_lds_supported(m) && !useTiled;
+    if (useTiled && kernels::fft_tiled_needs_scratch(m))
+        JST_CHECK(scratchA.create(device(), DataType::CF32, {transforms * m}));
     if (useGlobalPasses) {  // ping-pong scratch for the pass-per-launch path
         uint32_t fact[64];
         const int nf = kernels::fft_plan_factors(m, fact);
@@ -666,6 +669,10 @@ Result Fft::innerTransform(float2* data, U64 length, U64 transforms, bool fwd, h
     L.outer_shape[0] = transforms;
     L.in_outer_stride[0] = L.out_outer_stride[0] = (int64_t)length;
     L.in_axis_stride = L.out_axis_stride = 1;
+    if (useTiled)
+        return hip_result(kernels::launch_fft_c2c_tiled(length, fwd, L, twiddles, data, data,
+                                                        ptr<float2>(scratchA), stream),
+                          "fft (tiled) kernel");
     if (useGlobalPasses)
         return hip_result(kernels::launch_fft_c2c_global(length, fwd, L, twiddles, data, data,
                                                          ptr<float2>(scratchA), ptr<float2>(scratchB),
@@ -713,6 +720,12 @@ Result Fft::computeSubmit(hipStream_t stream) {
                                                          ptr<const float2>(bk), n, n2, stream),
                           "bluestein output kernel");
     }
+    if (useTiled)
+        return hip_result(
+            kernels::launch_fft_c2c_tiled(input.shape(resolvedAxis), forward, L, twiddles,
+                                          ptr<const float2>(input), ptr<float2>(output),
+                                          ptr<float2>(scratchA), stream),
+            "fft (tiled) kernel");
     if (useGlobalPasses)
         return hip_result(
             kernels::launch_fft_c2c_global(input.shape(resolvedAxis), forward, L, twiddles,
@@ -985,7 +998,10 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     const Tensor& win = mul->b;
     const Index axis = fft->resolvedAxis;
     const U64 n = sig.shape(axis);
-    if (!kernels::fft_fused_supported(n)) return false;
+    const bool tiled = !kernels::fft_fused_supported(n);
+    if (tiled && (kernels::fft_lds_supported(n) || !kernels::fft_tiled_supported(n) ||
+                  kernels::fft_bluestein_size(n) != 0))
+        return false;
     if (!fft->input.contiguous() || !fft->output.contiguous() || !amp->output.contiguous())
         return false;
     for (Index ax = 0; ax < win.rank(); ++ax)
@@ -1005,7 +1021,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     name = "spectrum_fused(" + mul->name() + "+" + fft->name() + "+" + amp->name() +
            (rng ? "+" + rng->name() : "") + ")";
 
-    submit = [mul, fft, amp, rng, axis, n, fast](hipStream_t stream) -> Result {
+    submit = [mul, fft, amp, rng, axis, n, fast, tiled](hipStream_t stream) -> Result {
         const Tensor& sig = mul->a;
         const Tensor& win = mul->b;
         const Tensor& out = rng ? rng->output : amp->output;
@@ -1026,6 +1042,15 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
         L.out_axis_stride = (int64_t)out.stride(axis);
         L.in_offset = sig.offset();
         L.out_offset = out.offset();
+        if (tiled)  // mixed radix / beyond 16384 points: LDS-tiled kernels, same functors
+            return hip_result(
+                kernels::launch_spectrum_fused_tiled(
+                    n, L, fft->twiddles, static_cast<const float2*>(sig.data()),
+                    static_cast<const float2*>(win.data()) + win.offset(),
+                    (int64_t)win.stride(axis), static_cast<float*>(out.data()), amp->scalingCoeff,
+                    rng != nullptr, rng ? rng->scalingCoeff : 0.0f, rng ? rng->offsetCoeff : 0.0f,
+                    fast, static_cast<float2*>(fft->scratchA.data()), stream),
+                "fused spectrum (tiled) kernel");
         return hip_result(
             kernels::launch_spectrum_fused(
                 n, L, fft->twiddles, static_cast<const float2*>(sig.data()),

@@ -116,7 +116,9 @@ class Fft : public Module {
     // one dense batch of `length`-point transforms, in place in `data` (the Bluestein inner FFTs)
     Result innerTransform(float2* data, U64 length, U64 transforms, bool fwd, hipStream_t stream);
     Tensor input, output, scratchA, scratchB, scratchH;
-    bool useGlobalPasses = false;
+    // which kernels run the passes at the working length (n, or the Bluestein length):
+    // register/LDS kernels (2^k <= 16384), the LDS-tiled mixed-radix path, or one launch per pass
+    bool useGlobalPasses = false, useTiled = false;
     bool forward = true, complexOutput = false;
     Index resolvedAxis = 0;
     const float2* twiddles = nullptr;

@@ -34,6 +34,8 @@ def main():
     torch.cuda.set_device(0)
     import cyberether_amd.jetstream as js
     rng = np.random.default_rng(1235)
+    only = set(a.upper() for a in sys.argv[1:])  # e.g. "C3 C5": run just these (for rocprofv3)
+    want = lambda tag: not only or tag in only
     class _Out(list):
         def append(self, line):
             print(json.dumps(line), flush=True)
@@ -41,6 +43,17 @@ def main():
 
     # ---- C1 ------------------------------------------------------------------------------------
     n, fs = 4096, 2.0e6
+    if want('C1'):
+        run_c1(js, out, n, fs)
+    if want('C3'):
+        run_c3(js, out, rng)
+    if want('C4'):
+        run_c4(js, out)
+    if want('C5'):
+        run_c5(js, out, rng)
+
+
+def run_c1(js, out, n, fs):
     gen = js.Module("signal_generator", {"signalType": "cosine", "signalDataType": "CF32",
                                          "sampleRate": fs, "frequency": 100.25 * fs / n,
                                          "bufferSize": n}, {}, "cw")
@@ -59,7 +72,9 @@ def main():
                 "note": "one fused launch per cycle inside a captured graph: launch-latency bound"})
     rt.destroy()
 
-    # ---- C3 ------------------------------------------------------------------------------------
+
+
+def run_c3(js, out, rng):
     b, s, taps, sr, bw = 100, 159750, 251, 20e6, 2e6
     t = np.arange(b * s) / sr
     x = (np.exp(2j * np.pi * 0.3e6 * t) + np.exp(2j * np.pi * 4.0e6 * t)).astype(np.complex64)
@@ -73,7 +88,9 @@ def main():
                 "note": "FFT overlap-add through pass-per-launch 160000-pt FFTs (HBM bound, 7 passes)"})
     rt.destroy()
 
-    # ---- C4 ------------------------------------------------------------------------------------
+
+
+def run_c4(js, out):
     b, s, taps, sr, bw = 10, 202400, 101, 20e6, 200e3  # conv 202500 = 2^2*3^4*5^4
     tt = np.arange(b * s) / sr
     audio = np.sin(2 * np.pi * 1e3 * tt) * 0.45 + 0.1 * np.sin(2 * np.pi * 19e3 * tt)
@@ -92,7 +109,9 @@ def main():
                 "note": "FM stereo decode is a serial recursion per lane (1 lane here): latency bound"})
     rt.destroy()
 
-    # ---- C5 (one stream on one GPU) ------------------------------------------------------------
+
+
+def run_c5(js, out, rng):
     n, b = 65536, 16
     x = (rng.standard_normal((b, n)) + 1j * rng.standard_normal((b, n))).astype(np.complex64)
     src = js.Tensor.from_numpy(x, batch=0, sample=1)
