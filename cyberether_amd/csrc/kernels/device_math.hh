@@ -187,7 +187,11 @@ __device__ __forceinline__ float amplitude_f32(float v, float coeff) {
 __device__ __forceinline__ float range_f32(float v, float scale, float offset) {
     if (scale == 0.0f) return 0.5f;
     const float normalized = v * scale + offset;
+#ifdef JST_TANH_SELECT_FORM
     return 0.5f + 0.5f * libm_tanhf(4.0f * (normalized - 0.5f));
+#else
+    return 0.5f + 0.5f * libm_tanhf_branchy(4.0f * (normalized - 0.5f));
+#endif
 }
 
 

@@ -419,33 +419,149 @@ __global__ void siggen_phase_kernel(double* __restrict__ phases, double* __restr
     }
     state[0] = ph;
 }
+// advanceChirpPhase (:165-190): per sample the phase grows by 2*pi*cycles, cycles = the integral of
+// the linear frequency sweep over dt, restarting at chirpDuration.  state = {phase, chirpTime}.
+__global__ void siggen_chirp_phase_kernel(double* __restrict__ phases, double* __restrict__ state,
+                                          uint64_t count, double sample_rate, double f0, double f1,
+                                          double duration) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const double period = 2.0 * 3.14159265358979323846;
+    const double dt = 1.0 / sample_rate;
+    const double rate = (f1 - f0) / duration;
+    double ph = state[0], tm = state[1];
+    for (uint64_t i = 0; i < count; ++i) {
+        phases[i] = ph;
+        double cycles = 0.0;
+        const double until = duration - tm;
+        if (dt < until) {
+            cycles = (f0 + rate * tm) * dt + 0.5 * rate * dt * dt;
+            tm += dt;
+        } else {
+            cycles = (f0 + rate * tm) * until + 0.5 * rate * until * until;
+            const double after = dt - until;
+            tm = after;
+            if (after > 0.0) cycles += (f0 + rate * 0.0) * after + 0.5 * rate * after * after;
+        }
+        const double w = fmod(ph + 2.0 * 3.14159265358979323846 * cycles, period);
+        ph = w < 0.0 ? w + period : w;
+    }
+    state[0] = ph;
+    state[1] = tm;
+}
+
+// waveform shapes of module_impl_native_cpu.cc:192-375, evaluated in F64 from the stored phase
+enum : int { kSine = 0, kCosine = 1, kSquare = 2, kTriangle = 3, kSawtooth = 4, kDc = 5 };
 __global__ __launch_bounds__(kBlock) void siggen_eval_kernel(float* __restrict__ out,
                                                              const double* __restrict__ phases,
                                                              uint64_t count, int complex_out,
-                                                             int sine, double amplitude,
+                                                             int shape, double amplitude,
                                                              double dc_offset) {
+    const double pi = 3.14159265358979323846;
     JST_GRID_STRIDE(i, count) {
-        const double ph = phases[i];
-        if (complex_out) {  // kernelCosineCF32 :222-231 (sine CF32 swaps the roles of cos and sin)
-            const double a = sine ? sin(ph) : cos(ph), b = sine ? -cos(ph) : sin(ph);
-            out[2 * i] = (float)(amplitude * a + dc_offset);
-            out[2 * i + 1] = (float)(amplitude * b);
+        const double ph = (shape == kDc) ? 0.0 : phases[i];
+        double re, im = 0.0;
+        if (shape == kCosine) {          // :213-231
+            re = amplitude * cos(ph) + dc_offset;
+            im = amplitude * sin(ph);
+        } else if (shape == kSine) {     // :192-211
+            re = amplitude * sin(ph) + dc_offset;
+            im = -amplitude * cos(ph);
+        } else if (shape == kSquare) {   // :233-253
+            re = amplitude * (ph < pi ? 1.0 : -1.0) + dc_offset;
+        } else if (shape == kSawtooth) { // :255-275
+            const double pv = ph / (2.0 * pi);
+            re = amplitude * (2.0 * pv - 1.0) + dc_offset;
+        } else if (shape == kTriangle) { // :277-299
+            const double pv = ph / (2.0 * pi);
+            re = amplitude * (pv < 0.5 ? 4.0 * pv - 1.0 : 3.0 - 4.0 * pv) + dc_offset;
+        } else {                         // dc :329-348
+            re = amplitude + dc_offset;
+        }
+        if (complex_out) {
+            out[2 * i] = (float)re;
+            out[2 * i + 1] = (float)im;
         } else {
-            out[i] = (float)(amplitude * (sine ? sin(ph) : cos(ph)) + dc_offset);
+            out[i] = (float)re;
         }
     }
 }
 
+// Noise (:301-327): clamp(scale * N(0,1) + dc).  The reference seeds std::mt19937 from
+// std::random_device, so only the distribution is specified; here a counter-based generator
+// (SplitMix64 over sample index + call counter) feeds Box-Muller in F64, one pair per sample.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(kBlock) void siggen_noise_kernel(float* __restrict__ out,
+                                                              const uint64_t* __restrict__ state,
+                                                              uint64_t count, int complex_out,
+                                                              double scale, double variance,
+                                                              double dc_offset) {
+    const double fmax = 3.40282346638528859811704183484516925e+38;
+    const uint64_t base = state[0];
+    JST_GRID_STRIDE(i, count) {
+        double n0 = 0.0, n1 = 0.0;
+        if (variance > 0.0) {
+            const uint64_t a = splitmix64(base + 2 * i), b = splitmix64(base + 2 * i + 1);
+            const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740992.0);  // (0, 1]
+            const double u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);         // [0, 1)
+            const double r = sqrt(-2.0 * log(u1));
+            n0 = r * cos(2.0 * 3.14159265358979323846 * u2);
+            n1 = r * sin(2.0 * 3.14159265358979323846 * u2);
+        }
+        double iv = scale * n0 + dc_offset, qv = scale * n1;
+        iv = iv < -fmax ? -fmax : (fmax < iv ? fmax : iv);
+        qv = qv < -fmax ? -fmax : (fmax < qv ? fmax : qv);
+        if (complex_out) {
+            out[2 * i] = (float)iv;
+            out[2 * i + 1] = (float)qv;
+        } else {
+            out[i] = (float)iv;
+        }
+    }
+}
+__global__ void siggen_noise_advance_kernel(uint64_t* state, uint64_t count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[0] += 2 * count;
+}
+
 }  // namespace
 
-hipError_t launch_signal_cosine(float* out, double* phases, double* state, uint64_t count,
-                                bool complex_out, double amplitude, double frequency,
-                                double sample_rate, double dc_offset, hipStream_t s) {
+hipError_t launch_signal_generator(float* out, double* phases, double* state, uint64_t count,
+                                   bool complex_out, const SignalParams& p, hipStream_t s) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(siggen_phase_kernel, dim3(1), dim3(64), 0, s, phases, state, count, frequency,
-                       sample_rate);
+    const int cx = complex_out ? 1 : 0;
+    switch (p.shape) {
+        case SignalShape::Noise:
+            hipLaunchKernelGGL(siggen_noise_kernel, dim3(grid_for(count)), dim3(kBlock), 0, s, out,
+                               reinterpret_cast<const uint64_t*>(state + 2), count, cx,
+                               p.amplitude * sqrt(p.noise_variance), p.noise_variance, p.dc_offset);
+            hipLaunchKernelGGL(siggen_noise_advance_kernel, dim3(1), dim3(64), 0, s,
+                               reinterpret_cast<uint64_t*>(state + 2), count);
+            return hipGetLastError();
+        case SignalShape::Dc:
+            hipLaunchKernelGGL(siggen_eval_kernel, dim3(grid_for(count)), dim3(kBlock), 0, s, out,
+                               (const double*)phases, count, cx, (int)kDc, p.amplitude, p.dc_offset);
+            return hipGetLastError();
+        case SignalShape::Chirp:
+            hipLaunchKernelGGL(siggen_chirp_phase_kernel, dim3(1), dim3(64), 0, s, phases, state, count,
+                               p.sample_rate, p.chirp_start, p.chirp_end, p.chirp_duration);
+            hipLaunchKernelGGL(siggen_eval_kernel, dim3(grid_for(count)), dim3(kBlock), 0, s, out,
+                               (const double*)phases, count, cx, (int)kCosine, p.amplitude, p.dc_offset);
+            return hipGetLastError();
+        default: break;
+    }
+    int shape = kCosine;
+    if (p.shape == SignalShape::Sine) shape = kSine;
+    if (p.shape == SignalShape::Square) shape = kSquare;
+    if (p.shape == SignalShape::Triangle) shape = kTriangle;
+    if (p.shape == SignalShape::Sawtooth) shape = kSawtooth;
+    hipLaunchKernelGGL(siggen_phase_kernel, dim3(1), dim3(64), 0, s, phases, state, count, p.frequency,
+                       p.sample_rate);
     hipLaunchKernelGGL(siggen_eval_kernel, dim3(grid_for(count)), dim3(kBlock), 0, s, out,
-                       (const double*)phases, count, complex_out ? 1 : 0, 0, amplitude, dc_offset);
+                       (const double*)phases, count, cx, shape, p.amplitude, p.dc_offset);
     return hipGetLastError();
 }
 

@@ -199,9 +199,16 @@ hipError_t launch_filter_taps(float2* out, double sample_rate, double bandwidth,
 hipError_t launch_arithmetic(const EwLayout& L, void* out, const void* in, bool complex, int op,
                              uint64_t r, int64_t r_stride, hipStream_t s);
 // cosine oscillator: phases = F64 scratch [count], state = F64[1] carried phase
-hipError_t launch_signal_cosine(float* out, double* phases, double* state, uint64_t count,
-                                bool complex_out, double amplitude, double frequency,
-                                double sample_rate, double dc_offset, hipStream_t s);
+// Signal generator (dsp/signal_generator/module_impl_native_cpu.cc:159-375).  state: F64[4] =
+// {oscillatorPhase, chirpTime, noise counter (u64 bits), unused}; phases: F64[count] scratch.
+enum class SignalShape { Sine, Cosine, Square, Triangle, Sawtooth, Noise, Dc, Chirp };
+struct SignalParams {
+    SignalShape shape;
+    double amplitude, frequency, sample_rate, dc_offset, noise_variance, chirp_start, chirp_end,
+        chirp_duration;
+};
+hipError_t launch_signal_generator(float* out, double* phases, double* state, uint64_t count,
+                                   bool complex_out, const SignalParams& p, hipStream_t s);
 size_t fm_state_bytes();
 hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
                      hipStream_t s);

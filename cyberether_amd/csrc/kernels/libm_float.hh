@@ -95,4 +95,74 @@ JST_FN float libm_tanhf(float x) {
     return r;
 }
 
+// Branch-structured variant of the same two functions, following the published control flow
+// (s_tanhf.c / s_expm1f.c) instead of computing every alternative: on the GPU a divergent `if`
+// costs an exec-mask update and is skipped outright when no lane of the wavefront takes it, which
+// is cheaper than the select form as soon as a reconstruction class is absent from a wavefront,
+// and it drops the cmp+cndmask pair per alternative.  Arithmetic identical, operation by operation.
+JST_FN float libm_expm1f_for_tanh_branchy(float x) {
+    constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f,
+                    invln2 = 1.4426950216e+00f, Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f,
+                    Q3 = -7.9365076090e-05f, Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+    const uint32_t bits = f2u(x);
+    const uint32_t hx = bits & 0x7fffffffu;
+    const bool neg = (bits >> 31) != 0;
+    int32_t k = 0;
+    float c = 0.0f;
+    if (hx > 0x3eb17218u) {          // |x| > 0.5 ln2
+        float hi, lo;
+        if (hx < 0x3F851592u) {      // and |x| < 1.5 ln2
+            hi = neg ? x + ln2_hi : x - ln2_hi;
+            lo = neg ? -ln2_lo : ln2_lo;
+            k = neg ? -1 : 1;
+        } else {
+            k = (int32_t)(invln2 * x + (neg ? -0.5f : 0.5f));
+            const float t = (float)k;
+            hi = x - t * ln2_hi;
+            lo = t * ln2_lo;
+        }
+        x = hi - lo;
+        c = (hi - x) - lo;
+    } else if (hx < 0x33000000u) {   // |x| < 2^-25
+        return x;
+    }
+    const float hfx = 0.5f * x;
+    const float hxs = x * hfx;
+    const float r1 = 1.0f + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+    float t = 3.0f - r1 * hfx;
+    float e = hxs * ((r1 - t) / (6.0f - x * t));
+    if (k == 0) return x - (x * e - hxs);
+    e = (x * (e - c) - c);
+    e -= hxs;
+    if (k == -1) return 0.5f * (x - e) - 0.5f;
+    if (k == 1) return (x < -0.25f) ? -2.0f * (e - (x + 0.5f)) : 1.0f + 2.0f * (x - e);
+    const uint32_t kshift = (uint32_t)k << 23;
+    if (k <= -2 || k > 56) return u2f(f2u(1.0f - (e - x)) + kshift) - 1.0f;
+    if (k < 23) {
+        t = u2f(0x3f800000u - (0x1000000u >> ((uint32_t)k & 31u)));  // 1 - 2^-k
+        return u2f(f2u(t - (e - x)) + kshift);
+    }
+    t = u2f((uint32_t)(0x7f - k) << 23);  // 2^-k
+    float y = x - (e + t);
+    y += 1.0f;
+    return u2f(f2u(y) + kshift);
+}
+
+JST_FN float libm_tanhf_branchy(float x) {
+    const uint32_t jx = f2u(x);
+    const uint32_t ix = jx & 0x7fffffffu;
+    const float ax = u2f(ix);
+    const bool ge1 = ix >= 0x3f800000u;
+    const float two_ax = 2.0f * ax;
+    // one expm1f evaluation serves both |x| >= 1 (argument 2|x|) and |x| < 1 (argument -2|x|)
+    const float t = libm_expm1f_for_tanh_branchy(ge1 ? two_ax : -two_ax);
+    const float q = (ge1 ? 2.0f : t) / (t + 2.0f);
+    float z = ge1 ? 1.0f - q : -q;             // one - two/(t+two)   |   -t/(t+two)
+    if (ix >= 0x41b00000u) z = 1.0f;           // |x| >= 22 (and +-inf): one - tiny == 1.0f
+    float r = ((jx >> 31) != 0) ? -z : z;
+    if (ix < 0x24000000u) r = x * (1.0f + x);  // |x| < 2^-55, including +-0
+    if (ix > 0x7f800000u) r = x + x;           // NaN
+    return r;
+}
+
 }  // namespace jst::dev

@@ -1000,43 +1000,118 @@ class Lineplot : public Module {
 };
 
 // ---- SignalGenerator (dsp/signal_generator/module_impl.cc:16-170, module_impl_native_cpu.cc) ---
-// Only the cosine oscillator (the CW tone of the BASELINE configs) is implemented on the device.
+// Every waveform of the reference.  The periodic ones and the chirp share a serial F64 phase walk
+// (bit-exact); noise is distribution-equivalent only (the reference seeds from random_device).
 class SignalGenerator : public Module {
  public:
     const char* type() const override { return "signal_generator"; }
     Result validate() override {
+        constexpr F64 maxF32 = 3.40282346638528859811704183484516925e+38;
+        constexpr F64 minF32 = 1.17549435082228750796873653722224568e-38;
         signalType = ConfigStr(config_, "signalType", "cosine");
         dataType = ConfigStr(config_, "signalDataType", "F32");
-        bool o1, o2, o3, o4, o5, o6;
-        sampleRate = ConfigF64(config_, "sampleRate", 1.0e6, &o1);
-        frequency = ConfigF64(config_, "frequency", 1000.0, &o2);
-        amplitude = ConfigF64(config_, "amplitude", 1.0, &o3);
-        phase = ConfigF64(config_, "phase", 0.0, &o4);
-        dcOffset = ConfigF64(config_, "dcOffset", 0.0, &o5);
-        bufferSize = ConfigU64(config_, "bufferSize", 8192, &o6);
-        static const char* kTypes[] = {"sine", "cosine", "square", "triangle", "sawtooth", "noise", "dc", "chirp"};
+        bool ok[10];
+        sampleRate = ConfigF64(config_, "sampleRate", 1.0e6, &ok[0]);
+        frequency = ConfigF64(config_, "frequency", 1000.0, &ok[1]);
+        amplitude = ConfigF64(config_, "amplitude", 1.0, &ok[2]);
+        phase = ConfigF64(config_, "phase", 0.0, &ok[3]);
+        dcOffset = ConfigF64(config_, "dcOffset", 0.0, &ok[4]);
+        bufferSize = ConfigU64(config_, "bufferSize", 8192, &ok[5]);
+        noiseVariance = ConfigF64(config_, "noiseVariance", 1.0, &ok[6]);
+        chirpStartFreq = ConfigF64(config_, "chirpStartFreq", 1000.0, &ok[7]);
+        chirpEndFreq = ConfigF64(config_, "chirpEndFreq", 10000.0, &ok[8]);
+        chirpDuration = ConfigF64(config_, "chirpDuration", 1.0, &ok[9]);
+        static const std::pair<const char*, kernels::SignalShape> kTypes[] = {
+            {"sine", kernels::SignalShape::Sine},         {"cosine", kernels::SignalShape::Cosine},
+            {"square", kernels::SignalShape::Square},     {"triangle", kernels::SignalShape::Triangle},
+            {"sawtooth", kernels::SignalShape::Sawtooth}, {"noise", kernels::SignalShape::Noise},
+            {"dc", kernels::SignalShape::Dc},             {"chirp", kernels::SignalShape::Chirp}};
         bool known = false;
-        for (const char* t : kTypes) known |= signalType == t;
+        for (const auto& t : kTypes)
+            if (signalType == t.first) {
+                known = true;
+                shape = t.second;
+            }
         if (!known) {
             JST_ERROR("[MODULE_SIGNAL_GENERATOR] Invalid signal type '%s'.", signalType.c_str());
             return Result::ERROR;
         }
         if (dataType != "F32" && dataType != "CF32") {
-            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Invalid signal data type '%s'.", dataType.c_str());
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Invalid data type '%s'.", dataType.c_str());
             return Result::ERROR;
         }
-        if (!(o1 && o2 && o3 && o4 && o5 && o6) || !std::isfinite(sampleRate) || sampleRate <= 0.0) {
-            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Sample rate must be positive.");
+        for (bool o : ok)
+            if (!o) {
+                JST_ERROR("[MODULE_SIGNAL_GENERATOR] Invalid numeric configuration value.");
+                return Result::ERROR;
+            }
+        const bool cx = dataType == "CF32";
+        const bool sinusoid = signalType == "sine" || signalType == "cosine";
+        const bool periodic = sinusoid || signalType == "square" || signalType == "triangle" ||
+                              signalType == "sawtooth";
+        const bool noise = signalType == "noise", dc = signalType == "dc", chirp = signalType == "chirp";
+        if (!std::isfinite(sampleRate) || sampleRate < minF32 || sampleRate > maxF32) {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Sample rate must be positive and within the F32 "
+                      "range (%g).", sampleRate);
+            return Result::ERROR;
+        }
+        const F64 nyquist = sampleRate * 0.5;
+        if (periodic) {
+            const F64 lo = cx && sinusoid ? -nyquist : 0.0;
+            if (!std::isfinite(frequency) || frequency < lo || frequency > nyquist) {
+                JST_ERROR("[MODULE_SIGNAL_GENERATOR] Frequency (%g) must be within the supported "
+                          "range [%g, %g].", frequency, lo, nyquist);
+                return Result::ERROR;
+            }
+        }
+        if (!std::isfinite(amplitude) || amplitude < 0.0 || amplitude > maxF32) {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Amplitude must be non-negative and within the F32 "
+                      "range (%g).", amplitude);
+            return Result::ERROR;
+        }
+        if ((periodic || chirp) && !std::isfinite(phase)) {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Phase must be finite (%g).", phase);
+            return Result::ERROR;
+        }
+        if (!std::isfinite(dcOffset) || std::abs(dcOffset) > maxF32) {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] DC offset must be within the F32 range (%g).", dcOffset);
+            return Result::ERROR;
+        }
+        if (dc) {
+            const F64 v = amplitude + dcOffset;
+            if (!std::isfinite(v) || std::abs(v) > maxF32) {
+                JST_ERROR("[MODULE_SIGNAL_GENERATOR] DC value exceeds the F32 output range.");
+                return Result::ERROR;
+            }
+        } else if (!noise && amplitude > maxF32 - std::abs(dcOffset)) {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Amplitude and DC offset exceed the F32 output range.");
             return Result::ERROR;
         }
         if (bufferSize == 0) {
             JST_ERROR("[MODULE_SIGNAL_GENERATOR] Buffer size cannot be zero.");
             return Result::ERROR;
         }
-        if (signalType != "cosine") {
-            JST_ERROR("[MODULE_SIGNAL_GENERATOR_NATIVE_HIP] Signal type '%s' is not implemented on the "
-                      "HIP device (cosine only).", signalType.c_str());
+        if (noise && (!std::isfinite(noiseVariance) || noiseVariance < 0.0 || noiseVariance > maxF32)) {
+            JST_ERROR("[MODULE_SIGNAL_GENERATOR] Noise variance must be non-negative and within the "
+                      "F32 range (%g).", noiseVariance);
             return Result::ERROR;
+        }
+        if (chirp) {
+            const F64 lo = cx ? -nyquist : 0.0;  // module_impl.cc:117-135
+            if (!std::isfinite(chirpStartFreq) || chirpStartFreq < lo || chirpStartFreq > nyquist) {
+                JST_ERROR("[MODULE_SIGNAL_GENERATOR] Chirp start frequency (%g) must be within "
+                          "[%g, %g].", chirpStartFreq, lo, nyquist);
+                return Result::ERROR;
+            }
+            if (!std::isfinite(chirpEndFreq) || chirpEndFreq < lo || chirpEndFreq > nyquist) {
+                JST_ERROR("[MODULE_SIGNAL_GENERATOR] Chirp end frequency (%g) must be within "
+                          "[%g, %g].", chirpEndFreq, lo, nyquist);
+                return Result::ERROR;
+            }
+            if (!std::isfinite(chirpDuration) || chirpDuration <= 0.0) {
+                JST_ERROR("[MODULE_SIGNAL_GENERATOR] Chirp duration must be positive (%g).", chirpDuration);
+                return Result::ERROR;
+            }
         }
         return Result::SUCCESS;
     }
@@ -1047,25 +1122,30 @@ class SignalGenerator : public Module {
         JST_CHECK(SetSignalAxes(signal, {.sample = Index{0}}));
         signal.setAttribute("sampleRate", AttrValue{(F64)(F32)sampleRate});
         JST_CHECK(phases.create(device(), DataType::F64, {bufferSize}));
-        JST_CHECK(oscillator.create(device(), DataType::F64, {1}));
+        JST_CHECK(oscillator.create(device(), DataType::F64, {4}));
         const F64 period = 2.0 * 3.14159265358979323846;
-        F64 w = std::fmod(phase, period);
-        if (w < 0.0) w += period;
-        JST_CHECK(oscillator.copyFromHost(&w, sizeof(w), nullptr));
+        F64 init[4] = {std::fmod(phase, period), 0.0, 0.0, 0.0};
+        if (init[0] < 0.0) init[0] += period;
+        const uint64_t seed = 0x243F6A8885A308D3ull ^ (uint64_t)reinterpret_cast<uintptr_t>(this);
+        std::memcpy(&init[2], &seed, sizeof(seed));  // noise counter base (any value: see kernel)
+        JST_CHECK(oscillator.copyFromHost(init, sizeof(init), nullptr));
         JST_HIP_CHECK(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
         produced("signal", signal);
         return Result::SUCCESS;
     }
     Result computeSubmit(hipStream_t s) override {
-        return hip_result(kernels::launch_signal_cosine(ptr<float>(signal), ptr<double>(phases),
-                                                        ptr<double>(oscillator), bufferSize,
-                                                        dataType == "CF32", amplitude, frequency,
-                                                        sampleRate, dcOffset, s),
+        kernels::SignalParams p{shape,          amplitude,      frequency,    sampleRate,   dcOffset,
+                                noiseVariance, chirpStartFreq, chirpEndFreq, chirpDuration};
+        return hip_result(kernels::launch_signal_generator(ptr<float>(signal), ptr<double>(phases),
+                                                           ptr<double>(oscillator), bufferSize,
+                                                           dataType == "CF32", p, s),
                           "signal_generator kernel");
     }
     Tensor signal, phases, oscillator;
     std::string signalType = "cosine", dataType = "F32";
+    kernels::SignalShape shape = kernels::SignalShape::Cosine;
     F64 sampleRate = 1.0e6, frequency = 1000.0, amplitude = 1.0, phase = 0.0, dcOffset = 0.0;
+    F64 noiseVariance = 1.0, chirpStartFreq = 1000.0, chirpEndFreq = 10000.0, chirpDuration = 1.0;
     U64 bufferSize = 8192;
 };
 

@@ -1185,6 +1185,54 @@ void jst_oracle_signal_cosine_cf32(float* out, uint64_t count, double amplitude,
     *phase = ph;
 }
 
+/* All deterministic waveforms (module_impl_native_cpu.cc:159-375).  shape: 0 sine, 1 cosine,
+ * 2 square, 3 triangle, 4 sawtooth, 5 dc, 6 chirp.  state[0] = oscillatorPhase, state[1] = chirpTime. */
+void jst_oracle_signal(float* out, uint64_t count, int complex_out, int shape, double amplitude,
+                       double frequency, double sample_rate, double dc_offset, double chirp_start,
+                       double chirp_end, double chirp_duration, double* state) {
+    const double period = 2.0 * JST_PI;
+    double ph = wrap_phase(state[0], period), tm = state[1];
+    for (uint64_t i = 0; i < count; ++i) {
+        double re, im = 0.0;
+        switch (shape) {
+            case 0: re = amplitude * sin(ph) + dc_offset; im = -amplitude * cos(ph); break;
+            case 1: case 6: re = amplitude * cos(ph) + dc_offset; im = amplitude * sin(ph); break;
+            case 2: re = amplitude * (ph < JST_PI ? 1.0 : -1.0) + dc_offset; break;
+            case 3: { const double pv = ph / (2.0 * JST_PI);
+                      re = amplitude * (pv < 0.5 ? 4.0 * pv - 1.0 : 3.0 - 4.0 * pv) + dc_offset; break; }
+            case 4: { const double pv = ph / (2.0 * JST_PI);
+                      re = amplitude * (2.0 * pv - 1.0) + dc_offset; break; }
+            default: re = amplitude + dc_offset; break;
+        }
+        if (complex_out) {
+            out[2 * i] = (float)re;
+            out[2 * i + 1] = (float)im;
+        } else {
+            out[i] = (float)re;
+        }
+        if (shape == 6) { /* advanceChirpPhase :165-190 */
+            const double dt = 1.0 / sample_rate;
+            const double rate = (chirp_end - chirp_start) / chirp_duration;
+            double cycles = 0.0;
+            const double until = chirp_duration - tm;
+            if (dt < until) {
+                cycles = (chirp_start + rate * tm) * dt + 0.5 * rate * dt * dt;
+                tm += dt;
+            } else {
+                cycles = (chirp_start + rate * tm) * until + 0.5 * rate * until * until;
+                const double after = dt - until;
+                tm = after;
+                if (after > 0.0) cycles += (chirp_start + rate * 0.0) * after + 0.5 * rate * after * after;
+            }
+            ph = wrap_phase(ph + 2.0 * JST_PI * cycles, period);
+        } else if (shape != 5) {
+            ph = wrap_phase(ph + 2.0 * JST_PI * frequency / sample_rate, period);
+        }
+    }
+    state[0] = ph;
+    state[1] = tm;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Fold (spectral decimation).  src/domains/dsp/fold/module_impl_native_cpu.cc:103-172.
  * Dense tensors; 'axis' is the fold axis; out[k] = (1/D) * sum_g in[(k + g*size - offset) mod axis]

@@ -288,6 +288,22 @@ def signal_cosine(count: int, amplitude_: float, frequency: float, sample_rate: 
 
 
 # ------------------------------------------------------------------------- composed chains
+_SHAPES = {"sine": 0, "cosine": 1, "square": 2, "triangle": 3, "sawtooth": 4, "dc": 5, "chirp": 6}
+
+
+def signal(shape: str, count: int, complex_out: bool, state, amplitude_=1.0, frequency=1000.0,
+           sample_rate=1.0e6, dc_offset=0.0, chirp_start=1000.0, chirp_end=10000.0, chirp_duration=1.0):
+    """Any deterministic waveform of the signal generator; state = [phase, chirpTime] is carried
+    (returned updated).  Returns (samples, new_state)."""
+    out = np.empty(count, dtype=np.complex64 if complex_out else np.float32)
+    st = (C.c_double * 2)(float(state[0]), float(state[1]))
+    lib().jst_oracle_signal(_p(out.view(np.float32)), C.c_uint64(count), C.c_int(1 if complex_out else 0),
+                            C.c_int(_SHAPES[shape]), C.c_double(amplitude_), C.c_double(frequency),
+                            C.c_double(sample_rate), C.c_double(dc_offset), C.c_double(chirp_start),
+                            C.c_double(chirp_end), C.c_double(chirp_duration), st)
+    return out, [st[0], st[1]]
+
+
 def spectrum_chain(x: np.ndarray, range_min=None, range_max=None):
     """Window -> Invert -> (reshape) -> Multiply -> FFT -> Amplitude -> [Range] over the last axis
     (src/domains/dsp/spectrum_engine/block_impl.cc:120-217).  Returns dict of every stage."""

@@ -5,13 +5,15 @@
 
 #include "../../cyberether_amd/csrc/kernels/libm_float.hh"
 
+// variant 0: select form (libm_tanhf); variant 1: branch-structured form (libm_tanhf_branchy)
 extern "C" uint64_t jst_tanhf_mismatches(uint32_t start, uint32_t stride, uint64_t count,
-                                         uint32_t* first_bad) {
+                                         uint32_t* first_bad, int variant) {
     uint64_t bad = 0;
     uint32_t u = start;
     for (uint64_t i = 0; i < count; ++i, u += stride) {
         const float x = jst::dev::u2f(u);
-        const float a = tanhf(x), b = jst::dev::libm_tanhf(x);
+        const float a = tanhf(x);
+        const float b = variant ? jst::dev::libm_tanhf_branchy(x) : jst::dev::libm_tanhf(x);
         if (isnan(a) && isnan(b)) continue;
         if (jst::dev::f2u(a) != jst::dev::f2u(b)) {
             if (bad == 0 && first_bad) *first_bad = u;
@@ -22,3 +24,4 @@ extern "C" uint64_t jst_tanhf_mismatches(uint32_t start, uint32_t stride, uint64
 }
 
 extern "C" float jst_tanhf_select(float x) { return jst::dev::libm_tanhf(x); }
+extern "C" float jst_tanhf_branchy(float x) { return jst::dev::libm_tanhf_branchy(x); }

@@ -212,5 +212,51 @@ def test_signal_generator_cosine_continuity(js, oracle):
             if dtype == "F32":
                 ref = np.ascontiguousarray(ref.real)
             assert_bit_equal(got, ref, f"{dtype} cycle {cycle}")
-    with pytest.raises(js.JetstreamError, match="not implemented on the HIP device"):
-        js.Module("signal_generator", {"signalType": "chirp"}, {})
+    with pytest.raises(js.JetstreamError, match="Invalid signal type 'warble'"):
+        js.Module("signal_generator", {"signalType": "warble"}, {})
+    with pytest.raises(js.JetstreamError, match="Frequency .* must be within the supported range"):
+        js.Module("signal_generator", {"signalType": "square", "frequency": -5.0}, {})
+
+
+@pytest.mark.parametrize("shape", ["sine", "square", "triangle", "sawtooth", "dc", "chirp"])
+@pytest.mark.parametrize("dtype", ["F32", "CF32"])
+def test_signal_generator_waveforms(js, oracle, shape, dtype):
+    """Every deterministic waveform (module_impl_native_cpu.cc:192-375) bit-exact vs the oracle,
+    oscillator phase / chirp time carried across submissions.  The negative-frequency sine covers
+    the downward phase walk."""
+    n, fs = 3000, 48000.0
+    cfg = {"signalType": shape, "signalDataType": dtype, "sampleRate": fs, "amplitude": 0.6, "dcOffset": -0.05,
+           "phase": 1.25, "bufferSize": n, "frequency": 997.3,
+           "chirpStartFreq": 100.0, "chirpEndFreq": 9000.0, "chirpDuration": 0.11}
+    if shape == "sine" and dtype == "CF32":
+        cfg["frequency"] = -4321.0
+    m = js.Module("signal_generator", cfg, {})
+    rt = js.Runtime([m], graph=True)
+    state = [1.25, 0.0]
+    for cycle in range(3):   # 9000 samples: the chirp wraps its 0.11 s sweep once
+        rt.compute()
+        ref, state = oracle.signal(shape, n, dtype == "CF32", state, 0.6, cfg["frequency"], fs, -0.05,
+                                   100.0, 9000.0, 0.11)
+        assert_bit_equal(m.output("signal").numpy(), ref, f"{shape} {dtype} cycle {cycle}")
+
+
+@pytest.mark.parametrize("dtype", ["F32", "CF32"])
+def test_signal_generator_noise_statistics(js, dtype):
+    """Noise is seeded from std::random_device in the reference, so only the distribution is
+    specified (signal_generator/module_tests.cc checks mean and variance the same way)."""
+    n = 1 << 18
+    m = js.Module("signal_generator", {"signalType": "noise", "signalDataType": dtype, "amplitude": 2.0,
+                                       "noiseVariance": 0.25, "dcOffset": 0.5, "bufferSize": n}, {})
+    rt = js.Runtime([m], graph=True)
+    rt.compute()
+    a = m.output("signal").numpy().copy()
+    rt.compute()
+    b = m.output("signal").numpy()
+    assert not np.array_equal(a, b)                      # the stream advances between submissions
+    re = a.real if dtype == "CF32" else a
+    assert abs(re.mean() - 0.5) < 0.01 and abs(re.std() - 1.0) < 0.01   # scale = 2 * sqrt(0.25)
+    if dtype == "CF32":
+        assert abs(a.imag.mean()) < 0.01 and abs(a.imag.std() - 1.0) < 0.01
+        assert abs(np.corrcoef(a.real, a.imag)[0, 1]) < 0.01
+    z = (re - 0.5)
+    assert abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 3.0) < 0.1   # gaussian moments

@@ -18,37 +18,43 @@ def checker(tmp_path_factory):
                            os.path.join(HERE, "native", "libm_check.cc"), "-o", str(out), "-lm"])
     lib = C.CDLL(str(out))
     lib.jst_tanhf_mismatches.restype = C.c_uint64
-    lib.jst_tanhf_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32)]
+    lib.jst_tanhf_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.c_int]
+    lib.jst_tanhf_branchy.restype = C.c_float
+    lib.jst_tanhf_branchy.argtypes = [C.c_float]
     lib.jst_tanhf_select.restype = C.c_float
     lib.jst_tanhf_select.argtypes = [C.c_float]
     return lib
 
 
-def test_every_257th_float(checker):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_every_257th_float(checker, variant):
     first = C.c_uint32(0)
     n = (1 << 32) // 257
-    bad = checker.jst_tanhf_mismatches(0, 257, n, C.byref(first))
+    bad = checker.jst_tanhf_mismatches(0, 257, n, C.byref(first), variant)
     assert bad == 0, f"{bad} mismatches, first at bits {first.value:#x}"
 
 
-def test_dense_where_range_lives(checker):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_dense_where_range_lives(checker, variant):
     # the Range module feeds 4*(normalized-0.5): |x| mostly in [2^-10, 8) -> every float there
     first = C.c_uint32(0)
     lo, hi = np.float32(2.0 ** -10).view(np.uint32), np.float32(8.0).view(np.uint32)
     for sign in (0, 0x80000000):
-        bad = checker.jst_tanhf_mismatches(int(lo) | sign, 3, (int(hi) - int(lo)) // 3, C.byref(first))
+        bad = checker.jst_tanhf_mismatches(int(lo) | sign, 3, (int(hi) - int(lo)) // 3, C.byref(first), variant)
         assert bad == 0, f"{bad} mismatches, first at bits {first.value:#x}"
 
 
-def test_branch_boundaries(checker):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_branch_boundaries(checker, variant):
     edges = [0x24000000, 0x33000000, 0x3eb17218, 0x3F851592, 0x3f800000, 0x41b00000, 0x7f800000,
              0x4195b844, 0x3e800000, 0x3f000000]
     first = C.c_uint32(0)
     for e in edges:
         for sign in (0, 0x80000000):
             start = ((e >> 1) - 64) | (sign >> 1)  # expm1 sees 2|x|: probe around e/2 ...
-            assert checker.jst_tanhf_mismatches((e - 64) | sign, 1, 128, C.byref(first)) == 0, hex(first.value)
-            assert checker.jst_tanhf_mismatches((e - 0x00800000 - 64) | sign, 1, 128, C.byref(first)) == 0
-    assert checker.jst_tanhf_select(0.0) == 0.0 and np.signbit(np.float32(checker.jst_tanhf_select(-0.0)))
-    assert checker.jst_tanhf_select(float("inf")) == 1.0 and checker.jst_tanhf_select(float("-inf")) == -1.0
-    assert np.isnan(checker.jst_tanhf_select(float("nan")))
+            assert checker.jst_tanhf_mismatches((e - 64) | sign, 1, 128, C.byref(first), variant) == 0, hex(first.value)
+            assert checker.jst_tanhf_mismatches((e - 0x00800000 - 64) | sign, 1, 128, C.byref(first), variant) == 0
+    fn = checker.jst_tanhf_branchy if variant else checker.jst_tanhf_select
+    assert fn(0.0) == 0.0 and np.signbit(np.float32(fn(-0.0)))
+    assert fn(float("inf")) == 1.0 and fn(float("-inf")) == -1.0
+    assert np.isnan(fn(float("nan")))
