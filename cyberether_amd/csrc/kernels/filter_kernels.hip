@@ -398,24 +398,41 @@ __global__ void siggen_phase_kernel(double* __restrict__ phases, double* __restr
     // x, x - period (Sterbenz) or x + period: a short select chain instead of a libm call.
     // Anything outside that window (first sample of a non-canonical phase, steps beyond one
     // turn, non-finite values) takes the general path below.
-    if (step >= 0.0 && step < period) {
-        for (; i < count && ph >= 0.0 && ph < period; ++i) {
-            phases[i] = ph;
-            const double x = ph + step, y = x - period;
-            if (!(x < 2.0 * period)) break;  // rounding carried x to 2*period: general path
-            ph = x < period ? x : y;
+    // Chunks of 32 samples run branch-free (the loop-carried chain is add, compare, subtract,
+    // select); the window condition is accumulated and checked once per chunk, and a chunk that
+    // left the window is redone by the general loop from its first sample.
+    const bool up = step >= 0.0 && step < period, down = step < 0.0 && step > -period;
+    while (i < count) {
+        if ((up || down) && i + 32 <= count && ph >= 0.0 && ph < period) {
+            double q = ph;
+            bool ok = true;
+            double buf[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                buf[k] = q;
+                const double x = q + step;
+                if (up) {
+                    ok = ok && (x < 2.0 * period);
+                    q = x < period ? x : x - period;
+                } else {
+                    q = x < 0.0 ? x + period : x;
+                    ok = ok && (q < period);
+                }
+            }
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) phases[i + k] = buf[k];
+                ph = q;
+                i += 32;
+                continue;
+            }
         }
-    } else if (step < 0.0 && step > -period) {
-        for (; i < count && ph >= 0.0 && ph < period; ++i) {
+        const uint64_t stop = (count - i < 32) ? count : i + 32;  // general path for this chunk
+        for (; i < stop; ++i) {
             phases[i] = ph;
-            const double x = ph + step;  // in (-period, period): fmod(x) == x
-            ph = x < 0.0 ? x + period : x;
+            const double w = fmod(ph + step, period);
+            ph = w < 0.0 ? w + period : w;
         }
-    }
-    for (; i < count; ++i) {
-        phases[i] = ph;
-        const double w = fmod(ph + step, period);
-        ph = w < 0.0 ? w + period : w;
     }
     state[0] = ph;
 }

@@ -95,6 +95,30 @@ JST_FN float libm_tanhf(float x) {
     return r;
 }
 
+// Correctly rounded a / b for the operand ranges tanhf produces (|b| in [1, 2^64], quotient and
+// residuals far from the subnormal range).  On the device this is the compiler's own FDIV32
+// expansion (rcp, two Newton steps on the reciprocal, two on the quotient, final fma) WITHOUT the
+// v_div_scale / v_div_fixup range handling and its VCC hazards; on the host it is the IEEE divide.
+// Both are correctly rounded, hence equal.
+#if defined(__HIP_DEVICE_COMPILE__)
+JST_FN float div_rn_midrange(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e0, r, r);
+    float q = a * r;
+    const float e1 = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e1, r, q);
+    const float e2 = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e2, r, q);
+}
+#else
+JST_FN float div_rn_midrange(float a, float b) { return a / b; }
+#endif
+// copysign(|magnitude|, sign_of): one v_bfi_b32 instead of a compare + select pair
+JST_FN float with_sign_of(float magnitude, float sign_of) {
+    return u2f((f2u(magnitude) & 0x7fffffffu) | (f2u(sign_of) & 0x80000000u));
+}
+
 // Branch-structured variant of the same two functions, following the published control flow
 // (s_tanhf.c / s_expm1f.c) instead of computing every alternative: on the GPU a divergent `if`
 // costs an exec-mask update and is skipped outright when no lane of the wavefront takes it, which
@@ -106,17 +130,16 @@ JST_FN float libm_expm1f_for_tanh_branchy(float x) {
                     Q3 = -7.9365076090e-05f, Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
     const uint32_t bits = f2u(x);
     const uint32_t hx = bits & 0x7fffffffu;
-    const bool neg = (bits >> 31) != 0;
     int32_t k = 0;
     float c = 0.0f;
     if (hx > 0x3eb17218u) {          // |x| > 0.5 ln2
         float hi, lo;
-        if (hx < 0x3F851592u) {      // and |x| < 1.5 ln2
-            hi = neg ? x + ln2_hi : x - ln2_hi;
-            lo = neg ? -ln2_lo : ln2_lo;
-            k = neg ? -1 : 1;
+        if (hx < 0x3F851592u) {      // and |x| < 1.5 ln2: k = +-1 by the sign of x
+            hi = x - with_sign_of(ln2_hi, x);   // x + ln2_hi == x - (-ln2_hi), bit for bit
+            lo = with_sign_of(ln2_lo, x);
+            k = 1 | ((int32_t)bits >> 31);      // neg ? -1 : 1
         } else {
-            k = (int32_t)(invln2 * x + (neg ? -0.5f : 0.5f));
+            k = (int32_t)(invln2 * x + with_sign_of(0.5f, x));
             const float t = (float)k;
             hi = x - t * ln2_hi;
             lo = t * ln2_lo;
@@ -130,7 +153,7 @@ JST_FN float libm_expm1f_for_tanh_branchy(float x) {
     const float hxs = x * hfx;
     const float r1 = 1.0f + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
     float t = 3.0f - r1 * hfx;
-    float e = hxs * ((r1 - t) / (6.0f - x * t));
+    float e = hxs * div_rn_midrange(r1 - t, 6.0f - x * t);
     if (k == 0) return x - (x * e - hxs);
     e = (x * (e - c) - c);
     e -= hxs;
@@ -156,10 +179,10 @@ JST_FN float libm_tanhf_branchy(float x) {
     const float two_ax = 2.0f * ax;
     // one expm1f evaluation serves both |x| >= 1 (argument 2|x|) and |x| < 1 (argument -2|x|)
     const float t = libm_expm1f_for_tanh_branchy(ge1 ? two_ax : -two_ax);
-    const float q = (ge1 ? 2.0f : t) / (t + 2.0f);
+    const float q = div_rn_midrange(ge1 ? 2.0f : t, t + 2.0f);
     float z = ge1 ? 1.0f - q : -q;             // one - two/(t+two)   |   -t/(t+two)
     if (ix >= 0x41b00000u) z = 1.0f;           // |x| >= 22 (and +-inf): one - tiny == 1.0f
-    float r = ((jx >> 31) != 0) ? -z : z;
+    float r = u2f(f2u(z) ^ (jx & 0x80000000u));  // (jx < 0) ? -z : z
     if (ix < 0x24000000u) r = x * (1.0f + x);  // |x| < 2^-55, including +-0
     if (ix > 0x7f800000u) r = x + x;           // NaN
     return r;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
 #pragma unroll
         for (int cp = 0; cp < COPIES; ++cp) k += hist[cp * copy_stride + e];
         k = k < 64u ? k : 64u;  // 0.02 * 51 > 1: the value is pinned at 1.0f long before 64 hits
-        for (uint32_t n = 0; n < k; ++n) {
+        for (uint32_t n = 0; n < k && w < 1.0f; ++n) {  // 1.0f is a fixed point of the update
             const float t = w + 0.02f;
             w = (1.0f < t) ? 1.0f : t;  // std::min(val + 0.02f, 1.0f)
         }
