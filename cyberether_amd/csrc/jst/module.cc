@@ -166,7 +166,9 @@ Runtime::~Runtime() { (void)destroy(); }
 
 Result Runtime::planOrder(const std::vector<Module*>& modules) {
     // Kahn's algorithm over "module B reads storage that module A produced"
-    // (src/scheduler_synchronous.cc:574-696).  Ties keep insertion order.
+    // (src/scheduler_synchronous.cc:574-696).  Ties keep insertion order; with FUSE a ready
+    // consumer of the module placed last goes first, so that producer/consumer chains end up
+    // adjacent and the fusion hooks (which look at neighbours) can see them.
     const size_t n = modules.size();
     std::map<const void*, size_t> producer;
     for (size_t i = 0; i < n; ++i)
@@ -185,18 +187,23 @@ Result Runtime::planOrder(const std::vector<Module*>& modules) {
     for (size_t i = 0; i < n; ++i) indeg[i] = deps[i].size();
     std::vector<bool> done(n, false);
     ordered_.clear();
+    size_t last = n;
     for (size_t placed = 0; placed < n; ++placed) {
         size_t pick = n;
-        for (size_t i = 0; i < n; ++i)
-            if (!done[i] && indeg[i] == 0) {
-                pick = i;
-                break;
-            }
+        if ((flags_ & FUSE) && last != n)
+            for (size_t u : users[last])
+                if (!done[u] && indeg[u] == 0) {
+                    pick = u;
+                    break;
+                }
+        for (size_t i = 0; pick == n && i < n; ++i)
+            if (!done[i] && indeg[i] == 0) pick = i;
         if (pick == n) {
             JST_ERROR("[SCHEDULER] Module graph contains a cycle.");
             return Result::ERROR;
         }
         done[pick] = true;
+        last = pick;
         ordered_.push_back(modules[pick]);
         for (size_t u : users[pick]) --indeg[u];
     }
@@ -272,7 +279,8 @@ Result Runtime::planUnits() {
 // [-> range] laid out consecutively in the order, with no other consumer of the intermediates
 // (the block wiring of src/domains/dsp/spectrum_engine/block_impl.cc:120-217).
 bool Runtime::tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed) {
-    return modules::TryFuseSpectrum(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
+    return modules::TryFuseSpectrum(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
+           modules::TryFuseFilter(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
 }
 
 Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {

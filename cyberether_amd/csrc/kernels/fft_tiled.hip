@@ -35,6 +35,17 @@ constexpr int kMaxThreads = 1024;  // workgroup size follows the tile: about 4 e
 constexpr uint32_t kTileElems = 8192;  // upper bound per LDS buffer (64 KiB); two buffers ping-pong
 constexpr uint64_t kWantGroups = 1024; // enough workgroups to cover 256 CUs several times
 
+// Pad fused into the first load (core/pad/module_impl_native_cpu.cc:75-140): positions at or beyond
+// `valid` along the transform axis read as zero, everything else comes from the unpadded tensor.
+struct LoadCF32Padded {
+    const float2* in;
+    uint32_t valid;
+    template <bool CONTIG>
+    __device__ __forceinline__ float2 load(int64_t base, int64_t axis_stride, int pos) const {
+        return (uint32_t)pos < valid ? in[base + (int64_t)pos * axis_stride] : mk(0.0f, 0.0f);
+    }
+};
+
 struct TiledPlan {
     uint32_t n, nf, g, R1, S;
     uint32_t CA, CB;        // columns / blocks per workgroup: powers of two (ragged last tile)
@@ -367,6 +378,14 @@ hipError_t launch_fft_c2c_tiled(uint64_t n, bool forward, const FftLayout& L, co
     TiledPlan p;
     if (!make_tiled_plan(n, L.transforms, p)) return hipErrorInvalidValue;
     return dispatch_dir(forward, p, L, W, LoadCF32{in}, StoreCF32{out}, scratch, s);
+}
+
+hipError_t launch_fft_c2c_tiled_padded(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,
+                                       const float2* W, const float2* in, float2* out,
+                                       float2* scratch, hipStream_t s) {
+    TiledPlan p;
+    if (valid > n || !make_tiled_plan(n, L.transforms, p)) return hipErrorInvalidValue;
+    return dispatch_dir(forward, p, L, W, LoadCF32Padded{in, (uint32_t)valid}, StoreCF32{out}, scratch, s);
 }
 
 hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const float2* W,

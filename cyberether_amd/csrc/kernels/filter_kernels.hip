@@ -84,6 +84,44 @@ __global__ __launch_bounds__(kBlock) void fold_kernel(float* __restrict__ out,
     }
 }
 
+// Fold over the last axis of a product a*b that is never written: same index walk as fold_kernel,
+// each addend formed with the Multiply module's arithmetic.
+__global__ __launch_bounds__(kBlock) void fold_product_kernel(float2* __restrict__ out,
+                                                              const float2* __restrict__ a,
+                                                              const float2* __restrict__ b,
+                                                              const EwLayout P, uint64_t axis_size,
+                                                              uint64_t fold_size, uint64_t scalar_offset,
+                                                              const uint64_t* __restrict__ chan_offsets,
+                                                              uint64_t chan_count, uint64_t chan_inner) {
+    const uint64_t decim = axis_size / fold_size, outer = P.size / axis_size;
+    const uint64_t total = outer * fold_size;
+    const double divisor = (double)decim;
+    JST_GRID_STRIDE(e, total) {
+        const uint64_t k = e % fold_size, o = e / fold_size;
+        const uint64_t off = chan_offsets ? chan_offsets[(e / chan_inner) % chan_count] % axis_size
+                                          : scalar_offset;
+        // operand offsets of row o of the product tensor (all axes but the last)
+        int64_t oa = (int64_t)P.offset[1], ob = (int64_t)P.offset[2];
+        uint64_t rem = o;
+        for (int ax = P.rank - 2; ax >= 0; --ax) {
+            const uint64_t c = rem % P.shape[ax];
+            rem /= P.shape[ax];
+            oa += (int64_t)c * P.stride[1][ax];
+            ob += (int64_t)c * P.stride[2][ax];
+        }
+        const int64_t sa = P.stride[1][P.rank - 1], sb = P.stride[2][P.rank - 1];
+        double sr = 0.0, si = 0.0;
+        for (uint64_t g = 0; g < decim; ++g) {
+            const uint64_t shifted = k + g * fold_size;
+            const uint64_t ia = shifted >= off ? shifted - off : axis_size - (off - shifted);
+            const float2 p = jst::dev::cmul_full(a[oa + (int64_t)ia * sa], b[ob + (int64_t)ia * sb]);
+            sr += (double)p.x;
+            si += (double)p.y;
+        }
+        out[e] = jst::dev::mk((float)(sr / divisor), (float)(si / divisor));
+    }
+}
+
 // ---- OverlapAdd (dsp/overlap_add/module_impl_native_cpu.cc:121-202) --------------------------
 struct OlaLayout {
     uint32_t rank;
@@ -624,6 +662,17 @@ hipError_t launch_fold(float* out, const float* in, bool complex, uint64_t outer
         hipLaunchKernelGGL(fold_kernel<false>, dim3(grid_for(total)), dim3(kBlock), 0, s, out, in,
                            outer, axis_size, fold_size, inner, scalar_offset, chan_offsets,
                            chan_count, chan_inner);
+    return hipGetLastError();
+}
+hipError_t launch_fold_product_cf32(float2* out, const float2* a, const float2* b, const EwLayout& P,
+                                    uint64_t axis_size, uint64_t fold_size, uint64_t scalar_offset,
+                                    const uint64_t* chan_offsets, uint64_t chan_count,
+                                    uint64_t chan_inner, hipStream_t s) {
+    if (P.rank < 1 || axis_size == 0 || fold_size == 0) return hipErrorInvalidValue;
+    const uint64_t total = (P.size / axis_size) * fold_size;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(fold_product_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, out, a, b, P,
+                       axis_size, fold_size, scalar_offset, chan_offsets, chan_count, chan_inner);
     return hipGetLastError();
 }
 hipError_t launch_overlap_add(void* out, const void* buf, const void* ovl, void* prev, bool complex,

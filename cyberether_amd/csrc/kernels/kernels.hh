@@ -86,6 +86,11 @@ bool fft_tiled_supported(uint64_t n);
 bool fft_tiled_needs_scratch(uint64_t n);
 hipError_t launch_fft_c2c_tiled(uint64_t n, bool forward, const FftLayout& L, const float2* W,
                                 const float2* in, float2* out, float2* scratch, hipStream_t stream);
+// Pad (zeros appended along the transform axis) fused into the first load: `in` is the UNPADDED
+// tensor (L.in_* describe it), `valid` its extent along the axis, n the padded transform length.
+hipError_t launch_fft_c2c_tiled_padded(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,
+                                       const float2* W, const float2* in, float2* out,
+                                       float2* scratch, hipStream_t stream);
 hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const float2* W,
                                        const float2* in, const float2* window,
                                        int64_t window_stride, float* out, float amp_coeff,
@@ -185,6 +190,13 @@ hipError_t launch_fold(float* out, const float* in, bool complex, uint64_t outer
                        uint64_t fold_size, uint64_t inner, uint64_t scalar_offset,
                        const uint64_t* chan_offsets, uint64_t chan_count, uint64_t chan_inner,
                        hipStream_t s);
+// Multiply (broadcast) fused into Fold: out[o, k] = mean_g( a[..] * b[..] ) with the product formed
+// exactly like the Multiply module (cmul_full, F32) and accumulated like Fold (F64).  P: the
+// multiply's operand layout (operand 0 = the product tensor that is never materialised).
+hipError_t launch_fold_product_cf32(float2* out, const float2* a, const float2* b, const EwLayout& P,
+                                    uint64_t axis_size, uint64_t fold_size, uint64_t scalar_offset,
+                                    const uint64_t* chan_offsets, uint64_t chan_count,
+                                    uint64_t chan_inner, hipStream_t s);
 hipError_t launch_overlap_add(void* out, const void* buf, const void* ovl, void* prev, bool complex,
                               uint32_t rank, int32_t batch_axis, const uint64_t* buf_shape,
                               const uint64_t* ovl_shape, hipStream_t s);

@@ -1149,6 +1149,94 @@ class SignalGenerator : public Module {
     U64 bufferSize = 8192;
 };
 
+// ---- fusion hooks for the Filter block's chain (filter/block_impl.cc:350-582) --------------------
+namespace {
+bool sole_consumer(const std::vector<Module*>& ordered, const Tensor& t, const Module* consumer) {
+    for (const Module* m : ordered) {
+        if (m == consumer) continue;
+        for (const auto& kv : m->inputs())
+            if (kv.second.storageId() == t.storageId()) return false;
+    }
+    return true;
+}
+}  // namespace
+
+bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& name,
+                   std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
+                   size_t& consumed) {
+    if (at + 1 >= ordered.size()) return false;
+    // pad(last axis) -> fft(same axis): the padded tensor is only ever read by the transform
+    if (auto* pad = dynamic_cast<Pad*>(ordered[at])) {
+        auto* fft = dynamic_cast<Fft*>(ordered[at + 1]);
+        if (!fft || fft->input.storageId() != pad->output.storageId()) return false;
+        if (!sole_consumer(ordered, pad->output, fft)) return false;
+        const Index axis = fft->resolvedAxis;
+        if (axis != pad->resolvedAxis || axis + 1 != pad->input.rank()) return false;
+        if (pad->input.dtype() != DataType::CF32 || !pad->input.contiguous() ||
+            !fft->input.contiguous() || fft->input.offset() != 0)
+            return false;
+        if (!fft->useTiled || fft->bluesteinSize != 0) return false;  // decided in computeInitialize
+        members = {pad, fft};
+        consumed = 2;
+        name = "fft_padded(" + pad->name() + "+" + fft->name() + ")";
+        submit = [pad, fft, axis](hipStream_t stream) -> Result {
+            dev::FftLayout L;
+            JST_CHECK(fft->layout(L));
+            int r = 0;  // input side of the layout: the UNPADDED tensor
+            for (Index ax = 0; ax < pad->input.rank(); ++ax) {
+                if (ax == axis) continue;
+                L.in_outer_stride[r++] = (int64_t)pad->input.stride(ax);
+            }
+            L.in_axis_stride = (int64_t)pad->input.stride(axis);
+            L.in_offset = pad->input.offset();
+            return hip_result(
+                kernels::launch_fft_c2c_tiled_padded(
+                    fft->input.shape(axis), pad->input.shape(axis), fft->forward, L, fft->twiddles,
+                    ptr<const float2>(pad->input), ptr<float2>(fft->output),
+                    ptr<float2>(fft->scratchA), stream),
+                "fft (tiled, padded) kernel");
+        };
+        return true;
+    }
+    // multiply(CF32, broadcast) -> fold(last axis): fold reads the operands and forms the product
+    if (auto* mul = dynamic_cast<Multiply*>(ordered[at])) {
+        auto* fold = dynamic_cast<Fold*>(ordered[at + 1]);
+        if (!fold || std::string(mul->type()) != "multiply") return false;
+        if (fold->input.storageId() != mul->c.storageId() || !sole_consumer(ordered, mul->c, fold))
+            return false;
+        if (mul->c.dtype() != DataType::CF32 || !mul->c.contiguous() || mul->c.offset() != 0) return false;
+        if (fold->resolvedAxis + 1 != mul->c.rank() || !fold->output.contiguous()) return false;
+        members = {mul, fold};
+        consumed = 2;
+        name = "fold_product(" + mul->name() + "+" + fold->name() + ")";
+        submit = [mul, fold](hipStream_t stream) -> Result {
+            EwLayout P;
+            if (!MakeEwLayout(mul->c, &mul->a, &mul->b, P)) {
+                JST_ERROR("[MODULE_MULTIPLY] Unsupported tensor rank.");
+                return Result::ERROR;
+            }
+            P.contiguous = 0;  // operands are addressed through their (broadcast) strides
+            const Index axis = fold->resolvedAxis;
+            U64 chanCount = 1, chanInner = 1;
+            if (fold->channelAxis) {
+                chanCount = fold->output.shape(*fold->channelAxis);
+                for (Index i = *fold->channelAxis + 1; i < fold->output.rank(); ++i)
+                    chanInner *= fold->output.shape(i);
+            }
+            return hip_result(
+                kernels::launch_fold_product_cf32(
+                    ptr<float2>(fold->output) + fold->output.offset(), ptr<const float2>(mul->a),
+                    ptr<const float2>(mul->b), P, mul->c.shape(axis), fold->size,
+                    fold->offset % mul->c.shape(axis),
+                    fold->channelAxis ? ptr<const uint64_t>(fold->devOffsets) : nullptr, chanCount,
+                    chanInner, stream),
+                "fold (of product) kernel");
+        };
+        return true;
+    }
+    return false;
+}
+
 JST_REGISTER_MODULE(SignalGenerator, "signal_generator", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Lineplot, "lineplot", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Pad, "pad", DeviceType::HIP, RuntimeType::NATIVE, "generic");

@@ -21,6 +21,12 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                      std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
                      size_t& consumed);
 
+// Filter-chain fusions (filter_modules.cc): pad -> fft (zeros synthesised in the FFT's first load)
+// and multiply -> fold (the broadcast product is never materialised).  Same contract.
+bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& name,
+                   std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
+                   size_t& consumed);
+
 // src/domains/dsp/window/{module_impl.cc, module_impl_native_cpu.cc, module_impl_native_cuda.cc}
 class Window : public Module {
  public:

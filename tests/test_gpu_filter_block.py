@@ -23,7 +23,8 @@ def two_tone(rng, b, s, sr, f1, f2):
     dict(sr=2e6, bw=0.7e6, center=[0.1e6], taps=65, s=960, b=2),            # no resampling, conv 1024
     dict(sr=20e6, bw=2e6, center=[0.0], taps=251, s=15750, b=2),            # conv 16000 (global FFT)
 ])
-def test_filter_block_matches_oracle_chain(js, oracle, case):
+@pytest.mark.parametrize("fuse", [False, True])
+def test_filter_block_matches_oracle_chain(js, oracle, case, fuse):
     rng = np.random.default_rng(1235)
     sr, bw, center, taps, s, b = (case[k] for k in ("sr", "bw", "center", "taps", "s", "b"))
     heads = len(center)
@@ -31,7 +32,14 @@ def test_filter_block_matches_oracle_chain(js, oracle, case):
     blk = js.Filter(src, sr, bw, center, taps, heads)
     plan = blk.plan
     assert plan == js.filter_plan(sr, bw, center, taps, heads, s)
-    rt = js.Runtime(blk.modules, graph=True)
+    rt = js.Runtime(blk.modules, graph=True, fuse=fuse)
+    units = rt.units
+    if fuse:  # pad -> fft and multiply -> fold collapse into one launch each (mixed-radix sizes)
+        conv_is_pow2 = plan["convolutionSize"] & (plan["convolutionSize"] - 1) == 0
+        assert any(u.startswith("fft_padded(") for u in units) == (not conv_is_pow2), units
+        assert any(u.startswith("fold_product(") for u in units) == plan["resample"], units
+    else:
+        assert not any("(" in u for u in units)
     state = {}
     outs = []
     for cycle in range(3):
