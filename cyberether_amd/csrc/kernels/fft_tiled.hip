@@ -32,7 +32,7 @@ using namespace jst::dev;
 namespace {
 
 constexpr int kMaxThreads = 1024;  // workgroup size follows the tile: about 4 elements per thread
-constexpr uint32_t kTileElems = 8192;  // upper bound per LDS buffer (64 KiB); two buffers ping-pong
+constexpr uint32_t kTileElems = 8192;  // upper bound of a tile (64 KiB of LDS, one buffer: passes run in place)
 constexpr uint64_t kWantGroups = 1024; // enough workgroups to cover 256 CUs several times
 
 // Pad fused into the first load (core/pad/module_impl_native_cpu.cc:75-140): positions at or beyond
@@ -52,18 +52,17 @@ struct TiledPlan {
     uint32_t ca_shift, cb_shift;
     uint32_t fact[20];
     uint32_t magic[20];     // ceil(2^32 / local ido of pass p): exact quotients for x < 2^16
+    uint32_t tw_off[20];    // start of pass p in the per-pass twiddle table (fft_pass_twiddle_*)
 };
 
-// Largest of {32,16,8} lanes whose tile fits and that still yields kWantGroups workgroups; the
-// smallest feasible one otherwise; 0 when even 8 lanes do not fit.
-uint32_t pick_lanes(uint32_t len, uint64_t lanes_total, uint32_t max_lanes = 32) {
-    uint32_t best = 0;
-    for (uint32_t c = 8; c <= max_lanes; c *= 2) {
-        if ((uint64_t)len * c > kTileElems) break;
-        if (best && (lanes_total + c - 1) / c < kWantGroups) break;
-        best = c;
-    }
-    return best;
+// Lanes (columns / blocks) per workgroup.  Occupancy decides: a tile of <= 4096 elements means
+// <= 512 threads and 32 KiB of LDS, i.e. three workgroups per CU whose load / pass / store phases
+// overlap; so take the widest of {32,16} lanes that stays within 4096 elements and still yields
+// kWantGroups workgroups, and fall back to 8 lanes (64-byte runs) up to the 8192-element cap.
+uint32_t pick_lanes(uint32_t len, uint64_t lanes_total) {
+    for (uint32_t c = 32; c >= 16; c /= 2)
+        if ((uint64_t)len * c <= 4096 && (lanes_total + c - 1) / c >= kWantGroups) return c;
+    return (uint64_t)len * 8 <= kTileElems ? 8u : 0u;
 }
 uint32_t ilog2(uint32_t v) {
     uint32_t s = 0;
@@ -129,6 +128,13 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
         m /= p.fact[q];
         p.magic[q] = magic_of(m);
     }
+    uint64_t off = 0, l1 = 1;
+    for (uint32_t q = 0; q < p.nf; ++q) {
+        const uint64_t ido = n / (l1 * p.fact[q]);
+        p.tw_off[q] = (uint32_t)off;
+        off += (uint64_t)(p.fact[q] - 1) * ido;
+        l1 *= p.fact[q];
+    }
     return true;
 }
 
@@ -144,49 +150,73 @@ __device__ __forceinline__ void outer_bases(const FftLayout& L, uint64_t t, int6
     }
 }
 
-// One radix-IP pass over an LDS tile.  Element (x, lane) lives at x * pitch + lane; `lanes` (a
-// power of two, 1 << lane_shift) independent sub-transforms of `len` points run side by side.
+// One radix-IP pass over an LDS tile, IN PLACE: every thread first reads the inputs of all of its
+// butterflies into registers, the workgroup synchronises, then the outputs go back to the same
+// buffer (Stockham positions) -- one buffer instead of a ping-pong pair, i.e. half the LDS and
+// twice the resident workgroups per CU.  The workgroup has at least tile/8 threads, so a thread
+// owns at most ceil(8/IP) butterflies: NB below is a compile-time function of the radix.
+// Element (x, lane) lives at x * pitch + lane; `lanes` (1 << lane_shift) independent
+// sub-transforms of `len` points run side by side.
 //   butterfly (i, k):  reads x = i + ido*(j + IP*k), writes x = i + ido*(k + l1loc*c)
-//   twiddle index:     tw_l1 * (tw_i0 + lane + tw_is * i)   (global l1 and global i; < n < 2^26)
+//   twiddle:           PT[(c-1)*ido_glob + ig], ig = tw_i0 + lane*tw_lane + tw_is*i the GLOBAL i of
+//                      the butterfly; PT is this pass's slice of the per-pass table (pocketfft's
+//                      own layout, comp_twiddle :1513-1535: tw[(j-1)*(ido-1)+i-1] = W[j*l1*i]), so
+//                      adjacent lanes read adjacent entries instead of gathering W at stride c*l1.
+template <int IP>
+constexpr int butterflies_per_thread() { return IP <= 3 ? 4 : (IP <= 7 ? 2 : 1); }
+
 template <int IP, bool FWD>
-__device__ __forceinline__ void tile_pass(const float2* __restrict__ src, float2* __restrict__ dst,
-                                          const float2* __restrict__ W, uint32_t len,
-                                          uint32_t lane_shift, uint32_t live_lanes, uint32_t pitch,
-                                          uint32_t ido, uint32_t ido_magic, uint32_t l1loc,
-                                          uint32_t tw_l1, uint32_t tw_is, uint32_t tw_i0,
-                                          uint32_t tw_lane) {
+__device__ __forceinline__ void tile_pass(float2* __restrict__ buf, const float2* __restrict__ PT,
+                                          uint32_t len, uint32_t lane_shift, uint32_t live_lanes,
+                                          uint32_t pitch, uint32_t ido, uint32_t ido_magic,
+                                          uint32_t l1loc, uint32_t ido_glob, uint32_t tw_is,
+                                          uint32_t tw_i0, uint32_t tw_lane) {
+    constexpr int NB = butterflies_per_thread<IP>();
     const uint32_t nb = (len / IP) << lane_shift;
-    for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) {
+    float2 x[NB][IP];
+    uint32_t wr_base[NB], step[NB];  // step = global i of the butterfly; 0xffffffff marks an idle slot
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        const uint32_t b = threadIdx.x + (uint32_t)r * blockDim.x;
         const uint32_t lane = b & ((1u << lane_shift) - 1u), rest = b >> lane_shift;
-        if (lane >= live_lanes) continue;  // ragged last tile
-        const uint32_t k = ido > 1 ? __umulhi(rest, ido_magic) : rest;
-        const uint32_t i = rest - k * ido;
-        float2 x[IP];
-        const float2* rd = src + (i + ido * IP * k) * pitch + lane;
+        step[r] = 0xffffffffu;
+        wr_base[r] = 0;
+        if (b < nb && lane < live_lanes) {
+            const uint32_t k = ido > 1 ? __umulhi(rest, ido_magic) : rest;
+            const uint32_t i = rest - k * ido;
+            const float2* rd = buf + (i + ido * IP * k) * pitch + lane;
 #pragma unroll
-        for (int j = 0; j < IP; ++j) x[j] = rd[(uint32_t)j * ido * pitch];
-        butterfly_any<IP, FWD>(x);
-        const uint32_t ig = tw_i0 + lane * tw_lane + tw_is * i;
-        if (ig != 0) {
-            const uint32_t step = tw_l1 * ig;
-#pragma unroll
-            for (int c = 1; c < IP; ++c) x[c] = special_mul<FWD>(x[c], W[(uint32_t)c * step]);
+            for (int j = 0; j < IP; ++j) x[r][j] = rd[(uint32_t)j * ido * pitch];
+            wr_base[r] = (i + ido * k) * pitch + lane;
+            step[r] = tw_i0 + lane * tw_lane + tw_is * i;
         }
-        float2* wr = dst + (i + ido * k) * pitch + lane;
-#pragma unroll
-        for (int c = 0; c < IP; ++c) wr[(uint32_t)c * l1loc * ido * pitch] = x[c];
     }
+    __syncthreads();  // every input of this pass is in registers
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+        if (step[r] == 0xffffffffu) continue;
+        butterfly_any<IP, FWD>(x[r]);
+        if (step[r] != 0) {
+#pragma unroll
+            for (int c = 1; c < IP; ++c)
+                x[r][c] = special_mul<FWD>(x[r][c], PT[(uint32_t)(c - 1) * ido_glob + step[r]]);
+        }
+        float2* wr = buf + wr_base[r];
+#pragma unroll
+        for (int c = 0; c < IP; ++c) wr[(uint32_t)c * l1loc * ido * pitch] = x[r][c];
+    }
+    __syncthreads();  // outputs visible before the next pass (or the store) reads them
 }
 
 template <bool FWD>
-__device__ __forceinline__ void tile_pass_any(uint32_t ip, const float2* src, float2* dst,
-                                              const float2* W, uint32_t len, uint32_t lane_shift,
-                                              uint32_t live_lanes, uint32_t pitch, uint32_t ido,
-                                              uint32_t ido_magic, uint32_t l1loc, uint32_t tw_l1,
-                                              uint32_t tw_is, uint32_t tw_i0, uint32_t tw_lane) {
+__device__ __forceinline__ void tile_pass_any(uint32_t ip, float2* buf, const float2* PT, uint32_t len,
+                                              uint32_t lane_shift, uint32_t live_lanes, uint32_t pitch,
+                                              uint32_t ido, uint32_t ido_magic, uint32_t l1loc,
+                                              uint32_t ido_glob, uint32_t tw_is, uint32_t tw_i0,
+                                              uint32_t tw_lane) {
 #define JST_TP(IP)                                                                                \
-    tile_pass<IP, FWD>(src, dst, W, len, lane_shift, live_lanes, pitch, ido, ido_magic, l1loc,    \
-                       tw_l1, tw_is, tw_i0, tw_lane)
+    tile_pass<IP, FWD>(buf, PT, len, lane_shift, live_lanes, pitch, ido, ido_magic, l1loc,        \
+                       ido_glob, tw_is, tw_i0, tw_lane)
     switch (ip) {
         case 2: JST_TP(2); break;
         case 3: JST_TP(3); break;
@@ -201,14 +231,13 @@ __device__ __forceinline__ void tile_pass_any(uint32_t ip, const float2* src, fl
 
 // ---- kernel A: passes 0..g-1 on CA adjacent columns ---------------------------------------------
 template <bool FWD, class Pro>
-__global__ __launch_bounds__(kMaxThreads) void fft_tile_columns_kernel(const FftLayout L,
+__global__ __launch_bounds__(kMaxThreads, 6) void fft_tile_columns_kernel(const FftLayout L,
                                                                     const TiledPlan P,
                                                                     const float2* __restrict__ W,
                                                                     const Pro pro,
                                                                     float2* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* buf0 = reinterpret_cast<float2*>(smem_raw);
-    float2* buf1 = buf0 + (size_t)P.R1 * P.CA;
     const uint32_t tiles_per_t = (P.S + P.CA - 1) >> P.ca_shift;
     const uint64_t t = blockIdx.x / tiles_per_t;
     const uint32_t c0 = (blockIdx.x % tiles_per_t) << P.ca_shift;
@@ -222,30 +251,24 @@ __global__ __launch_bounds__(kMaxThreads) void fft_tile_columns_kernel(const Fft
             buf0[idx] = pro.template load<false>(in_base, L.in_axis_stride, (int)(c0 + col + P.S * r));
     }
     __syncthreads();
-    const float2* src = buf0;
-    float2* dst = buf1;
     uint32_t l1 = 1, m = P.R1;
     for (uint32_t p = 0; p < P.g; ++p) {
         const uint32_t ip = P.fact[p];
         m /= ip;  // local ido'
-        tile_pass_any<FWD>(ip, src, dst, W, P.R1, P.ca_shift, live, P.CA, m, P.magic[p], l1, l1, P.S,
-                           c0, 1u);
-        __syncthreads();
-        float2* tmp = const_cast<float2*>(src);
-        src = dst;
-        dst = tmp;
+        tile_pass_any<FWD>(ip, buf0, W + P.tw_off[p], P.R1, P.ca_shift, live, P.CA, m, P.magic[p], l1,
+                           m * P.S, P.S, c0, 1u);
         l1 *= ip;
     }
     float2* o = scratch + t * P.n;
     for (uint32_t idx = threadIdx.x; idx < tile; idx += blockDim.x) {
         const uint32_t r = idx >> P.ca_shift, col = idx & (P.CA - 1u);
-        if (col < live) o[c0 + col + P.S * r] = src[idx];
+        if (col < live) o[c0 + col + P.S * r] = buf0[idx];
     }
 }
 
 // ---- kernel B: passes g..nf-1 on CB adjacent blocks (or whole transforms when g == 0) -----------
 template <bool FWD, class Pro, class Epi>
-__global__ __launch_bounds__(kMaxThreads) void fft_tile_blocks_kernel(const FftLayout L,
+__global__ __launch_bounds__(kMaxThreads, 6) void fft_tile_blocks_kernel(const FftLayout L,
                                                                    const TiledPlan P,
                                                                    const float2* __restrict__ W,
                                                                    const Pro pro, const Epi epi,
@@ -254,7 +277,6 @@ __global__ __launch_bounds__(kMaxThreads) void fft_tile_blocks_kernel(const FftL
     __shared__ int64_t lane_in[32], lane_out[32];  // per lane of the tile: tensor row bases
     const uint32_t pitch = P.CB | 1u;  // odd pitch: the x-major global loops stay conflict-free
     float2* buf0 = reinterpret_cast<float2*>(smem_raw);
-    float2* buf1 = buf0 + (size_t)P.S * pitch;
     // R1 > 1: a tile is CB adjacent blocks of ONE transform; R1 == 1: CB adjacent transforms
     uint64_t t0;
     uint32_t k0, live;
@@ -287,17 +309,12 @@ __global__ __launch_bounds__(kMaxThreads) void fft_tile_blocks_kernel(const FftL
     }
     __syncthreads();
     const float2* src = buf0;
-    float2* dst = buf1;
     uint32_t l1 = P.R1, ido = P.S;
     for (uint32_t p = P.g; p < P.nf; ++p) {
         const uint32_t ip = P.fact[p];
         ido /= ip;
-        tile_pass_any<FWD>(ip, src, dst, W, P.S, P.cb_shift, live, pitch, ido, P.magic[p], l1 / P.R1,
-                           l1, 1u, 0u, 0u);
-        __syncthreads();
-        float2* tmp = const_cast<float2*>(src);
-        src = dst;
-        dst = tmp;
+        tile_pass_any<FWD>(ip, buf0, W + P.tw_off[p], P.S, P.cb_shift, live, pitch, ido, P.magic[p],
+                           l1 / P.R1, ido, 1u, 0u, 0u);
         l1 *= ip;
     }
     // store result q of block (t, k) at k + R1*q: block index fastest when R1 > 1 (adjacent k are
@@ -318,8 +335,10 @@ __global__ __launch_bounds__(kMaxThreads) void fft_tile_blocks_kernel(const FftL
     }
 }
 
+// at least tile/8 threads (the in-place passes hold <= 8 points per thread); a multiple of 256 so
+// that every SIMD of the CU gets the same number of wavefronts and a second / third workgroup fits
 inline unsigned threads_for(uint64_t tile_elems) {
-    uint64_t t = ((tile_elems / 4 + 63) / 64) * 64;
+    uint64_t t = ((tile_elems / 8 + 255) / 256) * 256;
     if (t < 256) t = 256;
     if (t > (uint64_t)kMaxThreads) t = kMaxThreads;
     return (unsigned)t;
@@ -332,7 +351,7 @@ hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W,
     (void)hipGetLastError();
     if (P.g > 0) {
         if (!scratch) return hipErrorInvalidValue;
-        const size_t lds_a = 2 * (size_t)P.R1 * P.CA * sizeof(float2);
+        const size_t lds_a = (size_t)P.R1 * P.CA * sizeof(float2);
         auto ka = fft_tile_columns_kernel<FWD, Pro>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ka),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
@@ -342,7 +361,7 @@ hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W,
         hipLaunchKernelGGL(ka, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.R1 * P.CA)), lds_a, s, L, P, W,
                            pro, scratch);
     }
-    const size_t lds_b = 2 * (size_t)P.S * (P.CB | 1u) * sizeof(float2);
+    const size_t lds_b = (size_t)P.S * (P.CB | 1u) * sizeof(float2);
     auto kb = fft_tile_blocks_kernel<FWD, Pro, Epi>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kb),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
@@ -363,6 +382,35 @@ hipError_t dispatch_dir(bool forward, const TiledPlan& P, const FftLayout& L, co
 }
 
 }  // namespace
+
+// Per-pass twiddle table for the tiled kernels: pass p occupies (ip-1)*ido entries laid out
+// [c-1][i] with value W[c * l1 * i] (i = 0 is present but never read).  Entry count / filler.
+uint64_t fft_pass_twiddle_count(uint64_t n) {
+    uint32_t fact[64];
+    const int nf = fft_plan_factors(n, fact);
+    uint64_t total = 0, l1 = 1;
+    for (int q = 0; q < nf; ++q) {
+        total += (uint64_t)(fact[q] - 1) * (n / (l1 * fact[q]));
+        l1 *= fact[q];
+    }
+    return total;
+}
+void fft_pass_twiddle_fill(uint64_t n, const float* w_interleaved, float* out_interleaved) {
+    uint32_t fact[64];
+    const int nf = fft_plan_factors(n, fact);
+    uint64_t off = 0, l1 = 1;
+    for (int q = 0; q < nf; ++q) {
+        const uint64_t ip = fact[q], ido = n / (l1 * ip);
+        for (uint64_t c = 1; c < ip; ++c)
+            for (uint64_t i = 0; i < ido; ++i) {
+                const uint64_t src = c * l1 * i, dst = off + (c - 1) * ido + i;
+                out_interleaved[2 * dst] = w_interleaved[2 * src];
+                out_interleaved[2 * dst + 1] = w_interleaved[2 * src + 1];
+            }
+        off += (ip - 1) * ido;
+        l1 *= ip;
+    }
+}
 
 bool fft_tiled_supported(uint64_t n) {
     TiledPlan p;

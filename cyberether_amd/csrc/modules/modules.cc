@@ -178,6 +178,29 @@ Result GetTwiddles(U64 n, const float2** table) {
     return Result::SUCCESS;
 }
 
+// Per-pass layout of the same values (tw[(j-1)*ido + i] = W[j*l1*i] for every pass of the plan),
+// cached per n: the LDS-tiled kernels read it with unit stride across adjacent butterflies.
+Result GetPassTwiddles(U64 n, const float2** table) {
+    static std::mutex mu;
+    static std::map<U64, float2*> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(n);
+    if (it == cache.end()) {
+        std::vector<float> w(2 * n);
+        ComputeTwiddles(n, w.data());
+        const U64 count = kernels::fft_pass_twiddle_count(n);
+        std::vector<float> host(2 * (count ? count : 1));
+        kernels::fft_pass_twiddle_fill(n, w.data(), host.data());
+        float2* d = nullptr;
+        JST_HIP_CHECK(hipMalloc(&d, (count ? count : 1) * sizeof(float2)), "hipMalloc(pass twiddles)");
+        JST_HIP_CHECK(hipMemcpy(d, host.data(), count * sizeof(float2), hipMemcpyHostToDevice),
+                      "hipMemcpy(pass twiddles)");
+        it = cache.emplace(n, d).first;
+    }
+    *table = it->second;
+    return Result::SUCCESS;
+}
+
 // ---- Window ------------------------------------------------------------------------------------
 Result Window::validate() {
     bool ok = true;
@@ -603,6 +626,7 @@ Result Fft::computeInitialize() {
     const U64 m = bluesteinSize ? bluesteinSize : n;
     JST_CHECK(GetTwiddles(m, &twiddles));
     useTiled = !kernels::fft_lds_supported(m) && kernels::fft_tiled_supported(m);
+    if (useTiled) JST_CHECK(GetPassTwiddles(m, &twiddles));  // the tiled kernels' table layout
     useGlobalPasses = !kernels::fft_lds_supported(m) && !useTiled;
     if (useTiled && kernels::fft_tiled_needs_scratch(m))
         JST_CHECK(scratchA.create(device(), DataType::CF32, {transforms * m}));

@@ -11,6 +11,7 @@ namespace jst::modules {
 
 // Device-resident pocketfft twiddle table W[k] = exp(+j 2 pi k / n), k in [0,n), cached per n.
 Result GetTwiddles(U64 n, const float2** table);
+Result GetPassTwiddles(U64 n, const float2** table);  // per-pass layout for the tiled kernels
 // Host generator (exposed for tests through the C ABI): pocketfft sincos_2pibyn<float> scheme.
 void ComputeTwiddles(U64 n, float* interleaved);
 
