@@ -378,11 +378,13 @@ uint64_t good_size_cmplx(uint64_t n) {
     return bestfac;
 }
 }  // namespace
-uint64_t fft_bluestein_size(uint64_t n) {
+uint64_t fft_bluestein_size(uint64_t n) { return fft_bluestein_size_scaled(n, 1.0); }
+// pocketfft_r weighs the direct plan with 0.5 (:2522), pocketfft_c with 1 (:2482)
+uint64_t fft_bluestein_size_scaled(uint64_t n, double direct_cost_factor) {
     if (n == 0) return 0;
     const uint64_t lpf = (n < 50) ? 0 : largest_prime_factor(n);
     if (lpf * lpf <= n) return 0;
-    const double comp1 = cost_guess(n);
+    const double comp1 = direct_cost_factor * cost_guess(n);
     double comp2 = 2 * cost_guess(good_size_cmplx(2 * n - 1));
     comp2 *= 1.5;  // the reference's fudge factor
     return (comp2 < comp1) ? good_size_cmplx(2 * n - 1) : 0;

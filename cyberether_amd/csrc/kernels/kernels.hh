@@ -103,6 +103,24 @@ hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const flo
 // convolution length n2 = good_size_cmplx(2n-1).  The three elementwise steps of fftblue::fft
 // (:2370-2399) around the two n2-point transforms; akf: dense CF32[transforms * n2].
 uint64_t fft_bluestein_size(uint64_t n);
+uint64_t fft_bluestein_size_scaled(uint64_t n, double direct_cost_factor);
+
+// ---- real-input transforms (rfft.hip): pocketfft rfftp, radices 2/3/4/5 ------------------------
+// Dense F32[transforms][n] work rows; tw = rfft_twiddle_fill layout (rfftp::comp_twiddle).
+int rfft_plan_factors(uint64_t n, uint32_t* factors /*[64]*/);
+bool rfft_supported(uint64_t n);        // plan uses radices <= 5 only (no radfg / radbg)
+uint64_t rfft_bluestein_size(uint64_t n);  // pocketfft_r's choice: 0 = rfftp, else n2
+uint64_t rfft_twiddle_count(uint64_t n);
+void rfft_twiddle_fill(uint64_t n, const float* w_interleaved, float* out);
+hipError_t launch_rfft_gather(const FftLayout& L, float* dense, const float* in, uint64_t n, hipStream_t s);
+hipError_t launch_rfft_scatter(const FftLayout& L, float* out, const float* dense, uint64_t n,
+                               bool complex_out, hipStream_t s);
+hipError_t launch_rfft_passes(uint64_t n, bool r2hc, uint64_t transforms, float* a, float* b,
+                              const float* tw, float** result, hipStream_t s);
+hipError_t launch_rfft_blue_in(float2* c, const float* dense, uint64_t transforms, uint64_t n, bool r2hc,
+                               hipStream_t s);
+hipError_t launch_rfft_blue_out(float* dense, const float2* c, uint64_t transforms, uint64_t n, bool r2hc,
+                                hipStream_t s);
 hipError_t launch_bluestein_pre(bool forward, const FftLayout& L, float2* akf, const float2* in,
                                 const float2* bk, uint64_t n, uint64_t n2, hipStream_t stream);
 hipError_t launch_bluestein_mul(bool forward, float2* akf, const float2* bkf, uint64_t transforms,

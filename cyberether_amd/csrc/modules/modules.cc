@@ -587,13 +587,20 @@ Result Fft::validate() {
         JST_ERROR("[MODULE_FFT] Input must contain valid signal axis metadata.");
         return Result::ERROR;
     }
-    if (in.dtype() != DataType::CF32) {
-        JST_ERROR("[MODULE_FFT_NATIVE_HIP] Data type '%s' is not implemented on the HIP device "
-                  "(CF32 complex-to-complex only).",
+    if (in.dtype() != DataType::CF32 && in.dtype() != DataType::F32) {
+        JST_ERROR("[MODULE_FFT_NATIVE_HIP] Data type '%s' is not implemented on the HIP device.",
                   DataTypeName(in.dtype()));
         return Result::ERROR;
     }
     const U64 n = in.shape(*axes.sample);
+    realInput = in.dtype() == DataType::F32;
+    complexOut = realInput && forward && complexOutput;  // fft/module_impl.cc:33-38
+    if (realInput && !kernels::rfft_supported(n) && kernels::rfft_bluestein_size(n) == 0) {
+        JST_ERROR("[MODULE_FFT_NATIVE_HIP] Real transform length %llu needs FFTPACK's generic radix "
+                  "(a prime factor above 5), which is not implemented on the HIP device.",
+                  (unsigned long long)n);
+        return Result::ERROR;
+    }
     if (!kernels::fft_lds_supported(n) && !kernels::fft_global_supported(n)) {
         JST_ERROR("[MODULE_FFT_NATIVE_HIP] Transform length %llu exceeds the supported range.",
                   (unsigned long long)n);
@@ -613,6 +620,14 @@ Result Fft::define() {
 }
 Result Fft::create() {
     input = inputs_.at("signal");
+    if (complexOut) {  // r2c: n/2 + 1 complex bins along the transform axis
+        Shape os = input.shape();
+        os[resolvedAxis] = input.shape(resolvedAxis) / 2 + 1;
+        JST_CHECK(output.create(device(), DataType::CF32, os));
+        JST_CHECK(output.propagateAttributes(input));
+        produced("signal", output);
+        return Result::SUCCESS;
+    }
     JST_CHECK(output.create(device(), input.dtype(), input.shape()));
     JST_CHECK(output.propagateAttributes(input));
     produced("signal", output);
@@ -621,7 +636,22 @@ Result Fft::create() {
 Result Fft::computeInitialize() {
     const U64 n = input.shape(resolvedAxis);
     const U64 transforms = input.size() / n;
-    bluesteinSize = kernels::fft_bluestein_size(n);
+    bluesteinSize = realInput ? kernels::rfft_bluestein_size(n) : kernels::fft_bluestein_size(n);
+    if (realInput) {
+        JST_CHECK(realA.create(device(), DataType::F32, {transforms * n}));
+        JST_CHECK(realB.create(device(), DataType::F32, {transforms * n}));
+        if (bluesteinSize) {
+            JST_CHECK(realLine.create(device(), DataType::CF32, {transforms * n}));
+        } else {
+            std::vector<float> w(2 * n), tw(kernels::rfft_twiddle_count(n) + 1, 0.0f);
+            ComputeTwiddles(n, w.data());
+            kernels::rfft_twiddle_fill(n, w.data(), tw.data());
+            JST_CHECK(realTw.create(device(), DataType::F32, {(U64)tw.size()}));
+            JST_CHECK(realTw.copyFromHost(tw.data(), tw.size() * sizeof(float), nullptr));
+            JST_HIP_CHECK(hipStreamSynchronize(nullptr), "hipStreamSynchronize(rfft twiddles)");
+            return Result::SUCCESS;  // no complex machinery needed
+        }
+    }
     // the length the pass kernels actually run at: n, or the Bluestein convolution length
     const U64 m = bluesteinSize ? bluesteinSize : n;
     JST_CHECK(GetTwiddles(m, &twiddles));
@@ -680,6 +710,10 @@ Result Fft::computeDeinitialize() {
     scratchA = Tensor();
     scratchB = Tensor();
     scratchH = Tensor();
+    realA = Tensor();
+    realB = Tensor();
+    realTw = Tensor();
+    realLine = Tensor();
     akf = Tensor();
     bk = Tensor();
     bkf = Tensor();
@@ -724,42 +758,70 @@ Result Fft::layout(FftLayout& L) const {
     L.out_offset = output.offset();
     return Result::SUCCESS;
 }
-Result Fft::computeSubmit(hipStream_t stream) {
-    FftLayout L;
-    JST_CHECK(layout(L));
+Result Fft::submitComplex(const FftLayout& L, const float2* in, float2* out, bool fwd,
+                          hipStream_t stream) {
+    const U64 n = input.shape(resolvedAxis);
     if (bluesteinSize) {  // fftblue::fft (pocketfft.hh:2370-2399)
-        const U64 n = input.shape(resolvedAxis), n2 = bluesteinSize;
-        JST_CHECK(hip_result(kernels::launch_bluestein_pre(forward, L, ptr<float2>(akf),
-                                                           ptr<const float2>(input),
+        const U64 n2 = bluesteinSize;
+        JST_CHECK(hip_result(kernels::launch_bluestein_pre(fwd, L, ptr<float2>(akf), in,
                                                            ptr<const float2>(bk), n, n2, stream),
                              "bluestein chirp kernel"));
         JST_CHECK(innerTransform(ptr<float2>(akf), n2, L.transforms, true, stream));
-        JST_CHECK(hip_result(kernels::launch_bluestein_mul(forward, ptr<float2>(akf),
+        JST_CHECK(hip_result(kernels::launch_bluestein_mul(fwd, ptr<float2>(akf),
                                                            ptr<const float2>(bkf), L.transforms,
                                                            n2, stream),
                              "bluestein convolution kernel"));
         JST_CHECK(innerTransform(ptr<float2>(akf), n2, L.transforms, false, stream));
-        return hip_result(kernels::launch_bluestein_post(forward, L, ptr<float2>(output),
-                                                         ptr<const float2>(akf),
+        return hip_result(kernels::launch_bluestein_post(fwd, L, out, ptr<const float2>(akf),
                                                          ptr<const float2>(bk), n, n2, stream),
                           "bluestein output kernel");
     }
     if (useTiled)
-        return hip_result(
-            kernels::launch_fft_c2c_tiled(input.shape(resolvedAxis), forward, L, twiddles,
-                                          ptr<const float2>(input), ptr<float2>(output),
-                                          ptr<float2>(scratchA), stream),
-            "fft (tiled) kernel");
+        return hip_result(kernels::launch_fft_c2c_tiled(n, fwd, L, twiddles, in, out,
+                                                        ptr<float2>(scratchA), stream),
+                          "fft (tiled) kernel");
     if (useGlobalPasses)
-        return hip_result(
-            kernels::launch_fft_c2c_global(input.shape(resolvedAxis), forward, L, twiddles,
-                                           ptr<const float2>(input), ptr<float2>(output),
-                                           ptr<float2>(scratchA), ptr<float2>(scratchB),
-                                           ptr<float2>(scratchH), stream),
-            "fft (global passes) kernel");
-    return hip_result(kernels::launch_fft_c2c(input.shape(resolvedAxis), forward, L, twiddles,
-                                              ptr<const float2>(input), ptr<float2>(output), stream),
-                      "fft kernel");
+        return hip_result(kernels::launch_fft_c2c_global(n, fwd, L, twiddles, in, out,
+                                                         ptr<float2>(scratchA), ptr<float2>(scratchB),
+                                                         ptr<float2>(scratchH), stream),
+                          "fft (global passes) kernel");
+    return hip_result(kernels::launch_fft_c2c(n, fwd, L, twiddles, in, out, stream), "fft kernel");
+}
+Result Fft::computeSubmit(hipStream_t stream) {
+    FftLayout L;
+    JST_CHECK(layout(L));
+    if (!realInput)
+        return submitComplex(L, ptr<const float2>(input), ptr<float2>(output), forward, stream);
+    // F32 input: gather rows, rfftp passes (or Bluestein on a complex line), scatter / re-pack
+    const U64 n = input.shape(resolvedAxis);
+    const bool r2hc = forward;  // r2r_fftpack(real2hermitian = forward, forward), and r2c
+    JST_CHECK(hip_result(kernels::launch_rfft_gather(L, ptr<float>(realA), ptr<const float>(input), n,
+                                                     stream),
+                         "rfft gather kernel"));
+    float* result = ptr<float>(realA);
+    if (bluesteinSize) {  // fftblue::exec_r (pocketfft.hh:2434-2457)
+        JST_CHECK(hip_result(kernels::launch_rfft_blue_in(ptr<float2>(realLine), ptr<const float>(realA),
+                                                          L.transforms, n, r2hc, stream),
+                             "rfft bluestein pack kernel"));
+        FftLayout D;
+        std::memset(&D, 0, sizeof(D));
+        D.transforms = L.transforms;
+        D.outer_rank = 1;
+        D.outer_shape[0] = L.transforms;
+        D.in_outer_stride[0] = D.out_outer_stride[0] = (int64_t)n;
+        D.in_axis_stride = D.out_axis_stride = 1;
+        JST_CHECK(submitComplex(D, ptr<const float2>(realLine), ptr<float2>(realLine), r2hc, stream));
+        JST_CHECK(hip_result(kernels::launch_rfft_blue_out(ptr<float>(realA), ptr<const float2>(realLine),
+                                                           L.transforms, n, r2hc, stream),
+                             "rfft bluestein unpack kernel"));
+    } else {
+        JST_CHECK(hip_result(kernels::launch_rfft_passes(n, r2hc, L.transforms, ptr<float>(realA),
+                                                         ptr<float>(realB), ptr<const float>(realTw),
+                                                         &result, stream),
+                             "rfft pass kernels"));
+    }
+    return hip_result(kernels::launch_rfft_scatter(L, ptr<float>(output), result, n, complexOut, stream),
+                      "rfft scatter kernel");
 }
 
 // ---- Amplitude ---------------------------------------------------------------------------------

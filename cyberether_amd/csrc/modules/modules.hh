@@ -122,6 +122,12 @@ class Fft : public Module {
     Result layout(dev::FftLayout& L) const;
     // one dense batch of `length`-point transforms, in place in `data` (the Bluestein inner FFTs)
     Result innerTransform(float2* data, U64 length, U64 transforms, bool fwd, hipStream_t stream);
+    // the complex transform of length n described by L (cfftp passes or Bluestein)
+    Result submitComplex(const dev::FftLayout& L, const float2* in, float2* out, bool fwd,
+                         hipStream_t stream);
+    // F32 input (fft/module_impl_native_cpu.cc:142-167): r2r_fftpack (halfcomplex) or r2c
+    bool realInput = false, complexOut = false;
+    Tensor realA, realB, realTw, realLine;  // dense F32 work rows, rfftp twiddles, Bluestein line
     Tensor input, output, scratchA, scratchB, scratchH;
     // which kernels run the passes at the working length (n, or the Bluestein length):
     // register/LDS kernels (2^k <= 16384), the LDS-tiled mixed-radix path, or one launch per pass

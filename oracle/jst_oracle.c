@@ -1000,6 +1000,476 @@ int jst_oracle_fft_c2c(const float* in, float* out, uint64_t n, uint64_t batch, 
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Real transforms: pocketfft's rfftp (FFTPACK halfcomplex), pocketfft.hh:1553-2358, for plans with
+ * radices 2, 3, 4, 5 (the generic radfg/radbg are not restated), plus fftblue::exec_r and the
+ * pocketfft_r plan choice (:2362-2457, 2508-2530).  The FFT module's F32 paths:
+ * r2r_fftpack(forward, forward) and r2c (module_impl_native_cpu.cc:142-167).
+ * ---------------------------------------------------------------------------------------- */
+#define RWA(x, i) wa[(i) + (x) * (ido - 1)]
+#define MULPM(a, b, c, d, e, f) { a = (c) * (e) + (d) * (f); b = (c) * (f) - (d) * (e); }
+
+static void radf2(uint64_t ido, uint64_t l1, const float* cc, float* ch, const float* wa) {
+#define CC(a, b, c) cc[(a) + ido * ((b) + l1 * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + 2 * (c))]
+    for (uint64_t k = 0; k < l1; k++) {
+        CH(0, 0, k) = CC(0, k, 0) + CC(0, k, 1);
+        CH(ido - 1, 1, k) = CC(0, k, 0) - CC(0, k, 1);
+    }
+    if ((ido & 1) == 0)
+        for (uint64_t k = 0; k < l1; k++) {
+            CH(0, 1, k) = -CC(ido - 1, k, 1);
+            CH(ido - 1, 0, k) = CC(ido - 1, k, 0);
+        }
+    if (ido <= 2) return;
+    for (uint64_t k = 0; k < l1; k++)
+        for (uint64_t i = 2; i < ido; i += 2) {
+            const uint64_t ic = ido - i;
+            float tr2, ti2;
+            MULPM(tr2, ti2, RWA(0, i - 2), RWA(0, i - 1), CC(i - 1, k, 1), CC(i, k, 1))
+            CH(i - 1, 0, k) = CC(i - 1, k, 0) + tr2;
+            CH(ic - 1, 1, k) = CC(i - 1, k, 0) - tr2;
+            CH(i, 0, k) = ti2 + CC(i, k, 0);
+            CH(ic, 1, k) = ti2 - CC(i, k, 0);
+        }
+#undef CC
+#undef CH
+}
+#define REARRANGE(rx, ix, ry, iy) { const float t1 = rx + ry, t2 = ry - rx, t3 = ix + iy, t4 = ix - iy; rx = t1; ix = t3; ry = t4; iy = t2; }
+static void radf3(uint64_t ido, uint64_t l1, const float* cc, float* ch, const float* wa) {
+    const float taur = -0.5f, taui = (float)0.8660254037844386467637231707529362L;
+#define CC(a, b, c) cc[(a) + ido * ((b) + l1 * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + 3 * (c))]
+    for (uint64_t k = 0; k < l1; k++) {
+        const float cr2 = CC(0, k, 1) + CC(0, k, 2);
+        CH(0, 0, k) = CC(0, k, 0) + cr2;
+        CH(0, 2, k) = taui * (CC(0, k, 2) - CC(0, k, 1));
+        CH(ido - 1, 1, k) = CC(0, k, 0) + taur * cr2;
+    }
+    if (ido == 1) return;
+    for (uint64_t k = 0; k < l1; k++)
+        for (uint64_t i = 2; i < ido; i += 2) {
+            const uint64_t ic = ido - i;
+            float di2, di3, dr2, dr3;
+            MULPM(dr2, di2, RWA(0, i - 2), RWA(0, i - 1), CC(i - 1, k, 1), CC(i, k, 1))
+            MULPM(dr3, di3, RWA(1, i - 2), RWA(1, i - 1), CC(i - 1, k, 2), CC(i, k, 2))
+            REARRANGE(dr2, di2, dr3, di3)
+            CH(i - 1, 0, k) = CC(i - 1, k, 0) + dr2;
+            CH(i, 0, k) = CC(i, k, 0) + di2;
+            const float tr2 = CC(i - 1, k, 0) + taur * dr2, ti2 = CC(i, k, 0) + taur * di2;
+            const float tr3 = taui * dr3, ti3 = taui * di3;
+            CH(i - 1, 2, k) = tr2 + tr3;
+            CH(ic - 1, 1, k) = tr2 - tr3;
+            CH(i, 2, k) = ti3 + ti2;
+            CH(ic, 1, k) = ti3 - ti2;
+        }
+#undef CC
+#undef CH
+}
+static void radf4(uint64_t ido, uint64_t l1, const float* cc, float* ch, const float* wa) {
+    const float hsqt2 = (float)0.707106781186547524400844362104849L;
+#define CC(a, b, c) cc[(a) + ido * ((b) + l1 * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + 4 * (c))]
+    for (uint64_t k = 0; k < l1; k++) {
+        const float tr1 = CC(0, k, 3) + CC(0, k, 1);
+        CH(0, 2, k) = CC(0, k, 3) - CC(0, k, 1);
+        const float tr2 = CC(0, k, 0) + CC(0, k, 2);
+        CH(ido - 1, 1, k) = CC(0, k, 0) - CC(0, k, 2);
+        CH(0, 0, k) = tr2 + tr1;
+        CH(ido - 1, 3, k) = tr2 - tr1;
+    }
+    if ((ido & 1) == 0)
+        for (uint64_t k = 0; k < l1; k++) {
+            const float ti1 = -hsqt2 * (CC(ido - 1, k, 1) + CC(ido - 1, k, 3));
+            const float tr1 = hsqt2 * (CC(ido - 1, k, 1) - CC(ido - 1, k, 3));
+            CH(ido - 1, 0, k) = CC(ido - 1, k, 0) + tr1;
+            CH(ido - 1, 2, k) = CC(ido - 1, k, 0) - tr1;
+            CH(0, 3, k) = ti1 + CC(ido - 1, k, 2);
+            CH(0, 1, k) = ti1 - CC(ido - 1, k, 2);
+        }
+    if (ido <= 2) return;
+    for (uint64_t k = 0; k < l1; k++)
+        for (uint64_t i = 2; i < ido; i += 2) {
+            const uint64_t ic = ido - i;
+            float ci2, ci3, ci4, cr2, cr3, cr4;
+            MULPM(cr2, ci2, RWA(0, i - 2), RWA(0, i - 1), CC(i - 1, k, 1), CC(i, k, 1))
+            MULPM(cr3, ci3, RWA(1, i - 2), RWA(1, i - 1), CC(i - 1, k, 2), CC(i, k, 2))
+            MULPM(cr4, ci4, RWA(2, i - 2), RWA(2, i - 1), CC(i - 1, k, 3), CC(i, k, 3))
+            const float tr1 = cr4 + cr2, tr4 = cr4 - cr2, ti1 = ci2 + ci4, ti4 = ci2 - ci4;
+            const float tr2 = CC(i - 1, k, 0) + cr3, tr3 = CC(i - 1, k, 0) - cr3;
+            const float ti2 = CC(i, k, 0) + ci3, ti3 = CC(i, k, 0) - ci3;
+            CH(i - 1, 0, k) = tr2 + tr1;
+            CH(ic - 1, 3, k) = tr2 - tr1;
+            CH(i, 0, k) = ti1 + ti2;
+            CH(ic, 3, k) = ti1 - ti2;
+            CH(i - 1, 2, k) = tr3 + ti4;
+            CH(ic - 1, 1, k) = tr3 - ti4;
+            CH(i, 2, k) = tr4 + ti3;
+            CH(ic, 1, k) = tr4 - ti3;
+        }
+#undef CC
+#undef CH
+}
+static void radf5(uint64_t ido, uint64_t l1, const float* cc, float* ch, const float* wa) {
+    const float tr11 = (float)0.3090169943749474241022934171828191L, ti11 = (float)0.9510565162951535721164393333793821L,
+                tr12 = (float)-0.8090169943749474241022934171828191L, ti12 = (float)0.5877852522924731291687059546390728L;
+#define CC(a, b, c) cc[(a) + ido * ((b) + l1 * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + 5 * (c))]
+    for (uint64_t k = 0; k < l1; k++) {
+        const float cr2 = CC(0, k, 4) + CC(0, k, 1), ci5 = CC(0, k, 4) - CC(0, k, 1);
+        const float cr3 = CC(0, k, 3) + CC(0, k, 2), ci4 = CC(0, k, 3) - CC(0, k, 2);
+        CH(0, 0, k) = CC(0, k, 0) + cr2 + cr3;
+        CH(ido - 1, 1, k) = CC(0, k, 0) + tr11 * cr2 + tr12 * cr3;
+        CH(0, 2, k) = ti11 * ci5 + ti12 * ci4;
+        CH(ido - 1, 3, k) = CC(0, k, 0) + tr12 * cr2 + tr11 * cr3;
+        CH(0, 4, k) = ti12 * ci5 - ti11 * ci4;
+    }
+    if (ido == 1) return;
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 2, ic = ido - 2; i < ido; i += 2, ic -= 2) {
+            float di2, di3, di4, di5, dr2, dr3, dr4, dr5;
+            MULPM(dr2, di2, RWA(0, i - 2), RWA(0, i - 1), CC(i - 1, k, 1), CC(i, k, 1))
+            MULPM(dr3, di3, RWA(1, i - 2), RWA(1, i - 1), CC(i - 1, k, 2), CC(i, k, 2))
+            MULPM(dr4, di4, RWA(2, i - 2), RWA(2, i - 1), CC(i - 1, k, 3), CC(i, k, 3))
+            MULPM(dr5, di5, RWA(3, i - 2), RWA(3, i - 1), CC(i - 1, k, 4), CC(i, k, 4))
+            REARRANGE(dr2, di2, dr5, di5)
+            REARRANGE(dr3, di3, dr4, di4)
+            CH(i - 1, 0, k) = CC(i - 1, k, 0) + dr2 + dr3;
+            CH(i, 0, k) = CC(i, k, 0) + di2 + di3;
+            const float tr2 = CC(i - 1, k, 0) + tr11 * dr2 + tr12 * dr3, ti2 = CC(i, k, 0) + tr11 * di2 + tr12 * di3;
+            const float tr3 = CC(i - 1, k, 0) + tr12 * dr2 + tr11 * dr3, ti3 = CC(i, k, 0) + tr12 * di2 + tr11 * di3;
+            const float tr5 = ti11 * dr5 + ti12 * dr4, ti5 = ti11 * di5 + ti12 * di4;
+            const float tr4 = ti12 * dr5 - ti11 * dr4, ti4 = ti12 * di5 - ti11 * di4;
+            CH(i - 1, 2, k) = tr2 + tr5;
+            CH(ic - 1, 1, k) = tr2 - tr5;
+            CH(i, 2, k) = ti5 + ti2;
+            CH(ic, 1, k) = ti5 - ti2;
+            CH(i - 1, 4, k) = tr3 + tr4;
+            CH(ic - 1, 3, k) = tr3 - tr4;
+            CH(i, 4, k) = ti4 + ti3;
+            CH(ic, 3, k) = ti4 - ti3;
+        }
+#undef CC
+#undef CH
+}
+static void radb2(uint64_t ido, uint64_t l1, const float* cc, float* ch, const float* wa) {
+#define CC(a, b, c) cc[(a) + ido * ((b) + 2 * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + l1 * (c))]
+    for (uint64_t k = 0; k < l1; k++) {
+        CH(0, k, 0) = CC(0, 0, k) + CC(ido - 1, 1, k);
+        CH(0, k, 1) = CC(0, 0, k) - CC(ido - 1, 1, k);
+    }
+    if ((ido & 1) == 0)
+        for (uint64_t k = 0; k < l1; k++) {
+            CH(ido - 1, k, 0) = 2 * CC(ido - 1, 0, k);
+            CH(ido - 1, k, 1) = -2 * CC(0, 1, k);
+        }
+    if (ido <= 2) return;
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 2; i < ido; i += 2) {
+            const uint64_t ic = ido - i;
+            CH(i - 1, k, 0) = CC(i - 1, 0, k) + CC(ic - 1, 1, k);
+            const float tr2 = CC(i - 1, 0, k) - CC(ic - 1, 1, k);
+            const float ti2 = CC(i, 0, k) + CC(ic, 1, k);
+            CH(i, k, 0) = CC(i, 0, k) - CC(ic, 1, k);
+            MULPM(CH(i, k, 1), CH(i - 1, k, 1), RWA(0, i - 2), RWA(0, i - 1), ti2, tr2)
+        }
+#undef CC
+#undef CH
+}
+static void radb3(uint64_t ido, uint64_t l1, const float* cc, float* ch, const float* wa) {
+    const float taur = -0.5f, taui = (float)0.8660254037844386467637231707529362L;
+#define CC(a, b, c) cc[(a) + ido * ((b) + 3 * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + l1 * (c))]
+    for (uint64_t k = 0; k < l1; k++) {
+        const float tr2 = 2 * CC(ido - 1, 1, k);
+        const float cr2 = CC(0, 0, k) + taur * tr2;
+        CH(0, k, 0) = CC(0, 0, k) + tr2;
+        const float ci3 = 2 * taui * CC(0, 2, k);
+        CH(0, k, 2) = cr2 + ci3;
+        CH(0, k, 1) = cr2 - ci3;
+    }
+    if (ido == 1) return;
+    for (uint64_t k = 0; k < l1; k++)
+        for (uint64_t i = 2, ic = ido - 2; i < ido; i += 2, ic -= 2) {
+            const float tr2 = CC(i - 1, 2, k) + CC(ic - 1, 1, k), ti2 = CC(i, 2, k) - CC(ic, 1, k);
+            const float cr2 = CC(i - 1, 0, k) + taur * tr2, ci2 = CC(i, 0, k) + taur * ti2;
+            CH(i - 1, k, 0) = CC(i - 1, 0, k) + tr2;
+            CH(i, k, 0) = CC(i, 0, k) + ti2;
+            const float cr3 = taui * (CC(i - 1, 2, k) - CC(ic - 1, 1, k)), ci3 = taui * (CC(i, 2, k) + CC(ic, 1, k));
+            const float dr3 = cr2 + ci3, dr2 = cr2 - ci3, di2 = ci2 + cr3, di3 = ci2 - cr3;
+            MULPM(CH(i, k, 1), CH(i - 1, k, 1), RWA(0, i - 2), RWA(0, i - 1), di2, dr2)
+            MULPM(CH(i, k, 2), CH(i - 1, k, 2), RWA(1, i - 2), RWA(1, i - 1), di3, dr3)
+        }
+#undef CC
+#undef CH
+}
+static void radb4(uint64_t ido, uint64_t l1, const float* cc, float* ch, const float* wa) {
+    const float sqrt2 = (float)1.414213562373095048801688724209698L;
+#define CC(a, b, c) cc[(a) + ido * ((b) + 4 * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + l1 * (c))]
+    for (uint64_t k = 0; k < l1; k++) {
+        const float tr2 = CC(0, 0, k) + CC(ido - 1, 3, k), tr1 = CC(0, 0, k) - CC(ido - 1, 3, k);
+        const float tr3 = 2 * CC(ido - 1, 1, k), tr4 = 2 * CC(0, 2, k);
+        CH(0, k, 0) = tr2 + tr3;
+        CH(0, k, 2) = tr2 - tr3;
+        CH(0, k, 3) = tr1 + tr4;
+        CH(0, k, 1) = tr1 - tr4;
+    }
+    if ((ido & 1) == 0)
+        for (uint64_t k = 0; k < l1; k++) {
+            const float ti1 = CC(0, 3, k) + CC(0, 1, k), ti2 = CC(0, 3, k) - CC(0, 1, k);
+            const float tr2 = CC(ido - 1, 0, k) + CC(ido - 1, 2, k), tr1 = CC(ido - 1, 0, k) - CC(ido - 1, 2, k);
+            CH(ido - 1, k, 0) = tr2 + tr2;
+            CH(ido - 1, k, 1) = sqrt2 * (tr1 - ti1);
+            CH(ido - 1, k, 2) = ti2 + ti2;
+            CH(ido - 1, k, 3) = -sqrt2 * (tr1 + ti1);
+        }
+    if (ido <= 2) return;
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 2; i < ido; i += 2) {
+            const uint64_t ic = ido - i;
+            const float tr2 = CC(i - 1, 0, k) + CC(ic - 1, 3, k), tr1 = CC(i - 1, 0, k) - CC(ic - 1, 3, k);
+            const float ti1 = CC(i, 0, k) + CC(ic, 3, k), ti2 = CC(i, 0, k) - CC(ic, 3, k);
+            const float tr4 = CC(i, 2, k) + CC(ic, 1, k), ti3 = CC(i, 2, k) - CC(ic, 1, k);
+            const float tr3 = CC(i - 1, 2, k) + CC(ic - 1, 1, k), ti4 = CC(i - 1, 2, k) - CC(ic - 1, 1, k);
+            CH(i - 1, k, 0) = tr2 + tr3;
+            const float cr3 = tr2 - tr3;
+            CH(i, k, 0) = ti2 + ti3;
+            const float ci3 = ti2 - ti3;
+            const float cr4 = tr1 + tr4, cr2 = tr1 - tr4, ci2 = ti1 + ti4, ci4 = ti1 - ti4;
+            MULPM(CH(i, k, 1), CH(i - 1, k, 1), RWA(0, i - 2), RWA(0, i - 1), ci2, cr2)
+            MULPM(CH(i, k, 2), CH(i - 1, k, 2), RWA(1, i - 2), RWA(1, i - 1), ci3, cr3)
+            MULPM(CH(i, k, 3), CH(i - 1, k, 3), RWA(2, i - 2), RWA(2, i - 1), ci4, cr4)
+        }
+#undef CC
+#undef CH
+}
+static void radb5(uint64_t ido, uint64_t l1, const float* cc, float* ch, const float* wa) {
+    const float tr11 = (float)0.3090169943749474241022934171828191L, ti11 = (float)0.9510565162951535721164393333793821L,
+                tr12 = (float)-0.8090169943749474241022934171828191L, ti12 = (float)0.5877852522924731291687059546390728L;
+#define CC(a, b, c) cc[(a) + ido * ((b) + 5 * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + l1 * (c))]
+    for (uint64_t k = 0; k < l1; k++) {
+        const float ti5 = CC(0, 2, k) + CC(0, 2, k), ti4 = CC(0, 4, k) + CC(0, 4, k);
+        const float tr2 = CC(ido - 1, 1, k) + CC(ido - 1, 1, k), tr3 = CC(ido - 1, 3, k) + CC(ido - 1, 3, k);
+        CH(0, k, 0) = CC(0, 0, k) + tr2 + tr3;
+        const float cr2 = CC(0, 0, k) + tr11 * tr2 + tr12 * tr3, cr3 = CC(0, 0, k) + tr12 * tr2 + tr11 * tr3;
+        float ci4, ci5;
+        MULPM(ci5, ci4, ti5, ti4, ti11, ti12)
+        CH(0, k, 4) = cr2 + ci5;
+        CH(0, k, 1) = cr2 - ci5;
+        CH(0, k, 3) = cr3 + ci4;
+        CH(0, k, 2) = cr3 - ci4;
+    }
+    if (ido == 1) return;
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 2, ic = ido - 2; i < ido; i += 2, ic -= 2) {
+            const float tr2 = CC(i - 1, 2, k) + CC(ic - 1, 1, k), tr5 = CC(i - 1, 2, k) - CC(ic - 1, 1, k);
+            const float ti5 = CC(i, 2, k) + CC(ic, 1, k), ti2 = CC(i, 2, k) - CC(ic, 1, k);
+            const float tr3 = CC(i - 1, 4, k) + CC(ic - 1, 3, k), tr4 = CC(i - 1, 4, k) - CC(ic - 1, 3, k);
+            const float ti4 = CC(i, 4, k) + CC(ic, 3, k), ti3 = CC(i, 4, k) - CC(ic, 3, k);
+            CH(i - 1, k, 0) = CC(i - 1, 0, k) + tr2 + tr3;
+            CH(i, k, 0) = CC(i, 0, k) + ti2 + ti3;
+            const float cr2 = CC(i - 1, 0, k) + tr11 * tr2 + tr12 * tr3, ci2 = CC(i, 0, k) + tr11 * ti2 + tr12 * ti3;
+            const float cr3 = CC(i - 1, 0, k) + tr12 * tr2 + tr11 * tr3, ci3 = CC(i, 0, k) + tr12 * ti2 + tr11 * ti3;
+            float ci4, ci5, cr5, cr4;
+            MULPM(cr5, cr4, tr5, tr4, ti11, ti12)
+            MULPM(ci5, ci4, ti5, ti4, ti11, ti12)
+            const float dr4 = cr3 + ci4, dr3 = cr3 - ci4, di3 = ci3 + cr4, di4 = ci3 - cr4;
+            const float dr5 = cr2 + ci5, dr2 = cr2 - ci5, di2 = ci2 + cr5, di5 = ci2 - cr5;
+            MULPM(CH(i, k, 1), CH(i - 1, k, 1), RWA(0, i - 2), RWA(0, i - 1), di2, dr2)
+            MULPM(CH(i, k, 2), CH(i - 1, k, 2), RWA(1, i - 2), RWA(1, i - 1), di3, dr3)
+            MULPM(CH(i, k, 3), CH(i - 1, k, 3), RWA(2, i - 2), RWA(2, i - 1), di4, dr4)
+            MULPM(CH(i, k, 4), CH(i - 1, k, 4), RWA(3, i - 2), RWA(3, i - 1), di5, dr5)
+        }
+#undef CC
+#undef CH
+}
+#undef REARRANGE
+#undef MULPM
+#undef RWA
+
+/* rfftp::factorize (:2277-2297): 4s, a lone 2 moved to the front, odd divisors ascending. */
+int jst_oracle_rfft_factors(uint64_t n, uint32_t* fact) {
+    int nf = 0;
+    uint64_t len = n;
+    if (len <= 1) return 0;
+    while ((len % 4) == 0) { fact[nf++] = 4; len >>= 2; }
+    if ((len % 2) == 0) {
+        len >>= 1;
+        fact[nf++] = 2;
+        const uint32_t t = fact[0];
+        fact[0] = fact[nf - 1];
+        fact[nf - 1] = t;
+    }
+    for (uint64_t d = 3; d * d <= len; d += 2)
+        while ((len % d) == 0) { fact[nf++] = (uint32_t)d; len /= d; }
+    if (len > 1) fact[nf++] = (uint32_t)len;
+    return nf;
+}
+/* pocketfft_r's plan choice (:2508-2527): 0 = rfftp, else the Bluestein length. */
+uint64_t jst_oracle_rfft_bluestein_size(uint64_t n) {
+    if (n == 0) return 0;
+    const uint64_t lpf = (n < 50) ? 0 : largest_prime_factor(n);
+    if (lpf * lpf <= n) return 0;
+    const double comp1 = 0.5 * cost_guess(n);
+    double comp2 = 2 * cost_guess(good_size_cmplx(2 * n - 1));
+    comp2 *= 1.5;
+    return (comp2 < comp1) ? good_size_cmplx(2 * n - 1) : 0;
+}
+
+typedef struct {
+    uint64_t n;
+    int nf;
+    uint32_t fact[64];
+    float* mem;
+    const float* tw[64];
+} rfftp_t;
+static int rfftp_init(rfftp_t* p, uint64_t n) {
+    memset(p, 0, sizeof(*p));
+    p->n = n;
+    if (n == 0) return -1;
+    if (n == 1) return 0;
+    p->nf = jst_oracle_rfft_factors(n, p->fact);
+    for (int k = 0; k < p->nf; ++k)
+        if (p->fact[k] > 5) return -2; /* radfg / radbg are not restated */
+    uint64_t twsz = 0, l1 = 1;
+    for (int k = 0; k < p->nf; ++k) {
+        const uint64_t ip = p->fact[k], ido = n / (l1 * ip);
+        twsz += (ip - 1) * (ido - 1);
+        l1 *= ip;
+    }
+    p->mem = (float*)calloc(twsz + 1, sizeof(float));
+    sincos_t s;
+    sincos_init(&s, n);
+    float* ptr = p->mem;
+    l1 = 1;
+    for (int k = 0; k < p->nf; ++k) { /* comp_twiddle :2311-2345 */
+        const uint64_t ip = p->fact[k], ido = n / (l1 * ip);
+        if (k < p->nf - 1) {
+            p->tw[k] = ptr;
+            for (uint64_t j = 1; j < ip; ++j)
+                for (uint64_t i = 1; i <= (ido - 1) / 2; ++i) {
+                    const c32 w = sincos_get(&s, j * l1 * i);
+                    ptr[(j - 1) * (ido - 1) + 2 * i - 2] = w.r;
+                    ptr[(j - 1) * (ido - 1) + 2 * i - 1] = w.i;
+                }
+            ptr += (ip - 1) * (ido - 1);
+        }
+        l1 *= ip;
+    }
+    sincos_free(&s);
+    return 0;
+}
+static void rfftp_free(rfftp_t* p) { free(p->mem); }
+/* rfftp::exec with fct == 1 (:2228-2272): c transformed in place, ch scratch. */
+static void rfftp_exec(const rfftp_t* p, float* c, float* ch, int r2hc) {
+    const uint64_t n = p->n;
+    if (n == 1) return;
+    float *p1 = c, *p2 = ch;
+    if (r2hc) {
+        uint64_t l1 = n;
+        for (int k1 = 0; k1 < p->nf; ++k1) {
+            const int k = p->nf - k1 - 1;
+            const uint64_t ip = p->fact[k], ido = n / l1;
+            l1 /= ip;
+            if (ip == 4) radf4(ido, l1, p1, p2, p->tw[k]);
+            else if (ip == 2) radf2(ido, l1, p1, p2, p->tw[k]);
+            else if (ip == 3) radf3(ido, l1, p1, p2, p->tw[k]);
+            else radf5(ido, l1, p1, p2, p->tw[k]);
+            float* t = p1; p1 = p2; p2 = t;
+        }
+    } else {
+        uint64_t l1 = 1;
+        for (int k = 0; k < p->nf; ++k) {
+            const uint64_t ip = p->fact[k], ido = n / (ip * l1);
+            if (ip == 4) radb4(ido, l1, p1, p2, p->tw[k]);
+            else if (ip == 2) radb2(ido, l1, p1, p2, p->tw[k]);
+            else if (ip == 3) radb3(ido, l1, p1, p2, p->tw[k]);
+            else radb5(ido, l1, p1, p2, p->tw[k]);
+            float* t = p1; p1 = p2; p2 = t;
+            l1 *= ip;
+        }
+    }
+    if (p1 != c) memcpy(c, p1, n * sizeof(float));
+}
+/* One real line in place: halfcomplex forward (r2hc) or backward; Bluestein via fftblue::exec_r
+ * (:2434-2457).  Returns 0, -2 when the plan needs radfg/radbg. */
+static int rfft_line(float* c, uint64_t n, int r2hc, const rfftp_t* rp, const fftblue_t* bp,
+                     float* scratch, c32* ctmp, c32* akf, c32* cscr) {
+    if (bp) {
+        if (r2hc) {
+            const float zero = 0.0f * c[0];
+            for (uint64_t m = 0; m < n; ++m) { ctmp[m].r = c[m]; ctmp[m].i = zero; }
+            fftblue_exec(bp, ctmp, akf, cscr, 1);
+            c[0] = ctmp[0].r;
+            memcpy(c + 1, &ctmp[1].r, (n - 1) * sizeof(float));
+        } else {
+            ctmp[0].r = c[0];
+            ctmp[0].i = c[0] * 0.0f;
+            memcpy(&ctmp[1].r, c + 1, (n - 1) * sizeof(float));
+            if ((n & 1) == 0) ctmp[n / 2].i = 0.0f * c[0];
+            for (uint64_t m = 1; 2 * m < n; ++m) { ctmp[n - m].r = ctmp[m].r; ctmp[n - m].i = -ctmp[m].i; }
+            fftblue_exec(bp, ctmp, akf, cscr, 0);
+            for (uint64_t m = 0; m < n; ++m) c[m] = ctmp[m].r;
+        }
+        return 0;
+    }
+    rfftp_exec(rp, c, scratch, r2hc);
+    return 0;
+}
+/* r2r_fftpack(real2hermitian = forward, forward) over dense rows (module_impl_native_cpu.cc:155-165). */
+int jst_oracle_fft_r2r(const float* in, float* out, uint64_t n, uint64_t batch, int forward) {
+    if (n == 0) return -1;
+    const uint64_t n2 = jst_oracle_rfft_bluestein_size(n);
+    rfftp_t rp;
+    fftblue_t bp;
+    int rc = 0;
+    if (n2) { if (fftblue_init(&bp, n, n2) != 0) return -1; }
+    else if ((rc = rfftp_init(&rp, n)) != 0) return rc;
+    float* scratch = (float*)malloc((n + 1) * sizeof(float));
+    c32* ctmp = (c32*)malloc((n + 1) * sizeof(c32));
+    c32* akf = (c32*)malloc(((n2 ? n2 : 1)) * sizeof(c32));
+    c32* cscr = (c32*)malloc(((n2 ? n2 : 1)) * sizeof(c32));
+    for (uint64_t r = 0; r < batch; ++r) {
+        float* row = out + r * n;
+        memcpy(row, in + r * n, n * sizeof(float));
+        rfft_line(row, n, forward, n2 ? NULL : &rp, n2 ? &bp : NULL, scratch, ctmp, akf, cscr);
+    }
+    free(scratch); free(ctmp); free(akf); free(cscr);
+    if (n2) fftblue_free(&bp); else rfftp_free(&rp);
+    return 0;
+}
+/* r2c forward (general_r2c, pocketfft.hh:3102-3150): n reals -> n/2+1 complex per row. */
+int jst_oracle_fft_r2c(const float* in, float* out, uint64_t n, uint64_t batch) {
+    if (n == 0) return -1;
+    const uint64_t n2 = jst_oracle_rfft_bluestein_size(n), no = n / 2 + 1;
+    rfftp_t rp;
+    fftblue_t bp;
+    int rc = 0;
+    if (n2) { if (fftblue_init(&bp, n, n2) != 0) return -1; }
+    else if ((rc = rfftp_init(&rp, n)) != 0) return rc;
+    float* t = (float*)malloc((n + 1) * sizeof(float));
+    float* scratch = (float*)malloc((n + 1) * sizeof(float));
+    c32* ctmp = (c32*)malloc((n + 1) * sizeof(c32));
+    c32* akf = (c32*)malloc(((n2 ? n2 : 1)) * sizeof(c32));
+    c32* cscr = (c32*)malloc(((n2 ? n2 : 1)) * sizeof(c32));
+    for (uint64_t r = 0; r < batch; ++r) {
+        memcpy(t, in + r * n, n * sizeof(float));
+        rfft_line(t, n, 1, n2 ? NULL : &rp, n2 ? &bp : NULL, scratch, ctmp, akf, cscr);
+        float* o = out + 2 * r * no;
+        o[0] = t[0];
+        o[1] = 0.0f;
+        uint64_t i = 1, ii = 1;
+        for (; i < n - 1; i += 2, ++ii) { o[2 * ii] = t[i]; o[2 * ii + 1] = t[i + 1]; }
+        if (i < n) { o[2 * ii] = t[i]; o[2 * ii + 1] = 0.0f; }
+    }
+    free(t); free(scratch); free(ctmp); free(akf); free(cscr);
+    if (n2) fftblue_free(&bp); else rfftp_free(&rp);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Amplitude.  src/domains/dsp/amplitude/module_impl.cc:44-60 (coefficient) and
  * module_impl_native_cpu.cc:73-99 (kernels); Backend::ApproxLog10 is
  * include/jetstream/backend/devices/cpu/helpers.hh:59-74 (frexpf + cubic, separate mul/add).

@@ -151,6 +151,39 @@ def fft_c2c(x: np.ndarray, forward: bool = True) -> np.ndarray:
     return out
 
 
+def fft_r2r(x: np.ndarray, forward: bool = True) -> np.ndarray:
+    """Restated pocketfft r2r_fftpack over the LAST axis (halfcomplex FFTPACK format).  Raises
+    NotImplementedError for plans that need the generic radix (a prime factor > 5 without Bluestein)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.shape[-1]
+    out = np.empty_like(x)
+    rc = lib().jst_oracle_fft_r2r(_p(x), _p(out), C.c_uint64(n), C.c_uint64(x.size // n if n else 0),
+                                  C.c_int(1 if forward else 0))
+    if rc == -2:
+        raise NotImplementedError(f"rfftp plan of {n} needs radfg/radbg")
+    if rc != 0:
+        raise ValueError("zero-length FFT requested")
+    return out
+
+
+def fft_r2c(x: np.ndarray) -> np.ndarray:
+    """Restated pocketfft r2c (forward) over the LAST axis: n reals -> n//2+1 complex."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n = x.shape[-1]
+    out = np.empty(x.shape[:-1] + (n // 2 + 1,), np.complex64)
+    rc = lib().jst_oracle_fft_r2c(_p(x), _p(out), C.c_uint64(n), C.c_uint64(x.size // n if n else 0))
+    if rc == -2:
+        raise NotImplementedError(f"rfftp plan of {n} needs radfg/radbg")
+    if rc != 0:
+        raise ValueError("zero-length FFT requested")
+    return out
+
+
+def rfft_bluestein_size(n: int) -> int:
+    lib().jst_oracle_rfft_bluestein_size.restype = C.c_uint64
+    return int(lib().jst_oracle_rfft_bluestein_size(C.c_uint64(n)))
+
+
 def fft_bluestein_size(n: int) -> int:
     """0 when pocketfft_c plans a cfftp of n, else the Bluestein convolution length n2."""
     lib().jst_oracle_fft_bluestein_size.restype = C.c_uint64

@@ -25,6 +25,16 @@ def signal(n: int) -> np.ndarray:
     return (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(np.complex64)
 
 
+REAL_LENGTHS = [1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 24, 25, 27, 30, 32, 36, 45, 48, 50, 60, 64, 75,
+                81, 100, 120, 125, 128, 150, 243, 256, 360, 500, 625, 1000, 1024, 2000,
+                191, 199, 211, 257, 401, 523]   # the last six: pocketfft_r picks Bluestein
+
+
+def real_signal(n: int) -> np.ndarray:
+    rng = np.random.default_rng(19700101 + n)
+    return rng.standard_normal((2, n)).astype(np.float32)
+
+
 def main():
     assert oracle.have_ref(), "oracle/_ref not built"
     out = {"lengths": np.array(LENGTHS, np.int64)}
@@ -33,6 +43,13 @@ def main():
         out[f"fwd_{n}"] = oracle.ref_fft_c2c(x, 1, True)
         out[f"bwd_{n}"] = oracle.ref_fft_c2c(x, 1, False)
         out[f"blue_{n}"] = np.array(oracle.fft_bluestein_size(n), np.int64)
+    out["real_lengths"] = np.array(REAL_LENGTHS, np.int64)
+    for n in REAL_LENGTHS:
+        x = real_signal(n)
+        out[f"r2r_fwd_{n}"] = oracle.ref_fft_r2r(x, 1, True)
+        out[f"r2r_bwd_{n}"] = oracle.ref_fft_r2r(x, 1, False)
+        out[f"r2c_{n}"] = oracle.ref_fft_r2c(x, 1)
+        out[f"rblue_{n}"] = np.array(oracle.rfft_bluestein_size(n), np.int64)
     np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pocketfft_ref_vectors.npz"), **out)
     kinds = sum(1 for n in LENGTHS if oracle.fft_bluestein_size(n))
     print(f"{len(LENGTHS)} lengths, {kinds} of them Bluestein")

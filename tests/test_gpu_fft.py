@@ -159,7 +159,45 @@ def test_bluestein_strided_and_special_values(js, oracle):
     assert np.array_equal(got.view(np.uint32)[fin], ref.view(np.uint32)[fin])
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 25, 27, 32, 45, 64, 100, 125, 128, 243, 360,
+                               1000, 1024, 4096, 6000, 8100, 65536,       # rfftp radices 2/3/4/5
+                               191, 211, 257, 401, 4099, 8191])                # pocketfft_r picks Bluestein
+def test_real_input_transforms_bit_exact(js, oracle, n):
+    """F32 input (fft/module_impl_native_cpu.cc:142-167): r2r_fftpack forward and backward
+    (FFTPACK halfcomplex) and r2c (complexOutput), all bit-identical to pocketfft's rfftp."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((3, n)).astype(np.float32)
+    t = lambda: js.Tensor.from_numpy(x, sample=1, batch=0)
+    m, out = run_module(js, "fft", {"forward": True}, {"signal": t()})
+    assert out["signal"].dtype == np.float32
+    assert_bit_equal(out["signal"], oracle.fft_r2r(x, True), f"r2r forward n={n}")
+    _, out = run_module(js, "fft", {"forward": False}, {"signal": t()})
+    assert_bit_equal(out["signal"], oracle.fft_r2r(x, False), f"r2r backward n={n}")
+    m, out = run_module(js, "fft", {"forward": True, "complexOutput": True}, {"signal": t()})
+    assert out["signal"].dtype == np.complex64 and out["signal"].shape == (3, n // 2 + 1)
+    assert_bit_equal(out["signal"], oracle.fft_r2c(x), f"r2c n={n}")
+    # complexOutput is only honoured for forward transforms of real input (fft/module_impl.cc:33-38)
+    m, out = run_module(js, "fft", {"forward": False, "complexOutput": True}, {"signal": t()})
+    assert out["signal"].dtype == np.float32 and out["signal"].shape == (3, n)
+
+
+def test_real_input_reference_kats_and_layouts(js, oracle):
+    """fft/module_tests.cc:149-223 (FFTPACK real forward / backward KATs) + a strided leading axis."""
+    _, out = run_module(js, "fft", {"forward": True}, {"signal": js.Tensor.from_numpy(np.array([1, 2, 3, 4], np.float32))})
+    assert np.allclose(out["signal"], [10.0, -2.0, 2.0, -2.0], atol=1e-4)
+    _, out = run_module(js, "fft", {"forward": False},
+                        {"signal": js.Tensor.from_numpy(np.array([10, -2, 2, -2], np.float32))})
+    assert np.allclose(out["signal"], [4.0, 8.0, 12.0, 16.0], atol=1e-4)       # unnormalised inverse
+    rng = np.random.default_rng(1)
+    lead = rng.standard_normal((60, 4)).astype(np.float32)                      # transform along axis 0
+    _, out = run_module(js, "fft", {"forward": True, "complexOutput": True},
+                        {"signal": js.Tensor.from_numpy(lead, sample=0, batch=1)})
+    assert_bit_equal(out["signal"], np.ascontiguousarray(oracle.fft_r2c(np.ascontiguousarray(lead.T)).T))
+
+
 def test_unsupported_cases_fail_loudly(js):
-    r = np.zeros((2, 16), np.float32)
-    with pytest.raises(js.JetstreamError, match="not implemented"):
+    r = np.zeros((2, 14), np.float32)      # 14 = 2 * 7: FFTPACK's generic radix (radfg) is not built
+    with pytest.raises(js.JetstreamError, match="generic radix"):
         js.Module("fft", {}, {"signal": js.Tensor.from_numpy(r, sample=1, batch=0)})
+    with pytest.raises(js.JetstreamError, match="not implemented"):
+        js.Module("fft", {}, {"signal": js.Tensor.from_numpy(np.zeros((2, 16), np.float64), sample=1, batch=0)})

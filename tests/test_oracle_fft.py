@@ -101,3 +101,43 @@ def test_restatement_matches_committed_reference_vectors(oracle):
         for key, fwd in (("fwd", True), ("bwd", False)):
             assert np.array_equal(oracle.fft_c2c(x, fwd).view(np.uint32), gold[f"{key}_{n}"].view(np.uint32)), (n, key)
     assert blue >= 8
+
+
+def test_real_transforms_bit_exact_vs_reference_pocketfft(oracle):
+    """rfftp (radices 2/3/4/5) and the real Bluestein path vs the reference, every supported length
+    up to 420 plus large ones; lengths that need radfg/radbg are reported as unsupported."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    rng = np.random.default_rng(11)
+    supported = 0
+    for n in list(range(1, 420)) + [1000, 1024, 4096, 6000, 8100, 16000, 65536, 4099, 8191]:
+        x = rng.standard_normal((2, n)).astype(np.float32)
+        try:
+            fwd = oracle.fft_r2r(x, True)
+        except NotImplementedError:
+            continue
+        supported += 1
+        assert np.array_equal(fwd.view(np.uint32), oracle.ref_fft_r2r(x, 1, True).view(np.uint32)), n
+        assert np.array_equal(oracle.fft_r2r(x, False).view(np.uint32),
+                              oracle.ref_fft_r2r(x, 1, False).view(np.uint32)), n
+        assert np.array_equal(oracle.fft_r2c(x).view(np.uint32), oracle.ref_fft_r2c(x, 1).view(np.uint32)), n
+    assert supported >= 100
+
+
+def test_real_restatement_matches_committed_reference_vectors(oracle):
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from make_pocketfft_golden import real_signal
+    gold = np.load(os.path.join(here, "golden", "pocketfft_ref_vectors.npz"))
+    blue = 0
+    for n in gold["real_lengths"]:
+        n = int(n)
+        x = real_signal(n)
+        assert oracle.rfft_bluestein_size(n) == int(gold[f"rblue_{n}"]), n
+        blue += int(gold[f"rblue_{n}"]) != 0
+        assert np.array_equal(oracle.fft_r2r(x, True).view(np.uint32), gold[f"r2r_fwd_{n}"].view(np.uint32)), n
+        assert np.array_equal(oracle.fft_r2r(x, False).view(np.uint32), gold[f"r2r_bwd_{n}"].view(np.uint32)), n
+        assert np.array_equal(oracle.fft_r2c(x).view(np.uint32), gold[f"r2c_{n}"].view(np.uint32)), n
+    assert blue >= 5
