@@ -532,7 +532,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
                 if (pipelined()) r = capturePipelined(timing);
                 else
                     for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c)
-                        r = submitAll(timing, c, false);
+                        r = submitAll(timing && (c % timingStride()) == 0, c, false);
                 hipGraph_t g = nullptr;
                 const hipError_t e = hipStreamEndCapture(stream_, &g);
                 if (r != Result::SUCCESS) {
@@ -555,7 +555,9 @@ Result Runtime::compute(U64 cycles, bool sync) {
             for (auto& u : units_) {  // (the in-graph nodes overwrite any unread eager samples)
                 if (u.is_static && u.settled) continue;
                 for (Module* m : u.modules) m->timing.cycles += period_;
-                if (timing) std::fill(u.span.recorded.begin(), u.span.recorded.end(), true);
+                if (timing)  // the graph holds event nodes for every timingStride()-th cycle only
+                    for (size_t c = 0; c < u.span.recorded.size(); ++c)
+                        u.span.recorded[c] = !pipelined() ? (c % timingStride()) == 0 : true;
             }
             timing_pending_ = timing;
             cycles_ += period_;

@@ -175,6 +175,9 @@ class Runtime {
     Result planOrder(const std::vector<Module*>& modules);
     Result planUnits();
     bool tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed);
+    // In a captured period only every timingStride()-th cycle carries event-record nodes: a pair
+    // costs ~2 us of queue time, sampling keeps Module::Timing live at a quarter of that cost.
+    U64 timingStride() const { return period_ >= 8 ? 4 : 1; }
     Result submitAll(bool record_events, U64 event_slot, bool count_cycles);
     Result harvestTiming();
     Result eagerCycle(bool& needs_sync);
