@@ -353,9 +353,14 @@ hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W,
         if (!scratch) return hipErrorInvalidValue;
         const size_t lds_a = (size_t)P.R1 * P.CA * sizeof(float2);
         auto ka = fft_tile_columns_kernel<FWD, Pro>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ka),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a);
-        if (e != hipSuccess) return e;
+        static bool raised_a = false;  // once per instantiation: tiles never exceed kTileElems
+        if (!raised_a) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ka),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(kTileElems * sizeof(float2)));
+            if (e != hipSuccess) return e;
+            raised_a = true;
+        }
         const uint64_t blocks = L.transforms * ((P.S + P.CA - 1) / P.CA);
         if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
         hipLaunchKernelGGL(ka, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.R1 * P.CA)), lds_a, s, L, P, W,
@@ -363,9 +368,15 @@ hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W,
     }
     const size_t lds_b = (size_t)P.S * (P.CB | 1u) * sizeof(float2);
     auto kb = fft_tile_blocks_kernel<FWD, Pro, Epi>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kb),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b);
-    if (e != hipSuccess) return e;
+    static bool raised_b = false;  // pitch CB|1 adds at most one lane of padding per row
+    if (!raised_b) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kb),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)(2 * kTileElems * sizeof(float2)));
+        if (e != hipSuccess) return e;
+        raised_b = true;
+    }
+    if (lds_b > 2 * kTileElems * sizeof(float2)) return hipErrorInvalidValue;
     const uint64_t blocks = P.R1 > 1 ? L.transforms * ((P.R1 + P.CB - 1) / P.CB)
                                      : (L.transforms + P.CB - 1) / P.CB;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;

@@ -1,8 +1,8 @@
 // rfft.hip -- real-input transforms of the FFT module: pocketfft's rfftp (FFTPACK halfcomplex
 // passes radf2/3/4/5 and radb2/3/4/5, pocketfft.hh:1574-2075) for the two calls the reference
 // makes with F32 input, r2r_fftpack(real2hermitian = forward, forward) and r2c
-// (src/domains/dsp/fft/module_impl_native_cpu.cc:142-167).  Plans with a radix above 5 would need
-// radfg / radbg, which are not restated: the module rejects those lengths.
+// (src/domains/dsp/fft/module_impl_native_cpu.cc:142-167), plus the generic radix radfg / radbg
+// (:1753-1893, 2076-2208) for prime factors above 5.
 //
 // Not a hot path (the spectrum chain casts F32 to CF32 first): one launch per pass over dense
 // F32[transforms][n] ping-pong buffers, one thread per work item.  A pass with (l1, ido) has, per
@@ -280,6 +280,217 @@ __global__ __launch_bounds__(kBlock) void rfft_pass_kernel(const float* __restri
     }
 }
 
+// ---- generic radix (radfg / radbg, pocketfft.hh:1753-1893, 2076-2208) ---------------------------
+// The reference walks whole arrays in phases and uses BOTH buffers (cc is overwritten); each phase
+// is independent per butterfly (j pair, k, i) or per column ik = i + ido*k, so every phase becomes
+// one launch.  C1/CH(a,b,c) = x[a + ido*(b + l1*c)], CC(a,b,c) = x[a + ido*(b + ip*c)],
+// C2/CH2(a,b) = x[a + idl1*b]; csarr = the ip-th roots of unity (comp_twiddle's tws).
+struct GenDims {
+    uint32_t n, ido, ip, l1, ipph, idl1, items;  // items = 1 + (ido-1)/2 per (j pair, k)
+};
+#define C1(x, a, b, c) x[(a) + d.ido * ((b) + d.l1 * (c))]
+#define CCX(x, a, b, c) x[(a) + d.ido * ((b) + d.ip * (c))]
+#define C2(x, a, b) x[(a) + d.idl1 * (b)]
+
+// radfg phase 1+2 (in place on cc): twiddle the (j, jc) pairs, MPINPLACE on i = 0
+__global__ __launch_bounds__(kBlock) void radfg_pre_kernel(float* __restrict__ ccbuf,
+                                                           const float* __restrict__ wa, GenDims d,
+                                                           uint64_t transforms) {
+    const uint64_t per_t = (uint64_t)(d.ipph - 1) * d.l1 * d.items, total = transforms * per_t;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        float* cc = ccbuf + (g / per_t) * d.n;
+        uint32_t w = (uint32_t)(g % per_t);
+        const uint32_t item = w % d.items;
+        w /= d.items;
+        const uint32_t k = w % d.l1, j = 1 + w / d.l1, jc = d.ip - j;
+        if (item == 0) {  // MPINPLACE(C1(0,k,jc), C1(0,k,j))
+            const float t = C1(cc, 0, k, jc);
+            C1(cc, 0, k, jc) = C1(cc, 0, k, jc) - C1(cc, 0, k, j);
+            C1(cc, 0, k, j) = t + C1(cc, 0, k, j);
+            continue;
+        }
+        const uint32_t i = 2 * item - 1;
+        const uint32_t idij = (j - 1) * (d.ido - 1) + i - 1, idij2 = (jc - 1) * (d.ido - 1) + i - 1;
+        const float t1 = C1(cc, i, k, j), t2 = C1(cc, i + 1, k, j), t3 = C1(cc, i, k, jc), t4 = C1(cc, i + 1, k, jc);
+        const float x1 = wa[idij] * t1 + wa[idij + 1] * t2, x2 = wa[idij] * t2 - wa[idij + 1] * t1,
+                    x3 = wa[idij2] * t3 + wa[idij2 + 1] * t4, x4 = wa[idij2] * t4 - wa[idij2 + 1] * t3;
+        C1(cc, i, k, j) = x3 + x1;
+        C1(cc, i + 1, k, jc) = x3 - x1;
+        C1(cc, i + 1, k, j) = x2 + x4;
+        C1(cc, i, k, jc) = x2 - x4;
+    }
+}
+// The l loop shared by radfg (FORWARD: cc -> ch, wrap test iang >= ip) and radbg (ch -> cc, wrap test
+// iang > ip), then the column sum into column 0 of `sum_dst` (radfg: ch, from cc; radbg: ch, in place).
+template <bool FORWARD>
+__global__ __launch_bounds__(kBlock) void radg_mix_kernel(const float* __restrict__ srcbuf,
+                                                          float* __restrict__ dstbuf,
+                                                          const float* __restrict__ csarr, GenDims d,
+                                                          uint64_t transforms) {
+    const uint64_t total = transforms * d.idl1;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t t = g / d.idl1;
+        const uint32_t ik = (uint32_t)(g % d.idl1);
+        const float* src = srcbuf + t * d.n;
+        float* dst = dstbuf + t * d.n;
+        for (uint32_t l = 1, lc = d.ip - 1; l < d.ipph; ++l, --lc) {
+            float a = C2(src, ik, 0) + csarr[2 * l] * C2(src, ik, 1) + csarr[4 * l] * C2(src, ik, 2);
+            float b = csarr[2 * l + 1] * C2(src, ik, d.ip - 1) + csarr[4 * l + 1] * C2(src, ik, d.ip - 2);
+            uint32_t iang = 2 * l, j = 3, jc = d.ip - 3;
+            auto step = [&]() {
+                iang += l;
+                if (FORWARD ? (iang >= d.ip) : (iang > d.ip)) iang -= d.ip;
+            };
+            for (; j + 3 < d.ipph; j += 4, jc -= 4) {
+                step();
+                const float ar1 = csarr[2 * iang], ai1 = csarr[2 * iang + 1];
+                step();
+                const float ar2 = csarr[2 * iang], ai2 = csarr[2 * iang + 1];
+                step();
+                const float ar3 = csarr[2 * iang], ai3 = csarr[2 * iang + 1];
+                step();
+                const float ar4 = csarr[2 * iang], ai4 = csarr[2 * iang + 1];
+                a += ar1 * C2(src, ik, j) + ar2 * C2(src, ik, j + 1) + ar3 * C2(src, ik, j + 2) + ar4 * C2(src, ik, j + 3);
+                b += ai1 * C2(src, ik, jc) + ai2 * C2(src, ik, jc - 1) + ai3 * C2(src, ik, jc - 2) + ai4 * C2(src, ik, jc - 3);
+            }
+            for (; j + 1 < d.ipph; j += 2, jc -= 2) {
+                step();
+                const float ar1 = csarr[2 * iang], ai1 = csarr[2 * iang + 1];
+                step();
+                const float ar2 = csarr[2 * iang], ai2 = csarr[2 * iang + 1];
+                a += ar1 * C2(src, ik, j) + ar2 * C2(src, ik, j + 1);
+                b += ai1 * C2(src, ik, jc) + ai2 * C2(src, ik, jc - 1);
+            }
+            for (; j < d.ipph; ++j, --jc) {
+                step();
+                const float ar = csarr[2 * iang], ai = csarr[2 * iang + 1];
+                a += ar * C2(src, ik, j);
+                b += ai * C2(src, ik, jc);
+            }
+            C2(dst, ik, l) = a;
+            C2(dst, ik, lc) = b;
+        }
+        if (FORWARD) {  // CH2(ik,0) = C2(ik,0) + C2(ik,1) + ... (:1869-1872)
+            float s0 = C2(src, ik, 0);
+            for (uint32_t j = 1; j < d.ipph; ++j) s0 += C2(src, ik, j);
+            C2(dst, ik, 0) = s0;
+        }
+    }
+}
+// radbg: CH2(ik,0) += CH2(ik,1) + ... in place (:2176-2178); separate launch because radg_mix
+// reads column 0 of ch for every l
+__global__ __launch_bounds__(kBlock) void radbg_sum_kernel(float* __restrict__ chbuf, GenDims d,
+                                                           uint64_t transforms) {
+    const uint64_t total = transforms * d.idl1;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        float* ch = chbuf + (g / d.idl1) * d.n;
+        const uint32_t ik = (uint32_t)(g % d.idl1);
+        float s0 = C2(ch, ik, 0);
+        for (uint32_t j = 1; j < d.ipph; ++j) s0 += C2(ch, ik, j);
+        C2(ch, ik, 0) = s0;
+    }
+}
+// radfg phase 5: CC <- CH (halfcomplex packing, :1877-1893); also the j = 0 plane
+__global__ __launch_bounds__(kBlock) void radfg_post_kernel(float* __restrict__ ccbuf,
+                                                            const float* __restrict__ chbuf, GenDims d,
+                                                            uint64_t transforms) {
+    const uint64_t pairs = (uint64_t)(d.ipph - 1) * d.l1 * d.items, plane = d.idl1;
+    const uint64_t per_t = pairs + plane, total = transforms * per_t;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t t = g / per_t;
+        float* cc = ccbuf + t * d.n;
+        const float* ch = chbuf + t * d.n;
+        uint64_t w = g % per_t;
+        if (w >= pairs) {  // CC(i,0,k) = CH(i,k,0)
+            const uint32_t ik = (uint32_t)(w - pairs), i = ik % d.ido, k = ik / d.ido;
+            CCX(cc, i, 0, k) = C1(ch, i, k, 0);
+            continue;
+        }
+        const uint32_t item = (uint32_t)(w % d.items);
+        w /= d.items;
+        const uint32_t k = (uint32_t)(w % d.l1), j = 1 + (uint32_t)(w / d.l1), jc = d.ip - j, j2 = 2 * j - 1;
+        if (item == 0) {
+            CCX(cc, d.ido - 1, j2, k) = C1(ch, 0, k, j);
+            CCX(cc, 0, j2 + 1, k) = C1(ch, 0, k, jc);
+            continue;
+        }
+        const uint32_t i = 2 * item - 1, ic = d.ido - i - 2;
+        CCX(cc, i, j2 + 1, k) = C1(ch, i, k, j) + C1(ch, i, k, jc);
+        CCX(cc, ic, j2, k) = C1(ch, i, k, j) - C1(ch, i, k, jc);
+        CCX(cc, i + 1, j2 + 1, k) = C1(ch, i + 1, k, j) + C1(ch, i + 1, k, jc);
+        CCX(cc, ic + 1, j2, k) = C1(ch, i + 1, k, jc) - C1(ch, i + 1, k, j);
+    }
+}
+// radbg phase A: CH <- CC (unpacking, :2095-2122)
+__global__ __launch_bounds__(kBlock) void radbg_pre_kernel(const float* __restrict__ ccbuf,
+                                                           float* __restrict__ chbuf, GenDims d,
+                                                           uint64_t transforms) {
+    const uint64_t pairs = (uint64_t)(d.ipph - 1) * d.l1 * d.items, plane = d.idl1;
+    const uint64_t per_t = pairs + plane, total = transforms * per_t;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t t = g / per_t;
+        const float* cc = ccbuf + t * d.n;
+        float* ch = chbuf + t * d.n;
+        uint64_t w = g % per_t;
+        if (w >= pairs) {
+            const uint32_t ik = (uint32_t)(w - pairs), i = ik % d.ido, k = ik / d.ido;
+            C1(ch, i, k, 0) = CCX(cc, i, 0, k);
+            continue;
+        }
+        const uint32_t item = (uint32_t)(w % d.items);
+        w /= d.items;
+        const uint32_t k = (uint32_t)(w % d.l1), j = 1 + (uint32_t)(w / d.l1), jc = d.ip - j, j2 = 2 * j - 1;
+        if (item == 0) {
+            C1(ch, 0, k, j) = 2 * CCX(cc, d.ido - 1, j2, k);
+            C1(ch, 0, k, jc) = 2 * CCX(cc, 0, j2 + 1, k);
+            continue;
+        }
+        const uint32_t i = 2 * item - 1, ic = d.ido - i - 2;
+        C1(ch, i, k, j) = CCX(cc, i, j2 + 1, k) + CCX(cc, ic, j2, k);
+        C1(ch, i, k, jc) = CCX(cc, i, j2 + 1, k) - CCX(cc, ic, j2, k);
+        C1(ch, i + 1, k, j) = CCX(cc, i + 1, j2 + 1, k) - CCX(cc, ic + 1, j2, k);
+        C1(ch, i + 1, k, jc) = CCX(cc, i + 1, j2 + 1, k) + CCX(cc, ic + 1, j2, k);
+    }
+}
+// radbg phases D+E: CH <- PM of C1, then the output twiddles (:2179-2207)
+__global__ __launch_bounds__(kBlock) void radbg_post_kernel(const float* __restrict__ ccbuf,
+                                                            float* __restrict__ chbuf,
+                                                            const float* __restrict__ wa, GenDims d,
+                                                            uint64_t transforms) {
+    const uint64_t per_t = (uint64_t)(d.ipph - 1) * d.l1 * d.items, total = transforms * per_t;
+    for (uint64_t g = (uint64_t)blockIdx.x * kBlock + threadIdx.x; g < total;
+         g += (uint64_t)gridDim.x * kBlock) {
+        const uint64_t t = g / per_t;
+        const float* cc = ccbuf + t * d.n;
+        float* ch = chbuf + t * d.n;
+        uint32_t w = (uint32_t)(g % per_t);
+        const uint32_t item = w % d.items;
+        w /= d.items;
+        const uint32_t k = w % d.l1, j = 1 + w / d.l1, jc = d.ip - j;
+        if (item == 0) {
+            C1(ch, 0, k, jc) = C1(cc, 0, k, j) + C1(cc, 0, k, jc);
+            C1(ch, 0, k, j) = C1(cc, 0, k, j) - C1(cc, 0, k, jc);
+            continue;
+        }
+        const uint32_t i = 2 * item - 1;
+        const float a0 = C1(cc, i, k, j) - C1(cc, i + 1, k, jc), b0 = C1(cc, i, k, j) + C1(cc, i + 1, k, jc);
+        const float a1 = C1(cc, i + 1, k, j) + C1(cc, i, k, jc), b1 = C1(cc, i + 1, k, j) - C1(cc, i, k, jc);
+        const uint32_t ij = (j - 1) * (d.ido - 1) + i - 1, ijc = (jc - 1) * (d.ido - 1) + i - 1;
+        C1(ch, i, k, j) = wa[ij] * a0 - wa[ij + 1] * a1;
+        C1(ch, i + 1, k, j) = wa[ij] * a1 + wa[ij + 1] * a0;
+        C1(ch, i, k, jc) = wa[ijc] * b0 - wa[ijc + 1] * b1;
+        C1(ch, i + 1, k, jc) = wa[ijc] * b1 + wa[ijc + 1] * b0;
+    }
+}
+#undef C1
+#undef CCX
+#undef C2
+
 // strided tensor row <-> dense row, and the r2c re-packing (general_r2c, pocketfft.hh:3102-3150)
 __global__ __launch_bounds__(kBlock) void rfft_gather_kernel(const FftLayout L, float* __restrict__ dense,
                                                              const float* __restrict__ in, uint32_t n) {
@@ -400,7 +611,7 @@ bool rfft_supported(uint64_t n) {
     const int nf = rfft_plan_factors(n, fact);
     if (nf < 0) return false;
     for (int i = 0; i < nf; ++i)
-        if (fact[i] > 5) return false;
+        if (fact[i] > 5 && fact[i] > 4096) return false;  // generic radix: one thread per column
     return true;
 }
 uint64_t rfft_twiddle_count(uint64_t n) {
@@ -409,6 +620,7 @@ uint64_t rfft_twiddle_count(uint64_t n) {
     uint64_t total = 0, l1 = 1;
     for (int k = 0; k < nf; ++k) {
         total += (uint64_t)(fact[k] - 1) * (n / (l1 * fact[k]) - 1);
+        if (fact[k] > 5) total += 2ull * fact[k];
         l1 *= fact[k];
     }
     return total;
@@ -425,6 +637,19 @@ void rfft_twiddle_fill(uint64_t n, const float* w, float* out) {  // comp_twiddl
                 out[off + (j - 1) * (ido - 1) + 2 * i - 1] = w[2 * (j * l1 * i) + 1];
             }
         off += (ip - 1) * (ido - 1);
+        if (ip > 5) {  // "special factors required by *g functions": the ip-th roots of unity
+            float* t = out + off;
+            t[0] = 1.0f;
+            t[1] = 0.0f;
+            for (uint64_t i = 2, ic = 2 * ip - 2; i <= ic; i += 2, ic -= 2) {
+                const uint64_t src = i / 2 * (n / ip);
+                t[i] = w[2 * src];
+                t[i + 1] = w[2 * src + 1];
+                t[ic] = w[2 * src];
+                t[ic + 1] = -w[2 * src + 1];
+            }
+            off += 2 * ip;
+        }
         l1 *= ip;
     }
 }
@@ -469,8 +694,37 @@ hipError_t launch_rfft_passes(uint64_t n, bool r2hc, uint64_t transforms, float*
     for (int k = 0; k < nf; ++k) {
         off[k] = o;
         o += (uint64_t)(fact[k] - 1) * (n / (l1 * fact[k]) - 1);
+        if (fact[k] > 5) o += 2ull * fact[k];
         l1 *= fact[k];
     }
+    auto generic = [&](int k, uint64_t ip, uint64_t ido, uint64_t pl1, float* cc, float* ch, bool fwd) {
+        GenDims d;
+        d.n = (uint32_t)n;
+        d.ido = (uint32_t)ido;
+        d.ip = (uint32_t)ip;
+        d.l1 = (uint32_t)pl1;
+        d.ipph = (uint32_t)((ip + 1) / 2);
+        d.idl1 = (uint32_t)(ido * pl1);
+        d.items = (uint32_t)(1 + (ido - 1) / 2);
+        const float* wa = tw + off[k];
+        const float* cs = wa + (ip - 1) * (ido - 1);
+        const uint64_t pairs = transforms * (d.ipph - 1) * pl1 * d.items, cols = transforms * d.idl1;
+        if (fwd) {  // result ends in cc
+            hipLaunchKernelGGL(radfg_pre_kernel, dim3(blocks_for(pairs)), dim3(kBlock), 0, s, cc, wa, d, transforms);
+            hipLaunchKernelGGL((radg_mix_kernel<true>), dim3(blocks_for(cols)), dim3(kBlock), 0, s,
+                               (const float*)cc, ch, cs, d, transforms);
+            hipLaunchKernelGGL(radfg_post_kernel, dim3(blocks_for(pairs + cols)), dim3(kBlock), 0, s, cc,
+                               (const float*)ch, d, transforms);
+        } else {    // result ends in ch
+            hipLaunchKernelGGL(radbg_pre_kernel, dim3(blocks_for(pairs + cols)), dim3(kBlock), 0, s,
+                               (const float*)cc, ch, d, transforms);
+            hipLaunchKernelGGL((radg_mix_kernel<false>), dim3(blocks_for(cols)), dim3(kBlock), 0, s,
+                               (const float*)ch, cc, cs, d, transforms);
+            hipLaunchKernelGGL(radbg_sum_kernel, dim3(blocks_for(cols)), dim3(kBlock), 0, s, ch, d, transforms);
+            hipLaunchKernelGGL(radbg_post_kernel, dim3(blocks_for(pairs)), dim3(kBlock), 0, s,
+                               (const float*)cc, ch, wa, d, transforms);
+        }
+    };
     float *p1 = a, *p2 = b;
     (void)hipGetLastError();
 #define JST_RPASS(IP, DIR)                                                                            \
@@ -489,7 +743,10 @@ hipError_t launch_rfft_passes(uint64_t n, bool r2hc, uint64_t transforms, float*
                 case 3: JST_RPASS(3, true); break;
                 case 4: JST_RPASS(4, true); break;
                 case 5: JST_RPASS(5, true); break;
-                default: return hipErrorInvalidValue;
+                default: {  // radfg leaves its result in the source buffer (the reference swaps twice)
+                    generic(k, ip, ido, pl1, p1, p2, true);
+                    float* u = p1; p1 = p2; p2 = u;
+                } break;
             }
             float* t = p1; p1 = p2; p2 = t;
         }
@@ -502,7 +759,7 @@ hipError_t launch_rfft_passes(uint64_t n, bool r2hc, uint64_t transforms, float*
                 case 3: JST_RPASS(3, false); break;
                 case 4: JST_RPASS(4, false); break;
                 case 5: JST_RPASS(5, false); break;
-                default: return hipErrorInvalidValue;
+                default: generic(k, ip, ido, pl1, p1, p2, false); break;
             }
             float* t = p1; p1 = p2; p2 = t;
             pl1 *= ip;

@@ -596,8 +596,8 @@ Result Fft::validate() {
     realInput = in.dtype() == DataType::F32;
     complexOut = realInput && forward && complexOutput;  // fft/module_impl.cc:33-38
     if (realInput && !kernels::rfft_supported(n) && kernels::rfft_bluestein_size(n) == 0) {
-        JST_ERROR("[MODULE_FFT_NATIVE_HIP] Real transform length %llu needs FFTPACK's generic radix "
-                  "(a prime factor above 5), which is not implemented on the HIP device.",
+        JST_ERROR("[MODULE_FFT_NATIVE_HIP] Real transform length %llu has a prime factor above the "
+                  "generic radix limit of the HIP device.",
                   (unsigned long long)n);
         return Result::ERROR;
     }

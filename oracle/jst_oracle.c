@@ -1289,6 +1289,213 @@ static void radb5(uint64_t ido, uint64_t l1, const float* cc, float* ch, const f
 #undef MULPM
 #undef RWA
 
+/* radfg (pocketfft.hh:1753-1893): generic radix, forward.  Works on BOTH arrays like the
+ * reference (cc is modified in place, the result ends in cc: the caller swaps once more). */
+static void radfg(uint64_t ido, uint64_t ip, uint64_t l1, float* cc, float* ch, const float* wa,
+                  const float* csarr) {
+    const uint64_t cdim = ip, ipph = (ip + 1) / 2, idl1 = ido * l1;
+#define CC(a, b, c) cc[(a) + ido * ((b) + cdim * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + l1 * (c))]
+#define C1(a, b, c) cc[(a) + ido * ((b) + l1 * (c))]
+#define C2(a, b) cc[(a) + idl1 * (b)]
+#define CH2(a, b) ch[(a) + idl1 * (b)]
+    if (ido > 1) {
+        for (uint64_t j = 1, jc = ip - 1; j < ipph; ++j, --jc) {
+            const uint64_t is = (j - 1) * (ido - 1), is2 = (jc - 1) * (ido - 1);
+            for (uint64_t k = 0; k < l1; ++k) {
+                uint64_t idij = is, idij2 = is2;
+                for (uint64_t i = 1; i <= ido - 2; i += 2) {
+                    const float t1 = C1(i, k, j), t2 = C1(i + 1, k, j), t3 = C1(i, k, jc), t4 = C1(i + 1, k, jc);
+                    const float x1 = wa[idij] * t1 + wa[idij + 1] * t2, x2 = wa[idij] * t2 - wa[idij + 1] * t1,
+                                x3 = wa[idij2] * t3 + wa[idij2 + 1] * t4, x4 = wa[idij2] * t4 - wa[idij2 + 1] * t3;
+                    C1(i, k, j) = x3 + x1;
+                    C1(i + 1, k, jc) = x3 - x1;
+                    C1(i + 1, k, j) = x2 + x4;
+                    C1(i, k, jc) = x2 - x4;
+                    idij += 2;
+                    idij2 += 2;
+                }
+            }
+        }
+    }
+    for (uint64_t j = 1, jc = ip - 1; j < ipph; ++j, --jc)
+        for (uint64_t k = 0; k < l1; ++k) { /* MPINPLACE(C1(0,k,jc), C1(0,k,j)) */
+            const float t = C1(0, k, jc);
+            C1(0, k, jc) = C1(0, k, jc) - C1(0, k, j);
+            C1(0, k, j) = t + C1(0, k, j);
+        }
+    for (uint64_t l = 1, lc = ip - 1; l < ipph; ++l, --lc) {
+        for (uint64_t ik = 0; ik < idl1; ++ik) {
+            CH2(ik, l) = C2(ik, 0) + csarr[2 * l] * C2(ik, 1) + csarr[4 * l] * C2(ik, 2);
+            CH2(ik, lc) = csarr[2 * l + 1] * C2(ik, ip - 1) + csarr[4 * l + 1] * C2(ik, ip - 2);
+        }
+        uint64_t iang = 2 * l, j = 3, jc = ip - 3;
+        for (; j < ipph - 3; j += 4, jc -= 4) {
+            iang += l; if (iang >= ip) iang -= ip;
+            const float ar1 = csarr[2 * iang], ai1 = csarr[2 * iang + 1];
+            iang += l; if (iang >= ip) iang -= ip;
+            const float ar2 = csarr[2 * iang], ai2 = csarr[2 * iang + 1];
+            iang += l; if (iang >= ip) iang -= ip;
+            const float ar3 = csarr[2 * iang], ai3 = csarr[2 * iang + 1];
+            iang += l; if (iang >= ip) iang -= ip;
+            const float ar4 = csarr[2 * iang], ai4 = csarr[2 * iang + 1];
+            for (uint64_t ik = 0; ik < idl1; ++ik) {
+                CH2(ik, l) += ar1 * C2(ik, j) + ar2 * C2(ik, j + 1) + ar3 * C2(ik, j + 2) + ar4 * C2(ik, j + 3);
+                CH2(ik, lc) += ai1 * C2(ik, jc) + ai2 * C2(ik, jc - 1) + ai3 * C2(ik, jc - 2) + ai4 * C2(ik, jc - 3);
+            }
+        }
+        for (; j < ipph - 1; j += 2, jc -= 2) {
+            iang += l; if (iang >= ip) iang -= ip;
+            const float ar1 = csarr[2 * iang], ai1 = csarr[2 * iang + 1];
+            iang += l; if (iang >= ip) iang -= ip;
+            const float ar2 = csarr[2 * iang], ai2 = csarr[2 * iang + 1];
+            for (uint64_t ik = 0; ik < idl1; ++ik) {
+                CH2(ik, l) += ar1 * C2(ik, j) + ar2 * C2(ik, j + 1);
+                CH2(ik, lc) += ai1 * C2(ik, jc) + ai2 * C2(ik, jc - 1);
+            }
+        }
+        for (; j < ipph; ++j, --jc) {
+            iang += l; if (iang >= ip) iang -= ip;
+            const float ar = csarr[2 * iang], ai = csarr[2 * iang + 1];
+            for (uint64_t ik = 0; ik < idl1; ++ik) {
+                CH2(ik, l) += ar * C2(ik, j);
+                CH2(ik, lc) += ai * C2(ik, jc);
+            }
+        }
+    }
+    for (uint64_t ik = 0; ik < idl1; ++ik) CH2(ik, 0) = C2(ik, 0);
+    for (uint64_t j = 1; j < ipph; ++j)
+        for (uint64_t ik = 0; ik < idl1; ++ik) CH2(ik, 0) += C2(ik, j);
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 0; i < ido; ++i) CC(i, 0, k) = CH(i, k, 0);
+    for (uint64_t j = 1, jc = ip - 1; j < ipph; ++j, --jc) {
+        const uint64_t j2 = 2 * j - 1;
+        for (uint64_t k = 0; k < l1; ++k) {
+            CC(ido - 1, j2, k) = CH(0, k, j);
+            CC(0, j2 + 1, k) = CH(0, k, jc);
+        }
+    }
+    if (ido == 1) return;
+    for (uint64_t j = 1, jc = ip - 1; j < ipph; ++j, --jc) {
+        const uint64_t j2 = 2 * j - 1;
+        for (uint64_t k = 0; k < l1; ++k)
+            for (uint64_t i = 1, ic = ido - i - 2; i <= ido - 2; i += 2, ic -= 2) {
+                CC(i, j2 + 1, k) = CH(i, k, j) + CH(i, k, jc);
+                CC(ic, j2, k) = CH(i, k, j) - CH(i, k, jc);
+                CC(i + 1, j2 + 1, k) = CH(i + 1, k, j) + CH(i + 1, k, jc);
+                CC(ic + 1, j2, k) = CH(i + 1, k, jc) - CH(i + 1, k, j);
+            }
+    }
+#undef CC
+#undef CH
+#undef C1
+#undef C2
+#undef CH2
+}
+/* radbg (pocketfft.hh:2076-2208): generic radix, backward; result in ch, cc used as scratch. */
+static void radbg(uint64_t ido, uint64_t ip, uint64_t l1, float* cc, float* ch, const float* wa,
+                  const float* csarr) {
+    const uint64_t cdim = ip, ipph = (ip + 1) / 2, idl1 = ido * l1;
+#define CC(a, b, c) cc[(a) + ido * ((b) + cdim * (c))]
+#define CH(a, b, c) ch[(a) + ido * ((b) + l1 * (c))]
+#define C1(a, b, c) cc[(a) + ido * ((b) + l1 * (c))]
+#define C2(a, b) cc[(a) + idl1 * (b)]
+#define CH2(a, b) ch[(a) + idl1 * (b)]
+    for (uint64_t k = 0; k < l1; ++k)
+        for (uint64_t i = 0; i < ido; ++i) CH(i, k, 0) = CC(i, 0, k);
+    for (uint64_t j = 1, jc = ip - 1; j < ipph; ++j, --jc) {
+        const uint64_t j2 = 2 * j - 1;
+        for (uint64_t k = 0; k < l1; ++k) {
+            CH(0, k, j) = 2 * CC(ido - 1, j2, k);
+            CH(0, k, jc) = 2 * CC(0, j2 + 1, k);
+        }
+    }
+    if (ido != 1) {
+        for (uint64_t j = 1, jc = ip - 1; j < ipph; ++j, --jc) {
+            const uint64_t j2 = 2 * j - 1;
+            for (uint64_t k = 0; k < l1; ++k)
+                for (uint64_t i = 1, ic = ido - i - 2; i <= ido - 2; i += 2, ic -= 2) {
+                    CH(i, k, j) = CC(i, j2 + 1, k) + CC(ic, j2, k);
+                    CH(i, k, jc) = CC(i, j2 + 1, k) - CC(ic, j2, k);
+                    CH(i + 1, k, j) = CC(i + 1, j2 + 1, k) - CC(ic + 1, j2, k);
+                    CH(i + 1, k, jc) = CC(i + 1, j2 + 1, k) + CC(ic + 1, j2, k);
+                }
+        }
+    }
+    for (uint64_t l = 1, lc = ip - 1; l < ipph; ++l, --lc) {
+        for (uint64_t ik = 0; ik < idl1; ++ik) {
+            C2(ik, l) = CH2(ik, 0) + csarr[2 * l] * CH2(ik, 1) + csarr[4 * l] * CH2(ik, 2);
+            C2(ik, lc) = csarr[2 * l + 1] * CH2(ik, ip - 1) + csarr[4 * l + 1] * CH2(ik, ip - 2);
+        }
+        uint64_t iang = 2 * l, j = 3, jc = ip - 3;
+        for (; j < ipph - 3; j += 4, jc -= 4) {
+            iang += l; if (iang > ip) iang -= ip;
+            const float ar1 = csarr[2 * iang], ai1 = csarr[2 * iang + 1];
+            iang += l; if (iang > ip) iang -= ip;
+            const float ar2 = csarr[2 * iang], ai2 = csarr[2 * iang + 1];
+            iang += l; if (iang > ip) iang -= ip;
+            const float ar3 = csarr[2 * iang], ai3 = csarr[2 * iang + 1];
+            iang += l; if (iang > ip) iang -= ip;
+            const float ar4 = csarr[2 * iang], ai4 = csarr[2 * iang + 1];
+            for (uint64_t ik = 0; ik < idl1; ++ik) {
+                C2(ik, l) += ar1 * CH2(ik, j) + ar2 * CH2(ik, j + 1) + ar3 * CH2(ik, j + 2) + ar4 * CH2(ik, j + 3);
+                C2(ik, lc) += ai1 * CH2(ik, jc) + ai2 * CH2(ik, jc - 1) + ai3 * CH2(ik, jc - 2) + ai4 * CH2(ik, jc - 3);
+            }
+        }
+        for (; j < ipph - 1; j += 2, jc -= 2) {
+            iang += l; if (iang > ip) iang -= ip;
+            const float ar1 = csarr[2 * iang], ai1 = csarr[2 * iang + 1];
+            iang += l; if (iang > ip) iang -= ip;
+            const float ar2 = csarr[2 * iang], ai2 = csarr[2 * iang + 1];
+            for (uint64_t ik = 0; ik < idl1; ++ik) {
+                C2(ik, l) += ar1 * CH2(ik, j) + ar2 * CH2(ik, j + 1);
+                C2(ik, lc) += ai1 * CH2(ik, jc) + ai2 * CH2(ik, jc - 1);
+            }
+        }
+        for (; j < ipph; ++j, --jc) {
+            iang += l; if (iang > ip) iang -= ip;
+            const float war = csarr[2 * iang], wai = csarr[2 * iang + 1];
+            for (uint64_t ik = 0; ik < idl1; ++ik) {
+                C2(ik, l) += war * CH2(ik, j);
+                C2(ik, lc) += wai * CH2(ik, jc);
+            }
+        }
+    }
+    for (uint64_t j = 1; j < ipph; ++j)
+        for (uint64_t ik = 0; ik < idl1; ++ik) CH2(ik, 0) += CH2(ik, j);
+    for (uint64_t j = 1, jc = ip - 1; j < ipph; ++j, --jc)
+        for (uint64_t k = 0; k < l1; ++k) {
+            CH(0, k, jc) = C1(0, k, j) + C1(0, k, jc);
+            CH(0, k, j) = C1(0, k, j) - C1(0, k, jc);
+        }
+    if (ido == 1) return;
+    for (uint64_t j = 1, jc = ip - 1; j < ipph; ++j, --jc)
+        for (uint64_t k = 0; k < l1; ++k)
+            for (uint64_t i = 1; i <= ido - 2; i += 2) {
+                CH(i, k, j) = C1(i, k, j) - C1(i + 1, k, jc);
+                CH(i, k, jc) = C1(i, k, j) + C1(i + 1, k, jc);
+                CH(i + 1, k, j) = C1(i + 1, k, j) + C1(i, k, jc);
+                CH(i + 1, k, jc) = C1(i + 1, k, j) - C1(i, k, jc);
+            }
+    for (uint64_t j = 1; j < ip; ++j) {
+        const uint64_t is = (j - 1) * (ido - 1);
+        for (uint64_t k = 0; k < l1; ++k) {
+            uint64_t idij = is;
+            for (uint64_t i = 1; i <= ido - 2; i += 2) {
+                const float t1 = CH(i, k, j), t2 = CH(i + 1, k, j);
+                CH(i, k, j) = wa[idij] * t1 - wa[idij + 1] * t2;
+                CH(i + 1, k, j) = wa[idij] * t2 + wa[idij + 1] * t1;
+                idij += 2;
+            }
+        }
+    }
+#undef CC
+#undef CH
+#undef C1
+#undef C2
+#undef CH2
+}
+
 /* rfftp::factorize (:2277-2297): 4s, a lone 2 moved to the front, odd divisors ascending. */
 int jst_oracle_rfft_factors(uint64_t n, uint32_t* fact) {
     int nf = 0;
@@ -1324,6 +1531,7 @@ typedef struct {
     uint32_t fact[64];
     float* mem;
     const float* tw[64];
+    const float* tws[64];
 } rfftp_t;
 static int rfftp_init(rfftp_t* p, uint64_t n) {
     memset(p, 0, sizeof(*p));
@@ -1331,12 +1539,11 @@ static int rfftp_init(rfftp_t* p, uint64_t n) {
     if (n == 0) return -1;
     if (n == 1) return 0;
     p->nf = jst_oracle_rfft_factors(n, p->fact);
-    for (int k = 0; k < p->nf; ++k)
-        if (p->fact[k] > 5) return -2; /* radfg / radbg are not restated */
     uint64_t twsz = 0, l1 = 1;
     for (int k = 0; k < p->nf; ++k) {
         const uint64_t ip = p->fact[k], ido = n / (l1 * ip);
         twsz += (ip - 1) * (ido - 1);
+        if (ip > 5) twsz += 2 * ip;
         l1 *= ip;
     }
     p->mem = (float*)calloc(twsz + 1, sizeof(float));
@@ -1355,6 +1562,20 @@ static int rfftp_init(rfftp_t* p, uint64_t n) {
                     ptr[(j - 1) * (ido - 1) + 2 * i - 1] = w.i;
                 }
             ptr += (ip - 1) * (ido - 1);
+        }
+        if (ip > 5) { /* special factors required by the *g functions */
+            float* t = ptr;
+            p->tws[k] = ptr;
+            ptr += 2 * ip;
+            t[0] = 1.0f;
+            t[1] = 0.0f;
+            for (uint64_t i = 2, ic = 2 * ip - 2; i <= ic; i += 2, ic -= 2) {
+                const c32 w = sincos_get(&s, i / 2 * (n / ip));
+                t[i] = w.r;
+                t[i + 1] = w.i;
+                t[ic] = w.r;
+                t[ic + 1] = -w.i;
+            }
         }
         l1 *= ip;
     }
@@ -1376,7 +1597,8 @@ static void rfftp_exec(const rfftp_t* p, float* c, float* ch, int r2hc) {
             if (ip == 4) radf4(ido, l1, p1, p2, p->tw[k]);
             else if (ip == 2) radf2(ido, l1, p1, p2, p->tw[k]);
             else if (ip == 3) radf3(ido, l1, p1, p2, p->tw[k]);
-            else radf5(ido, l1, p1, p2, p->tw[k]);
+            else if (ip == 5) radf5(ido, l1, p1, p2, p->tw[k]);
+            else { radfg(ido, ip, l1, p1, p2, p->tw[k], p->tws[k]); float* u = p1; p1 = p2; p2 = u; }
             float* t = p1; p1 = p2; p2 = t;
         }
     } else {
@@ -1386,7 +1608,8 @@ static void rfftp_exec(const rfftp_t* p, float* c, float* ch, int r2hc) {
             if (ip == 4) radb4(ido, l1, p1, p2, p->tw[k]);
             else if (ip == 2) radb2(ido, l1, p1, p2, p->tw[k]);
             else if (ip == 3) radb3(ido, l1, p1, p2, p->tw[k]);
-            else radb5(ido, l1, p1, p2, p->tw[k]);
+            else if (ip == 5) radb5(ido, l1, p1, p2, p->tw[k]);
+            else radbg(ido, ip, l1, p1, p2, p->tw[k], p->tws[k]);
             float* t = p1; p1 = p2; p2 = t;
             l1 *= ip;
         }

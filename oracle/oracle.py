@@ -152,15 +152,13 @@ def fft_c2c(x: np.ndarray, forward: bool = True) -> np.ndarray:
 
 
 def fft_r2r(x: np.ndarray, forward: bool = True) -> np.ndarray:
-    """Restated pocketfft r2r_fftpack over the LAST axis (halfcomplex FFTPACK format).  Raises
-    NotImplementedError for plans that need the generic radix (a prime factor > 5 without Bluestein)."""
+    """Restated pocketfft r2r_fftpack over the LAST axis (halfcomplex FFTPACK format): radices
+    2/3/4/5, the generic radix (radfg/radbg) for larger prime factors, and the real Bluestein path."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     n = x.shape[-1]
     out = np.empty_like(x)
     rc = lib().jst_oracle_fft_r2r(_p(x), _p(out), C.c_uint64(n), C.c_uint64(x.size // n if n else 0),
                                   C.c_int(1 if forward else 0))
-    if rc == -2:
-        raise NotImplementedError(f"rfftp plan of {n} needs radfg/radbg")
     if rc != 0:
         raise ValueError("zero-length FFT requested")
     return out
@@ -172,8 +170,6 @@ def fft_r2c(x: np.ndarray) -> np.ndarray:
     n = x.shape[-1]
     out = np.empty(x.shape[:-1] + (n // 2 + 1,), np.complex64)
     rc = lib().jst_oracle_fft_r2c(_p(x), _p(out), C.c_uint64(n), C.c_uint64(x.size // n if n else 0))
-    if rc == -2:
-        raise NotImplementedError(f"rfftp plan of {n} needs radfg/radbg")
     if rc != 0:
         raise ValueError("zero-length FFT requested")
     return out

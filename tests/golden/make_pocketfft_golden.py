@@ -27,7 +27,8 @@ def signal(n: int) -> np.ndarray:
 
 REAL_LENGTHS = [1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 24, 25, 27, 30, 32, 36, 45, 48, 50, 60, 64, 75,
                 81, 100, 120, 125, 128, 150, 243, 256, 360, 500, 625, 1000, 1024, 2000,
-                191, 199, 211, 257, 401, 523]   # the last six: pocketfft_r picks Bluestein
+                191, 199, 211, 257, 401, 523,   # these six: pocketfft_r picks Bluestein
+                7, 11, 13, 14, 21, 22, 26, 35, 49, 77, 91, 98, 121, 143, 169, 182, 343, 1001, 2401, 8050]  # radfg / radbg
 
 
 def real_signal(n: int) -> np.ndarray:

@@ -65,8 +65,8 @@ def test_validation_errors_mirror_the_reference(js):
     x = np.zeros((2, 14), np.complex64)
     with pytest.raises(js.JetstreamError, match=r"\[MODULE_FFT\] Input must contain valid signal axis"):
         js.Module("fft", {}, {"signal": _host_view(js, x)})  # rank 2 without axes (axis.cc:231-245)
-    with pytest.raises(js.JetstreamError, match="Real transform length 14 needs FFTPACK's generic radix"):
-        js.Module("fft", {}, {"signal": _host_view(js, np.zeros((2, 14), np.float32), sample=1, batch=0)})
+    with pytest.raises(js.JetstreamError, match="Data type 'F64' is not implemented on the HIP device"):
+        js.Module("fft", {}, {"signal": js.Tensor.wrap(x.ctypes.data, x.nbytes, "hip", "F64", (2, 14)).set_axes(sample=1, batch=0)})
     with pytest.raises(js.JetstreamError, match=r"\[MODULE_SPECTROGRAM\] Invalid height value"):
         js.Module("spectrogram", {"height": 0}, {})
     with pytest.raises(js.JetstreamError, match=r"\[MODULE_SPECTROGRAM\] Invalid height value"):

@@ -161,7 +161,9 @@ def test_bluestein_strided_and_special_values(js, oracle):
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 25, 27, 32, 45, 64, 100, 125, 128, 243, 360,
                                1000, 1024, 4096, 6000, 8100, 65536,       # rfftp radices 2/3/4/5
-                               191, 211, 257, 401, 4099, 8191])                # pocketfft_r picks Bluestein
+                               191, 211, 257, 401, 4099, 8191,                 # pocketfft_r picks Bluestein
+                               7, 11, 13, 14, 21, 22, 26, 35, 49, 77, 91, 98, 121, 143, 169, 182, 343, 1001,
+                               2401, 8050, 30030, 44100])                      # generic radix (radfg / radbg)
 def test_real_input_transforms_bit_exact(js, oracle, n):
     """F32 input (fft/module_impl_native_cpu.cc:142-167): r2r_fftpack forward and backward
     (FFTPACK halfcomplex) and r2c (complexOutput), all bit-identical to pocketfft's rfftp."""
@@ -196,8 +198,5 @@ def test_real_input_reference_kats_and_layouts(js, oracle):
 
 
 def test_unsupported_cases_fail_loudly(js):
-    r = np.zeros((2, 14), np.float32)      # 14 = 2 * 7: FFTPACK's generic radix (radfg) is not built
-    with pytest.raises(js.JetstreamError, match="generic radix"):
-        js.Module("fft", {}, {"signal": js.Tensor.from_numpy(r, sample=1, batch=0)})
     with pytest.raises(js.JetstreamError, match="not implemented"):
         js.Module("fft", {}, {"signal": js.Tensor.from_numpy(np.zeros((2, 16), np.float64), sample=1, batch=0)})

@@ -104,24 +104,21 @@ def test_restatement_matches_committed_reference_vectors(oracle):
 
 
 def test_real_transforms_bit_exact_vs_reference_pocketfft(oracle):
-    """rfftp (radices 2/3/4/5) and the real Bluestein path vs the reference, every supported length
-    up to 420 plus large ones; lengths that need radfg/radbg are reported as unsupported."""
+    """rfftp (radices 2/3/4/5 and the generic radfg/radbg) and the real Bluestein path vs the
+    reference: every length up to 420 plus large ones."""
     if not oracle.have_ref():
         pytest.skip("oracle/_ref not built (no /root/reference)")
     rng = np.random.default_rng(11)
     supported = 0
-    for n in list(range(1, 420)) + [1000, 1024, 4096, 6000, 8100, 16000, 65536, 4099, 8191]:
+    for n in list(range(1, 420)) + [1000, 1024, 4096, 6000, 8100, 16000, 65536, 4099, 8191, 8050, 10007, 30030]:
         x = rng.standard_normal((2, n)).astype(np.float32)
-        try:
-            fwd = oracle.fft_r2r(x, True)
-        except NotImplementedError:
-            continue
+        fwd = oracle.fft_r2r(x, True)
         supported += 1
         assert np.array_equal(fwd.view(np.uint32), oracle.ref_fft_r2r(x, 1, True).view(np.uint32)), n
         assert np.array_equal(oracle.fft_r2r(x, False).view(np.uint32),
                               oracle.ref_fft_r2r(x, 1, False).view(np.uint32)), n
         assert np.array_equal(oracle.fft_r2c(x).view(np.uint32), oracle.ref_fft_r2c(x, 1).view(np.uint32)), n
-    assert supported >= 100
+    assert supported >= 430
 
 
 def test_real_restatement_matches_committed_reference_vectors(oracle):
