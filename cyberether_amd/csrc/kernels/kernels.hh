@@ -218,6 +218,16 @@ hipError_t launch_fold_product_cf32(float2* out, const float2* a, const float2* 
                                     uint64_t axis_size, uint64_t fold_size, uint64_t scalar_offset,
                                     const uint64_t* chan_offsets, uint64_t chan_count,
                                     uint64_t chan_inner, hipStream_t s);
+// Direct-form polyphase FIR + decimation of a continuous CF32 stream with real taps (fir.hip): the
+// time-domain equivalent of the Filter block's FFT overlap-add chain, provider "fast".
+bool fir_decimate_supported(uint64_t row_samples, uint64_t taps, uint64_t decimation);
+size_t fir_table_floats(uint64_t taps, uint64_t decimation, uint64_t heads);
+// table: the taps re-laid out per (polyphase branch, chunk) for scalar loads; depends only on the taps
+hipError_t launch_fir_table(float* table, const float2* taps, uint64_t ntaps, uint64_t decimation,
+                            uint64_t heads, hipStream_t s);
+hipError_t launch_fir_decimate(float2* out, const float2* in, const float* table, float2* history,
+                               uint64_t rows, uint64_t row_samples, uint64_t ntaps, uint64_t decimation,
+                               uint64_t heads, hipStream_t s);
 hipError_t launch_overlap_add(void* out, const void* buf, const void* ovl, void* prev, bool complex,
                               uint32_t rank, int32_t batch_axis, const uint64_t* buf_shape,
                               const uint64_t* ovl_shape, hipStream_t s);

@@ -391,6 +391,135 @@ class OverlapAdd : public Module {
     std::optional<Index> batchAxis;
 };
 
+// ---- FirTaps + FirDecimate: the Filter block as ONE time-domain kernel (provider "fast") ---------
+// No reference counterpart as modules: together they replace the block's pad -> fft -> multiply ->
+// fold -> ifft -> normalize -> unpad -> overlap_add chain (filter/block_impl.cc:350-582) when every
+// head is centred on 0 Hz (real taps, no fold offset, no phase correction).  Same ports as the block
+// sees: signal CF32 [S] or [B, S] in, coeffs CF32 [heads, T] from filter_taps, buffer CF32
+// [heads, S/r] or [B, heads, S/r] out, stream continuity across rows and cycles through a history
+// tensor.  fir_taps re-lays the (static) coefficients out for the kernel's scalar loads: stateless on
+// a static input, so the scheduler settles it once like filter_taps itself.
+class FirTaps : public Module {
+ public:
+    const char* type() const override { return "fir_taps"; }
+    Result validate() override {
+        bool ok;
+        decimation = ConfigU64(config_, "decimation", 1, &ok);
+        if (!ok || decimation == 0) {
+            JST_ERROR("[MODULE_FIR_TAPS] Decimation must be a positive integer.");
+            return Result::ERROR;
+        }
+        if (!inputs_.count("coeffs")) return Result::SUCCESS;
+        const Tensor& h = inputs_.at("coeffs");
+        if (h.dtype() != DataType::CF32 || h.rank() != 2 || !h.contiguous() || h.shape(1) == 0 ||
+            decimation > h.shape(1) || decimation > 32 || h.shape(1) > 16384) {
+            JST_ERROR("[MODULE_FIR_TAPS] Expected contiguous CF32 coeffs [heads, T] with decimation <= min(T, 32).");
+            return Result::ERROR;
+        }
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineTaint(STATELESS));
+        JST_CHECK(defineInterfaceInput("coeffs"));
+        return defineInterfaceOutput("table");
+    }
+    Result create() override {
+        coeffs = inputs_.at("coeffs");
+        const U64 heads = coeffs.shape(0), taps = coeffs.shape(1);
+        JST_CHECK(table.create(device(), DataType::F32, {(U64)kernels::fir_table_floats(taps, decimation, heads)}));
+        table.setAttribute("taps", AttrValue{(U64)taps});
+        table.setAttribute("heads", AttrValue{(U64)heads});
+        table.setAttribute("decimation", AttrValue{(U64)decimation});
+        produced("table", table);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        return hip_result(
+            kernels::launch_fir_table(ptr<float>(table),
+                                      reinterpret_cast<const float2*>(ptr<char>(coeffs) + coeffs.offsetBytes()),
+                                      coeffs.shape(1), decimation, coeffs.shape(0), s),
+            "fir_taps kernel");
+    }
+    Tensor coeffs, table;
+    U64 decimation = 1;
+};
+
+class FirDecimate : public Module {
+ public:
+    const char* type() const override { return "fir_decimate"; }
+    Result validate() override {
+        if (!inputs_.count("signal") || !inputs_.count("table")) return Result::SUCCESS;
+        const Tensor& x = inputs_.at("signal");
+        const Tensor& t = inputs_.at("table");
+        auto u64_attr = [&](const char* key, U64& out) {
+            const AttrValue* a = t.attribute(key);
+            if (!a || !std::holds_alternative<U64>(*a)) return false;
+            out = std::get<U64>(*a);
+            return true;
+        };
+        if (t.dtype() != DataType::F32 || !u64_attr("taps", taps) || !u64_attr("heads", heads) ||
+            !u64_attr("decimation", decimation) || decimation == 0 ||
+            t.size() != kernels::fir_table_floats(taps, decimation, heads)) {
+            JST_ERROR("[MODULE_FIR_DECIMATE] The table input must come from a fir_taps module.");
+            return Result::ERROR;
+        }
+        if (x.dtype() != DataType::CF32) {
+            JST_ERROR("[MODULE_FIR_DECIMATE_NATIVE_HIP] The signal must be CF32.");
+            return Result::ERROR;
+        }
+        if (x.rank() < 1 || x.rank() > 2 || !x.contiguous()) {
+            JST_ERROR("[MODULE_FIR_DECIMATE] Expected a contiguous signal [S] or [B, S].");
+            return Result::ERROR;
+        }
+        SignalAxes axes;
+        if (ResolveSignalAxes(x, axes) != Result::SUCCESS || *axes.sample != x.rank() - 1) {
+            JST_ERROR("[MODULE_FIR_DECIMATE] The sample axis must be the last axis of the signal.");
+            return Result::ERROR;
+        }
+        if (!kernels::fir_decimate_supported(x.shape(x.rank() - 1), taps, decimation)) {
+            JST_ERROR("[MODULE_FIR_DECIMATE_NATIVE_HIP] Unsupported plan: %llu samples per row, %llu taps, "
+                      "decimation %llu.", (unsigned long long)x.shape(x.rank() - 1),
+                      (unsigned long long)taps, (unsigned long long)decimation);
+            return Result::ERROR;
+        }
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineInterfaceInput("signal"));
+        JST_CHECK(defineInterfaceInput("table"));
+        return defineInterfaceOutput("buffer");
+    }
+    Result create() override {
+        signal = inputs_.at("signal");
+        table = inputs_.at("table");
+        const bool batched = signal.rank() == 2;
+        rows = batched ? signal.shape(0) : 1;
+        rowSamples = signal.shape(signal.rank() - 1);
+        const U64 m = rowSamples / decimation;
+        if (batched) JST_CHECK(output.create(device(), DataType::CF32, {rows, heads, m}));
+        else JST_CHECK(output.create(device(), DataType::CF32, {heads, m}));
+        SignalAxes axes;
+        axes.sample = Index{batched ? 2u : 1u};
+        axes.channel = Index{batched ? 1u : 0u};
+        if (batched) axes.batch = Index{0};
+        JST_CHECK(SetSignalAxes(output, axes));
+        JST_CHECK(history.create(device(), DataType::CF32, {std::max<U64>(taps - 1, 1)}));  // zeroed
+        produced("buffer", output);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        return hip_result(
+            kernels::launch_fir_decimate(ptr<float2>(output),
+                                         reinterpret_cast<const float2*>(ptr<char>(signal) + signal.offsetBytes()),
+                                         reinterpret_cast<const float*>(ptr<char>(table) + table.offsetBytes()),
+                                         ptr<float2>(history), rows, rowSamples, taps, decimation, heads, s),
+            "fir_decimate kernel");
+    }
+    const Tensor* state(const std::string& key) const override { return key == "history" ? &history : nullptr; }
+    Tensor signal, table, output, history;
+    U64 decimation = 1, rows = 1, rowSamples = 0, heads = 1, taps = 1;
+};
+
 // ---- PhaseCorrection (dsp/phase_correction/module_impl.cc, module_impl_native_cpu.cc:36-115) ---
 class PhaseCorrection : public Module {
  public:
@@ -1243,6 +1372,8 @@ JST_REGISTER_MODULE(Pad, "pad", DeviceType::HIP, RuntimeType::NATIVE, "generic")
 JST_REGISTER_MODULE(Unpad, "unpad", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Fold, "fold", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(OverlapAdd, "overlap_add", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(FirTaps, "fir_taps", DeviceType::HIP, RuntimeType::NATIVE, "fast");
+JST_REGISTER_MODULE(FirDecimate, "fir_decimate", DeviceType::HIP, RuntimeType::NATIVE, "fast");
 JST_REGISTER_MODULE(PhaseCorrection, "phase_correction", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(FilterTaps, "filter_taps", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Arithmetic, "arithmetic", DeviceType::HIP, RuntimeType::NATIVE, "generic");

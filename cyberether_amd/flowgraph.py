@@ -16,7 +16,8 @@ geometry) is ignored, `note` blocks are dropped, host sinks (`audio`) and decode
 attributes frequency / sampleRate) that the caller feeds with `Flowgraph.feed()`.
 
 ``device:`` is overridden to ``hip`` for every node (this library has no other device);
-``provider:`` is honoured where a module registers more than one ("fast" amplitude/range).
+``provider:`` is honoured where a module registers more than one ("fast" amplitude/range, and the
+"fast" Filter block = one direct-form FIR kernel).
 """
 from __future__ import annotations
 
@@ -215,7 +216,8 @@ class Flowgraph:
             center = (_number_list(cfg.get("center", [0.0])) + [0.0] * heads)[:heads]
             flt = js.Filter(inputs["signal"], float(cfg.get("sampleRate", 2.0e6)),
                             float(cfg.get("bandwidth", 1.0e6)), center, int(cfg.get("taps", 101)),
-                            heads, name=name)
+                            heads, name=name,
+                            provider=provider if provider in ("generic", "fast") else "generic")
             node.impl, node.modules, node.outputs = flt, flt.modules, {"buffer": flt.buffer}
         elif block == "decimator":
             dec = js.Decimator(inputs["buffer"], int(cfg.get("ratio", 4)), name=name)

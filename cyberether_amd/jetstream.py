@@ -174,7 +174,7 @@ class Tensor:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _lib is not None:  # module globals are already gone at interpreter shutdown
             _lib.jst_tensor_destroy(h)
 
     # -- construction ---------------------------------------------------------------------
@@ -358,7 +358,7 @@ class Module:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _lib is not None:
             _lib.jst_module_destroy(h)
 
     def output(self, port: str) -> Tensor:
@@ -411,7 +411,7 @@ class Runtime:
 
     def destroy(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _lib is not None:
             _lib.jst_runtime_destroy(h)
 
     def compute(self, cycles: int = 1, sync: bool = True):
@@ -555,7 +555,11 @@ class Filter:
 
     def __init__(self, signal: Tensor, sample_rate: float = 2.0e6, bandwidth: float = 1.0e6,
                  center: Sequence[float] = (0.0,), taps: int = 101, heads: int = 1,
-                 name: str = "filter"):
+                 name: str = "filter", provider: str = "generic"):
+        """provider "fast": when every head is centred on 0 Hz the whole chain collapses into ONE
+        direct-form polyphase FIR + decimate kernel (csrc/kernels/fir.hip) -- same ports, same stream
+        continuity, results within the reference's own 1e-5-of-peak tolerance instead of bit-exact.
+        Any other plan keeps the FFT overlap-add chain (``self.direct`` tells which one was built)."""
         import math
         axes = signal.axes
         rank = len(signal.shape)
@@ -575,6 +579,22 @@ class Filter:
                                                   "taps": taps}, {}, p + "filter_taps")
         filt = self.filter_taps.output("coeffs").set_axes(sample=1, channel=0)
         self.cast_signal = Module("cast", {"outputType": "CF32"}, {"buffer": signal}, p + "cast_signal")
+        ratio = int(sr / bw) if plan["resample"] else 1
+        self.direct = (provider == "fast" and all(c == 0.0 for c in ctr) and s_axis == rank - 1
+                       and rank <= 2 and (rank == 1 or batch == 0) and taps - 1 <= signal_size
+                       and ratio <= min(32, taps))
+        self.fir = None
+        if self.direct:
+            self.fir_taps = Module("fir_taps", {"decimation": ratio}, {"coeffs": filt}, p + "fir_taps",
+                                   provider="fast")
+            self.fir = Module("fir_decimate", {},
+                              {"signal": self.cast_signal.output("buffer"),
+                               "table": self.fir_taps.output("table")},
+                              p + "fir_decimate", provider="fast")
+            self.buffer = self.fir.output("buffer").set_axes(**out_axes)
+            if plan["resample"]:
+                self.buffer.set_attribute("sampleRate", plan["resampledSampleRate"])
+            return
         self.expand_signal = Module("expand_dims", {"axis": head_axis},
                                     {"buffer": self.cast_signal.output("buffer")}, p + "expand_signal")
         sig_in = self.expand_signal.output("buffer").set_axes(**out_axes)
@@ -632,6 +652,8 @@ class Filter:
 
     @property
     def modules(self) -> List[Module]:
+        if self.direct:
+            return [self.filter_taps, self.fir_taps, self.cast_signal, self.fir]
         ms = [self.filter_taps, self.cast_signal, self.expand_signal, self.pad_signal, self.pad_filter,
               self.fft_signal, self.fft_filter, self.reshape_filter, self.multiply, self.fold, self.ifft,
               self.normalize, self.phase_correction, self.unpad, self.overlap]
