@@ -82,8 +82,7 @@ __global__ __launch_bounds__(kFirThreads) void fir_decimate_kernel(float2* __res
     // stage samples n = n_base + e = u*r - p into slot p*UL + s (s = e / r, p = r - 1 - e % r).
     // One buffer descriptor per row: [row start - back, row end) with back = T-1 samples of the
     // previous row; everything outside (before the stream, past the row) reads as zero by the
-    // descriptor's range check.  (s, p) advance incrementally by the workgroup size: no division,
-    // no 64-bit addresses in the loop; kFirStage loads are in flight per thread.
+    // descriptor's range check.  kFirStage loads are in flight per thread.
     const uint32_t threads = blockDim.x;
     const int32_t n_base = ((int32_t)m0 - (int32_t)d.Q) * (int32_t)d.r + 1;
     const uint32_t real = (d.OW + d.Q - 1) * d.r;
@@ -95,29 +94,27 @@ __global__ __launch_bounds__(kFirThreads) void fir_decimate_kernel(float2* __res
         return (d.r - 1 - (e - sidx * d.r)) * d.UL + sidx;
     };
     {
-        const uint32_t q_t = d.r == 1 ? threads : __umulhi(threads, d.magic_r), m_t = threads - q_t * d.r;
-        const uint32_t step = q_t - m_t * d.UL, wrap = 1 + d.r * d.UL;  // modulo 2^32
-        uint32_t e = tid, pr = tid - (d.r == 1 ? tid : __umulhi(tid, d.magic_r)) * d.r, slot = slot_of(tid);
+        // A staging stride that is a multiple of r keeps every thread on ONE polyphase branch: element
+        // e = tid + k*stride lands in slot (r-1-tid%r)*UL + tid/r + k*stride/r, so each step is two adds
+        // (the few threads past the stride sit the staging out).
+        const uint32_t q_t = d.r == 1 ? threads : __umulhi(threads, d.magic_r), stride = q_t * d.r;
+        const uint32_t full = real / stride;  // iterations in which every participating thread has a sample
+        const bool stager = tid < stride;
+        uint32_t slot = slot_of(tid);
         uint32_t off = (uint32_t)(n_base + (int32_t)back + (int32_t)tid) * 8u;  // negative n: far out of range
-        while (e < real) {  // uniform trip count up to the last partial batch
-            float2 v[kFirStage];
-            uint32_t sl[kFirStage];
+        if (stager) {
+            for (uint32_t k0 = 0; k0 <= full; k0 += kFirStage) {  // uniform trip count
+                float2 v[kFirStage];
 #pragma unroll
-            for (int k = 0; k < kFirStage; ++k) {
-                sl[k] = e < real ? slot : 0xffffffffu;
-                v[k] = buf_load_f2(rs, e < real ? off : 0xfffffff8u, 0);
-                e += threads;
-                off += threads * 8u;
-                pr += m_t;
-                slot += step;
-                if (pr >= d.r) {
-                    pr -= d.r;
-                    slot += wrap;
+                for (int k = 0; k < kFirStage; ++k) v[k] = buf_load_f2(rs, off + k * stride * 8u, 0);
+#pragma unroll
+                for (int k = 0; k < kFirStage; ++k) {
+                    const uint32_t it = k0 + k;  // uniform
+                    if (it < full || (it == full && tid + it * stride < real)) lds[slot + k * q_t] = v[k];
                 }
+                off += kFirStage * stride * 8u;
+                slot += kFirStage * q_t;
             }
-#pragma unroll
-            for (int k = 0; k < kFirStage; ++k)
-                if (sl[k] != 0xffffffffu) lds[sl[k]] = v[k];
         }
     }
     {   // slots past the tile's last sample (chunk round-up) only ever meet zero taps: keep them finite
@@ -213,8 +210,11 @@ namespace {
 
 // J outputs per thread decide the FMAs per LDS byte (a CU reads 16 samples per clock from LDS and
 // issues 128 FMA lanes; a sample feeds 2*J FMAs) against the LDS footprint of a tile of threads*J
-// outputs (r * 8 bytes per output).  Measured on the 251-tap /10 case (tools/fir_sweep.py): (2, 256)
-// -- three 45 KB workgroups per CU, dense 16-byte LDS reads -- beats larger J at lower occupancy.
+// outputs (r * 8 bytes per output).  J = 2 is LDS-bandwidth bound at half the FMA peak (measured:
+// VALU busy 48 %, LDS 50-80 %); even J > 2 reads 16 bytes at a 32-byte lane stride (2-way bank
+// conflict: no gain), odd J is conflict-free with 8-byte reads but its tile no longer leaves room
+// for three workgroups per CU.  tools/fir_sweep.py on the 251-tap /10 case: (2, 256) 48.7 us,
+// (3, 256) 52.6, (5, 128) 69, (4, 128) 69 per cycle.
 struct FirPlan {
     int J = 2, threads = 256;
     uint32_t UL = 0, chunks = 0;

@@ -6,7 +6,7 @@ torch.cuda.set_device(0)
 import cyberether_amd.jetstream as js
 from bench_configs import timed
 rng = np.random.default_rng(0)
-b, s, taps, sr, bw = 100, 159750, 251, 20e6, 2e6
+b, s, taps, sr, bw = int(os.environ.get("FIR_ROWS", "100")), 159750, 251, 20e6, 2e6
 x = (rng.standard_normal((b, s)) + 1j * rng.standard_normal((b, s))).astype(np.complex64)
 src = js.Tensor.from_numpy(x, batch=0, sample=1)
 ref = None
