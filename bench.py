@@ -84,8 +84,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="no hipEvent nodes in the graph")
     ap.add_argument("--pipeline", action="store_true",
-                    help="run the spectrogram on a second captured stream beside the next cycle's "
-                         "spectrum kernel (measured slower on ROCm 7.2: graph branches do not overlap)")
+                    help="run the spectrogram as its own graph on a second stream, one ring period behind "
+                         "the spectrum graph (two hardware queues: +6 %% throughput, the spectrum kernel "
+                         "itself stretches ~5 %% while it shares the CUs)")
     ap.add_argument("--provider", default="generic", choices=["generic", "fast"],
                     help="amplitude/range arithmetic: generic = bit-identical to the reference CPU "
                          "path; fast = hardware transcendentals (within 3e-7 of it)")
@@ -97,10 +98,18 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # JST_BENCH_BACKEND=gloo: dry run of the multi-rank path on a box with fewer GPUs than ranks (ranks
+    # share devices, control plane on CPU tensors); the driver's runs use the default, RCCL.
+    backend = os.environ.get("JST_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
 
@@ -111,7 +120,7 @@ def main() -> None:
         if world > 1:
             dist.barrier()
 
-    def measure(provider: str, seed_offset: int = 0):
+    def measure(provider: str, seed_offset: int = 0, pipeline: bool = args.pipeline):
         """Builds ring_source -> spectrum_engine -> spectrogram with the given amplitude/range
         provider, runs W untimed + K timed steps; returns (runtime, elapsed seconds over ranks)."""
         source = js.Module("ring_source", {"batches": BATCHES, "samples": N_FFT, "slots": args.slots},
@@ -127,7 +136,7 @@ def main() -> None:
                                 "spectrogram")
         rt = js.Runtime([source] + engine.modules + [spectrogram], graph=not args.no_graph,
                         fuse=not args.no_fuse, timing=not args.no_timing,
-                        pipeline=args.pipeline)
+                        pipeline=pipeline)
         rt._keep = (source, engine, spectrogram)  # module handles must outlive the runtime
         rt.compute(args.warmup, sync=True)
         rt.reset_timing()
@@ -140,7 +149,7 @@ def main() -> None:
         elapsed = time.perf_counter() - t0
         barrier()
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return rt, elapsed
@@ -207,6 +216,15 @@ def main() -> None:
                                     "ms_per_step": elapsed2 / args.steps * 1e3, "kernel_ms": ms2,
                                     "roofline_frac": (ach2 / HBM_PEAK_GBS) if ach2 else None}
             rt2.destroy()
+        if world == 1 and not args.pipeline and not args.no_graph:
+            # informational third measurement: the spectrogram as a graph of its own on a second stream
+            # (second hardware queue), one period behind the spectrum graph -- see --pipeline
+            rt3, elapsed3 = measure(args.provider, seed_offset=0, pipeline=True)
+            raw3, pair3, ms3, ach3 = kernel_time(rt3)
+            line["alt_pipelined"] = {"value": samples / elapsed3 / 1e6, "unit": "MS/s",
+                                     "ms_per_step": elapsed3 / args.steps * 1e3, "kernel_ms": ms3,
+                                     "roofline_frac": (ach3 / HBM_PEAK_GBS) if ach3 else None}
+            rt3.destroy()
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         else:

@@ -316,9 +316,12 @@ Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
 }
 
 // PIPELINE planning: SURFACE units (spectrogram, waterfall, lineplot: pure consumers with their
-// own state) move to a side stream so that cycle c's surfaces overlap cycle c+1's producers.
-// Every tensor they read from a dynamic producer becomes a 2-slot ring (cycle c uses slot c%2);
-// a producer of cycle c+2 waits for the surfaces of cycle c before it overwrites the slot.
+// own state) move to a second stream.  hipGraph branches inside ONE graph are executed one after
+// the other on this ROCm, but two graphs launched on two streams run on two hardware queues and do
+// overlap, so each lane gets its own graph of period_ cycles: the surface graph of period k runs
+// beside the producer graph of period k+1.  Every tensor the surfaces read from a dynamic producer
+// becomes a ring of 2*period_ slots (period k uses half k%2); the producers of period k+2 wait for
+// the surfaces of period k before they overwrite that half.
 Result Runtime::planPipeline() {
     std::vector<size_t> surfaces;
     for (size_t i = 0; i < units_.size(); ++i) {
@@ -345,65 +348,55 @@ Result Runtime::planPipeline() {
     if (ring.empty()) return Result::SUCCESS;
     for (Tensor& t : ring)
         if (t.ringSlots() != 1) return Result::SUCCESS;  // already a ring (a source): leave as is
-    for (Tensor& t : ring) JST_CHECK(t.promoteToRing(2));
+    for (Tensor& t : ring) JST_CHECK(t.promoteToRing(2 * period_));
     pipelined_ = ring;
     for (size_t si : surfaces) units_[si].lane = 1;
-    if (period_ % 2) period_ *= 2;
     JST_HIP_CHECK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking), "hipStreamCreate");
-    lane_events_.assign(2 * period_ + 1, nullptr);
-    for (auto& e : lane_events_)
-        JST_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
-    // timing events were sized for the old period
-    for (auto& u : units_) {
-        if (!((flags_ & TIMING) && u.timed)) continue;
-        while (u.span.begin.size() < period_) {
-            hipEvent_t b = nullptr, e = nullptr;
-            JST_HIP_CHECK(hipEventCreate(&b), "hipEventCreate");
-            JST_HIP_CHECK(hipEventCreate(&e), "hipEventCreate");
-            u.span.begin.push_back(b);
-            u.span.end.push_back(e);
-            u.span.recorded.push_back(false);
-        }
-    }
+    for (auto& lane : lane_done_)
+        for (auto& e : lane) JST_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
     return Result::SUCCESS;
 }
 
-Result Runtime::capturePipelined(bool timing) {
-    auto submit_lane = [&](int lane, hipStream_t s, U64 slot) -> Result {
+// One lane's units for period_ consecutive cycles on ring half `half`, as a graph of its own.
+Result Runtime::captureLane(int lane, int half, bool timing) {
+    hipStream_t s = lane == 0 ? stream_ : side_stream_;
+    JST_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+    Result r = Result::SUCCESS;
+    for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c) {
+        for (Tensor& t : pipelined_) JST_CHECK(t.ringSelect((U64)half * period_ + c));
         for (auto& u : units_) {
             if (u.lane != lane || (u.is_static && u.settled)) continue;
-            const bool rec = timing && slot < u.span.begin.size();
-            if (rec) JST_HIP_CHECK(hipEventRecord(u.span.begin[slot], s), "hipEventRecord");
-            const Result r = u.submit(s);
+            // event nodes only in the half-0 graphs (the same events cannot sit in two graphs)
+            const bool rec = timing && half == 0 && (c % timingStride()) == 0 && c < u.span.begin.size();
+            if (rec) JST_HIP_CHECK(hipEventRecord(u.span.begin[c], s), "hipEventRecord");
+            r = u.submit(s);
             if (r != Result::SUCCESS && r != Result::RELOAD) {
-                JST_ERROR("[RUNTIME] computeSubmit failed in '%s' (%s): %s", u.name.c_str(),
-                          ResultName(r), last_error());
-                return r;
+                JST_ERROR("[RUNTIME] computeSubmit failed in '%s' (%s): %s", u.name.c_str(), ResultName(r),
+                          last_error());
+                break;
             }
-            if (rec) {
-                JST_HIP_CHECK(hipEventRecord(u.span.end[slot], s), "hipEventRecord");
-                u.span.recorded[slot] = true;
-            }
+            r = Result::SUCCESS;
+            if (rec) JST_HIP_CHECK(hipEventRecord(u.span.end[c], s), "hipEventRecord");
         }
-        return Result::SUCCESS;
-    };
-    hipEvent_t fork = lane_events_[2 * period_];
-    JST_HIP_CHECK(hipEventRecord(fork, stream_), "hipEventRecord");
-    JST_HIP_CHECK(hipStreamWaitEvent(side_stream_, fork, 0), "hipStreamWaitEvent");
-    for (U64 c = 0; c < period_; ++c) {
-        for (Tensor& t : pipelined_) JST_CHECK(t.ringSelect((cycles_ + c) % 2));
-        if (c >= 2)  // the slot is free once the surfaces of two cycles ago have read it
-            JST_HIP_CHECK(hipStreamWaitEvent(stream_, lane_events_[2 * (c - 2) + 1], 0),
-                          "hipStreamWaitEvent");
-        JST_CHECK(submit_lane(0, stream_, c));
-        JST_HIP_CHECK(hipEventRecord(lane_events_[2 * c], stream_), "hipEventRecord");
-        JST_HIP_CHECK(hipStreamWaitEvent(side_stream_, lane_events_[2 * c], 0), "hipStreamWaitEvent");
-        JST_CHECK(submit_lane(1, side_stream_, c));
-        JST_HIP_CHECK(hipEventRecord(lane_events_[2 * c + 1], side_stream_), "hipEventRecord");
     }
-    // join: the origin stream ends after the last two surface cycles
-    for (U64 c = (period_ >= 2 ? period_ - 2 : 0); c < period_; ++c)
-        JST_HIP_CHECK(hipStreamWaitEvent(stream_, lane_events_[2 * c + 1], 0), "hipStreamWaitEvent");
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &g);
+    if (r != Result::SUCCESS) {
+        if (g) (void)hipGraphDestroy(g);
+        return r;
+    }
+    JST_HIP_CHECK(e, "hipStreamEndCapture");
+    lane_graph_[lane][half] = g;
+    JST_HIP_CHECK(hipGraphInstantiate(&lane_exec_[lane][half], g, nullptr, nullptr, 0), "hipGraphInstantiate");
+    return Result::SUCCESS;
+}
+
+// Both lanes idle, readers see the most recent cycle's slot.
+Result Runtime::joinLanes() {
+    JST_HIP_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    if (side_stream_) JST_HIP_CHECK(hipStreamSynchronize(side_stream_), "hipStreamSynchronize");
+    side_pending_ = false;
+    for (Tensor& t : pipelined_) JST_CHECK(t.ringSelect(last_slot_));
     return Result::SUCCESS;
 }
 
@@ -416,9 +409,15 @@ Result Runtime::destroy() {
         (void)hipStreamDestroy(side_stream_);
         side_stream_ = nullptr;
     }
-    for (hipEvent_t e : lane_events_)
-        if (e) (void)hipEventDestroy(e);
-    lane_events_.clear();
+    for (int lane = 0; lane < 2; ++lane)
+        for (int half = 0; half < 2; ++half) {
+            if (lane_exec_[lane][half]) (void)hipGraphExecDestroy(lane_exec_[lane][half]);
+            if (lane_graph_[lane][half]) (void)hipGraphDestroy(lane_graph_[lane][half]);
+            if (lane_done_[lane][half]) (void)hipEventDestroy(lane_done_[lane][half]);
+            lane_exec_[lane][half] = nullptr;
+            lane_graph_[lane][half] = nullptr;
+            lane_done_[lane][half] = nullptr;
+        }
     pipelined_.clear();
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
     if (graph_) (void)hipGraphDestroy(graph_);
@@ -492,7 +491,11 @@ Result Runtime::eagerCycle(bool& needs_sync) {
             JST_CHECK(harvestTiming());
         }
     }
-    for (Tensor& t : pipelined_) JST_CHECK(t.ringSelect(cycles_ % 2));
+    if (pipelined()) {  // everything on the segment stream, after whatever the side lane still runs
+        if (side_pending_) JST_CHECK(joinLanes());
+        last_slot_ = cycles_ % (2 * period_);
+        for (Tensor& t : pipelined_) JST_CHECK(t.ringSelect(last_slot_));
+    }
     JST_CHECK(submitAll(timing, slot, true));
     timing_pending_ = timing_pending_ || timing;
     ++cycles_;
@@ -514,13 +517,21 @@ Result Runtime::compute(U64 cycles, bool sync) {
         bool any_unsettled_static = false;
         for (auto& u : units_) any_unsettled_static |= (u.is_static && !u.settled);
         bool use_graph = (flags_ & GRAPH) && !any_unsettled_static && cycles >= period_;
-        if (use_graph && !graph_exec_) {
+        if (use_graph && !graphActive()) {
             bool capturable = true;
             for (auto& u : units_)
                 for (Module* m : u.modules) capturable &= (u.is_static || m->capturable());
             if (!capturable) {
                 flags_ &= ~GRAPH;  // a module needs per-cycle host arguments: stay eager
                 use_graph = false;
+            } else if (pipelined()) {
+                // Four graphs: {producer lane, surface lane} x {ring half 0, 1}.  Host-side cursors
+                // advance by a whole period per capture, i.e. come back to the phase they had.
+                capture_phase_ = cycles_ % period_;
+                JST_CHECK(joinLanes());
+                for (int half = 0; half < 2; ++half)
+                    for (int lane = 0; lane < 2; ++lane) JST_CHECK(captureLane(lane, half, timing));
+                for (auto& u : units_) std::fill(u.span.recorded.begin(), u.span.recorded.end(), false);
             } else {
                 // Capture period_ consecutive cycles.  Host-side cursors (ring sources) advance
                 // during capture exactly as they would while running, so after the capture they
@@ -529,10 +540,8 @@ Result Runtime::compute(U64 cycles, bool sync) {
                 JST_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal),
                               "hipStreamBeginCapture");
                 Result r = Result::SUCCESS;
-                if (pipelined()) r = capturePipelined(timing);
-                else
-                    for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c)
-                        r = submitAll(timing && (c % timingStride()) == 0, c, false);
+                for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c)
+                    r = submitAll(timing && (c % timingStride()) == 0, c, false);
                 hipGraph_t g = nullptr;
                 const hipError_t e = hipStreamEndCapture(stream_, &g);
                 if (r != Result::SUCCESS) {
@@ -551,15 +560,30 @@ Result Runtime::compute(U64 cycles, bool sync) {
             // No harvest between replays: the in-graph event nodes are simply re-recorded, and the
             // final synchronise reads the last replay's period_ samples per unit.  Replays
             // therefore queue back to back with no host round trip.
-            JST_HIP_CHECK(hipGraphLaunch(graph_exec_, stream_), "hipGraphLaunch");
+            if (pipelined()) {
+                const int h = (int)(lane_launches_ % 2);
+                if (lane_launches_ >= 2)  // this half is free once the surfaces of two periods ago are done
+                    JST_HIP_CHECK(hipStreamWaitEvent(stream_, lane_done_[1][h], 0), "hipStreamWaitEvent");
+                JST_HIP_CHECK(hipGraphLaunch(lane_exec_[0][h], stream_), "hipGraphLaunch");
+                JST_HIP_CHECK(hipEventRecord(lane_done_[0][h], stream_), "hipEventRecord");
+                JST_HIP_CHECK(hipStreamWaitEvent(side_stream_, lane_done_[0][h], 0), "hipStreamWaitEvent");
+                JST_HIP_CHECK(hipGraphLaunch(lane_exec_[1][h], side_stream_), "hipGraphLaunch");
+                JST_HIP_CHECK(hipEventRecord(lane_done_[1][h], side_stream_), "hipEventRecord");
+                last_slot_ = (U64)h * period_ + (period_ - 1);
+                side_pending_ = true;
+                ++lane_launches_;
+            } else {
+                JST_HIP_CHECK(hipGraphLaunch(graph_exec_, stream_), "hipGraphLaunch");
+            }
+            const bool events_ran = !pipelined() || (lane_launches_ % 2) == 1;  // the half-0 graphs carry them
             for (auto& u : units_) {  // (the in-graph nodes overwrite any unread eager samples)
                 if (u.is_static && u.settled) continue;
                 for (Module* m : u.modules) m->timing.cycles += period_;
-                if (timing)  // the graph holds event nodes for every timingStride()-th cycle only
+                if (timing && events_ran)  // event nodes sit on every timingStride()-th cycle only
                     for (size_t c = 0; c < u.span.recorded.size(); ++c)
-                        u.span.recorded[c] = !pipelined() ? (c % timingStride()) == 0 : true;
+                        u.span.recorded[c] = (c % timingStride()) == 0;
             }
-            timing_pending_ = timing;
+            timing_pending_ = timing_pending_ || timing;
             cycles_ += period_;
             cycles -= period_;
             continue;
@@ -568,7 +592,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
         --cycles;
     }
     if (needs_sync) {
-        JST_HIP_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+        JST_CHECK(joinLanes());
         JST_CHECK(harvestTiming());
     }
     return Result::SUCCESS;
@@ -576,7 +600,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
 
 Result Runtime::synchronize() {
     if (!stream_) return Result::SUCCESS;
-    JST_HIP_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+    JST_CHECK(joinLanes());
     return harvestTiming();
 }
 

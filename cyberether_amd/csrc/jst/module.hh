@@ -152,7 +152,7 @@ class Runtime {
     hipStream_t stream() const { return stream_; }
     const std::vector<std::string>& order() const { return order_names_; }
     const std::vector<std::string>& units() const { return unit_names_; }
-    bool graphActive() const { return graph_exec_ != nullptr; }
+    bool graphActive() const { return graph_exec_ != nullptr || lane_exec_[0][0] != nullptr; }
     // Mean device time (ms) of the named unit over the cycles run with TIMING; <0 if unknown.
     F64 unitMeanMs(const std::string& name);
     // Mean duration of an EMPTY event pair recorded in the same graph/stream (one kernel-less
@@ -193,13 +193,20 @@ class Runtime {
     U64 period_ = 1;
     U64 capture_phase_ = 0;
     std::string calibration_unit_;
-    // PIPELINE: a second captured stream for SURFACE units and double-buffered intermediates
+    // PIPELINE: SURFACE units run as their own graphs on a second stream (a second hardware queue),
+    // one period behind the producers; the tensors in between are rings of two periods.
     hipStream_t side_stream_ = nullptr;
-    std::vector<Tensor> pipelined_;        // producer->surface tensors, promoted to 2-slot rings
-    std::vector<hipEvent_t> lane_events_;  // [2*period]: lane-0 done / lane-1 done per cycle
+    std::vector<Tensor> pipelined_;        // producer->surface tensors, promoted to 2*period-slot rings
+    hipGraph_t lane_graph_[2][2] = {};     // [lane][half of the ring]
+    hipGraphExec_t lane_exec_[2][2] = {};
+    hipEvent_t lane_done_[2][2] = {};      // lane L finished its latest launch on half h
+    U64 lane_launches_ = 0;
+    U64 last_slot_ = 0;                    // ring slot of the most recent cycle (what a reader sees)
+    bool side_pending_ = false;
     bool pipelined() const { return !pipelined_.empty(); }
     Result planPipeline();
-    Result capturePipelined(bool timing);
+    Result captureLane(int lane, int half, bool timing);
+    Result joinLanes();
     bool timing_pending_ = false;
     bool created_ = false;
 };

@@ -73,8 +73,8 @@ def test_spectrogram_state_over_cycles_with_graph(js, oracle, pipeline):
         rt.compute()
         oracle.spectrogram(ref_bins, ref_out, h)
         assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), ref_bins, f"cycle {cycle}")
-    if pipeline:  # the pipelined graph holds 2 cycles: single-cycle calls above ran eagerly
-        assert rt.period == 2 and not rt.graph_active
+    if pipeline:  # producer and surface lanes are separate graphs on two streams; several periods in flight
+        assert rt.period == 1 and rt.graph_active
         rt.compute(4)
         for _ in range(4):
             oracle.spectrogram(ref_bins, ref_out, h)
