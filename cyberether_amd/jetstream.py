@@ -581,16 +581,19 @@ class Filter:
         self.cast_signal = Module("cast", {"outputType": "CF32"}, {"buffer": signal}, p + "cast_signal")
         ratio = int(sr / bw) if plan["resample"] else 1
         self.direct = (provider == "fast" and all(c == 0.0 for c in ctr) and s_axis == rank - 1
-                       and rank <= 2 and (rank == 1 or batch == 0) and taps - 1 <= signal_size
-                       and ratio <= min(32, taps))
-        self.fir = None
+                       and rank <= 2 and (rank == 1 or batch == 0))
+        self.fir = self.fir_taps = None
         if self.direct:
-            self.fir_taps = Module("fir_taps", {"decimation": ratio}, {"coeffs": filt}, p + "fir_taps",
-                                   provider="fast")
-            self.fir = Module("fir_decimate", {},
-                              {"signal": self.cast_signal.output("buffer"),
-                               "table": self.fir_taps.output("table")},
-                              p + "fir_decimate", provider="fast")
+            try:  # the kernel's own plan check decides (taps vs. row length, decimation, LDS tile)
+                self.fir_taps = Module("fir_taps", {"decimation": ratio}, {"coeffs": filt}, p + "fir_taps",
+                                       provider="fast")
+                self.fir = Module("fir_decimate", {},
+                                  {"signal": self.cast_signal.output("buffer"),
+                                   "table": self.fir_taps.output("table")},
+                                  p + "fir_decimate", provider="fast")
+            except JetstreamError:
+                self.direct, self.fir, self.fir_taps = False, None, None  # keep the FFT overlap-add chain
+        if self.direct:
             self.buffer = self.fir.output("buffer").set_axes(**out_axes)
             if plan["resample"]:
                 self.buffer.set_attribute("sampleRate", plan["resampledSampleRate"])
