@@ -362,6 +362,12 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
     constexpr int NB = 8 / IP;  // butterflies per thread (8 points per thread)
     constexpr bool LAST = (P == plan.nf - 1);
     static_assert(BUT == NB * T, "T must be N/8");
+    // Wave priority: the passes are coupled by workgroup barriers (a late wave stalls seven others),
+    // the epilogue is a long barrier-free VALU stream.  With both co-resident workgroups at equal
+    // priority the epilogue of one delays the passes of the other; passes at priority 3 and the
+    // epilogue at 0 gave 30.8 -> 28.9 us (exact) and 21.0 -> 20.1 us (fast) per 1024 x 4096 launch.
+    if constexpr (P == 0) __builtin_amdgcn_s_setprio(3);
+    if constexpr (LAST) __builtin_amdgcn_s_setprio(0);
     // x[] holds CC(i,b,k) for butterfly j at x[j*IP + b]
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
