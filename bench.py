@@ -83,6 +83,9 @@ def main() -> None:
     ap.add_argument("--no-fuse", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="no hipEvent nodes in the graph")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the informational alt_provider / alt_pipelined measurements (profiling runs: "
+                         "one kernel variant, one launch pattern per trace)")
     ap.add_argument("--pipeline", action="store_true",
                     help="run the spectrogram as its own graph on a second stream, one ring period behind "
                          "the spectrum graph (two hardware queues: +6 %% throughput, the spectrum kernel "
@@ -207,7 +210,7 @@ def main() -> None:
                          "event_pair_overhead_ms": pair_ms,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
-        if world == 1 and args.provider == "generic" and not args.no_fuse:
+        if world == 1 and args.provider == "generic" and not args.no_fuse and not args.no_alt:
             # informational second measurement: same chain with provider "fast" (hardware
             # transcendentals for amplitude/range, within 3e-7 of the CPU path; BASELINE allows 1e-5)
             rt2, elapsed2 = measure("fast", seed_offset=0)
@@ -216,7 +219,7 @@ def main() -> None:
                                     "ms_per_step": elapsed2 / args.steps * 1e3, "kernel_ms": ms2,
                                     "roofline_frac": (ach2 / HBM_PEAK_GBS) if ach2 else None}
             rt2.destroy()
-        if world == 1 and not args.pipeline and not args.no_graph:
+        if world == 1 and not args.pipeline and not args.no_graph and not args.no_alt:
             # informational third measurement: the spectrogram as a graph of its own on a second stream
             # (second hardware queue), one period behind the spectrum graph -- see --pipeline
             rt3, elapsed3 = measure(args.provider, seed_offset=0, pipeline=True)
