@@ -4,6 +4,8 @@
 // (SURVEY 2b); every kernel restates the CPU arithmetic in the CPU's order (F64 where the CPU
 // uses F64) so results are bit-identical, except FM whose libm atan2f/sinf/cosf are replaced by
 // the device's (tolerance stated in the tests; the reference's own FM tests use 1e-2).
+#include <cstdlib>
+
 #include "device_math.hh"
 #include "kernels.hh"
 
@@ -385,6 +387,279 @@ __global__ __launch_bounds__(64) void fm_kernel(float* __restrict__ out, const f
     st.has_prev = 1;
     states[lane] = st;
 }
+// ---- wide FM as a wavefront pipeline -------------------------------------------------------------
+// The stereo decoder is a chain of serial recurrences (pilot phase, four one-poles, eight biquads, two
+// de-emphasis one-poles) with element-wise transcendental stages in between.  fm_kernel above walks
+// it with one thread per lane, every dependent operation paying full latency: ~0.9 us per sample.
+// Here one workgroup per lane splits the sample loop by stage, keeping every chain's operations and
+// order (same bits):
+//   A  all threads   d[n] = discriminator                                   (element-wise)
+//   B  one thread    phase[n]: the pilot phase recurrence, data independent (runs beside A)
+//   C  all threads   xc, xs = d * cosf / sinf(phase)
+//   D  4 lanes       the pilot one-poles as a 2-deep lane pipeline: lane 0/2 the first pole of sample
+//                    n, lane 1/3 the second pole of sample n-1, fed by a DPP row shift
+//   E  all threads   pilot offset atan2f, carrier sinf, xd = 2 d carrier
+//   F  8 lanes       notch + 3 low-pass biquads of the sum path (lanes 0-3) and of the difference path
+//                    (lanes 4-7) as a 4-deep lane pipeline: lane k works on sample n - k%4
+//   G  2 lanes       de-emphasis of left / right, then all threads write the output
+// A non-finite discriminator sample leaves every filter state untouched (fm/module_impl_native_cpu.cc:
+// 96-112): it travels down the lane pipelines as a bubble.
+struct FmWideScratch {  // per lane, each array `n` floats
+    float *d, *phase, *xc, *xs, *pcos, *psin, *xd, *sum, *diff;
+};
+__device__ __forceinline__ float dpp_row_shr1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
+}
+// take ? a : b as ONE v_bfi_b32 on a lane mask: the serial stretches must stay straight-line code (the
+// compiler turns a ?: around a recurrence step into an exec-mask branch per sample)
+__device__ __forceinline__ float fm_pick(uint32_t take_mask, float a, float b) {
+    return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, a) & take_mask) |
+                                         (__builtin_bit_cast(uint32_t, b) & ~take_mask));
+}
+constexpr int kFmChunk = 2048;  // samples staged in LDS per serial stretch
+constexpr int kFmThreads = 256;
+
+__global__ __launch_bounds__(kFmThreads) void fm_wide_kernel(float* __restrict__ out,
+                                                              const float2* __restrict__ in,
+                                                              FmState* __restrict__ states, const FmCoeffs k,
+                                                              const FmLayout L, float* __restrict__ scratch) {
+    // serial stretches: inputs and results of a chunk live in LDS (coalesced traffic on both sides, no
+    // global access inside the recurrences)
+    __shared__ float in_a[kFmChunk + 8], in_b[kFmChunk + 8], out_a[kFmChunk + 8], out_b[kFmChunk + 8],
+        spill[kFmChunk + 8];  // where the lanes without a result write (all to the same words: never read)
+    const uint32_t tid = threadIdx.x;
+    const uint64_t lane = blockIdx.x, n_total = L.batches * L.samples;
+    int64_t in_off, out_off;
+    fm_lane_offsets(L, lane, in_off, out_off);
+    FmWideScratch w;
+    {
+        float* base = scratch + lane * 9 * n_total;
+        w.d = base;
+        w.phase = base + n_total;
+        w.xc = base + 2 * n_total;
+        w.xs = base + 3 * n_total;
+        w.pcos = base + 4 * n_total;
+        w.psin = base + 5 * n_total;
+        w.xd = base + 6 * n_total;
+        w.sum = base + 7 * n_total;
+        w.diff = base + 8 * n_total;
+    }
+    FmState st = states[lane];
+    const float nan = __builtin_nanf("");
+    auto in_at = [&](uint64_t n) {
+        return in[in_off + (int64_t)(n / L.samples) * L.in_batch_stride + (int64_t)(n % L.samples) * L.in_sample_stride];
+    };
+    // ---- A (threads 64..255) beside B (thread 0) ----
+    if (tid >= 64) {
+        for (uint64_t n = tid - 64; n < n_total; n += kFmThreads - 64) {
+            const float2 cur = in_at(n);
+            const float2 prev = n ? in_at(n - 1) : mk(st.prev_re, st.prev_im);
+            w.d[n] = fm_discriminate(prev, cur, n ? true : st.has_prev != 0, k.ref);
+        }
+    } else if (tid == 0) {
+        // (double)ph >= 2.0f * pi_f64 (6.283185307179586) <=> ph >= the float just above it: the
+        // common step is one F32 add and one F32 compare, the F64 wrap runs every ~10th sample
+        const double two_pi = 2.0f * 3.14159265358979323846;
+        const float wrap_at = __builtin_bit_cast(float, 0x40C90FDBu);  // 6.2831854820251465
+        float ph = st.pilot_phase;
+        for (uint64_t n = 0; n < n_total; ++n) {
+            w.phase[n] = ph;
+            ph += k.pilot_inc;
+            if (ph >= wrap_at) ph = (float)((double)ph - two_pi);
+        }
+        st.pilot_phase = ph;
+    }
+    __syncthreads();
+    // ---- C ----
+    for (uint64_t n = tid; n < n_total; n += kFmThreads) {
+        const float d = w.d[n], ph = w.phase[n];
+        const bool fin = __builtin_isfinite(d);
+        w.xc[n] = fin ? d * cosf(ph) : nan;  // non-finite discriminator sample = bubble
+        w.xs[n] = fin ? d * sinf(ph) : nan;
+    }
+    __syncthreads();
+    // A serial stretch over n_total + skew pipeline steps in chunks: stage(i) fills in_a/in_b, wave 0
+    // runs step(i0, i) eight iterations at a time (inputs of the head lanes prefetched from LDS), then
+    // flush(i) moves out_a/out_b to their destination.
+    auto stretch = [&](uint64_t steps, auto&& stage, auto&& body, auto&& flush) {
+        for (uint64_t c0 = 0; c0 < steps; c0 += kFmChunk) {
+            const uint32_t cnt = (uint32_t)((steps - c0) < (uint64_t)kFmChunk ? (steps - c0) : (uint64_t)kFmChunk);
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt + 8; i += kFmThreads) stage(c0 + i, i, i < cnt);
+            __syncthreads();
+            if (tid < 64) body(cnt);
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += kFmThreads) flush(c0 + i, i);
+        }
+    };
+    // ---- D: lanes 0,1 = cosine poles (first, second), 2,3 = sine poles ----
+    {
+        float pole = 0.0f;  // this lane's one-pole state
+        if (tid == 0) pole = st.pilot_cos_stage;
+        if (tid == 1) pole = st.pilot_cos;
+        if (tid == 2) pole = st.pilot_sin_stage;
+        if (tid == 3) pole = st.pilot_sin;
+        const bool head = (tid & 1u) == 0;  // first pole of a pair: reads the staged input
+        const float* src = tid < 2 ? in_a : in_b;
+        float* res = tid == 1 ? out_a : (tid == 3 ? out_b : spill);
+        float handed = nan;                 // what this lane passes to its right neighbour: a bubble first
+        stretch(
+            n_total + 1,
+            [&](uint64_t n, uint32_t i, bool) {
+                in_a[i] = n < n_total ? w.xc[n] : nan;
+                in_b[i] = n < n_total ? w.xs[n] : nan;
+            },
+            [&](uint32_t cnt) {
+                for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+                    float xin[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xin[j] = src[i0 + j];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float from_left = dpp_row_shr1(handed);
+                        const float x = head ? xin[j] : from_left;
+                        const uint32_t fin = __builtin_isfinite(x) ? 0xffffffffu : 0u;
+                        const float upd = pole + k.pilot_alpha * (x - pole);
+                        pole = fm_pick(fin, upd, pole);
+                        handed = fm_pick(fin, upd, x);
+                        res[i0 + j] = handed;
+                    }
+                }
+            },
+            [&](uint64_t n, uint32_t i) {  // second poles work on sample n - 1
+                if (n >= 1 && __builtin_isfinite(out_a[i])) w.pcos[n - 1] = out_a[i];
+                if (n >= 1 && __builtin_isfinite(out_b[i])) w.psin[n - 1] = out_b[i];
+            });
+        if (tid == 0) st.pilot_cos_stage = pole;
+        if (tid == 1) states[lane].pilot_cos = pole;
+        if (tid == 2) states[lane].pilot_sin_stage = pole;
+        if (tid == 3) states[lane].pilot_sin = pole;
+    }
+    __syncthreads();
+    // ---- E ----
+    for (uint64_t n = tid; n < n_total; n += kFmThreads) {
+        const float d = w.d[n];
+        if (!__builtin_isfinite(d)) {
+            w.xd[n] = nan;
+            continue;
+        }
+        const float po = atan2f(w.pcos[n], w.psin[n]);
+        const float carrier = sinf(2.0f * (w.phase[n] + po));
+        w.xd[n] = 2.0f * d * carrier;
+    }
+    __syncthreads();
+    // ---- F: lanes 0-3 sum path (notch, lp0, lp1, lp2), lanes 4-7 difference path ----
+    {
+        const uint32_t stage = tid & 3u;
+        const bool diff_path = (tid & 4u) != 0, active = tid < 8;
+        float c[5] = {0, 0, 0, 0, 0}, s0 = 0.0f, s1 = 0.0f;
+        if (active) {
+            const float* cc = stage == 0 ? k.notch : k.lp[stage - 1];
+            const float* ss = stage == 0 ? (diff_path ? st.diff_notch : st.sum_notch)
+                                         : (diff_path ? st.diff_filter[stage - 1] : st.sum_filter[stage - 1]);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) c[j] = cc[j];
+            s0 = ss[0];
+            s1 = ss[1];
+        }
+        const float* src = diff_path ? in_b : in_a;
+        float* res = tid == 3 ? out_a : (tid == 7 ? out_b : spill);
+        float handed = nan;
+        stretch(
+            n_total + 3,
+            [&](uint64_t n, uint32_t i, bool) {
+                in_a[i] = n < n_total ? w.d[n] : nan;  // non-finite d = bubble
+                in_b[i] = n < n_total ? w.xd[n] : nan;
+            },
+            [&](uint32_t cnt) {
+                for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+                    float xin[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xin[j] = src[i0 + j];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float from_left = dpp_row_shr1(handed);
+                        const float x = stage == 0 ? xin[j] : from_left;
+                        const uint32_t fin = __builtin_isfinite(x) ? 0xffffffffu : 0u;
+                        const float y = c[0] * x + s0;
+                        const float n0 = c[1] * x - c[3] * y + s1;
+                        const float n1 = c[2] * x - c[4] * y;
+                        s0 = fm_pick(fin, n0, s0);
+                        s1 = fm_pick(fin, n1, s1);
+                        handed = fm_pick(fin, y, x);
+                        res[i0 + j] = handed;
+                    }
+                }
+            },
+            [&](uint64_t n, uint32_t i) {  // the last stages work on sample n - 3
+                if (n >= 3 && __builtin_isfinite(out_a[i])) w.sum[n - 3] = out_a[i];
+                if (n >= 3 && __builtin_isfinite(out_b[i])) w.diff[n - 3] = out_b[i];
+            });
+        if (active) {
+            float* ss = stage == 0 ? (diff_path ? states[lane].diff_notch : states[lane].sum_notch)
+                                   : (diff_path ? states[lane].diff_filter[stage - 1] : states[lane].sum_filter[stage - 1]);
+            ss[0] = s0;
+            ss[1] = s1;
+        }
+    }
+    __syncthreads();
+    // ---- G ----
+    auto out_at = [&](uint64_t n) {
+        return out_off + (int64_t)(n / L.samples) * L.out_batch_stride + (int64_t)(n % L.samples) * L.out_sample_stride;
+    };
+    if (!k.deemph_enabled) {
+        for (uint64_t n = tid; n < n_total; n += kFmThreads) {
+            const float d = w.d[n];
+            const bool fin = __builtin_isfinite(d);
+            const float sum = w.sum[n], diff = w.diff[n];
+            out[out_at(n)] = fin ? sum + diff : d;
+            out[out_at(n) + L.out_channel_stride] = fin ? sum - diff : d;
+        }
+    } else {
+        float de = tid == 0 ? st.left_de : st.right_de;
+        const float* src = tid == 0 ? in_a : in_b;
+        float* res = tid == 0 ? out_a : (tid == 1 ? out_b : spill);
+        stretch(
+            n_total,
+            [&](uint64_t n, uint32_t i, bool) {
+                const bool fin = n < n_total && __builtin_isfinite(w.d[n]);
+                in_a[i] = fin ? w.sum[n] + w.diff[n] : nan;
+                in_b[i] = fin ? w.sum[n] - w.diff[n] : nan;
+            },
+            [&](uint32_t cnt) {
+                for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+                    float xin[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xin[j] = src[i0 + j];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = xin[j];
+                        const uint32_t fin = __builtin_isfinite(x) ? 0xffffffffu : 0u;
+                        const float upd = de + k.deemph_alpha * (x - de);
+                        de = fm_pick(fin, upd, de);
+                        res[i0 + j] = fm_pick(fin, upd, x);
+                    }
+                }
+            },
+            [&](uint64_t n, uint32_t i) {
+                const float d = w.d[n];
+                const bool fin = __builtin_isfinite(d);
+                out[out_at(n)] = fin ? out_a[i] : d;
+                out[out_at(n) + L.out_channel_stride] = fin ? out_b[i] : d;
+            });
+        if (tid == 0) states[lane].left_de = de;
+        if (tid == 1) states[lane].right_de = de;
+    }
+    if (tid == 0) {
+        const float2 last = in_at(n_total - 1);
+        states[lane].prev_re = last.x;
+        states[lane].prev_im = last.y;
+        states[lane].has_prev = 1;
+        states[lane].pilot_phase = st.pilot_phase;
+        states[lane].pilot_cos_stage = st.pilot_cos_stage;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void fm_narrow_parallel_kernel(
     float* __restrict__ out, const float2* __restrict__ in, const FmState* __restrict__ states,
     const FmCoeffs k, const FmLayout L) {
@@ -742,9 +1017,17 @@ hipError_t launch_arithmetic(const EwLayout& L, void* out, const void* in, bool 
 #undef JST_ARITH
     return hipGetLastError();
 }
+size_t fm_scratch_floats(const FmCoeffs& k, const FmLayout& L) {
+    return k.wide ? (size_t)(9 * L.lanes * L.batches * L.samples) : 0;
+}
 hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
-                     hipStream_t s) {
+                     float* scratch, hipStream_t s) {
     (void)hipGetLastError();
+    if (k.wide && scratch && L.batches * L.samples > 0 && !getenv("JST_FM_SERIAL")) {
+        hipLaunchKernelGGL(fm_wide_kernel, dim3((unsigned)L.lanes), dim3(kFmThreads), 0, s, out, in,
+                           (FmState*)states, k, L, scratch);
+        return hipGetLastError();
+    }
     if (!k.wide && !k.deemph_enabled) {
         const uint64_t total = L.lanes * L.batches * L.samples;
         hipLaunchKernelGGL(fm_narrow_parallel_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, out,

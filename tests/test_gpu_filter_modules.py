@@ -260,3 +260,40 @@ def test_signal_generator_noise_statistics(js, dtype):
         assert abs(np.corrcoef(a.real, a.imag)[0, 1]) < 0.01
     z = (re - 0.5)
     assert abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 3.0) < 0.1   # gaussian moments
+
+
+@pytest.mark.parametrize("deemph", ["none", "75us"])
+def test_fm_wide_wavefront_pipeline_equals_serial_walk(js, monkeypatch, deemph):
+    """The stage-split wide decoder (fm_wide_kernel: lane pipelines over DPP for the one-poles and the
+    biquad cascades) against the one-thread-per-lane walk of the same recurrences (JST_FM_SERIAL=1):
+    identical bits, over submissions, with non-finite samples travelling through as bubbles."""
+    rng = np.random.default_rng(8)
+    sr, lanes, batches, samples = 240e3, 2, 3, 2311   # several LDS chunks with a ragged tail
+    outs = {}
+    for variant in ("serial", "pipeline"):
+        if variant == "serial":
+            monkeypatch.setenv("JST_FM_SERIAL", "1")
+        else:
+            monkeypatch.delenv("JST_FM_SERIAL", raising=False)
+        rng = np.random.default_rng(8)
+        t = js.Tensor.create("hip", "CF32", (batches, lanes, samples)).set_axes(batch=0, sample=2)
+        m = js.Module("fm", {"mode": "wide", "deemphasis": deemph, "sampleRate": sr}, {"signal": t})
+        rt = js.Runtime([m])
+        got = []
+        for cycle in range(3):
+            x = np.stack([fm_signal(rng, batches * samples, sr, 75e3, True).reshape(batches, samples)
+                          for _ in range(lanes)], axis=1)
+            if cycle >= 1:
+                x[0, 1, 10] = complex(np.nan, 0)
+                x[1, 0, 0] = complex(np.inf, 1)
+                x[2, 1, samples - 1] = complex(0, -np.inf)
+                x[1, 1, 100:103] = complex(np.nan, np.nan)
+            t.copy_from(x)
+            rt.compute()
+            got.append(m.output("signal").numpy().copy())
+        outs[variant] = got
+        rt.destroy()
+    for cycle in range(3):
+        a, b = outs["serial"][cycle], outs["pipeline"][cycle]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), cycle
+        assert np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(b)]), cycle
