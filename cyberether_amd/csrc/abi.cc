@@ -416,6 +416,17 @@ jst_result jst_fft_twiddles(uint64_t n, float* out) {
     modules::ComputeTwiddles(n, out);
     return R(Result::SUCCESS);
 }
+jst_result jst_probe_amplitude_range(const float* in, float* out_exact, float* out_fast, uint64_t count,
+                                     float amplitude_coeff, float range_scale, float range_offset,
+                                     float guard_h0, float guard_h1) {
+    JST_ARG(in && out_exact && out_fast, "null argument");
+    JST_HIP_CHECK(kernels::launch_amplitude_range_probe(out_exact, out_fast, reinterpret_cast<const float2*>(in),
+                                                        count, amplitude_coeff, range_scale, range_offset,
+                                                        guard_h0, guard_h1, nullptr),
+                  "amplitude/range probe");
+    JST_HIP_CHECK(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
+    return R(Result::SUCCESS);
+}
 jst_result jst_probe_tanhf(const float* in, float* out, uint64_t count) {
     JST_ARG(in && out, "null argument");
     JST_HIP_CHECK(kernels::launch_tanhf_probe(out, in, count, nullptr), "tanhf probe");

@@ -218,4 +218,36 @@ __device__ __forceinline__ float range_f32_fast(float v, float scale, float offs
     return 0.5f + 0.5f * tanhf_fast(4.0f * (normalized - 0.5f));
 }
 
+// Provider "fast" with exact bins.  A Spectrogram consumer quantises the range value r to
+// bin = trunc(r * height) (hit <=> 1 <= r * height < height); the fast value may differ from the
+// libm-exact one by a few 1e-7, which flips a bin only when r * height lies that close to an integer.
+// So: whenever the fast r * height is within `guard` of an integer k >= 1, the element is recomputed
+// with the exact amplitude + range arithmetic (and stored exactly); every other element keeps the fast
+// value, whose bin equals the exact one.  guard = height * 7.5e-7: the two F32 roundings of the
+// products (<= height * 1.2e-7) plus twice the largest fast-vs-exact difference over dense sweeps
+// (< 3e-7: one-ulp v_exp/v_rcp/v_sqrt against the libm restatement; tests/test_gpu_fast_provider.py
+// asserts the bound).  About 4e-4 of the elements take the exact path at height 256.
+struct BinGuard {
+    float h0 = 0.0f, h1 = 0.0f;  // consumer heights (0 = none)
+};
+__device__ __forceinline__ bool near_bin_edge(float r, float h) {
+    const float f = r * h, fr = f - __builtin_floorf(f);  // v_fract_f32
+    return f >= 0.5f && __builtin_fabsf(fr - 0.5f) > 0.5f - h * 7.5e-7f;
+}
+// one out-of-line copy of the exact arithmetic for the rare guarded elements (inlined into each of the
+// eight unrolled epilogue slots it triples the kernel's code)
+__device__ __attribute__((noinline)) float amplitude_range_exact_cold(f2 v, float coeff, float scale,
+                                                                      float offset) {
+    return range_f32(amplitude_cf32(v, coeff), scale, offset);
+}
+__device__ __forceinline__ float amplitude_range_fast_guarded(f2 v, float coeff, float scale, float offset,
+                                                              const BinGuard& g) {
+    float r = range_f32_fast(amplitude_cf32_fast(v, coeff), scale, offset);
+    if (g.h0 > 0.0f) {  // wave-uniform
+        if (near_bin_edge(r, g.h0) || (g.h1 > 0.0f && near_bin_edge(r, g.h1)))
+            r = amplitude_range_exact_cold(v, coeff, scale, offset);
+    }
+    return r;
+}
+
 }  // namespace jst::dev

@@ -264,6 +264,30 @@ hipError_t launch_cast(const EwLayout& L, void* out, const void* in, CastKind ki
 #undef JST_CAST_CPLX
     return hipErrorInvalidValue;
 }
+namespace {
+__global__ __launch_bounds__(256) void amplitude_range_probe_kernel(float* __restrict__ out_exact,
+                                                                    float* __restrict__ out_fast,
+                                                                    const float2* __restrict__ in, uint64_t count,
+                                                                    float coeff, float scale, float offset,
+                                                                    dev::BinGuard guard) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const float2 v = in[i];
+        out_exact[i] = range_f32(amplitude_cf32(v, coeff), scale, offset);
+        out_fast[i] = amplitude_range_fast_guarded(v, coeff, scale, offset, guard);
+    }
+}
+}  // namespace
+hipError_t launch_amplitude_range_probe(float* out_exact, float* out_fast, const float2* in, uint64_t count,
+                                        float amp_coeff, float range_scale, float range_offset,
+                                        float guard_h0, float guard_h1, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    (void)hipGetLastError();
+    const uint64_t blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(amplitude_range_probe_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
+                       s, out_exact, out_fast, in, count, amp_coeff, range_scale, range_offset,
+                       dev::BinGuard{guard_h0, guard_h1});
+    return hipGetLastError();
+}
 hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipStream_t s) {
     EwLayout L{};
     L.size = count;

@@ -147,15 +147,16 @@ hipError_t launch_fft_c2c(uint64_t n, bool forward, const FftLayout& L, const fl
 hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W,
                                  const float2* in, const float2* window, int64_t window_stride,
                                  float* out, float amp_coeff, bool with_range, float range_scale,
-                                 float range_offset, bool fast, hipStream_t stream) {
+                                 float range_offset, bool fast, float guard_h0, float guard_h1,
+                                 hipStream_t stream) {
     const LoadCF32TimesWindow pro{in, window, window_stride};
     if (with_range) {
         if (fast)
             return dispatch_fused_n(n, L, W, pro,
-                                    StoreAmplitudeRangeT<true>{out, amp_coeff, range_scale, range_offset},
+                                    StoreAmplitudeRangeT<true>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}},
                                     stream);
         return dispatch_fused_n(n, L, W, pro,
-                                StoreAmplitudeRangeT<false>{out, amp_coeff, range_scale, range_offset},
+                                StoreAmplitudeRangeT<false>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}},
                                 stream);
     }
     if (fast) return dispatch_fused_n(n, L, W, pro, StoreAmplitudeT<true>{out, amp_coeff}, stream);

@@ -197,18 +197,20 @@ template <bool FAST>
 struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_native_cpu.cc:67-82)
     float* out;
     float coeff, scale, offset;
+    BinGuard guard;  // FAST only: heights of the Spectrogram consumers (device_math.hh)
     static constexpr uint32_t kElemBytes = 4;
     __device__ __forceinline__ const void* row(int64_t base) const { return out + base; }
+    __device__ __forceinline__ float value(float2 v) const {
+        if constexpr (FAST) return amplitude_range_fast_guarded(v, coeff, scale, offset, guard);
+        else return range_f32(amplitude_cf32(v, coeff), scale, offset);
+    }
     __device__ __forceinline__ void store_buf(rsrc_t r, uint32_t voff, uint32_t soff, float2 v) const {
-        buf_store_f1(r, voff, soff,
-                     FAST ? range_f32_fast(amplitude_cf32_fast(v, coeff), scale, offset)
-                          : range_f32(amplitude_cf32(v, coeff), scale, offset));
+        buf_store_f1(r, voff, soff, value(v));
     }
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
                                           float2 v) const {
-        const float r = FAST ? range_f32_fast(amplitude_cf32_fast(v, coeff), scale, offset)
-                             : range_f32(amplitude_cf32(v, coeff), scale, offset);
+        const float r = value(v);
         if constexpr (CONTIG) (out + base)[(unsigned)pos] = r;
         else out[base + (int64_t)pos * axis_stride] = r;
     }

@@ -451,17 +451,18 @@ hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const flo
                                        const float2* in, const float2* window,
                                        int64_t window_stride, float* out, float amp_coeff,
                                        bool with_range, float range_scale, float range_offset,
-                                       bool fast, float2* scratch, hipStream_t s) {
+                                       bool fast, float guard_h0, float guard_h1, float2* scratch,
+                                       hipStream_t s) {
     TiledPlan p;
     if (!make_tiled_plan(n, L.transforms, p)) return hipErrorInvalidValue;
     const LoadCF32TimesWindow pro{in, window, window_stride};
     if (with_range) {
         if (fast)
             return launch_tiled<true>(p, L, W, pro,
-                                      StoreAmplitudeRangeT<true>{out, amp_coeff, range_scale, range_offset},
+                                      StoreAmplitudeRangeT<true>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}},
                                       scratch, s);
         return launch_tiled<true>(p, L, W, pro,
-                                  StoreAmplitudeRangeT<false>{out, amp_coeff, range_scale, range_offset},
+                                  StoreAmplitudeRangeT<false>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}},
                                   scratch, s);
     }
     if (fast) return launch_tiled<true>(p, L, W, pro, StoreAmplitudeT<true>{out, amp_coeff}, scratch, s);

@@ -98,7 +98,8 @@ hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const flo
                                        const float2* in, const float2* window,
                                        int64_t window_stride, float* out, float amp_coeff,
                                        bool with_range, float range_scale, float range_offset,
-                                       bool fast, float2* scratch, hipStream_t stream);
+                                       bool fast, float guard_h0, float guard_h1, float2* scratch,
+                                       hipStream_t stream);
 // pocketfft_c's plan choice (pocketfft.hh:2472-2489): 0 = cfftp of n, else the Bluestein
 // convolution length n2 = good_size_cmplx(2n-1).  The three elementwise steps of fftblue::fft
 // (:2370-2399) around the two n2-point transforms; akf: dense CF32[transforms * n2].
@@ -131,7 +132,15 @@ hipError_t launch_bluestein_post(bool forward, const FftLayout& L, float2* out, 
 hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W,
                                  const float2* in, const float2* window, int64_t window_stride,
                                  float* out, float amp_coeff, bool with_range, float range_scale,
-                                 float range_offset, bool fast, hipStream_t stream);
+                                 float range_offset, bool fast, float guard_h0, float guard_h1,
+                                 hipStream_t stream);
+// guard_h0/h1 (fast + range only): heights of the Spectrogram modules that will quantise the output;
+// elements whose value * height lies within the fast path's error of a bin edge are computed with the
+// exact arithmetic instead, so the bins equal the exact provider's (dev::BinGuard, device_math.hh).
+// Test probe: both epilogues on arbitrary complex inputs (DEVICE pointers).
+hipError_t launch_amplitude_range_probe(float* out_exact, float* out_fast, const float2* in, uint64_t count,
+                                        float amp_coeff, float range_scale, float range_offset,
+                                        float guard_h0, float guard_h1, hipStream_t stream);
 
 // ---- elementwise modules (elementwise.hip) -----------------------------------------------------
 hipError_t launch_multiply_cf32(const EwLayout& L, float2* c, const float2* a, const float2* b,

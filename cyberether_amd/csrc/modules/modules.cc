@@ -1101,13 +1101,31 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     Tensor final_out = rng ? rng->output : amp->output;
     if (!final_out.contiguous()) return false;
 
+    // provider "fast" with Spectrogram consumers: their heights guard the bin edges (device_math.hh)
+    float guard[2] = {0.0f, 0.0f};
+    if (fast && rng) {
+        int found = 0;
+        for (const Module* m : ordered) {
+            const auto* spec = dynamic_cast<const Spectrogram*>(m);
+            if (!spec) continue;
+            for (const auto& kv : m->inputs()) {
+                if (kv.second.storageId() != rng->output.storageId()) continue;
+                const float h = (float)spec->height;
+                if (h == guard[0] || h == guard[1]) continue;
+                if (found == 2) return false;  // three different quantisers: leave the chain unfused
+                guard[found++] = h;
+            }
+        }
+    }
+    const float guard0 = guard[0], guard1 = guard[1];
+
     members = {mul, fft, amp};
     if (rng) members.push_back(rng);
     consumed = members.size();
     name = "spectrum_fused(" + mul->name() + "+" + fft->name() + "+" + amp->name() +
            (rng ? "+" + rng->name() : "") + ")";
 
-    submit = [mul, fft, amp, rng, axis, n, fast, tiled](hipStream_t stream) -> Result {
+    submit = [mul, fft, amp, rng, axis, n, fast, tiled, guard0, guard1](hipStream_t stream) -> Result {
         const Tensor& sig = mul->a;
         const Tensor& win = mul->b;
         const Tensor& out = rng ? rng->output : amp->output;
@@ -1135,14 +1153,14 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                     static_cast<const float2*>(win.data()) + win.offset(),
                     (int64_t)win.stride(axis), static_cast<float*>(out.data()), amp->scalingCoeff,
                     rng != nullptr, rng ? rng->scalingCoeff : 0.0f, rng ? rng->offsetCoeff : 0.0f,
-                    fast, static_cast<float2*>(fft->scratchA.data()), stream),
+                    fast, guard0, guard1, static_cast<float2*>(fft->scratchA.data()), stream),
                 "fused spectrum (tiled) kernel");
         return hip_result(
             kernels::launch_spectrum_fused(
                 n, L, fft->twiddles, static_cast<const float2*>(sig.data()),
                 static_cast<const float2*>(win.data()) + win.offset(), (int64_t)win.stride(axis),
                 static_cast<float*>(out.data()), amp->scalingCoeff, rng != nullptr,
-                rng ? rng->scalingCoeff : 0.0f, rng ? rng->offsetCoeff : 0.0f, fast, stream),
+                rng ? rng->scalingCoeff : 0.0f, rng ? rng->offsetCoeff : 0.0f, fast, guard0, guard1, stream),
             "fused spectrum kernel");
     };
     return true;

@@ -186,6 +186,13 @@ jst_result jst_runtime_reset_timing(jst_runtime r);
 jst_result jst_fft_twiddles(uint64_t n, float* interleaved_out);
 /* out[i] = device restatement of libm tanhf(in[i]); both DEVICE pointers. */
 jst_result jst_probe_tanhf(const float* in_device, float* out_device, uint64_t count);
+/* The fused Amplitude -> Range epilogues on arbitrary complex inputs (interleaved re,im; DEVICE
+ * pointers): out_exact = the generic provider's arithmetic, out_fast = the fast provider's with the
+ * Spectrogram bin guard for heights guard_h0 / guard_h1 (0 = none).  Test hook for the guarantee that
+ * trunc(out_fast * height) == trunc(out_exact * height). */
+jst_result jst_probe_amplitude_range(const float* in_device, float* out_exact_device, float* out_fast_device,
+                                     uint64_t count, float amplitude_coeff, float range_scale,
+                                     float range_offset, float guard_h0, float guard_h1);
 
 #ifdef __cplusplus
 }

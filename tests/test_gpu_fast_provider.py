@@ -35,11 +35,15 @@ def test_fast_chain_within_tolerance_and_bins_exact(js, oracle, fuse):
     oracle.spectrogram(bins, got, h)
     oracle.spectrogram(bins, got, h)
     assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins)
-    # ... and differs from the all-CPU chain only where a value sits within an ulp of a bin edge
     ref_bins = np.zeros(n * h, np.float32)
     oracle.spectrogram(ref_bins, ref["range"], h)
     oracle.spectrogram(ref_bins, ref["range"], h)
-    assert np.mean(bins != ref_bins) < 1e-4
+    if fuse:
+        # ... and, fused, equals the all-CPU chain bin for bin: the epilogue recomputes with the exact
+        # arithmetic whatever falls within the fast path's error of a bin edge (dev::BinGuard)
+        assert_bit_equal(bins, ref_bins, "spectrogram bins, fast provider with bin guard")
+    else:  # module by module the range module cannot know its consumer: edge cases may move a bin
+        assert np.mean(bins != ref_bins) < 1e-4
 
 
 def test_fast_modules_edge_values(js, oracle):
@@ -67,3 +71,53 @@ def test_mixed_providers_are_not_fused(js):
     rt = js.Runtime(eng.modules[:-1] + [fast_range], fuse=True)
     assert not any("fast_range" in u and u.startswith("spectrum_fused") for u in rt.units)
     rt.compute()
+
+
+def _bins(r, h):
+    """The Spectrogram bin rule (spectrogram.hip): hit <=> 1 <= f < h with f = r * h in F32; -1 = no hit."""
+    f = r.astype(np.float32) * np.float32(h)
+    with np.errstate(invalid="ignore"):
+        hit = (f >= 1.0) & (f < h)
+    return np.where(hit, f.astype(np.int64, casting="unsafe"), -1)
+
+
+@pytest.mark.parametrize("h0,h1", [(256.0, 0.0), (100.0, 0.0), (2048.0, 256.0), (17.0, 1000.0)])
+def test_bin_guard_makes_fast_bins_exact_on_dense_sweeps(js, h0, h1):
+    """The fused fast epilogue against the exact one on 2^24 arbitrary spectrum values per case (magnitudes
+    log-uniform over the whole range window and beyond, zeros, huge and tiny values): every bin equal for
+    both guarded heights, floats within 3e-7; and the same sweep WITHOUT the guard does move bins, i.e.
+    the sweep is dense enough to see the effect the guard removes."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(int(h0) * 7 + int(h1))
+    n = 1 << 24
+    mag = 10.0 ** rng.uniform(-7.5, 1.5, n)
+    ph = rng.uniform(0, 2 * np.pi, n)
+    v = (mag * np.exp(1j * ph)).astype(np.complex64)
+    v[:1000] = 0
+    v[1000:2000] *= 1e20
+    v[2000:3000] *= 1e-30
+    x = torch.from_numpy(v.view(np.float32).copy()).cuda()
+    exact = torch.empty(n, dtype=torch.float32, device="cuda")
+    fast = torch.empty_like(exact)
+    coeff = float(np.float32(20.0 * np.log10(1.0 / 4096.0)))
+    lo, hi = -100.0, 0.0
+    scale, offset = float(np.float32(1.0 / (hi - lo))), float(np.float32(-lo / (hi - lo)))
+
+    def run(g0, g1):
+        r = js._lib.jst_probe_amplitude_range(C.c_void_p(x.data_ptr()), C.c_void_p(exact.data_ptr()),
+                                              C.c_void_p(fast.data_ptr()), n, coeff, scale, offset, g0, g1)
+        assert r == 0, js._lib.jst_last_error()
+        return exact.cpu().numpy(), fast.cpu().numpy()
+
+    e, f = run(h0, h1)
+    assert np.max(np.abs(e - f)) <= RANGE_TOL_ABS
+    print("max |fast - exact| =", float(np.max(np.abs(e - f))))
+    for h in (h0, h1):
+        if h:
+            assert np.array_equal(_bins(e, h), _bins(f, h)), h
+    e2, f2 = run(0.0, 0.0)  # unguarded: same floats tolerance, but some bins move
+    assert np.max(np.abs(e2 - f2)) <= RANGE_TOL_ABS
+    moved = int(np.sum(_bins(e2, h0) != _bins(f2, h0)))
+    assert moved > 0, "sweep too sparse to exercise the guard"
+    assert moved < 1e-3 * n
