@@ -170,3 +170,51 @@ def test_fast_provider_random_chain_within_tolerance(js, oracle, seed):
     ref = oracle.spectrum_chain(x, -110.0, -10.0)["range"]
     assert np.max(np.abs(eng.buffer.numpy() - ref)) <= 1e-5   # range output lives in [0, 1]
     rt.destroy()
+
+
+def _random_view(js, rng, dtype_complex):
+    """A random dense storage tensor of rank 1..4 and a random strided/offset view of it (steps 1..3 on
+    every axis); returns (device view, the same view as a contiguous numpy array)."""
+    rank = int(rng.integers(1, 5))
+    shape = [int(rng.integers(1, 9)) for _ in range(rank)]
+    shape[-1] = int(rng.integers(1, 70))
+    store = csignal(rng, shape) if dtype_complex else rng.standard_normal(shape).astype(np.float32)
+    t = js.Tensor.from_numpy(store)
+    idx = []
+    for ax, n in enumerate(shape):
+        step = int(rng.integers(1, 4))
+        start = int(rng.integers(0, n))
+        stop = int(rng.integers(start + 1, n + 1))
+        t.slice(ax, start, stop, step)
+        idx.append(slice(start, stop, step))
+    return t, np.ascontiguousarray(store[tuple(idx)])
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_elementwise_modules_on_random_strided_views(js, oracle, seed):
+    """multiply / add with broadcast partners, amplitude, range, invert, multiply_constant on random
+    strided, offset views of random rank: the mixed-radix index decode of the element-wise kernels
+    (AutomaticIterator traversal, include/jetstream/tools/automatic_iterator.hh:108-343)."""
+    rng = np.random.default_rng(7000 + seed)
+    cplx = bool(rng.integers(0, 2))
+    ta, a = _random_view(js, rng, cplx)
+    # a broadcast partner: same rank, a random subset of the axes collapsed to 1
+    bshape = [n if rng.integers(0, 2) else 1 for n in a.shape]
+    b = csignal(rng, bshape) if cplx else rng.standard_normal(bshape).astype(np.float32)
+    for kind in ("multiply", "add"):
+        ref = oracle.multiply(a, b) if kind == "multiply" else oracle.add(a, b)
+        out_port = "product" if kind == "multiply" else "sum"
+        _, out = run_module(js, kind, {}, {"a": ta, "b": js.Tensor.from_numpy(b)}, outputs=(out_port,))
+        assert_bit_equal(out[out_port], ref, f"{kind} seed={seed} shape={a.shape} b={bshape}")
+    last = len(a.shape) - 1
+    ta.set_axes(sample=last)
+    if cplx:
+        _, out = run_module(js, "amplitude", {}, {"signal": ta})
+        assert_bit_equal(out["signal"], oracle.amplitude(a, a.shape[-1]), f"amplitude seed={seed}")
+    else:
+        lo = float(rng.uniform(-3, 0))
+        hi = float(lo + rng.uniform(0.5, 4))
+        _, out = run_module(js, "range", {"min": lo, "max": hi}, {"signal": ta})
+        assert_bit_equal(out["signal"], oracle.range_(a, lo, hi), f"range seed={seed}")
+    _, out = run_module(js, "invert", {}, {"signal": ta})
+    assert_bit_equal(out["signal"], oracle.invert(a, axis=last), f"invert seed={seed}")
