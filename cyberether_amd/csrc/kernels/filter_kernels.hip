@@ -660,6 +660,68 @@ __global__ __launch_bounds__(kFmThreads) void fm_wide_kernel(float* __restrict__
     }
 }
 
+// Narrow FM with de-emphasis: the discriminator is element-wise, the de-emphasis one recurrence
+// (narrow_deemph += alpha * (d - narrow_deemph), fm/module_impl_native_cpu.cc:114-120).  Same split as
+// the wide decoder: all threads fill an LDS chunk with d, one lane walks it, all threads store.
+__global__ __launch_bounds__(kFmThreads) void fm_narrow_deemph_kernel(float* __restrict__ out,
+                                                                       const float2* __restrict__ in,
+                                                                       FmState* __restrict__ states,
+                                                                       const FmCoeffs k, const FmLayout L) {
+    __shared__ float in_a[kFmChunk + 8], out_a[kFmChunk + 8];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t lane = blockIdx.x, n_total = L.batches * L.samples;
+    int64_t in_off, out_off;
+    fm_lane_offsets(L, lane, in_off, out_off);
+    const FmState st = states[lane];
+    auto in_at = [&](uint64_t n) {
+        return in[in_off + (int64_t)(n / L.samples) * L.in_batch_stride + (int64_t)(n % L.samples) * L.in_sample_stride];
+    };
+    float de = st.narrow_deemph;
+    for (uint64_t c0 = 0; c0 < n_total; c0 += kFmChunk) {
+        const uint32_t cnt = (uint32_t)((n_total - c0) < (uint64_t)kFmChunk ? (n_total - c0) : (uint64_t)kFmChunk);
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt + 8; i += kFmThreads) {
+            const uint64_t n = c0 + i;
+            float d = __builtin_nanf("");
+            if (i < cnt) {
+                const float2 cur = in_at(n);
+                const float2 prev = n ? in_at(n - 1) : mk(st.prev_re, st.prev_im);
+                d = fm_discriminate(prev, cur, n ? true : st.has_prev != 0, k.ref);
+            }
+            in_a[i] = d;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+                float xin[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xin[j] = in_a[i0 + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float x = xin[j];
+                    const uint32_t fin = __builtin_isfinite(x) ? 0xffffffffu : 0u;
+                    const float upd = de + k.deemph_alpha * (x - de);
+                    de = fm_pick(fin, upd, de);
+                    out_a[i0 + j] = fm_pick(fin, upd, x);  // a non-finite sample goes out as it is
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += kFmThreads) {
+            const uint64_t n = c0 + i;
+            out[out_off + (int64_t)(n / L.samples) * L.out_batch_stride + (int64_t)(n % L.samples) * L.out_sample_stride] =
+                out_a[i];
+        }
+    }
+    if (tid == 0) {
+        const float2 last = in_at(n_total - 1);
+        states[lane].prev_re = last.x;
+        states[lane].prev_im = last.y;
+        states[lane].has_prev = 1;
+        states[lane].narrow_deemph = de;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void fm_narrow_parallel_kernel(
     float* __restrict__ out, const float2* __restrict__ in, const FmState* __restrict__ states,
     const FmCoeffs k, const FmLayout L) {
@@ -1023,6 +1085,11 @@ size_t fm_scratch_floats(const FmCoeffs& k, const FmLayout& L) {
 hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
                      float* scratch, hipStream_t s) {
     (void)hipGetLastError();
+    if (!k.wide && k.deemph_enabled && L.batches * L.samples > 0 && !getenv("JST_FM_SERIAL")) {
+        hipLaunchKernelGGL(fm_narrow_deemph_kernel, dim3((unsigned)L.lanes), dim3(kFmThreads), 0, s, out, in,
+                           (FmState*)states, k, L);
+        return hipGetLastError();
+    }
     if (k.wide && scratch && L.batches * L.samples > 0 && !getenv("JST_FM_SERIAL")) {
         hipLaunchKernelGGL(fm_wide_kernel, dim3((unsigned)L.lanes), dim3(kFmThreads), 0, s, out, in,
                            (FmState*)states, k, L, scratch);

@@ -262,8 +262,8 @@ def test_signal_generator_noise_statistics(js, dtype):
     assert abs((z ** 3).mean()) < 0.03 and abs((z ** 4).mean() - 3.0) < 0.1   # gaussian moments
 
 
-@pytest.mark.parametrize("deemph", ["none", "75us"])
-def test_fm_wide_wavefront_pipeline_equals_serial_walk(js, monkeypatch, deemph):
+@pytest.mark.parametrize("mode,deemph", [("wide", "none"), ("wide", "75us"), ("narrow", "50us")])
+def test_fm_wide_wavefront_pipeline_equals_serial_walk(js, monkeypatch, mode, deemph):
     """The stage-split wide decoder (fm_wide_kernel: lane pipelines over DPP for the one-poles and the
     biquad cascades) against the one-thread-per-lane walk of the same recurrences (JST_FM_SERIAL=1):
     identical bits, over submissions, with non-finite samples travelling through as bubbles."""
@@ -277,11 +277,11 @@ def test_fm_wide_wavefront_pipeline_equals_serial_walk(js, monkeypatch, deemph):
             monkeypatch.delenv("JST_FM_SERIAL", raising=False)
         rng = np.random.default_rng(8)
         t = js.Tensor.create("hip", "CF32", (batches, lanes, samples)).set_axes(batch=0, sample=2)
-        m = js.Module("fm", {"mode": "wide", "deemphasis": deemph, "sampleRate": sr}, {"signal": t})
+        m = js.Module("fm", {"mode": mode, "deemphasis": deemph, "sampleRate": sr}, {"signal": t})
         rt = js.Runtime([m])
         got = []
         for cycle in range(3):
-            x = np.stack([fm_signal(rng, batches * samples, sr, 75e3, True).reshape(batches, samples)
+            x = np.stack([fm_signal(rng, batches * samples, sr, 75e3, mode == "wide").reshape(batches, samples)
                           for _ in range(lanes)], axis=1)
             if cycle >= 1:
                 x[0, 1, 10] = complex(np.nan, 0)
