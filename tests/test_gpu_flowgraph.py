@@ -78,3 +78,50 @@ def test_two_station_fm_flowgraph(js, oracle):
     assert tuple(got_audio.shape) == (4, 800)
     assert np.max(np.abs(got_audio.reshape(-1) - np.asarray(ref_audio).reshape(-1))) <= 2e-6
     rt.destroy()
+
+
+def test_flowgraph_provider_fast_override(js, oracle):
+    """`provider: fast` (here as the loader's override) selects the hardware-transcendental amplitude/range
+    with the bin guard and, for a Filter block centred on 0 Hz, the direct-form FIR: the same file, floats
+    within BASELINE's 1e-5, the two-head filter of the other fixture keeps its FFT chain."""
+    import tempfile
+    from cyberether_amd.flowgraph import Flowgraph
+    text = """
+version: 2
+title: low-pass console (fixture)
+graph:
+  - name: sdr
+    module: soapy
+    device: cpu
+    config: {sampleRate: 2000000, frequency: 100000000.0, numberOfTimeSamples: 6000, numberOfBatches: 3}
+  - name: lp
+    module: filter
+    device: cpu
+    config: {taps: 101, heads: 1, center: '[0]', bandwidth: 200000, sampleRate: 2000000}
+    input: {signal: '${graph.sdr.output.signal}'}
+  - name: eng
+    module: spectrum_engine
+    device: cpu
+    config: {rangeMin: -100, rangeMax: 0, enableScale: true}
+    input: {buffer: '${graph.sdr.output.signal}'}
+"""
+    with tempfile.NamedTemporaryFile("w", suffix=".yml", delete=False) as f:
+        f.write(text)
+        path = f.name
+    fg = Flowgraph(path, ring_slots=1, provider="fast")
+    assert fg.nodes["lp"].impl.direct
+    rng = np.random.default_rng(5)
+    x = csignal(rng, (3, 6000), 0.2)
+    fg.feed("sdr", x)
+    rt = fg.runtime(graph=True, fuse=True)
+    rt.compute(1)
+    plan = fg.nodes["lp"].impl.plan
+    ref = oracle.filter_block(x, plan, 2.0e6, 200e3, [0.0], 101, {})
+    got = fg.output("lp", "buffer").numpy()
+    assert np.max(np.abs(got - ref)) <= 1e-5 * np.max(np.abs(ref))
+    spec = oracle.spectrum_chain(x, -100.0, 0.0)["range"]
+    assert np.max(np.abs(fg.output("eng", "buffer").numpy() - spec)) <= 1e-5
+    rt.destroy()
+    two = Flowgraph(os.path.join(FIXTURES, "two_station_fm.yml"), ring_slots=1, provider="fast")
+    assert not two.nodes["flt"].impl.direct   # off-centre heads: FFT overlap-add chain
+    os.unlink(path)
