@@ -391,243 +391,154 @@ __global__ __launch_bounds__(64) void fm_kernel(float* __restrict__ out, const f
 // The stereo decoder is a chain of serial recurrences (pilot phase, four one-poles, eight biquads, two
 // de-emphasis one-poles) with element-wise transcendental stages in between.  fm_kernel above walks
 // it with one thread per lane, every dependent operation paying full latency: ~0.9 us per sample.
-// Here one workgroup per lane splits the sample loop by stage, keeping every chain's operations and
-// order (same bits):
-//   A  all threads   d[n] = discriminator                                   (element-wise)
-//   B  one thread    phase[n]: the pilot phase recurrence, data independent (runs beside A)
-//   C  all threads   xc, xs = d * cosf / sinf(phase)
-//   D  4 lanes       the pilot one-poles as a 2-deep lane pipeline: lane 0/2 the first pole of sample
-//                    n, lane 1/3 the second pole of sample n-1, fed by a DPP row shift
-//   E  all threads   pilot offset atan2f, carrier sinf, xd = 2 d carrier
-//   F  8 lanes       notch + 3 low-pass biquads of the sum path (lanes 0-3) and of the difference path
-//                    (lanes 4-7) as a 4-deep lane pipeline: lane k works on sample n - k%4
-//   G  2 lanes       de-emphasis of left / right, then all threads write the output
+// Here one workgroup of eight wavefronts per lane runs the stages as a SOFTWARE PIPELINE over chunks of
+// 1024 samples: in step s (steps are separated by one workgroup barrier)
+//   wave 0     B  pilot phase recurrence of chunk s          (one lane; data independent)
+//   waves 4-7  A  d = discriminator of chunk s               (element-wise)
+//              C  xc, xs = d * cosf / sinf(phase) of chunk s-1
+//              E  pilot offset atan2f, carrier sinf, xd = 2 d carrier of chunk s-3
+//   wave 1     D  the pilot one-poles of chunk s-2 as a 2-deep LANE pipeline: lane 0/2 the first pole
+//                 of sample n, lane 1/3 the second pole of sample n-1, fed by a DPP row shift
+//   wave 2     F  notch + 3 low-pass biquads of the sum path (lanes 0-3) and of the difference path
+//                 (lanes 4-7) of chunk s-4 as a 4-deep lane pipeline: lane k works on sample n - k%4
+//              L  left = sum + diff, right = sum - diff of chunk s-5;  O  the output of chunk s-7
+//   wave 3     G  de-emphasis of left / right of chunk s-6 (two lanes)
+// so the four serial stretches run side by side on four SIMDs and the decode costs the time of the
+// longest of them (the biquad cascade, ~50 cycles per sample) instead of their sum.  Chunks travel
+// between stages through LDS rings; every chain keeps its operations and their order (same bits).
 // A non-finite discriminator sample leaves every filter state untouched (fm/module_impl_native_cpu.cc:
-// 96-112): it travels down the lane pipelines as a bubble.
-struct FmWideScratch {  // per lane, each array `n` floats
-    float *d, *phase, *xc, *xs, *pcos, *psin, *xd, *sum, *diff;
-};
+// 96-112): it travels down the lane pipelines as a bubble, and each serial stage flushes its lane
+// pipeline with bubbles at the end of a chunk so that a chunk's results are complete within its step.
 __device__ __forceinline__ float dpp_row_shr1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false));
 }
-// take ? a : b as ONE v_bfi_b32 on a lane mask: the serial stretches must stay straight-line code (the
-// compiler turns a ?: around a recurrence step into an exec-mask branch per sample)
+// take ? a : b on a lane mask: the serial stretches must stay straight-line code (the compiler turns
+// a ?: around a recurrence step into an exec-mask branch per sample)
 __device__ __forceinline__ float fm_pick(uint32_t take_mask, float a, float b) {
     return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, a) & take_mask) |
                                          (__builtin_bit_cast(uint32_t, b) & ~take_mask));
 }
-constexpr int kFmChunk = 2048;  // samples staged in LDS per serial stretch
+constexpr int kFmChunk = 2048;   // narrow + de-emphasis: samples staged in LDS per serial stretch
 constexpr int kFmThreads = 256;
+constexpr int kFmWideThreads = 512, kFmCh = 1024, kFmSlot = kFmCh + 16;  // slot: chunk + flush/prefetch slack
 
-__global__ __launch_bounds__(kFmThreads) void fm_wide_kernel(float* __restrict__ out,
-                                                              const float2* __restrict__ in,
-                                                              FmState* __restrict__ states, const FmCoeffs k,
-                                                              const FmLayout L, float* __restrict__ scratch) {
-    // serial stretches: inputs and results of a chunk live in LDS (coalesced traffic on both sides, no
-    // global access inside the recurrences)
-    __shared__ float in_a[kFmChunk + 8], in_b[kFmChunk + 8], out_a[kFmChunk + 8], out_b[kFmChunk + 8],
-        spill[kFmChunk + 8];  // where the lanes without a result write (all to the same words: never read)
-    const uint32_t tid = threadIdx.x;
+__global__ __launch_bounds__(kFmWideThreads) void fm_wide_kernel(float* __restrict__ out,
+                                                                  const float2* __restrict__ in,
+                                                                  FmState* __restrict__ states, const FmCoeffs k,
+                                                                  const FmLayout L) {
+    // LDS rings, indexed by chunk % depth; depth = steps between the producer and the last consumer
+    __shared__ float r_phase[4][kFmSlot], r_d[8][kFmSlot], r_xc[2][kFmSlot], r_xs[2][kFmSlot],
+        r_pcos[2][kFmSlot], r_psin[2][kFmSlot], r_xd[2][kFmSlot], r_sum[2][kFmSlot], r_diff[2][kFmSlot],
+        r_left[3][kFmSlot], r_right[3][kFmSlot],
+        spill[kFmSlot];  // where lanes without a result write (never read)
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lid = tid & 63u;
     const uint64_t lane = blockIdx.x, n_total = L.batches * L.samples;
+    const uint32_t chunks = (uint32_t)((n_total + kFmCh - 1) / kFmCh);
     int64_t in_off, out_off;
     fm_lane_offsets(L, lane, in_off, out_off);
-    FmWideScratch w;
-    {
-        float* base = scratch + lane * 9 * n_total;
-        w.d = base;
-        w.phase = base + n_total;
-        w.xc = base + 2 * n_total;
-        w.xs = base + 3 * n_total;
-        w.pcos = base + 4 * n_total;
-        w.psin = base + 5 * n_total;
-        w.xd = base + 6 * n_total;
-        w.sum = base + 7 * n_total;
-        w.diff = base + 8 * n_total;
-    }
-    FmState st = states[lane];
+    const FmState st = states[lane];
     const float nan = __builtin_nanf("");
     auto in_at = [&](uint64_t n) {
         return in[in_off + (int64_t)(n / L.samples) * L.in_batch_stride + (int64_t)(n % L.samples) * L.in_sample_stride];
     };
-    // ---- A (threads 64..255) beside B (thread 0) ----
-    if (tid >= 64) {
-        for (uint64_t n = tid - 64; n < n_total; n += kFmThreads - 64) {
-            const float2 cur = in_at(n);
-            const float2 prev = n ? in_at(n - 1) : mk(st.prev_re, st.prev_im);
-            w.d[n] = fm_discriminate(prev, cur, n ? true : st.has_prev != 0, k.ref);
-        }
-    } else if (tid == 0) {
-        // (double)ph >= 2.0f * pi_f64 (6.283185307179586) <=> ph >= the float just above it: the
-        // common step is one F32 add and one F32 compare, the F64 wrap runs every ~10th sample
-        const double two_pi = 2.0f * 3.14159265358979323846;
-        const float wrap_at = __builtin_bit_cast(float, 0x40C90FDBu);  // 6.2831854820251465
-        float ph = st.pilot_phase;
-        for (uint64_t n = 0; n < n_total; ++n) {
-            w.phase[n] = ph;
-            ph += k.pilot_inc;
-            if (ph >= wrap_at) ph = (float)((double)ph - two_pi);
-        }
-        st.pilot_phase = ph;
-    }
-    __syncthreads();
-    // ---- C ----
-    for (uint64_t n = tid; n < n_total; n += kFmThreads) {
-        const float d = w.d[n], ph = w.phase[n];
-        const bool fin = __builtin_isfinite(d);
-        w.xc[n] = fin ? d * cosf(ph) : nan;  // non-finite discriminator sample = bubble
-        w.xs[n] = fin ? d * sinf(ph) : nan;
-    }
-    __syncthreads();
-    // A serial stretch over n_total + skew pipeline steps in chunks: stage(i) fills in_a/in_b, wave 0
-    // runs step(i0, i) eight iterations at a time (inputs of the head lanes prefetched from LDS), then
-    // flush(i) moves out_a/out_b to their destination.
-    auto stretch = [&](uint64_t steps, auto&& stage, auto&& body, auto&& flush) {
-        for (uint64_t c0 = 0; c0 < steps; c0 += kFmChunk) {
-            const uint32_t cnt = (uint32_t)((steps - c0) < (uint64_t)kFmChunk ? (steps - c0) : (uint64_t)kFmChunk);
-            __syncthreads();
-            for (uint32_t i = tid; i < cnt + 8; i += kFmThreads) stage(c0 + i, i, i < cnt);
-            __syncthreads();
-            if (tid < 64) body(cnt);
-            __syncthreads();
-            for (uint32_t i = tid; i < cnt; i += kFmThreads) flush(c0 + i, i);
-        }
+    auto count_of = [&](uint32_t c) {
+        const uint64_t left = n_total - (uint64_t)c * kFmCh;
+        return (uint32_t)(left < (uint64_t)kFmCh ? left : (uint64_t)kFmCh);
     };
-    // ---- D: lanes 0,1 = cosine poles (first, second), 2,3 = sine poles ----
-    {
-        float pole = 0.0f;  // this lane's one-pole state
-        if (tid == 0) pole = st.pilot_cos_stage;
-        if (tid == 1) pole = st.pilot_cos;
-        if (tid == 2) pole = st.pilot_sin_stage;
-        if (tid == 3) pole = st.pilot_sin;
-        const bool head = (tid & 1u) == 0;  // first pole of a pair: reads the staged input
-        const float* src = tid < 2 ? in_a : in_b;
-        float* res = tid == 1 ? out_a : (tid == 3 ? out_b : spill);
-        float handed = nan;                 // what this lane passes to its right neighbour: a bubble first
-        stretch(
-            n_total + 1,
-            [&](uint64_t n, uint32_t i, bool) {
-                in_a[i] = n < n_total ? w.xc[n] : nan;
-                in_b[i] = n < n_total ? w.xs[n] : nan;
-            },
-            [&](uint32_t cnt) {
-                for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+    // per-stage state, alive in the registers of the wave that owns the stage
+    float ph = st.pilot_phase;                       // B (wave 0, lane 0)
+    float pole = 0.0f, pole_handed = nan;            // D (wave 1, lanes 0-3)
+    float c5[5] = {0, 0, 0, 0, 0}, s0 = 0.0f, s1 = 0.0f, bq_handed = nan;  // F (wave 2, lanes 0-7)
+    float de = 0.0f;                                 // G (wave 3, lanes 0-1)
+    if (wave == 1) {
+        if (lid == 0) pole = st.pilot_cos_stage;
+        if (lid == 1) pole = st.pilot_cos;
+        if (lid == 2) pole = st.pilot_sin_stage;
+        if (lid == 3) pole = st.pilot_sin;
+    }
+    const uint32_t stage = lid & 3u;
+    const bool diff_path = (lid & 4u) != 0;
+    if (wave == 2 && lid < 8) {
+        const float* cc = stage == 0 ? k.notch : k.lp[stage - 1];
+        const float* ss = stage == 0 ? (diff_path ? st.diff_notch : st.sum_notch)
+                                     : (diff_path ? st.diff_filter[stage - 1] : st.sum_filter[stage - 1]);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) c5[j] = cc[j];
+        s0 = ss[0];
+        s1 = ss[1];
+    }
+    if (wave == 3) de = lid == 0 ? st.left_de : st.right_de;
+    const double two_pi = 2.0f * 3.14159265358979323846;  // F32 op F64 like the reference
+    // (double)ph >= two_pi (6.283185307179586) <=> ph >= the float just above it: the common step is
+    // one F32 add and one F32 compare, the F64 wrap runs every ~10th sample
+    const float wrap_at = __builtin_bit_cast(float, 0x40C90FDBu);  // 6.2831854820251465
+
+    for (uint32_t s = 0; s < chunks + 7; ++s) {
+        if (wave == 0) {
+            // ---- B: chunk s ----
+            if (s < chunks && lid == 0) {
+                const uint32_t cnt = count_of(s);
+                float* dst = r_phase[s & 3];
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    dst[i] = ph;
+                    ph += k.pilot_inc;
+                    if (ph >= wrap_at) ph = (float)((double)ph - two_pi);
+                }
+            }
+        } else if (wave == 1) {
+            // ---- D: chunk s-2; lanes 0,1 = cosine poles (first, second), 2,3 = sine poles ----
+            if (s >= 2 && s - 2 < chunks) {
+                const uint32_t c = s - 2, cnt = count_of(c);
+                const bool head = (lid & 1u) == 0;  // first pole of a pair: reads the staged input
+                const float* src = lid < 2 ? r_xc[c & 1] : r_xs[c & 1];
+                float* res = lid == 1 ? r_pcos[c & 1] : (lid == 3 ? r_psin[c & 1] : spill);
+                for (uint32_t i0 = 0; i0 < cnt + 1; i0 += 8) {  // +1: flush the lane pipeline with a bubble
                     float xin[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) xin[j] = src[i0 + j];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float from_left = dpp_row_shr1(handed);
+                        const float from_left = dpp_row_shr1(pole_handed);
                         const float x = head ? xin[j] : from_left;
                         const uint32_t fin = __builtin_isfinite(x) ? 0xffffffffu : 0u;
                         const float upd = pole + k.pilot_alpha * (x - pole);
                         pole = fm_pick(fin, upd, pole);
-                        handed = fm_pick(fin, upd, x);
-                        res[i0 + j] = handed;
+                        pole_handed = fm_pick(fin, upd, x);
+                        res[i0 + j] = pole_handed;  // second poles: the value of sample i0 + j - 1
                     }
                 }
-            },
-            [&](uint64_t n, uint32_t i) {  // second poles work on sample n - 1
-                if (n >= 1 && __builtin_isfinite(out_a[i])) w.pcos[n - 1] = out_a[i];
-                if (n >= 1 && __builtin_isfinite(out_b[i])) w.psin[n - 1] = out_b[i];
-            });
-        if (tid == 0) st.pilot_cos_stage = pole;
-        if (tid == 1) states[lane].pilot_cos = pole;
-        if (tid == 2) states[lane].pilot_sin_stage = pole;
-        if (tid == 3) states[lane].pilot_sin = pole;
-    }
-    __syncthreads();
-    // ---- E ----
-    for (uint64_t n = tid; n < n_total; n += kFmThreads) {
-        const float d = w.d[n];
-        if (!__builtin_isfinite(d)) {
-            w.xd[n] = nan;
-            continue;
-        }
-        const float po = atan2f(w.pcos[n], w.psin[n]);
-        const float carrier = sinf(2.0f * (w.phase[n] + po));
-        w.xd[n] = 2.0f * d * carrier;
-    }
-    __syncthreads();
-    // ---- F: lanes 0-3 sum path (notch, lp0, lp1, lp2), lanes 4-7 difference path ----
-    {
-        const uint32_t stage = tid & 3u;
-        const bool diff_path = (tid & 4u) != 0, active = tid < 8;
-        float c[5] = {0, 0, 0, 0, 0}, s0 = 0.0f, s1 = 0.0f;
-        if (active) {
-            const float* cc = stage == 0 ? k.notch : k.lp[stage - 1];
-            const float* ss = stage == 0 ? (diff_path ? st.diff_notch : st.sum_notch)
-                                         : (diff_path ? st.diff_filter[stage - 1] : st.sum_filter[stage - 1]);
-#pragma unroll
-            for (int j = 0; j < 5; ++j) c[j] = cc[j];
-            s0 = ss[0];
-            s1 = ss[1];
-        }
-        const float* src = diff_path ? in_b : in_a;
-        float* res = tid == 3 ? out_a : (tid == 7 ? out_b : spill);
-        float handed = nan;
-        stretch(
-            n_total + 3,
-            [&](uint64_t n, uint32_t i, bool) {
-                in_a[i] = n < n_total ? w.d[n] : nan;  // non-finite d = bubble
-                in_b[i] = n < n_total ? w.xd[n] : nan;
-            },
-            [&](uint32_t cnt) {
-                for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+            }
+        } else if (wave == 2) {
+            // ---- F: chunk s-4; lanes 0-3 sum path (notch, lp0, lp1, lp2), lanes 4-7 difference path ----
+            if (s >= 4 && s - 4 < chunks) {
+                const uint32_t c = s - 4, cnt = count_of(c);
+                const float* src = diff_path ? r_xd[c & 1] : r_d[c & 7];
+                float* res = lid == 3 ? r_sum[c & 1] : (lid == 7 ? r_diff[c & 1] : spill);
+                for (uint32_t i0 = 0; i0 < cnt + 3; i0 += 8) {  // +3: flush
                     float xin[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) xin[j] = src[i0 + j];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float from_left = dpp_row_shr1(handed);
+                        const float from_left = dpp_row_shr1(bq_handed);
                         const float x = stage == 0 ? xin[j] : from_left;
                         const uint32_t fin = __builtin_isfinite(x) ? 0xffffffffu : 0u;
-                        const float y = c[0] * x + s0;
-                        const float n0 = c[1] * x - c[3] * y + s1;
-                        const float n1 = c[2] * x - c[4] * y;
+                        const float y = c5[0] * x + s0;
+                        const float n0 = c5[1] * x - c5[3] * y + s1;
+                        const float n1 = c5[2] * x - c5[4] * y;
                         s0 = fm_pick(fin, n0, s0);
                         s1 = fm_pick(fin, n1, s1);
-                        handed = fm_pick(fin, y, x);
-                        res[i0 + j] = handed;
+                        bq_handed = fm_pick(fin, y, x);
+                        res[i0 + j] = bq_handed;  // last stages: the value of sample i0 + j - 3
                     }
                 }
-            },
-            [&](uint64_t n, uint32_t i) {  // the last stages work on sample n - 3
-                if (n >= 3 && __builtin_isfinite(out_a[i])) w.sum[n - 3] = out_a[i];
-                if (n >= 3 && __builtin_isfinite(out_b[i])) w.diff[n - 3] = out_b[i];
-            });
-        if (active) {
-            float* ss = stage == 0 ? (diff_path ? states[lane].diff_notch : states[lane].sum_notch)
-                                   : (diff_path ? states[lane].diff_filter[stage - 1] : states[lane].sum_filter[stage - 1]);
-            ss[0] = s0;
-            ss[1] = s1;
-        }
-    }
-    __syncthreads();
-    // ---- G ----
-    auto out_at = [&](uint64_t n) {
-        return out_off + (int64_t)(n / L.samples) * L.out_batch_stride + (int64_t)(n % L.samples) * L.out_sample_stride;
-    };
-    if (!k.deemph_enabled) {
-        for (uint64_t n = tid; n < n_total; n += kFmThreads) {
-            const float d = w.d[n];
-            const bool fin = __builtin_isfinite(d);
-            const float sum = w.sum[n], diff = w.diff[n];
-            out[out_at(n)] = fin ? sum + diff : d;
-            out[out_at(n) + L.out_channel_stride] = fin ? sum - diff : d;
-        }
-    } else {
-        float de = tid == 0 ? st.left_de : st.right_de;
-        const float* src = tid == 0 ? in_a : in_b;
-        float* res = tid == 0 ? out_a : (tid == 1 ? out_b : spill);
-        stretch(
-            n_total,
-            [&](uint64_t n, uint32_t i, bool) {
-                const bool fin = n < n_total && __builtin_isfinite(w.d[n]);
-                in_a[i] = fin ? w.sum[n] + w.diff[n] : nan;
-                in_b[i] = fin ? w.sum[n] - w.diff[n] : nan;
-            },
-            [&](uint32_t cnt) {
-                for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+            }
+        } else if (wave == 3) {
+            // ---- G: chunk s-6: de-emphasis of left (lane 0) and right (lane 1), in place ----
+            if (k.deemph_enabled && s >= 6 && s - 6 < chunks && lid < 2) {
+                const uint32_t c = s - 6, cnt = count_of(c);
+                float* src = lid == 0 ? r_left[c % 3] : r_right[c % 3];
+                for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {  // past the chunk and for non-finite d: bubbles
                     float xin[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) xin[j] = src[i0 + j];
@@ -637,26 +548,107 @@ __global__ __launch_bounds__(kFmThreads) void fm_wide_kernel(float* __restrict__
                         const uint32_t fin = __builtin_isfinite(x) ? 0xffffffffu : 0u;
                         const float upd = de + k.deemph_alpha * (x - de);
                         de = fm_pick(fin, upd, de);
-                        res[i0 + j] = fm_pick(fin, upd, x);
+                        src[i0 + j] = fm_pick(fin, upd, x);
                     }
                 }
-            },
-            [&](uint64_t n, uint32_t i) {
-                const float d = w.d[n];
-                const bool fin = __builtin_isfinite(d);
-                out[out_at(n)] = fin ? out_a[i] : d;
-                out[out_at(n) + L.out_channel_stride] = fin ? out_b[i] : d;
-            });
-        if (tid == 0) states[lane].left_de = de;
-        if (tid == 1) states[lane].right_de = de;
+            }
+        } else {
+            const uint32_t et = tid - 256;  // 256 element-wise threads
+            // ---- A: chunk s ----
+            if (s < chunks) {
+                const uint32_t cnt = count_of(s);
+                float* dst = r_d[s & 7];
+                for (uint32_t i = et; i < kFmSlot; i += 256) {
+                    float d = nan;  // past the chunk: bubbles (flush + prefetch slack of the serial stages)
+                    if (i < cnt) {
+                        const uint64_t n = (uint64_t)s * kFmCh + i;
+                        const float2 cur = in_at(n);
+                        const float2 prev = n ? in_at(n - 1) : mk(st.prev_re, st.prev_im);
+                        d = fm_discriminate(prev, cur, n ? true : st.has_prev != 0, k.ref);
+                    }
+                    dst[i] = d;
+                }
+            }
+            // ---- C: chunk s-1 ----
+            if (s >= 1 && s - 1 < chunks) {
+                const uint32_t c = s - 1, cnt = count_of(c);
+                const float* dch = r_d[c & 7];
+                const float* pch = r_phase[c & 3];
+                for (uint32_t i = et; i < kFmSlot; i += 256) {
+                    const float d = i < cnt ? dch[i] : nan;
+                    const bool fin = __builtin_isfinite(d);
+                    const float p = fin ? pch[i] : 0.0f;
+                    r_xc[c & 1][i] = fin ? d * cosf(p) : nan;  // non-finite discriminator sample = bubble
+                    r_xs[c & 1][i] = fin ? d * sinf(p) : nan;
+                }
+            }
+            // ---- E: chunk s-3 ----
+            if (s >= 3 && s - 3 < chunks) {
+                const uint32_t c = s - 3, cnt = count_of(c);
+                const float* dch = r_d[c & 7];
+                const float* pch = r_phase[c & 3];
+                for (uint32_t i = et; i < kFmSlot; i += 256) {
+                    const float d = i < cnt ? dch[i] : nan;
+                    float v = nan;
+                    if (__builtin_isfinite(d)) {  // D's results sit 1 slot late
+                        const float po = atan2f(r_pcos[c & 1][i + 1], r_psin[c & 1][i + 1]);
+                        const float carrier = sinf(2.0f * (pch[i] + po));
+                        v = 2.0f * d * carrier;
+                    }
+                    r_xd[c & 1][i] = v;
+                }
+            }
+            // ---- L: chunk s-5: left = sum + diff, right = sum - diff (F's results sit 3 slots late) ----
+            if (s >= 5 && s - 5 < chunks) {
+                const uint32_t c = s - 5, cnt = count_of(c);
+                const float* dch = r_d[c & 7];
+                for (uint32_t i = et; i < kFmSlot; i += 256) {
+                    const bool fin = i < cnt && __builtin_isfinite(dch[i]);
+                    const float a = fin ? r_sum[c & 1][i + 3] : nan, b = fin ? r_diff[c & 1][i + 3] : nan;
+                    r_left[c % 3][i] = a + b;
+                    r_right[c % 3][i] = a - b;
+                }
+            }
+            // ---- O: chunk s-7: the output ----
+            if (s >= 7 && s - 7 < chunks) {
+                const uint32_t c = s - 7, cnt = count_of(c);
+                const float* dch = r_d[c & 7];
+                for (uint32_t i = et; i < cnt; i += 256) {
+                    const uint64_t n = (uint64_t)c * kFmCh + i;
+                    const float d = dch[i];
+                    const bool fin = __builtin_isfinite(d);
+                    const int64_t oo = out_off + (int64_t)(n / L.samples) * L.out_batch_stride +
+                                       (int64_t)(n % L.samples) * L.out_sample_stride;
+                    out[oo] = fin ? r_left[c % 3][i] : d;
+                    out[oo + L.out_channel_stride] = fin ? r_right[c % 3][i] : d;
+                }
+            }
+        }
+        __syncthreads();
     }
-    if (tid == 0) {
+    // ---- state ----
+    if (wave == 0 && lid == 0) {
         const float2 last = in_at(n_total - 1);
         states[lane].prev_re = last.x;
         states[lane].prev_im = last.y;
         states[lane].has_prev = 1;
-        states[lane].pilot_phase = st.pilot_phase;
-        states[lane].pilot_cos_stage = st.pilot_cos_stage;
+        states[lane].pilot_phase = ph;
+    }
+    if (wave == 1) {
+        if (lid == 0) states[lane].pilot_cos_stage = pole;
+        if (lid == 1) states[lane].pilot_cos = pole;
+        if (lid == 2) states[lane].pilot_sin_stage = pole;
+        if (lid == 3) states[lane].pilot_sin = pole;
+    }
+    if (wave == 2 && lid < 8) {
+        float* ss = stage == 0 ? (diff_path ? states[lane].diff_notch : states[lane].sum_notch)
+                               : (diff_path ? states[lane].diff_filter[stage - 1] : states[lane].sum_filter[stage - 1]);
+        ss[0] = s0;
+        ss[1] = s1;
+    }
+    if (wave == 3 && k.deemph_enabled) {
+        if (lid == 0) states[lane].left_de = de;
+        if (lid == 1) states[lane].right_de = de;
     }
 }
 
@@ -1079,20 +1071,17 @@ hipError_t launch_arithmetic(const EwLayout& L, void* out, const void* in, bool 
 #undef JST_ARITH
     return hipGetLastError();
 }
-size_t fm_scratch_floats(const FmCoeffs& k, const FmLayout& L) {
-    return k.wide ? (size_t)(9 * L.lanes * L.batches * L.samples) : 0;
-}
 hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
-                     float* scratch, hipStream_t s) {
+                     hipStream_t s) {
     (void)hipGetLastError();
     if (!k.wide && k.deemph_enabled && L.batches * L.samples > 0 && !getenv("JST_FM_SERIAL")) {
         hipLaunchKernelGGL(fm_narrow_deemph_kernel, dim3((unsigned)L.lanes), dim3(kFmThreads), 0, s, out, in,
                            (FmState*)states, k, L);
         return hipGetLastError();
     }
-    if (k.wide && scratch && L.batches * L.samples > 0 && !getenv("JST_FM_SERIAL")) {
-        hipLaunchKernelGGL(fm_wide_kernel, dim3((unsigned)L.lanes), dim3(kFmThreads), 0, s, out, in,
-                           (FmState*)states, k, L, scratch);
+    if (k.wide && L.batches * L.samples > 0 && !getenv("JST_FM_SERIAL")) {
+        hipLaunchKernelGGL(fm_wide_kernel, dim3((unsigned)L.lanes), dim3(kFmWideThreads), 0, s, out, in,
+                           (FmState*)states, k, L);
         return hipGetLastError();
     }
     if (!k.wide && !k.deemph_enabled) {

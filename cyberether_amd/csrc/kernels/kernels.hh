@@ -262,9 +262,7 @@ struct SignalParams {
 hipError_t launch_signal_generator(float* out, double* phases, double* state, uint64_t count,
                                    bool complex_out, const SignalParams& p, hipStream_t s);
 size_t fm_state_bytes();
-// scratch: fm_scratch_floats() floats (wide mode: the stage arrays of the wavefront pipeline)
-size_t fm_scratch_floats(const FmCoeffs& k, const FmLayout& L);
 hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
-                     float* scratch, hipStream_t s);
+                     hipStream_t s);
 
 }  // namespace jst::kernels

@@ -970,10 +970,6 @@ class Fm : public Module {
         JST_CHECK(SetSignalAxes(output, out_axes));
         output.setAttribute("frequency", AttrValue{F64{0.0}});
         JST_CHECK(states.create(device(), DataType::U8, {laneCount * (U64)kernels::fm_state_bytes()}));
-        if (wide) {  // stage arrays of the wavefront pipeline (kernels/filter_kernels.hip, fm_wide_kernel)
-            const U64 per_lane = input.shape(*axes.sample) * (axes.batch ? input.shape(*axes.batch) : 1);
-            JST_CHECK(scratch.create(device(), DataType::F32, {std::max<U64>(9 * laneCount * per_lane, 1)}));
-        }
         produced("signal", output);
         return Result::SUCCESS;
     }
@@ -999,11 +995,10 @@ class Fm : public Module {
         L.lane_rank = r;
         L.in_offset = input.offset();
         L.out_offset = output.offset();
-        return hip_result(kernels::launch_fm(ptr<float>(output), ptr<const float2>(input), states.data(), k, L,
-                                             k.wide ? ptr<float>(scratch) : nullptr, s),
+        return hip_result(kernels::launch_fm(ptr<float>(output), ptr<const float2>(input), states.data(), k, L, s),
                           "fm kernel");
     }
-    Tensor input, output, states, scratch;
+    Tensor input, output, states;
     std::string mode = "narrow", deemphasis = "none";
     F32 sampleRate = 240e3f;
     SignalAxes axes;

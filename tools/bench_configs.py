@@ -118,7 +118,7 @@ def run_c4(js, out):
     out.append({"config": "C4: WBFM 20 MS/s -> Filter(/100) -> FM wide 75us -> Decimator(/4)",
                 "ms_per_cycle": dt * 1e3, "MS_per_s_in": b * s / dt / 1e6,
                 "audio_shape": list(dec.buffer.shape),
-                "note": "FM stereo decode = serial recurrences per lane (1 lane here), run as wavefront lane pipelines (fm_wide_kernel); 17.9 ms with the one-thread walk (JST_FM_SERIAL=1)"})
+                "note": "FM stereo decode = serial recurrences per lane (1 lane here), run as software-pipelined wavefront stages with DPP lane pipelines inside (fm_wide_kernel); 17.9 ms with the one-thread walk (JST_FM_SERIAL=1)"})
     rt.destroy()
     # the same decoder on many stations at once: lanes are independent workgroups
     lanes, nb, ns = 64, 10, 2024
