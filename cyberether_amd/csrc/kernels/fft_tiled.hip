@@ -300,12 +300,23 @@ __global__ __launch_bounds__(kMaxThreads, 6) void fft_tile_blocks_kernel(const F
     const uint32_t tile = P.S * live;
     // load: x fastest (contiguous in memory for both the dense scratch and a dense input row)
     const float2* blk = scratch + (t0 * P.R1 + k0) * P.S;  // only dereferenced when g > 0
-    for (uint32_t idx = threadIdx.x; idx < tile; idx += blockDim.x) {
-        const uint32_t kb = idx / P.S, x = idx - kb * P.S;
-        float2 v;
-        if (P.g == 0) v = pro.template load<false>(lane_in[kb], L.in_axis_stride, (int)x);
-        else v = blk[idx];
-        buf0[x * pitch + kb] = v;
+    for (uint32_t i0 = threadIdx.x; i0 < tile; i0 += 8 * blockDim.x) {  // eight loads in flight per thread
+        float2 v[8];
+        uint32_t slot[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t idx = i0 + (uint32_t)k * blockDim.x;
+            slot[k] = 0xffffffffu;
+            if (idx < tile) {
+                const uint32_t kb = idx / P.S, x = idx - kb * P.S;
+                if (P.g == 0) v[k] = pro.template load<false>(lane_in[kb], L.in_axis_stride, (int)x);
+                else v[k] = blk[idx];
+                slot[k] = x * pitch + kb;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (slot[k] != 0xffffffffu) buf0[slot[k]] = v[k];
     }
     __syncthreads();
     const float2* src = buf0;
