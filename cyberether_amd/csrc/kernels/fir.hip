@@ -18,10 +18,12 @@
 // (Q = ceil(T/r)) are staged with coalesced loads into LDS, de-interleaved by polyphase branch:
 // lds[p][s] = x[u*r - p], s = u - (m0 - Q + 1), so a branch's samples are contiguous.  Rows before the
 // first come from the previous row or the module's history tensor.  Thread t evaluates J consecutive
-// outputs; per branch it walks samples s = J*t + i (i < J + Q - 1) in chunks of 8 -- four 16-byte LDS
-// reads at compile-time offsets, dense across the wavefront for J = 2 -- and feeds each sample into
-// its J accumulators, so one LDS read serves 4*J FMAs.  Tap values are wave-uniform: they come from a
-// zero-padded per-branch table through scalar loads and enter the FMAs as SGPR operands.
+// outputs; per branch it walks samples s = J*t + i (i < J + Q - 1) in chunks of 32 -- sixteen 16-byte
+// LDS reads at compile-time offsets, dense across the wavefront for J = 2 -- and feeds each sample into
+// its J accumulators (even and odd samples separately: 2*J independent FMA chains), so one 16-byte LDS
+// read serves 4*J FMAs.  Tap values are wave-uniform: the window of taps a chunk needs comes from a
+// step-major table (built once by the statically settled fir_taps module) through scalar loads and
+// enters the FMAs as SGPR operands.
 #include <cstdio>
 #include <cstdlib>
 
