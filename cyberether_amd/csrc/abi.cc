@@ -305,6 +305,20 @@ jst_result jst_module_destroy(jst_module m) {
     delete m;
     return R(Result::SUCCESS);
 }
+jst_result jst_module_reconfigure(jst_module m, const char* const* config, uint32_t n_config, int validate_only) {
+    JST_ARG(m, "null argument");
+    JST_ARG(n_config == 0 || config, "null config");
+    Config cfg;
+    for (uint32_t i = 0; i < n_config; ++i) {
+        const char* eq = config[i] ? std::strchr(config[i], '=') : nullptr;
+        if (!eq) {
+            JST_ERROR("[ABI] Config entry %u is not of the form key=value.", i);
+            return R(Result::ERROR);
+        }
+        cfg[std::string(config[i], eq - config[i])] = std::string(eq + 1);
+    }
+    return R(m->m->reconfigure(cfg, validate_only != 0));
+}
 jst_result jst_module_output(jst_module m, const char* port, jst_tensor* out) {
     JST_ARG(m && port && out, "null argument");
     auto it = m->m->outputs().find(port);

@@ -121,6 +121,35 @@ Result Module::teardown() {
     return destroy();
 }
 
+Result Module::reconfigure(const Config& config, bool validateOnly) {
+    if (!created_) return Result::RECREATE;  // DESTROYED / ERRORED (src/module.cc:234-236)
+    Config candidate = config_;
+    for (const auto& kv : config) candidate[kv.first] = kv.second;
+    if (candidate == config_) return Result::SUCCESS;
+    const Config staged = config_;
+    auto restore = [&]() {  // validate() parses config_ into the members: put both back
+        config_ = staged;
+        (void)validate();
+    };
+    config_ = candidate;
+    const Result v = validate();
+    if (v != Result::SUCCESS && v != Result::RELOAD) {
+        restore();
+        return v;
+    }
+    if (validateOnly) {
+        restore();
+        return Result::SUCCESS;
+    }
+    const Result r = reconfigureImpl(staged);
+    if (r != Result::SUCCESS && r != Result::RELOAD) {
+        restore();
+        return r;
+    }
+    ++config_generation_;
+    return Result::SUCCESS;
+}
+
 // ---- Registry ----------------------------------------------------------------------------------
 namespace {
 std::string registry_key(const std::string& type, DeviceType d, RuntimeType r,
@@ -506,11 +535,36 @@ Result Runtime::eagerCycle(bool& needs_sync) {
     return Result::SUCCESS;
 }
 
+U64 Runtime::configGenerations() const {
+    U64 g = 0;
+    for (const Module* m : ordered_) g += m->configGeneration();
+    return g;
+}
+
+// A reconfigured module has new kernel arguments: the captured graphs hold the old ones.
+Result Runtime::dropGraphs() {
+    JST_CHECK(joinLanes());
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+    graph_exec_ = nullptr;
+    graph_ = nullptr;
+    for (int lane = 0; lane < 2; ++lane)
+        for (int half = 0; half < 2; ++half) {
+            if (lane_exec_[lane][half]) (void)hipGraphExecDestroy(lane_exec_[lane][half]);
+            if (lane_graph_[lane][half]) (void)hipGraphDestroy(lane_graph_[lane][half]);
+            lane_exec_[lane][half] = nullptr;
+            lane_graph_[lane][half] = nullptr;
+        }
+    lane_launches_ = 0;
+    return Result::SUCCESS;
+}
+
 Result Runtime::compute(U64 cycles, bool sync) {
     if (!created_) {
         JST_ERROR("[RUNTIME] compute() before create().");
         return Result::ERROR;
     }
+    if (graphActive() && configGenerations() != captured_generation_) JST_CHECK(dropGraphs());
     const bool timing = (flags_ & TIMING) != 0;
     bool needs_sync = sync;
     while (cycles > 0) {
@@ -531,6 +585,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
                 JST_CHECK(joinLanes());
                 for (int half = 0; half < 2; ++half)
                     for (int lane = 0; lane < 2; ++lane) JST_CHECK(captureLane(lane, half, timing));
+                captured_generation_ = configGenerations();
                 for (auto& u : units_) std::fill(u.span.recorded.begin(), u.span.recorded.end(), false);
             } else {
                 // Capture period_ consecutive cycles.  Host-side cursors (ring sources) advance
@@ -552,6 +607,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
                 graph_ = g;
                 JST_HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0),
                               "hipGraphInstantiate");
+                captured_generation_ = configGenerations();
                 for (auto& u : units_)  // nothing ran yet: the capture only recorded nodes
                     std::fill(u.span.recorded.begin(), u.span.recorded.end(), false);
             }

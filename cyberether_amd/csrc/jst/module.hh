@@ -43,6 +43,13 @@ class Module {
     Result construct(const std::string& name, const Config& config,
                      const std::map<std::string, Tensor>& inputs);
     Result teardown();
+    // Module::reconfigure (src/module.cc:233-290): overlay `config` on the staged configuration; an
+    // unchanged configuration is SUCCESS, an invalid one is rejected with the staged one intact, a
+    // change the module cannot absorb in place is RECREATE (the caller tears down and rebuilds), anything
+    // else is applied by reconfigureImpl().  validateOnly stops after validation.  The runtime re-captures
+    // its hipGraph when a module's configuration generation moved.
+    Result reconfigure(const Config& config, bool validateOnly);
+    U64 configGeneration() const { return config_generation_; }
 
     // ---- Module::Impl hooks --------------------------------------------------------------------
     virtual const char* type() const = 0;
@@ -50,6 +57,9 @@ class Module {
     virtual Result define() = 0;
     virtual Result create() = 0;
     virtual Result destroy() { return Result::SUCCESS; }
+    // Module::Impl::reconfigure (detail/module_impl.hh:47; default src/module_impl.cc:61-63): called with
+    // the members already parsed from the NEW configuration by validate(); `previous` is the staged one.
+    virtual Result reconfigureImpl(const Config& previous) { (void)previous; return Result::RECREATE; }
 
     // ---- NativeHipRuntimeContext ---------------------------------------------------------------
     virtual Result computeInitialize() { return Result::SUCCESS; }
@@ -90,6 +100,7 @@ class Module {
     std::vector<std::string> input_ports_, output_ports_;
     U64 taint_ = CLEAN;
     bool created_ = false;
+    U64 config_generation_ = 0;
 };
 
 // ---- Registry ----------------------------------------------------------------------------------
@@ -191,6 +202,9 @@ class Runtime {
     hipGraphExec_t graph_exec_ = nullptr;
     U64 cycles_ = 0;
     U64 period_ = 1;
+    U64 captured_generation_ = 0;  // sum of the modules' configuration generations baked into the graphs
+    U64 configGenerations() const;
+    Result dropGraphs();
     U64 capture_phase_ = 0;
     std::string calibration_unit_;
     // PIPELINE: SURFACE units run as their own graphs on a second stream (a second hardware queue),

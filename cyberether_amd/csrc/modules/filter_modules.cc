@@ -1098,6 +1098,10 @@ class Lineplot : public Module {
         normalizationFactor = 1.0f / (0.5f * static_cast<F32>(numberOfBatches));
         return Result::SUCCESS;
     }
+    // lineplot/module_impl.cc:234-246: the averaging moves in place, the geometry does not
+    Result reconfigureImpl(const Config& previous) override {
+        return ConfigU64(previous, "decimation", 1) == decimation ? Result::SUCCESS : Result::RECREATE;
+    }
     Result define() override {
         JST_CHECK(defineTaint(SURFACE));
         return defineInterfaceInput("signal");
@@ -1241,6 +1245,16 @@ class SignalGenerator : public Module {
                 return Result::ERROR;
             }
         }
+        return Result::SUCCESS;
+    }
+    // signal_generator/module_impl.cc:185-211: waveform parameters move in place (the running phase is
+    // state and stays); type, sample format, rate and buffer size need a rebuild
+    Result reconfigureImpl(const Config& previous) override {
+        if (ConfigStr(previous, "signalType", "cosine") != signalType ||
+            ConfigStr(previous, "signalDataType", "F32") != dataType ||
+            ConfigF64(previous, "sampleRate", 1.0e6) != sampleRate ||
+            ConfigU64(previous, "bufferSize", 8192) != bufferSize)
+            return Result::RECREATE;
         return Result::SUCCESS;
     }
     Result define() override { return defineInterfaceOutput("signal"); }

@@ -279,6 +279,11 @@ class Agc : public Module {
         }
         return Result::SUCCESS;
     }
+    // agc/module_impl.cc:84-94: every parameter moves in place -- except that the tile count sizes this
+    // implementation's device buffers, so a new tileSize asks for a rebuild
+    Result reconfigureImpl(const Config& previous) override {
+        return ConfigU64(previous, "tileSize", 1024) == tileSize ? Result::SUCCESS : Result::RECREATE;
+    }
     Result define() override {
         JST_CHECK(defineTaint(STATELESS));
         JST_CHECK(defineInterfaceInput("signal"));

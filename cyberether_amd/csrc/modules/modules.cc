@@ -545,6 +545,9 @@ Result MultiplyConstant::validate() {
     }
     return Result::SUCCESS;
 }
+Result MultiplyConstant::reconfigureImpl(const Config& previous) {  // multiply_constant/module_impl.cc:26-35
+    return (F32)ConfigF64(previous, "constant", 1.0) != constant ? Result::SUCCESS : Result::RECREATE;
+}
 Result MultiplyConstant::define() {
     JST_CHECK(defineTaint(DISCONTIGUOUS | STATELESS));
     JST_CHECK(defineInterfaceInput("factor"));
@@ -893,9 +896,8 @@ Result Range::define() {
     JST_CHECK(defineInterfaceOutput("signal"));
     return defineInterfaceInput("signal");
 }
-Result Range::create() {
-    input = inputs_.at("signal");
-    const F32 lower = std::min(min, max), upper = std::max(min, max);  // range/module_impl.cc:51-62
+void Range::updateCoefficients() {  // range/module_impl.cc:51-62
+    const F32 lower = std::min(min, max), upper = std::max(min, max);
     if (lower == upper) {
         scalingCoeff = 0.0f;
         offsetCoeff = 0.5f;
@@ -903,6 +905,14 @@ Result Range::create() {
         scalingCoeff = 1.0f / (upper - lower);
         offsetCoeff = -lower * scalingCoeff;
     }
+}
+Result Range::reconfigureImpl(const Config&) {  // range/module_impl.cc:40-49: min / max move in place
+    updateCoefficients();
+    return Result::SUCCESS;
+}
+Result Range::create() {
+    input = inputs_.at("signal");
+    updateCoefficients();
     JST_CHECK(output.create(device(), input.dtype(), input.shape()));
     JST_CHECK(output.propagateAttributes(input));
     produced("signal", output);

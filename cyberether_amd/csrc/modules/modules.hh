@@ -103,6 +103,7 @@ class MultiplyConstant : public Module {
     Result validate() override;
     Result define() override;
     Result create() override;
+    Result reconfigureImpl(const Config& previous) override;
     Result computeSubmit(hipStream_t stream) override;
     Tensor input, output;
     F32 constant = 1.0f;
@@ -161,7 +162,9 @@ class Range : public Module {
     Result validate() override;
     Result define() override;
     Result create() override;
+    Result reconfigureImpl(const Config& previous) override;
     Result computeSubmit(hipStream_t stream) override;
+    void updateCoefficients();
     Tensor input, output;
     F32 min = -1.0f, max = 1.0f, scalingCoeff = 0.0f, offsetCoeff = 0.5f;
 };
@@ -192,6 +195,10 @@ class Waterfall : public Module {
     Result validate() override;
     Result define() override;
     Result create() override;
+    // waterfall/module_impl.cc:121-130: `interpolate` (a render option) moves in place, the height does not
+    Result reconfigureImpl(const Config& previous) override {
+        return ConfigU64(previous, "height", 512) != height ? Result::RECREATE : Result::SUCCESS;
+    }
     Result computeSubmit(hipStream_t stream) override;
     const Tensor* state(const std::string& key) const override {
         if (key == "frequencyBins") return &frequencyBins;

@@ -110,6 +110,7 @@ _sig("jst_tensor_copy_from_host_async", R, _h, C.c_void_p, C.c_size_t)
 _sig("jst_module_create", R, C.c_char_p, C.c_uint8, C.c_char_p, C.c_char_p, _strs, C.c_uint32,
      _strs, _hp, C.c_uint32, _hp)
 _sig("jst_module_destroy", R, _h)
+_sig("jst_module_reconfigure", R, _h, _strs, C.c_uint32, C.c_int)
 _sig("jst_module_output", R, _h, C.c_char_p, _hp)
 _sig("jst_module_state", R, _h, C.c_char_p, _hp)
 _sig("jst_module_taint", C.c_uint64, _h)
@@ -362,6 +363,19 @@ class Module:
         h, self._h = getattr(self, "_h", None), None
         if h and _lib is not None:
             _lib.jst_module_destroy(h)
+
+    def reconfigure(self, config: dict, validate_only: bool = False) -> str:
+        """Module::reconfigure (src/module.cc:233-290): "success" when the change was applied in place (or
+        nothing changed), "recreate" when the module must be rebuilt for it (nothing was changed); an
+        invalid configuration raises and leaves the module as it was.  A Runtime holding the module
+        re-captures its graph on the next compute()."""
+        cfg = [f"{k}={_cfg_value(v)}".encode() for k, v in config.items()]
+        arr = (C.c_char_p * max(len(cfg), 1))(*cfg)
+        r = _lib.jst_module_reconfigure(self._h, arr, len(cfg), 1 if validate_only else 0)
+        if r == 7:
+            return "recreate"
+        _check(r)
+        return "success"
 
     def output(self, port: str) -> Tensor:
         out = C.c_void_p()

@@ -150,6 +150,12 @@ jst_result jst_module_create(const char* type, uint8_t device, const char* provi
                              const char* const* input_ports, const jst_tensor* input_tensors,
                              uint32_t n_inputs, jst_module* out);
 jst_result jst_module_destroy(jst_module m);
+/* Module::reconfigure (src/module.cc:233-290, Module::Impl::reconfigure detail/module_impl.hh:47): overlay
+ * "key=value" entries on the module's configuration.  JST_SUCCESS: applied in place (or unchanged);
+ * JST_RECREATE (7): valid, but this module cannot absorb the change without being rebuilt -- nothing was
+ * changed; JST_ERROR: rejected by validate(), nothing was changed.  validate_only != 0 stops after the
+ * validation.  A runtime holding the module re-captures its hipGraph on the next compute(). */
+jst_result jst_module_reconfigure(jst_module m, const char* const* config, uint32_t n_config, int validate_only);
 jst_result jst_module_output(jst_module m, const char* port, jst_tensor* out);
 /* internal state tensors: spectrogram/waterfall "frequencyBins", waterfall "ringState" */
 jst_result jst_module_state(jst_module m, const char* key, jst_tensor* out);
