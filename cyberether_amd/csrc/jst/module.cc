@@ -465,13 +465,31 @@ Result Runtime::destroy() {
     return Result::SUCCESS;
 }
 
+// The result convention of src/runtime/native/cpu/impl.cc:98-148: SUCCESS | RELOAD continue; SKIP marks the
+// unit's outputs skipped for this cycle and every unit reading a skipped tensor is skipped in turn;
+// YIELD | TIMEOUT end the cycle quietly (a source without data); anything else fails the cycle.
 Result Runtime::submitAll(bool record_events, U64 slot, bool count_cycles) {
+    std::set<U64> skipped;  // producers (ProducerAttribute) whose outputs do not exist this cycle
+    auto producer_of = [](const Tensor& t) -> U64 {
+        const AttrValue* a = t.attribute(ProducerAttribute);
+        return a && std::holds_alternative<U64>(*a) ? std::get<U64>(*a) : 0;
+    };
     for (auto& u : units_) {
         if (u.is_static && u.settled) continue;
+        bool starved = false;
+        for (Module* m : u.modules)
+            for (const auto& kv : m->inputs()) starved |= skipped.count(producer_of(kv.second)) != 0;
+        if (starved) {
+            for (Module* m : u.modules) skipped.insert((U64)reinterpret_cast<uintptr_t>(m));
+            continue;
+        }
         const bool rec = record_events && slot < u.span.begin.size();
         if (rec) JST_HIP_CHECK(hipEventRecord(u.span.begin[slot], stream_), "hipEventRecord");
         const Result r = u.submit(stream_);
-        if (r != Result::SUCCESS && r != Result::RELOAD) {
+        if (r == Result::YIELD || r == Result::TIMEOUT) return r;
+        if (r == Result::SKIP) {
+            for (Module* m : u.modules) skipped.insert((U64)reinterpret_cast<uintptr_t>(m));
+        } else if (r != Result::SUCCESS && r != Result::RELOAD) {
             JST_ERROR("[RUNTIME] computeSubmit failed in '%s' (%s): %s", u.name.c_str(),
                       ResultName(r), last_error());
             return r;
@@ -525,7 +543,11 @@ Result Runtime::eagerCycle(bool& needs_sync) {
         last_slot_ = cycles_ % (2 * period_);
         for (Tensor& t : pipelined_) JST_CHECK(t.ringSelect(last_slot_));
     }
-    JST_CHECK(submitAll(timing, slot, true));
+    {
+        const Result r = submitAll(timing, slot, true);
+        if (r == Result::YIELD || r == Result::TIMEOUT) return r;  // no data: the cycle did not happen
+        if (r != Result::SUCCESS) return r;
+    }
     timing_pending_ = timing_pending_ || timing;
     ++cycles_;
     // STATIC modules settle after one successful cycle (scheduler_synchronous.cc:534-546).
@@ -644,7 +666,17 @@ Result Runtime::compute(U64 cycles, bool sync) {
             cycles -= period_;
             continue;
         }
-        JST_CHECK(eagerCycle(needs_sync));
+        {
+            const Result r = eagerCycle(needs_sync);
+            if (r == Result::YIELD || r == Result::TIMEOUT) {  // quiet end: what was queued still completes
+                if (sync) {
+                    JST_CHECK(joinLanes());
+                    JST_CHECK(harvestTiming());
+                }
+                return r;
+            }
+            if (r != Result::SUCCESS) return r;
+        }
         --cycles;
     }
     if (needs_sync) {

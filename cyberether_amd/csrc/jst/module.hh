@@ -23,6 +23,7 @@
 namespace jst {
 
 using Config = std::map<std::string, std::string>;
+constexpr const char* ProducerAttribute = "producer";
 
 bool ConfigBool(const Config& c, const std::string& key, bool fallback, bool* ok = nullptr);
 U64 ConfigU64(const Config& c, const std::string& key, U64 fallback, bool* ok = nullptr);
@@ -90,7 +91,14 @@ class Module {
     Result defineTaint(U64 taint) { taint_ = taint; return Result::SUCCESS; }
     Result defineInterfaceInput(const std::string& port) { input_ports_.push_back(port); return Result::SUCCESS; }
     Result defineInterfaceOutput(const std::string& port) { output_ports_.push_back(port); return Result::SUCCESS; }
-    void produced(const std::string& port, const Tensor& t) { outputs_[port] = t; }
+    // outputs()[port].produced(name(), port, tensor) (include/jetstream/tensor_link.hh:22-34): the link
+    // remembers its producer -- here as an attribute that travels with every copy of the handle, so
+    // that the runtime can tell a skipped producer's tensor from another view of the same storage
+    void produced(const std::string& port, const Tensor& t) {
+        Tensor link = t;
+        (void)link.setAttribute(ProducerAttribute, AttrValue{(U64)reinterpret_cast<uintptr_t>(this)});
+        outputs_[port] = link;
+    }
 
     std::string name_;
     std::string provider_ = "generic";

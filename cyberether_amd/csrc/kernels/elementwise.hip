@@ -264,6 +264,43 @@ hipError_t launch_cast(const EwLayout& L, void* out, const void* in, CastKind ki
 #undef JST_CAST_CPLX
     return hipErrorInvalidValue;
 }
+// ---- Squelch (dsp/squelch/module_impl_native_cpu.cc:66-98): peak = max |x| over the whole tensor ----
+// std::max(peak, v) keeps `peak` when v is NaN, so NaNs never win; |z| of a complex sample is libm
+// hypotf, i.e. (float)sqrt((double)re*re + (double)im*im) with the infinity rule in front.  All values
+// are >= +0, so their bit patterns order like the floats: one atomicMax on the bits per wavefront.
+namespace {
+__global__ __launch_bounds__(256) void peak_abs_kernel(uint32_t* __restrict__ peak_bits, const float* __restrict__ in,
+                                                       uint64_t count, int complex) {
+    float best = 0.0f;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        float v;
+        if (complex) {
+            const float re = in[2 * i], im = in[2 * i + 1];
+            if (__builtin_isinf(re) || __builtin_isinf(im)) v = __builtin_inff();
+            else v = (float)__builtin_sqrt((double)re * (double)re + (double)im * (double)im);
+        } else {
+            v = __builtin_fabsf(in[i]);
+        }
+        best = (v > best) ? v : best;  // false for NaN
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float other = __shfl_xor(best, off);
+        best = other > best ? other : best;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(peak_bits, __builtin_bit_cast(uint32_t, best));
+}
+}  // namespace
+hipError_t launch_peak_abs(float* peak, const void* in, uint64_t count, bool complex, hipStream_t s) {
+    (void)hipGetLastError();
+    hipError_t e = hipMemsetAsync(peak, 0, sizeof(float), s);
+    if (e != hipSuccess || count == 0) return e;
+    const uint64_t blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(peak_abs_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s,
+                       reinterpret_cast<uint32_t*>(peak), static_cast<const float*>(in), count, complex ? 1 : 0);
+    return hipGetLastError();
+}
+
 namespace {
 __global__ __launch_bounds__(256) void amplitude_range_probe_kernel(float* __restrict__ out_exact,
                                                                     float* __restrict__ out_fast,

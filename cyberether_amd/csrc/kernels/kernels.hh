@@ -187,6 +187,8 @@ hipError_t launch_agc(void* out, const void* in, bool complex, double* gains, co
 // Window: Blackman taps evaluated in F64 (window/module_impl_native_cpu.cc:20-37).
 hipError_t launch_window(float2* out, uint64_t n, hipStream_t stream);
 // libm-faithful tanhf sweep helper for the parity tests (out[i] = libm_tanhf(in[i])).
+// Squelch: peak[0] = max |x| (NaNs ignored like std::max, complex magnitude = libm hypotf), device scalar
+hipError_t launch_peak_abs(float* peak, const void* in, uint64_t count, bool complex, hipStream_t stream);
 hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipStream_t stream);
 
 // ---- Spectrogram (spectrogram.hip) -------------------------------------------------------------

@@ -340,7 +340,72 @@ class Agc : public Module {
     F64 reference = 1.0, epsilon = 1e-12, minGain = 0.01, maxGain = 100.0, maxGainChange = 4.0;
 };
 
+// ---- Squelch (dsp/squelch/module_impl.cc:8-62, module_impl_native_cpu.cc:28-98) -----------------
+// Passes its input on (the output is a view of it) when the peak amplitude of the buffer exceeds the
+// threshold, answers SKIP otherwise: the runtime then skips everything downstream for this cycle.  The
+// decision is the host's, so the cycle waits for one device scalar -- not graph-capturable.
+class Squelch : public Module {
+ public:
+    const char* type() const override { return "squelch"; }
+    Result validate() override {
+        bool ok = true;
+        threshold = (F32)ConfigF64(config_, "threshold", 0.1, &ok);
+        if (!ok || !std::isfinite(threshold) || threshold < 0.0f) {
+            JST_ERROR("[MODULE_SQUELCH] Invalid threshold '%s', must be non-negative.",
+                      ConfigStr(config_, "threshold", "?").c_str());
+            return Result::ERROR;
+        }
+        if (!inputs_.count("signal")) return Result::SUCCESS;
+        const Tensor& in = inputs_.at("signal");
+        if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+        if (in.dtype() != DataType::CF32 && in.dtype() != DataType::F32) {
+            JST_ERROR("[MODULE_SQUELCH_NATIVE_HIP] Unsupported data type '%s'.", DataTypeName(in.dtype()));
+            return Result::ERROR;
+        }
+        return Result::SUCCESS;
+    }
+    Result define() override {
+        JST_CHECK(defineInterfaceInput("signal"));
+        return defineInterfaceOutput("signal");
+    }
+    Result create() override {
+        input = inputs_.at("signal");
+        output = input.clone();
+        JST_CHECK(peak.create(device(), DataType::F32, {1}));
+        JST_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&hostPeak), sizeof(float), hipHostMallocDefault),
+                      "hipHostMalloc");
+        *hostPeak = 0.0f;
+        passing = false;
+        produced("signal", output);
+        return Result::SUCCESS;
+    }
+    Result destroy() override {
+        if (hostPeak) (void)hipHostFree(hostPeak);
+        hostPeak = nullptr;
+        passing = false;
+        return Result::SUCCESS;
+    }
+    Result reconfigureImpl(const Config&) override { return Result::SUCCESS; }  // the threshold moves in place
+    Result computeSubmit(hipStream_t s) override {
+        JST_HIP_CHECK(kernels::launch_peak_abs(static_cast<float*>(peak.data()),
+                                               static_cast<const char*>(input.data()) + input.offsetBytes(),
+                                               input.size(), input.dtype() == DataType::CF32, s),
+                      "squelch peak kernel");
+        JST_HIP_CHECK(hipMemcpyAsync(hostPeak, peak.data(), sizeof(float), hipMemcpyDeviceToHost, s), "hipMemcpyAsync");
+        JST_HIP_CHECK(hipStreamSynchronize(s), "hipStreamSynchronize");
+        passing = *hostPeak > threshold;
+        return passing ? Result::SUCCESS : Result::SKIP;
+    }
+    bool capturable() const override { return false; }
+    const Tensor* state(const std::string& key) const override { return key == "amplitude" ? &peak : nullptr; }
+    Tensor input, output, peak;
+    float* hostPeak = nullptr;
+    F32 threshold = 0.1f;
+    bool passing = false;
+};
+
 JST_REGISTER_MODULE(Slice, "slice", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Agc, "agc", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(Squelch, "squelch", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 
 }  // namespace jst::modules

@@ -1039,6 +1039,19 @@ Result RingSource::validate() {
         JST_ERROR("[MODULE_RING_SOURCE] batches, samples and slots must be positive integers.");
         return Result::ERROR;
     }
+    bool o4 = true, o5 = true;
+    live = ConfigBool(config_, "live", false, &o4);
+    published = ConfigU64(config_, "published", 0, &o5);
+    if (!o4 || !o5) {
+        JST_ERROR("[MODULE_RING_SOURCE] Invalid live / published value.");
+        return Result::ERROR;
+    }
+    return Result::SUCCESS;
+}
+Result RingSource::reconfigureImpl(const Config& previous) {  // the counters move in place, the geometry does not
+    if (ConfigU64(previous, "batches", 8) != batches || ConfigU64(previous, "samples", 2048) != samples ||
+        ConfigU64(previous, "slots", 1) != slots || ConfigBool(previous, "live", false) != live)
+        return Result::RECREATE;
     return Result::SUCCESS;
 }
 Result RingSource::define() { return defineInterfaceOutput("buffer"); }
@@ -1048,11 +1061,18 @@ Result RingSource::create() {
     output.setAttribute("sampleRate", AttrValue{ConfigF64(config_, "sampleRate", 2.0e6)});
     output.setAttribute("frequency", AttrValue{ConfigF64(config_, "frequency", 96.9e6)});
     cursor = 0;
+    consumed = 0;
     first = true;
     produced("buffer", output);
     return Result::SUCCESS;
 }
 Result RingSource::computeSubmit(hipStream_t) {
+    if (live) {
+        if (consumed >= published) return Result::YIELD;  // nothing new from the host: no cycle
+        const U64 slot = consumed % slots;
+        ++consumed;
+        return output.ringSelect(slot);
+    }
     // First cycle exposes slot 0, then round-robin; no data moves.
     if (first) first = false;
     else cursor = (cursor + 1) % slots;

@@ -221,10 +221,16 @@ class RingSource : public Module {
     Result define() override;
     Result create() override;
     Result computeSubmit(hipStream_t stream) override;
-    U64 cyclePeriod() const override { return slots; }
+    U64 cyclePeriod() const override { return live ? 1 : slots; }
     bool launchesKernels() const override { return false; }
+    bool capturable() const override { return !live; }  // live: every cycle asks the host-side counters
+    Result reconfigureImpl(const Config& previous) override;
     Tensor output;
     U64 batches = 8, samples = 2048, slots = 1, cursor = 0;
+    // live: the host fills slot (published % slots), then raises `published` by reconfigure(); a cycle
+    // consumes one published slot, or YIELDs when there is none (io/soapy/module_impl_native_cpu.cc:47-60)
+    bool live = false;
+    U64 published = 0, consumed = 0;
     bool first = true;
 };
 

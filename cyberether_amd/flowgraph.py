@@ -66,7 +66,7 @@ _DROPPED = {"note": "documentation node"}
 _SKIPPED = {"audio": "host audio sink (resampler + sound device): outside the device path, SURVEY §8",
             "adsb": "ADS-B decoder: not on the north-star path",
             "file_writer": "host file sink", "websocket": "network sink", "constellation": "render surface",
-            "squelch": "not on the north-star path", "am": "not on the north-star path",
+            "am": "not on the north-star path",
             "psk_demod": "not on the north-star path", "rrc_filter": "not on the north-star path"}
 
 
@@ -219,6 +219,10 @@ class Flowgraph:
                             heads, name=name,
                             provider=provider if provider in ("generic", "fast") else "generic")
             node.impl, node.modules, node.outputs = flt, flt.modules, {"buffer": flt.buffer}
+        elif block == "squelch":  # dsp/squelch/block_impl.cc: one module, ports signal -> signal
+            sq = js.Module("squelch", {"threshold": float(cfg.get("threshold", 0.1))},
+                           {"signal": inputs["signal"]}, name + ".squelch")
+            node.modules, node.outputs = [sq], {"signal": sq.output("signal")}
         elif block == "decimator":
             dec = js.Decimator(inputs["buffer"], int(cfg.get("ratio", 4)), name=name)
             node.impl, node.modules, node.outputs = dec, dec.modules, {"buffer": dec.buffer}

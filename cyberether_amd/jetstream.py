@@ -430,8 +430,17 @@ class Runtime:
         if h and _lib is not None:
             _lib.jst_runtime_destroy(h)
 
-    def compute(self, cycles: int = 1, sync: bool = True):
-        _check(_lib.jst_runtime_compute(self._h, cycles, 1 if sync else 0))
+    def compute(self, cycles: int = 1, sync: bool = True) -> str:
+        """Runs `cycles` compute cycles.  "success", or -- the reference runtime's quiet endings
+        (src/runtime/native/cpu/impl.cc:121-124) -- "yield" / "timeout" when a source had no data: the
+        cycle in which that happened, and the rest of the request, did not run."""
+        r = _lib.jst_runtime_compute(self._h, cycles, 1 if sync else 0)
+        if r == 5:
+            return "yield"
+        if r == 8:
+            return "timeout"
+        _check(r)
+        return "success"
 
     def synchronize(self):
         _check(_lib.jst_runtime_synchronize(self._h))

@@ -533,3 +533,23 @@ def add(a: np.ndarray, b: np.ndarray) -> np.ndarray:
     """core/add/module_impl_native_cpu.cc:83-98 (broadcasting like multiply)."""
     assert a.dtype == b.dtype and a.dtype in (np.float32, np.complex64)
     return (a + b).astype(a.dtype)
+
+
+def squelch(x: np.ndarray, threshold: float):
+    """dsp/squelch/module_impl_native_cpu.cc:66-98: (passing, peak) with peak = max |x| in F32 -- std::max
+    keeps the running peak when a value is NaN; |z| of a complex sample is libm hypotf =
+    (float)sqrt((double)re*re + (double)im*im), infinite as soon as a part is."""
+    x = np.asarray(x)
+    if np.iscomplexobj(x):
+        z = x.astype(np.complex64).reshape(-1)
+        re, im = z.real.astype(np.float64), z.imag.astype(np.float64)
+        with np.errstate(invalid="ignore", over="ignore"):
+            mag = np.sqrt(re * re + im * im).astype(np.float32)
+        mag[np.isinf(re) | np.isinf(im)] = np.inf
+    else:
+        mag = np.abs(x.astype(np.float32).reshape(-1))
+    peak = np.float32(0.0)
+    finite_or_inf = mag[~np.isnan(mag)]
+    if finite_or_inf.size:
+        peak = np.float32(max(peak, finite_or_inf.max()))
+    return bool(peak > np.float32(threshold)), peak
