@@ -61,7 +61,7 @@ DataType to_dtype(uint8_t d) {
         case JST_DTYPE_U64: return DataType::U64;
         default:
             // the integer sample formats share their numeric value with jst::DataType
-            if (d >= JST_DTYPE_I8 && d <= JST_DTYPE_CU32) return static_cast<DataType>(d);
+            if (d >= JST_DTYPE_I8 && d <= JST_DTYPE_CF64) return static_cast<DataType>(d);
             return DataType::None;
     }
 }
@@ -237,6 +237,23 @@ jst_result jst_tensor_set_attribute_f64v(jst_tensor t, const char* key, const do
 jst_result jst_tensor_remove_attribute(jst_tensor t, const char* key) {
     JST_ARG(t && key, "null argument");
     return R(t->t.removeAttribute(key));
+}
+jst_result jst_tensor_get_attribute_f64v(jst_tensor t, const char* key, double* values, uint64_t* count) {
+    JST_ARG(t && key && count && (values || *count == 0), "null argument");
+    const AttrValue* v = t->t.attribute(key);
+    if (!v) {
+        JST_ERROR("[ABI] tensor has no attribute '%s'", key);
+        return R(Result::ERROR);
+    }
+    std::vector<double> flat;
+    if (const U64* u = std::get_if<U64>(v)) flat = {(double)*u};
+    else if (const F64* f = std::get_if<F64>(v)) flat = {*f};
+    else if (const auto* fv = std::get_if<std::vector<F64>>(v)) flat = *fv;
+    else if (const auto* uv = std::get_if<std::vector<U64>>(v)) flat.assign(uv->begin(), uv->end());
+    const uint64_t room = *count;
+    *count = flat.size();
+    for (uint64_t i = 0; i < flat.size() && i < room; ++i) values[i] = flat[i];
+    return R(Result::SUCCESS);
 }
 jst_result jst_tensor_copy_from_host(jst_tensor t, const void* src, size_t bytes) {
     JST_ARG(t && (src || bytes == 0), "null argument");

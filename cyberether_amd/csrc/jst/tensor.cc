@@ -28,11 +28,12 @@ const char* DataTypeName(DataType t) {
         case DataType::CI32: return "CI32";
         case DataType::U32: return "U32";
         case DataType::CU32: return "CU32";
+        case DataType::CF64: return "CF64";
         default: return "None";
     }
 }
 DataType NameToDataType(const std::string& name) {
-    for (uint8_t v = 1; v <= static_cast<uint8_t>(DataType::CU32); ++v)
+    for (uint8_t v = 1; v <= static_cast<uint8_t>(DataType::CF64); ++v)
         if (name == DataTypeName(static_cast<DataType>(v))) return static_cast<DataType>(v);
     return DataType::None;
 }

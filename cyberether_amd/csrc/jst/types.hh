@@ -48,7 +48,7 @@ enum class RuntimeType : uint8_t { NATIVE = 0 };
 
 enum class DataType : uint8_t {
     None = 0, F32 = 1, CF32 = 2, F64 = 3, U64 = 4, I8 = 5, CI8 = 6, I16 = 7, CI16 = 8, U8 = 9,
-    CU8 = 10, U16 = 11, CU16 = 12, I32 = 13, CI32 = 14, U32 = 15, CU32 = 16
+    CU8 = 10, U16 = 11, CU16 = 12, I32 = 13, CI32 = 14, U32 = 15, CU32 = 16, CF64 = 17
 };
 
 inline size_t DataTypeSize(DataType t) {
@@ -69,6 +69,7 @@ inline size_t DataTypeSize(DataType t) {
         case DataType::CI32: return 8;
         case DataType::U32: return 4;
         case DataType::CU32: return 8;
+        case DataType::CF64: return 16;
         default: return 0;
     }
 }

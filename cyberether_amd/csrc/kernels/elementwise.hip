@@ -325,6 +325,24 @@ hipError_t launch_amplitude_range_probe(float* out_exact, float* out_fast, const
                        dev::BinGuard{guard_h0, guard_h1});
     return hipGetLastError();
 }
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void fill_kernel(T* __restrict__ out, uint64_t count, T even, T odd) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256)
+        out[i] = (i & 1) ? odd : even;
+}
+}  // namespace
+hipError_t launch_fill_ones(void* out, uint64_t count, int elem_bytes, bool pair, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    (void)hipGetLastError();
+    const bool f64 = (elem_bytes == 8 && !pair) || elem_bytes == 16;
+    const uint64_t words = pair ? 2 * count : count;
+    const uint64_t blocks = (words + 255) / 256;
+    const dim3 grid((unsigned)(blocks < 8192 ? blocks : 8192));
+    if (f64) hipLaunchKernelGGL(fill_kernel<double>, grid, dim3(256), 0, s, (double*)out, words, 1.0, pair ? 0.0 : 1.0);
+    else hipLaunchKernelGGL(fill_kernel<float>, grid, dim3(256), 0, s, (float*)out, words, 1.0f, pair ? 0.0f : 1.0f);
+    return hipGetLastError();
+}
 hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipStream_t s) {
     EwLayout L{};
     L.size = count;

@@ -714,6 +714,69 @@ __global__ __launch_bounds__(kFmThreads) void fm_narrow_deemph_kernel(float* __r
     }
 }
 
+// ---- AM (dsp/am/module_impl_native_cpu.cc:40-101): envelope + one-pole DC blocker --------------
+//     e[n] = |x[n]|  (std::abs of a complex<float> = libm hypotf);  y[n] = e[n] - e[n-1] + alpha*y[n-1]
+// per lane, batches walked as one sequence.  The reference evaluates (e[n] - e[n-1]) + (alpha*y[n-1])
+// left to right in F32 with no contraction, so the differences are computed by all threads (each
+// is ONE rounding of two exactly known envelopes) and only the two-operation recurrence is walked
+// by one thread per lane, out of LDS -- the same split as the narrow-FM de-emphasis kernel above.
+struct AmState {
+    float prev_envelope, prev_output;
+};
+__device__ __forceinline__ float am_envelope(float2 v) {
+    if (__builtin_isinf(v.x) || __builtin_isinf(v.y)) return __builtin_inff();
+    return (float)__builtin_sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);
+}
+__global__ __launch_bounds__(kFmThreads) void am_kernel(float* __restrict__ out, const float2* __restrict__ in,
+                                                        AmState* __restrict__ states, const float alpha,
+                                                        const FmLayout L) {
+    __shared__ float diff_a[kFmChunk + 8], out_a[kFmChunk + 8];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t lane = blockIdx.x, n_total = L.batches * L.samples;
+    int64_t in_off, out_off;
+    fm_lane_offsets(L, lane, in_off, out_off);
+    const AmState st = states[lane];
+    auto env_at = [&](uint64_t n) {
+        return am_envelope(
+            in[in_off + (int64_t)(n / L.samples) * L.in_batch_stride + (int64_t)(n % L.samples) * L.in_sample_stride]);
+    };
+    float y = st.prev_output;
+    for (uint64_t c0 = 0; c0 < n_total; c0 += kFmChunk) {
+        const uint32_t cnt = (uint32_t)((n_total - c0) < (uint64_t)kFmChunk ? (n_total - c0) : (uint64_t)kFmChunk);
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt + 8; i += kFmThreads) {
+            const uint64_t n = c0 + i;
+            float d = 0.0f;
+            if (i < cnt) d = env_at(n) - (n ? env_at(n - 1) : st.prev_envelope);
+            diff_a[i] = d;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+                float d[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = diff_a[i0 + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    y = d[j] + alpha * y;
+                    out_a[i0 + j] = y;
+                }
+            }
+            y = out_a[cnt - 1];  // the tail of the last group of 8 ran past cnt on zeros
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += kFmThreads) {
+            const uint64_t n = c0 + i;
+            out[out_off + (int64_t)(n / L.samples) * L.out_batch_stride + (int64_t)(n % L.samples) * L.out_sample_stride] =
+                out_a[i];
+        }
+    }
+    if (tid == 0 && n_total) {
+        states[lane].prev_envelope = env_at(n_total - 1);
+        states[lane].prev_output = y;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void fm_narrow_parallel_kernel(
     float* __restrict__ out, const float2* __restrict__ in, const FmState* __restrict__ states,
     const FmCoeffs k, const FmLayout L) {
@@ -1069,6 +1132,14 @@ hipError_t launch_arithmetic(const EwLayout& L, void* out, const void* in, bool 
         else JST_ARITH(float, 3);
     }
 #undef JST_ARITH
+    return hipGetLastError();
+}
+size_t am_state_bytes() { return sizeof(AmState); }
+hipError_t launch_am(float* out, const float2* in, void* states, float alpha, const FmLayout& L, hipStream_t s) {
+    (void)hipGetLastError();
+    if (L.lanes == 0 || L.batches * L.samples == 0) return hipSuccess;
+    hipLaunchKernelGGL(am_kernel, dim3((unsigned)L.lanes), dim3(kFmThreads), 0, s, out, in, (AmState*)states, alpha,
+                       L);
     return hipGetLastError();
 }
 hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,

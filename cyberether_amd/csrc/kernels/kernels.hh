@@ -189,6 +189,8 @@ hipError_t launch_window(float2* out, uint64_t n, hipStream_t stream);
 // libm-faithful tanhf sweep helper for the parity tests (out[i] = libm_tanhf(in[i])).
 // Squelch: peak[0] = max |x| (NaNs ignored like std::max, complex magnitude = libm hypotf), device scalar
 hipError_t launch_peak_abs(float* peak, const void* in, uint64_t count, bool complex, hipStream_t stream);
+// ones_tensor: count elements of 1 (elem_bytes 4 = F32, 8 with pair = CF32 (1,0), 8 = F64, 16 = CF64 (1,0))
+hipError_t launch_fill_ones(void* out, uint64_t count, int elem_bytes, bool pair, hipStream_t stream);
 hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipStream_t stream);
 
 // ---- Spectrogram (spectrogram.hip) -------------------------------------------------------------
@@ -263,6 +265,9 @@ struct SignalParams {
 };
 hipError_t launch_signal_generator(float* out, double* phases, double* state, uint64_t count,
                                    bool complex_out, const SignalParams& p, hipStream_t s);
+// AM: envelope + DC blocker, states = lanes x {previous envelope, previous output} (zero = fresh)
+size_t am_state_bytes();
+hipError_t launch_am(float* out, const float2* in, void* states, float alpha, const FmLayout& L, hipStream_t s);
 size_t fm_state_bytes();
 hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
                      hipStream_t s);

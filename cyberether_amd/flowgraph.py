@@ -57,6 +57,9 @@ _SIMPLE = {
     "phase_correction": ("phase_correction", {"signal": "signal"}),
     "arithmetic": ("arithmetic", {"buffer": "buffer"}),
     "fm": ("fm", {"signal": "signal"}),
+    "am": ("am", {"signal": "signal"}),
+    "signal_axes": ("signal_axes", {"buffer": "buffer"}),
+    "ones_tensor": ("ones_tensor", {"buffer": "buffer"}),
     "signal_generator": ("signal_generator", {"signal": "signal"}),
     "lineplot": ("lineplot", {}),
     "waterfall": ("waterfall", {}),
@@ -66,7 +69,6 @@ _DROPPED = {"note": "documentation node"}
 _SKIPPED = {"audio": "host audio sink (resampler + sound device): outside the device path, SURVEY §8",
             "adsb": "ADS-B decoder: not on the north-star path",
             "file_writer": "host file sink", "websocket": "network sink", "constellation": "render surface",
-            "am": "not on the north-star path",
             "psk_demod": "not on the north-star path", "rrc_filter": "not on the north-star path"}
 
 
@@ -141,7 +143,8 @@ class Flowgraph:
             pending.append(e)
         # instantiate in dependency order (the file order is the editor's, not topological)
         done = set()
-        composite = {"soapy", "spectrum_engine", "filter", "decimator", "slice", "filter_taps"}
+        composite = {"soapy", "spectrum_engine", "filter", "decimator", "slice", "filter_taps", "squelch", "flatten",
+                     "permutation"}
         while pending:
             progressed = False
             for e in list(pending):
@@ -243,6 +246,20 @@ class Flowgraph:
                                           "center": [float(np.float32(c)) for c in center],
                                           "taps": int(cfg.get("taps", 101))}, {}, name)
             node.modules, node.outputs = [m], {"coeffs": m.output("coeffs")}
+        elif block in ("flatten", "permutation"):
+            # flatten/block_impl.cc:50-60 copies BEFORE the view (flatten needs dense input),
+            # permutation/block_impl.cc:56-64 copies AFTER it (densifies the strided view)
+            contiguous = bool(cfg.pop("contiguous", False))
+            src, mods = inputs["buffer"], []
+            if contiguous and block == "flatten":
+                mods.append(js.Module("duplicate", {}, {"buffer": src}, name + ".duplicate"))
+                src = mods[-1].output("buffer")
+            mods.append(js.Module(block, cfg, {"buffer": src}, name + "." + block))
+            src = mods[-1].output("buffer")
+            if contiguous and block == "permutation":
+                mods.append(js.Module("duplicate", {}, {"buffer": src}, name + ".duplicate"))
+                src = mods[-1].output("buffer")
+            node.modules, node.outputs = mods, {"buffer": src}
         elif block in _SIMPLE:
             mtype, ports = _SIMPLE[block]
             if block == "fft":
@@ -253,7 +270,7 @@ class Flowgraph:
             node.outputs = {bp: m.output(mp) for bp, mp in ports.items()}
         else:
             raise FlowgraphError(f"node '{name}': block type '{block}' is not implemented on the HIP "
-                                 f"device (implemented: {sorted(set(_SIMPLE) | {'soapy', 'spectrum_engine', 'filter', 'decimator', 'slice', 'filter_taps'})})")
+                                 f"device (implemented: {sorted(set(_SIMPLE) | {'soapy', 'spectrum_engine', 'filter', 'decimator', 'slice', 'filter_taps', 'flatten', 'permutation', 'squelch'})})")
         self.nodes[name] = node
         self.order.append(name)
 

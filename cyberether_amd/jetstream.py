@@ -37,11 +37,12 @@ MAX_RANK = 8
 DEVICE = {"none": 1, "cpu": 2, "hip": 64}
 DEVICE_NAME = {v: k for k, v in DEVICE.items()}
 DTYPE = {"F32": 1, "CF32": 2, "F64": 3, "U64": 4, "I8": 5, "CI8": 6, "I16": 7, "CI16": 8, "U8": 9,
-         "CU8": 10, "U16": 11, "CU16": 12, "I32": 13, "CI32": 14, "U32": 15, "CU32": 16}
+         "CU8": 10, "U16": 11, "CU16": 12, "I32": 13, "CI32": 14, "U32": 15, "CU32": 16,
+         "CF64": 17}
 # complex integer formats are interleaved (re, im) pairs: numpy sees them as a trailing axis of 2
 _CINT = {6: np.int8, 8: np.int16, 10: np.uint8, 12: np.uint16, 14: np.int32, 16: np.uint32}
 NP_DTYPE = {1: np.float32, 2: np.complex64, 3: np.float64, 4: np.uint64, 5: np.int8, 7: np.int16,
-            9: np.uint8, 11: np.uint16, 13: np.int32, 15: np.uint32}
+            9: np.uint8, 11: np.uint16, 13: np.int32, 15: np.uint32, 17: np.complex128}
 DTYPE_OF_NP = {np.dtype(v): k for k, v in NP_DTYPE.items()}
 RESULT_NAMES = ["SUCCESS", "ERROR", "WARNING", "FATAL", "SKIP", "YIELD", "RELOAD", "RECREATE",
                 "TIMEOUT", "INCOMPLETE"]
@@ -104,6 +105,7 @@ _sig("jst_tensor_set_attribute_f64", R, _h, C.c_char_p, C.c_double)
 _sig("jst_tensor_set_attribute_u64v", R, _h, C.c_char_p, _u64p, C.c_uint64)
 _sig("jst_tensor_set_attribute_f64v", R, _h, C.c_char_p, C.POINTER(C.c_double), C.c_uint64)
 _sig("jst_tensor_remove_attribute", R, _h, C.c_char_p)
+_sig("jst_tensor_get_attribute_f64v", R, _h, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64))
 _sig("jst_tensor_copy_from_host", R, _h, C.c_void_p, C.c_size_t)
 _sig("jst_tensor_copy_to_host", R, _h, C.c_void_p, C.c_size_t)
 _sig("jst_tensor_copy_from_host_async", R, _h, C.c_void_p, C.c_size_t)
@@ -315,6 +317,15 @@ class Tensor:
         return self
 
     # -- data movement (dense only) -------------------------------------------------------------
+    def attribute(self, key: str):
+        """Scalar attributes come back as float, vector attributes as a list; raises when absent."""
+        n = C.c_uint64(0)
+        _check(_lib.jst_tensor_get_attribute_f64v(self._h, key.encode(), None, C.byref(n)))
+        buf = (C.c_double * max(n.value, 1))()
+        _check(_lib.jst_tensor_get_attribute_f64v(self._h, key.encode(), buf, C.byref(n)))
+        vals = [float(buf[i]) for i in range(n.value)]
+        return vals[0] if n.value == 1 else vals
+
     def copy_from(self, array: np.ndarray, asynchronous: bool = False):
         code = self._desc().dtype
         if code in _CINT:  # interleaved (re, im) integer pairs: array[..., 2]

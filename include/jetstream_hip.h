@@ -56,7 +56,7 @@ enum {
     JST_DTYPE_F32 = 1, JST_DTYPE_CF32 = 2, JST_DTYPE_F64 = 3, JST_DTYPE_U64 = 4,
     JST_DTYPE_I8 = 5, JST_DTYPE_CI8 = 6, JST_DTYPE_I16 = 7, JST_DTYPE_CI16 = 8, JST_DTYPE_U8 = 9,
     JST_DTYPE_CU8 = 10, JST_DTYPE_U16 = 11, JST_DTYPE_CU16 = 12, JST_DTYPE_I32 = 13,
-    JST_DTYPE_CI32 = 14, JST_DTYPE_U32 = 15, JST_DTYPE_CU32 = 16
+    JST_DTYPE_CI32 = 14, JST_DTYPE_U32 = 15, JST_DTYPE_CU32 = 16, JST_DTYPE_CF64 = 17
 };
 
 /* Runtime flags. */
@@ -135,6 +135,10 @@ jst_result jst_tensor_set_attribute_u64v(jst_tensor t, const char* key, const ui
 jst_result jst_tensor_set_attribute_f64v(jst_tensor t, const char* key, const double* values,
                                          uint64_t count);
 jst_result jst_tensor_remove_attribute(jst_tensor t, const char* key);
+/* scalar read-back (Index attributes widen to double); values[0..count) for the vector kinds with *count
+ * set to the stored length (pass capacity in *count).  JST_ERROR when the key is absent: the metadata a
+ * module publishes ("frequency", "sampleRate", "center", ...) is part of its output contract. */
+jst_result jst_tensor_get_attribute_f64v(jst_tensor t, const char* key, double* values, uint64_t* count);
 /* dense copies, synchronous on return (tensor.cc:882-963) */
 jst_result jst_tensor_copy_from_host(jst_tensor t, const void* src, size_t bytes);
 jst_result jst_tensor_copy_to_host(jst_tensor t, void* dst, size_t bytes);

@@ -553,3 +553,29 @@ def squelch(x: np.ndarray, threshold: float):
     if finite_or_inf.size:
         peak = np.float32(max(peak, finite_or_inf.max()))
     return bool(peak > np.float32(threshold)), peak
+
+
+class AmLane:
+    """One lane of the AM demodulator (dsp/am/module_impl_native_cpu.cc:40-101): envelope = |x| (libm hypotf
+    like `squelch`), y[n] = (e[n] - e[n-1]) + alpha * y[n-1] in F32, state carried across calls."""
+
+    def __init__(self, dc_alpha: float = 0.995):
+        self.alpha = np.float32(dc_alpha)
+        self.prev_env = np.float32(0.0)
+        self.prev_out = np.float32(0.0)
+
+    def __call__(self, x: np.ndarray) -> np.ndarray:
+        z = np.ascontiguousarray(np.asarray(x).reshape(-1), dtype=np.complex64)
+        re, im = z.real.astype(np.float64), z.imag.astype(np.float64)
+        with np.errstate(invalid="ignore", over="ignore"):
+            env = np.sqrt(re * re + im * im).astype(np.float32)
+            env[np.isinf(re) | np.isinf(im)] = np.inf
+            diff = env - np.concatenate(([self.prev_env], env[:-1])).astype(np.float32)  # one F32 rounding each
+            out = np.empty(z.size, np.float32)
+            y, a = self.prev_out, self.alpha
+            for n in range(z.size):
+                y = np.float32(diff[n] + np.float32(a * y))
+                out[n] = y
+        if z.size:
+            self.prev_env, self.prev_out = env[-1], y
+        return out

@@ -203,3 +203,19 @@ def test_cast_scalers(oracle):
         assert z.dtype == np.complex64 and z.shape == x.shape
         assert np.array_equal(z.real, y) and np.array_equal(z.imag, y[::-1])
     assert s["CI8"] == 128.0 and s["CI16"] == 32768.0 and s["CU32"] == 2147483648.0
+
+
+def test_am_kats(oracle):
+    """dsp/am/module_tests.cc:52-187, 317-365: the DC blocker's step response decays below 0.1 within 1024
+    samples, a modulated carrier yields a varying output, and batches of one lane form ONE sequence."""
+    lane = oracle.AmLane(0.995)
+    y = lane(np.ones(1024, np.complex64))
+    assert y[0] == 1.0 and abs(y[-1]) < 0.1
+    assert np.array_equal(y[:4], np.float32(0.995) ** np.arange(4, dtype=np.float32).astype(np.float32)) or \
+        np.allclose(y[:4], 0.995 ** np.arange(4), rtol=1e-6)
+    t = np.arange(2048) / 240e3
+    x = ((1 + 0.5 * np.cos(2 * np.pi * 1e3 * t)) * np.exp(2j * np.pi * 10e3 * t)).astype(np.complex64)
+    whole = oracle.AmLane(0.995)(x)
+    assert whole.max() - whole.min() > 0.01
+    split = oracle.AmLane(0.995)
+    assert np.array_equal(np.concatenate([split(x[:700]), split(x[700:])]), whole)
