@@ -16,11 +16,6 @@ template <class T>
 T* ptr(const Tensor& t) {
     return static_cast<T*>(t.data());
 }
-Result hip_result(hipError_t e, const char* what) {
-    if (e == hipSuccess) return Result::SUCCESS;
-    JST_ERROR("[HIP] %s failed: %s", what, hipGetErrorString(e));
-    return Result::ERROR;
-}
 // src/memory/axis.cc:196-212 (ResolveAxis): negative axes count from the end.
 std::optional<Index> resolve_axis(I64 axis, Index rank) {
     if (rank == 0) return std::nullopt;

@@ -12,12 +12,6 @@ namespace jst::modules {
 
 namespace {
 
-Result hip_result(hipError_t e, const char* what) {
-    if (e == hipSuccess) return Result::SUCCESS;
-    JST_ERROR("[HIP] %s failed: %s", what, hipGetErrorString(e));
-    return Result::ERROR;
-}
-
 const char* kSpace = " \t\n\r\f\v";
 
 bool is_unsigned(const std::string& v) {

@@ -91,12 +91,6 @@ Result parse_shape(const std::string& s, Shape& out, const char* tag) {
     return Result::SUCCESS;
 }
 
-Result hip_result(hipError_t e, const char* what) {
-    if (e == hipSuccess) return Result::SUCCESS;
-    JST_ERROR("[HIP] %s failed: %s", what, hipGetErrorString(e));
-    return Result::ERROR;
-}
-
 }  // namespace
 
 // ---- twiddles ----------------------------------------------------------------------------------

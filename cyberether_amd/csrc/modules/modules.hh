@@ -9,6 +9,13 @@
 
 namespace jst::modules {
 
+// A failed launch becomes the module's diagnostic (JST_ERROR) and Result::ERROR.
+inline Result hip_result(hipError_t e, const char* what) {
+    if (e == hipSuccess) return Result::SUCCESS;
+    JST_ERROR("[HIP] %s failed: %s", what, hipGetErrorString(e));
+    return Result::ERROR;
+}
+
 // Device-resident pocketfft twiddle table W[k] = exp(+j 2 pi k / n), k in [0,n), cached per n.
 Result GetTwiddles(U64 n, const float2** table);
 Result GetPassTwiddles(U64 n, const float2** table);  // per-pass layout for the tiled kernels

@@ -13,12 +13,6 @@ namespace jst::modules {
 
 namespace {
 
-Result hip_result(hipError_t e, const char* what) {
-    if (e == hipSuccess) return Result::SUCCESS;
-    JST_ERROR("[HIP] %s failed: %s", what, hipGetErrorString(e));
-    return Result::ERROR;
-}
-
 std::string trim(const std::string& s) {
     size_t b = 0, e = s.size();
     while (b < e && std::isspace((unsigned char)s[b])) ++b;
