@@ -51,6 +51,8 @@ def main():
         run_c4(js, out)
     if want('C5'):
         run_c5(js, out, rng)
+    if want('AM'):
+        run_am(js, out)
 
 
 def run_c1(js, out, n, fs):
@@ -135,6 +137,33 @@ def run_c4(js, out):
                 "note": "one workgroup per station: the decode time of one station covers all of them"})
     rt.destroy()
 
+
+
+def run_am(js, out):
+    """AM broadcast side chain with C4's shape: 20 MS/s -> Filter(/100) -> AM envelope + DC blocker -> Decimator(/4)."""
+    b, s, taps, sr, bw = 10, 202400, 101, 20e6, 200e3
+    tt = np.arange(b * s) / sr
+    x = ((1.0 + 0.5 * np.cos(2 * np.pi * 1e3 * tt)) * np.exp(2j * np.pi * 10e3 * tt)).astype(np.complex64)
+    src = js.Tensor.from_numpy(x.reshape(b, s), batch=0, sample=1)
+    filt = js.Filter(src, sr, bw, [0.0], taps, 1)
+    squeeze = js.Module("squeeze_dims", {"axis": 1}, {"buffer": filt.buffer}, "squeeze_head")
+    iq = squeeze.output("buffer").set_axes(batch=0, sample=1)
+    am = js.Module("am", {"sampleRate": 200e3, "dcAlpha": 0.995}, {"signal": iq}, "am")
+    dec = js.Decimator(am.output("signal"), 4)
+    rt = js.Runtime(filt.modules + [squeeze, am] + dec.modules, graph=True, fuse=True, timing=True)
+    dt = timed(rt, 20, 3)
+    out.append({"config": "AM: 20 MS/s -> Filter(/100) -> AM (dcAlpha 0.995) -> Decimator(/4)",
+                "ms_per_cycle": dt * 1e3, "MS_per_s_in": b * s / dt / 1e6, "am_kernel_ms": rt.unit_mean_ms("am"),
+                "note": "one lane: envelope and first difference in parallel, the DC-blocker recurrence walked by one thread out of LDS"})
+    rt.destroy()
+    lanes, n = 64, 1 << 18
+    t = js.Tensor.from_numpy(np.ascontiguousarray(np.broadcast_to(x[:n], (lanes, n))), channel=0, sample=1)
+    am = js.Module("am", {"sampleRate": 200e3}, {"signal": t}, "am64")
+    rt = js.Runtime([am], graph=True)
+    dt = timed(rt, 20, 3)
+    out.append({"config": "AMb: AM on 64 lanes x 262144 samples (am module only)", "ms_per_cycle": dt * 1e3,
+                "MS_per_s_per_lane": n / dt / 1e6, "MS_per_s_total": lanes * n / dt / 1e6})
+    rt.destroy()
 
 
 def run_c5(js, out, rng):
