@@ -720,6 +720,8 @@ __global__ __launch_bounds__(kFmThreads) void fm_narrow_deemph_kernel(float* __r
 // left to right in F32 with no contraction, so the differences are computed by all threads (each
 // is ONE rounding of two exactly known envelopes) and only the two-operation recurrence is walked
 // by one thread per lane, out of LDS -- the same split as the narrow-FM de-emphasis kernel above.
+// A lone wavefront issues one VALU instruction every ~3.4 ns on this part whatever its dependencies, so the walk
+// costs its instruction count: mul + add + ~1 register move per sample = 10.8 ns (92 MS/s per lane).
 struct AmState {
     float prev_envelope, prev_output;
 };
@@ -727,12 +729,18 @@ __device__ __forceinline__ float am_envelope(float2 v) {
     if (__builtin_isinf(v.x) || __builtin_isinf(v.y)) return __builtin_inff();
     return (float)__builtin_sqrt((double)v.x * (double)v.x + (double)v.y * (double)v.y);
 }
+// Pipeline over chunks of kFmChunk samples, one workgroup barrier per step: in step s wave 0 walks the
+// recurrence of chunk s (LDS -> LDS) while waves 1..3 write chunk s-1 to HBM and stage the differences of
+// chunk s+1 (each envelope is computed once; a lane gets its left neighbour's by DPP-free shuffle).
 __global__ __launch_bounds__(kFmThreads) void am_kernel(float* __restrict__ out, const float2* __restrict__ in,
                                                         AmState* __restrict__ states, const float alpha,
                                                         const FmLayout L) {
-    __shared__ float diff_a[kFmChunk + 8], out_a[kFmChunk + 8];
+    __shared__ __attribute__((aligned(16))) float diff_a[2][kFmChunk + 16];
+    __shared__ __attribute__((aligned(16))) float out_a[2][kFmChunk + 16];
+    constexpr uint32_t kStagers = kFmThreads - 64;
     const uint32_t tid = threadIdx.x;
     const uint64_t lane = blockIdx.x, n_total = L.batches * L.samples;
+    if (n_total == 0) return;
     int64_t in_off, out_off;
     fm_lane_offsets(L, lane, in_off, out_off);
     const AmState st = states[lane];
@@ -740,38 +748,91 @@ __global__ __launch_bounds__(kFmThreads) void am_kernel(float* __restrict__ out,
         return am_envelope(
             in[in_off + (int64_t)(n / L.samples) * L.in_batch_stride + (int64_t)(n % L.samples) * L.in_sample_stride]);
     };
-    float y = st.prev_output;
-    for (uint64_t c0 = 0; c0 < n_total; c0 += kFmChunk) {
-        const uint32_t cnt = (uint32_t)((n_total - c0) < (uint64_t)kFmChunk ? (n_total - c0) : (uint64_t)kFmChunk);
-        __syncthreads();
-        for (uint32_t i = tid; i < cnt + 8; i += kFmThreads) {
-            const uint64_t n = c0 + i;
-            float d = 0.0f;
-            if (i < cnt) d = env_at(n) - (n ? env_at(n - 1) : st.prev_envelope);
-            diff_a[i] = d;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
-                float d[8];
+    const uint64_t chunks = (n_total + kFmChunk - 1) / kFmChunk;
+    auto count = [&](uint64_t c) {
+        const uint64_t left = n_total - c * kFmChunk;
+        return (uint32_t)(left < (uint64_t)kFmChunk ? left : (uint64_t)kFmChunk);
+    };
+    // differences of chunk c by `width` threads numbered `t` (whole wavefronts).  All of a thread's samples are
+    // requested before the first is used: one HBM round trip per chunk instead of one per sample.
+    auto stage = [&](uint64_t c, uint32_t t, auto width_c) {
+        constexpr uint32_t width = decltype(width_c)::value;
+        constexpr uint32_t kIter = (kFmChunk + 64 + width - 1) / width;
+        const uint32_t cnt = count(c);
+        const uint32_t limit = (cnt + 8 + 63) & ~63u;  // whole waves take the shuffle
+        float* dst = diff_a[c & 1];
+        auto at = [&](uint64_t n) {
+            return in[in_off + (int64_t)(n / L.samples) * L.in_batch_stride + (int64_t)(n % L.samples) * L.in_sample_stride];
+        };
+        float2 v[kIter], edge[kIter];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = diff_a[i0 + j];
+        for (uint32_t k = 0; k < kIter; ++k) {
+            const uint32_t i = t + k * width;
+            const uint64_t n = c * kFmChunk + i;
+            v[k] = i < cnt ? at(n) : mk(0.0f, 0.0f);
+            edge[k] = ((i & 63u) == 0u && i < cnt && n) ? at(n - 1) : mk(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kIter; ++k) {
+            const uint32_t i = t + k * width;
+            if (i >= limit) break;  // wave-uniform
+            const float e = i < cnt ? am_envelope(v[k]) : 0.0f;
+            float left = __shfl_up(e, 1);
+            if ((i & 63u) == 0u && i < cnt) left = (c * kFmChunk + i) ? am_envelope(edge[k]) : st.prev_envelope;
+            if (i < cnt + 8) dst[i] = i < cnt ? e - left : 0.0f;
+        }
+    };
+    auto flush = [&](uint64_t c, uint32_t t, uint32_t width) {
+        const uint32_t cnt = count(c);
+        const float* src = out_a[c & 1] + 8;
+        for (uint32_t i = t; i < cnt; i += width) {
+            const uint64_t n = c * kFmChunk + i;
+            out[out_off + (int64_t)(n / L.samples) * L.out_batch_stride + (int64_t)(n % L.samples) * L.out_sample_stride] =
+                src[i];
+        }
+    };
+    stage(0, tid, std::integral_constant<uint32_t, (uint32_t)kFmThreads>{});
+    __syncthreads();
+    float y = st.prev_output;
+    for (uint64_t c = 0; c < chunks; ++c) {
+        if (tid >= 64) {
+            if (c) flush(c - 1, tid - 64, kStagers);
+            if (c + 1 < chunks) stage(c + 1, tid - 64, std::integral_constant<uint32_t, kStagers>{});
+        } else if (tid == 0) {
+            const uint32_t cnt = count(c);
+            const float* src = diff_a[c & 1];
+            float* dst = out_a[c & 1];  // results start at dst[8]: the first iteration stores a dummy group in front
+            float4 nlo = *reinterpret_cast<const float4*>(&src[0]);
+            float4 nhi = *reinterpret_cast<const float4*>(&src[4]);
+            float4 plo = make_float4(0.f, 0.f, 0.f, 0.f), phi = plo;
+            for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
+                const float4 lo = nlo, hi = nhi;
+                // LDS traffic first -- the next group's loads and the PREVIOUS group's stores -- so that both
+                // round trips run under this group's 16 dependent operations instead of in front of them
+                nlo = *reinterpret_cast<const float4*>(&src[i0 + 8]);
+                nhi = *reinterpret_cast<const float4*>(&src[i0 + 12]);
+                *reinterpret_cast<float4*>(&dst[i0]) = plo;
+                *reinterpret_cast<float4*>(&dst[i0 + 4]) = phi;
+                __builtin_amdgcn_sched_barrier(0);
+                float d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     y = d[j] + alpha * y;
-                    out_a[i0 + j] = y;
+                    d[j] = y;
                 }
+                plo = make_float4(d[0], d[1], d[2], d[3]);
+                phi = make_float4(d[4], d[5], d[6], d[7]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            y = out_a[cnt - 1];  // the tail of the last group of 8 ran past cnt on zeros
+            const uint32_t last = (cnt + 7u) & ~7u;
+            *reinterpret_cast<float4*>(&dst[last]) = plo;
+            *reinterpret_cast<float4*>(&dst[last + 4]) = phi;
+            y = dst[8 + cnt - 1];  // the last group of 8 ran past cnt on zeros
         }
         __syncthreads();
-        for (uint32_t i = tid; i < cnt; i += kFmThreads) {
-            const uint64_t n = c0 + i;
-            out[out_off + (int64_t)(n / L.samples) * L.out_batch_stride + (int64_t)(n % L.samples) * L.out_sample_stride] =
-                out_a[i];
-        }
     }
-    if (tid == 0 && n_total) {
+    flush(chunks - 1, tid, kFmThreads);
+    if (tid == 0) {
         states[lane].prev_envelope = env_at(n_total - 1);
         states[lane].prev_output = y;
     }
