@@ -969,6 +969,7 @@ class Fm : public Module {
         return Result::SUCCESS;
     }
     Result computeSubmit(hipStream_t s) override {
+        if (laneCount == 0) return Result::SUCCESS;  // empty input: no axes were resolved
         dev::FmLayout L;
         std::memset(&L, 0, sizeof(L));
         L.lanes = laneCount;

@@ -393,6 +393,7 @@ class Am : public Module {
         return Result::SUCCESS;
     }
     Result computeSubmit(hipStream_t s) override {
+        if (laneCount == 0) return Result::SUCCESS;  // empty input: no axes were resolved
         dev::FmLayout L;
         std::memset(&L, 0, sizeof(L));
         L.lanes = laneCount;
