@@ -721,7 +721,7 @@ __global__ __launch_bounds__(kFmThreads) void fm_narrow_deemph_kernel(float* __r
 // is ONE rounding of two exactly known envelopes) and only the two-operation recurrence is walked
 // by one thread per lane, out of LDS -- the same split as the narrow-FM de-emphasis kernel above.
 // A lone wavefront issues one VALU instruction every ~3.4 ns on this part whatever its dependencies, so the walk
-// costs its instruction count: mul + add + ~1 register move per sample = 10.8 ns (92 MS/s per lane).
+// costs its instruction count: mul + add per sample plus one exposed LDS wait per 16 = 9.8 ns (102 MS/s per lane).
 struct AmState {
     float prev_envelope, prev_output;
 };
@@ -735,8 +735,8 @@ __device__ __forceinline__ float am_envelope(float2 v) {
 __global__ __launch_bounds__(kFmThreads) void am_kernel(float* __restrict__ out, const float2* __restrict__ in,
                                                         AmState* __restrict__ states, const float alpha,
                                                         const FmLayout L) {
-    __shared__ __attribute__((aligned(16))) float diff_a[2][kFmChunk + 16];
-    __shared__ __attribute__((aligned(16))) float out_a[2][kFmChunk + 16];
+    __shared__ __attribute__((aligned(16))) float diff_a[2][kFmChunk + 32];
+    __shared__ __attribute__((aligned(16))) float out_a[2][kFmChunk + 32];
     constexpr uint32_t kStagers = kFmThreads - 64;
     const uint32_t tid = threadIdx.x;
     const uint64_t lane = blockIdx.x, n_total = L.batches * L.samples;
@@ -757,9 +757,10 @@ __global__ __launch_bounds__(kFmThreads) void am_kernel(float* __restrict__ out,
     // requested before the first is used: one HBM round trip per chunk instead of one per sample.
     auto stage = [&](uint64_t c, uint32_t t, auto width_c) {
         constexpr uint32_t width = decltype(width_c)::value;
-        constexpr uint32_t kIter = (kFmChunk + 64 + width - 1) / width;
+        constexpr uint32_t kSlack = 24;  // the walk reads two groups ahead of the last sample
+        constexpr uint32_t kIter = (kFmChunk + kSlack + 63 + width - 1) / width;
         const uint32_t cnt = count(c);
-        const uint32_t limit = (cnt + 8 + 63) & ~63u;  // whole waves take the shuffle
+        const uint32_t limit = (cnt + kSlack + 63) & ~63u;  // whole waves take the shuffle
         float* dst = diff_a[c & 1];
         auto at = [&](uint64_t n) {
             return in[in_off + (int64_t)(n / L.samples) * L.in_batch_stride + (int64_t)(n % L.samples) * L.in_sample_stride];
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(kFmThreads) void am_kernel(float* __restrict__ out,
             const float e = i < cnt ? am_envelope(v[k]) : 0.0f;
             float left = __shfl_up(e, 1);
             if ((i & 63u) == 0u && i < cnt) left = (c * kFmChunk + i) ? am_envelope(edge[k]) : st.prev_envelope;
-            if (i < cnt + 8) dst[i] = i < cnt ? e - left : 0.0f;
+            if (i < cnt + kSlack) dst[i] = i < cnt ? e - left : 0.0f;
         }
     };
     auto flush = [&](uint64_t c, uint32_t t, uint32_t width) {
@@ -802,32 +803,38 @@ __global__ __launch_bounds__(kFmThreads) void am_kernel(float* __restrict__ out,
             const uint32_t cnt = count(c);
             const float* src = diff_a[c & 1];
             float* dst = out_a[c & 1];  // results start at dst[8]: the first iteration stores a dummy group in front
-            float4 nlo = *reinterpret_cast<const float4*>(&src[0]);
-            float4 nhi = *reinterpret_cast<const float4*>(&src[4]);
-            float4 plo = make_float4(0.f, 0.f, 0.f, 0.f), phi = plo;
-            for (uint32_t i0 = 0; i0 < cnt; i0 += 8) {
-                const float4 lo = nlo, hi = nhi;
-                // LDS traffic first -- the next group's loads and the PREVIOUS group's stores -- so that both
-                // round trips run under this group's 16 dependent operations instead of in front of them
-                nlo = *reinterpret_cast<const float4*>(&src[i0 + 8]);
-                nhi = *reinterpret_cast<const float4*>(&src[i0 + 12]);
-                *reinterpret_cast<float4*>(&dst[i0]) = plo;
-                *reinterpret_cast<float4*>(&dst[i0 + 4]) = phi;
-                __builtin_amdgcn_sched_barrier(0);
-                float d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            // Two groups of 8 per iteration in registers of their own (no rotation moves): LDS traffic first --
+            // the next group's loads and the PREVIOUS group's stores -- so that both round trips run under
+            // the 16 dependent operations of the group being walked instead of in front of them.
+            auto ld = [&](uint32_t at, float (&d)[8]) {
+                const float4 lo = *reinterpret_cast<const float4*>(&src[at]);
+                const float4 hi = *reinterpret_cast<const float4*>(&src[at + 4]);
+                d[0] = lo.x, d[1] = lo.y, d[2] = lo.z, d[3] = lo.w, d[4] = hi.x, d[5] = hi.y, d[6] = hi.z, d[7] = hi.w;
+            };
+            auto st8 = [&](uint32_t at, const float (&d)[8]) {
+                *reinterpret_cast<float4*>(&dst[at]) = make_float4(d[0], d[1], d[2], d[3]);
+                *reinterpret_cast<float4*>(&dst[at + 4]) = make_float4(d[4], d[5], d[6], d[7]);
+            };
+            auto walk = [&](const float (&d)[8], float (&r)[8]) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    y = d[j] + alpha * y;
-                    d[j] = y;
-                }
-                plo = make_float4(d[0], d[1], d[2], d[3]);
-                phi = make_float4(d[4], d[5], d[6], d[7]);
+                for (int j = 0; j < 8; ++j) r[j] = y = d[j] + alpha * y;
+            };
+            float a[8], b[8], ra[8], rb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            ld(0, a);
+            for (uint32_t i0 = 0; i0 < cnt; i0 += 16) {
+                ld(i0 + 8, b);
+                st8(i0, rb);  // samples i0-8 .. i0-1 (a dummy group the first time)
+                __builtin_amdgcn_sched_barrier(0);
+                walk(a, ra);
+                __builtin_amdgcn_sched_barrier(0);
+                ld(i0 + 16, a);
+                st8(i0 + 8, ra);
+                __builtin_amdgcn_sched_barrier(0);
+                walk(b, rb);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const uint32_t last = (cnt + 7u) & ~7u;
-            *reinterpret_cast<float4*>(&dst[last]) = plo;
-            *reinterpret_cast<float4*>(&dst[last + 4]) = phi;
-            y = dst[8 + cnt - 1];  // the last group of 8 ran past cnt on zeros
+            st8((cnt + 15u) & ~15u, rb);
+            y = dst[8 + cnt - 1];  // the last iteration ran past cnt on zeros
         }
         __syncthreads();
     }
