@@ -404,7 +404,10 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                     // The per-position operand of the prologue (window taps) is not kept live
                     // across the passes: element e is re-requested from L2 as soon as output e
                     // has retired, into the registers that output just freed.
-                    if (more) {
+                    // CONTIG: unconditional (r_opnd has zero records past the last transform) -- a load
+                    // under `if (more)` is copied out of a phi right behind the epilogue, and the wait
+                    // for that copy also waits for every store issued before it.
+                    if (CONTIG || more) {
                         constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
                         const int e = j * IP + c;  // constant after unrolling
                         const int u0 = tid + (e / IP0) * T;
@@ -534,28 +537,32 @@ __global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 2
         const uint64_t tn = t + gridDim.x;
         const bool more = tn < L.transforms;
         int64_t nin = 0, nout = 0;
-        if (more) {
-            fft_bases(L, tn, nin, nout);
-            const rsrc_t r_in = make_rsrc(pro.row(nin), (uint32_t)N * 8u);
+        if constexpr (CONTIG) {
+            // UNCONDITIONAL loads: under `if (more)` the loaded registers meet the old ones in a phi, the
+            // compiler copies them right behind the loads and the s_waitcnt for those copies exposes the
+            // whole HBM round trip in front of the passes.  Past the last transform the descriptor has
+            // zero records: the loads return 0 without touching memory.
+            fft_bases(L, more ? tn : t, nin, nout);
+            const rsrc_t r_in = make_rsrc(pro.row(nin), more ? (uint32_t)N * 8u : 0u);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if constexpr (CONTIG)
-                    raw[e] = buf_load_f2(r_in, (uint32_t)pos0[e / IP0] * 8u,
-                                         (uint32_t)(IDO0 * (e % IP0)) * 8u);
-                else
-                    raw[e] = pro.template load_raw<CONTIG>(nin, L.in_axis_stride,
-                                                           IDO0 * (e % IP0), pos0[e / IP0]);
-            }
+            for (int e = 0; e < 8; ++e)
+                raw[e] = buf_load_f2(r_in, (uint32_t)pos0[e / IP0] * 8u, (uint32_t)(IDO0 * (e % IP0)) * 8u);
+        } else if (more) {
+            fft_bases(L, tn, nin, nout);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                raw[e] = pro.template load_raw<CONTIG>(nin, L.in_axis_stride, IDO0 * (e % IP0), pos0[e / IP0]);
         }
         const rsrc_t r_out = make_rsrc(epi.row(out_base), (uint32_t)N * Epi::kElemBytes);
+        const rsrc_t r_opnd_next = make_rsrc(pro.operand_row(), more ? (uint32_t)N * 8u : 0u);
         if (flip)
             pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufB, bufA, twr, twl, tid, out_base,
                                                         L.out_axis_stride, epi, pro, opnd,
-                                                        more, r_out, r_opnd JST_TL_PASS);
+                                                        more, r_out, r_opnd_next JST_TL_PASS);
         else
             pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
                                                         L.out_axis_stride, epi, pro, opnd,
-                                                        more, r_out, r_opnd JST_TL_PASS);
+                                                        more, r_out, r_opnd_next JST_TL_PASS);
 #ifdef JST_FFT_TIMELINE
         ++tl_it;
         if (threadIdx.x == 0) jst_tl_base[blockIdx.x * 64 + 63] = wall_clock64();
