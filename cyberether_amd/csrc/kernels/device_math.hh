@@ -184,7 +184,7 @@ __device__ __forceinline__ float amplitude_f32(float v, float coeff) {
 // ---- Range ---------------------------------------------------------------------------------
 // tanhf: see libm_float.hh (select-form restatement of the host libm's FDLIBM tanhf/expm1f).
 // range/module_impl_native_cpu.cc:67-82.
-__device__ __forceinline__ float range_f32(float v, float scale, float offset) {
+__device__ __forceinline__ float range_f32_general(float v, float scale, float offset) {
     if (scale == 0.0f) return 0.5f;
     const float normalized = v * scale + offset;
 #ifdef JST_TANH_SELECT_FORM
@@ -193,7 +193,108 @@ __device__ __forceinline__ float range_f32(float v, float scale, float offset) {
     return 0.5f + 0.5f * libm_tanhf_branchy(4.0f * (normalized - 0.5f));
 #endif
 }
+__device__ __attribute__((noinline)) float range_f32_cold(float v, float scale, float offset) {
+    return range_f32_general(v, scale, offset);
+}
+// The Range module's element function: the main-path tanhf (libm_float.hh) with one bail-out to the general
+// ladder for arguments outside [2^-26, 7.5).
+__device__ __forceinline__ float range_f32(float v, float scale, float offset) {
+    if (scale == 0.0f) return 0.5f;
+    const float normalized = v * scale + offset;
+    bool rare;
+    float r = 0.5f + 0.5f * libm_tanhf_main(4.0f * (normalized - 0.5f), rare);
+    if (__builtin_expect(rare, 0)) r = range_f32_cold(v, scale, offset);
+    return r;
+}
 
+// ---- main-path form of the exact Amplitude -> Range epilogue ----------------------------------
+// The general forms above are ladders of classes (zero / subnormal / inf magnitude in the compiler's
+// sqrt expansion and in frexpf, the tanhf classes); in a fused FFT epilogue every element walks all of
+// them and each costs compare + select pairs at half rate.  The main path below is ONE straight-line
+// sequence that is bit-identical to the general form on the operands a spectrum actually produces --
+// power in [2^-100, 2^100], tanh argument in [2^-26, 7.5) -- and a single wave-uniform bail-out to the
+// general form (one out-of-line copy, exec-masked) for wavefronts holding anything else (exact zeros,
+// inf/NaN, values 1.4 display ranges outside the display range).
+
+// Correctly rounded sqrt for 2^-100 <= p <= 2^100 without the input scaling and class handling of the
+// compiler's general expansion: Markstein's coupled iteration from v_rsq_f32 (1 ulp), g -> sqrt(p),
+// h -> 1/(2 sqrt(p)), one exact residual and one fused correction.  Swept against the compiler's
+// correctly rounded expansion for EVERY float of the interval on the device (tests/test_gpu_exact_sweep.py).
+__device__ __forceinline__ float sqrt_markstein(float p) {
+    const float y = __builtin_amdgcn_rsqf(p);
+    float g = p * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    const float d = __builtin_fmaf(-g, g, p);
+    return __builtin_fmaf(d, h, g);
+}
+// shorter candidates (see tools/ubench/exact_sweep.hip): hardware sqrt + one fused correction
+__device__ __forceinline__ float sqrt_v2(float p) {
+    const float s = __builtin_amdgcn_sqrtf(p), y = __builtin_amdgcn_rsqf(p);
+    const float d = __builtin_fmaf(-s, s, p);
+    return __builtin_fmaf(d, 0.5f * y, s);
+}
+__device__ __forceinline__ float sqrt_v4(float p) {
+    const float y = __builtin_amdgcn_rsqf(p);
+    const float g = p * y, h = 0.5f * y;
+    const float d = __builtin_fmaf(-g, g, p);
+    return __builtin_fmaf(d, h, g);
+}
+// All three are correctly rounded on every float of [2^-100, 2^100] (0 mismatches of 2^31-ish arguments each,
+// MI355X, round 2; the raw v_sqrt_f32 differs on 253 545 200 of them): the shortest one ships.
+#ifndef JST_SQRT_MAIN
+#define JST_SQRT_MAIN(p) sqrt_v4(p)
+#endif
+
+constexpr uint32_t kPowerLo = 0x0d800000u, kPowerHi = 0x71800000u;  // 2^-100, 2^100
+
+// Amplitude from the power re^2 + im^2 in [2^-100, 2^100]: the magnitude is a normal float, so frexpf is
+// two bit operations and the zero test is void.  Same operations as approx_log10 / amplitude_cf32.
+__device__ __forceinline__ float amplitude_from_power_main(float p, float coeff) {
+    const uint32_t mb = f2u(JST_SQRT_MAIN(p));
+    const float f = u2f((mb & 0x007fffffu) | 0x3f000000u);
+    const float e = (float)((int32_t)(mb >> 23) - 126);
+    float y = 1.23149591368684f;
+    y *= f;
+    y += -4.11852516267426f;
+    y *= f;
+    y += 6.02197014179219f;
+    y *= f;
+    y += -3.13396450166353f;
+    y += e;
+    return 20.0f * (y * 0.3010299956639812f) + coeff;
+}
+__device__ __forceinline__ float amplitude_from_power(float p, float coeff) {  // general form
+    const float mag = __builtin_sqrtf(p);
+    return (mag == 0.0f) ? -__builtin_inff() : 20.0f * approx_log10(mag) + coeff;
+}
+__device__ __attribute__((noinline)) float amplitude_from_power_cold(float p, float coeff) {
+    return amplitude_from_power(p, coeff);
+}
+__device__ __attribute__((noinline)) float amplitude_range_from_power_cold(float p, float coeff, float scale,
+                                                                           float offset) {
+    return range_f32_general(amplitude_from_power(p, coeff), scale, offset);
+}
+__device__ __forceinline__ float amplitude_exact(f2 v, float coeff) {
+    const float p = (v.x * v.x) + (v.y * v.y);
+    float r = amplitude_from_power_main(p, coeff);
+    if (__builtin_expect((f2u(p) - kPowerLo) > (kPowerHi - kPowerLo), 0)) r = amplitude_from_power_cold(p, coeff);
+    return r;
+}
+__device__ __forceinline__ float amplitude_range_from_power(float p, float coeff, float scale, float offset) {
+    if (scale == 0.0f) return 0.5f;  // wave-uniform
+    const float normalized = amplitude_from_power_main(p, coeff) * scale + offset;
+    bool rare;
+    const float t = libm_tanhf_main(4.0f * (normalized - 0.5f), rare);
+    float r = 0.5f + 0.5f * t;
+    rare |= (f2u(p) - kPowerLo) > (kPowerHi - kPowerLo);
+    if (__builtin_expect(rare, 0)) r = amplitude_range_from_power_cold(p, coeff, scale, offset);
+    return r;
+}
+__device__ __forceinline__ float amplitude_range_exact(f2 v, float coeff, float scale, float offset) {
+    return amplitude_range_from_power((v.x * v.x) + (v.y * v.y), coeff, scale, offset);
+}
 
 // ---- "fast" provider variants ----------------------------------------------------------------
 // Registered as provider "fast" (the registry's 4th key exists to select alternative
@@ -202,9 +303,12 @@ __device__ __forceinline__ float range_f32(float v, float scale, float offset) {
 // amplitude stays within 2e-6 dB and range within 3e-7 absolute of the reference CPU path
 // (tests/test_gpu_fast_provider.py), well inside BASELINE.json's 1e-5 tolerance for float
 // spectra, for ~1/8 of the instructions.
-__device__ __forceinline__ float amplitude_cf32_fast(f2 v, float coeff) {
-    const float mag = __builtin_amdgcn_sqrtf((v.x * v.x) + (v.y * v.y));
+__device__ __forceinline__ float amplitude_from_power_fast(float p, float coeff) {
+    const float mag = __builtin_amdgcn_sqrtf(p);
     return (mag == 0.0f) ? -__builtin_inff() : 20.0f * approx_log10(mag) + coeff;
+}
+__device__ __forceinline__ float amplitude_cf32_fast(f2 v, float coeff) {
+    return amplitude_from_power_fast((v.x * v.x) + (v.y * v.y), coeff);
 }
 __device__ __forceinline__ float tanhf_fast(float a) {
     const float ax = __builtin_fabsf(a);
@@ -234,20 +338,22 @@ __device__ __forceinline__ bool near_bin_edge(float r, float h) {
     const float f = r * h, fr = f - __builtin_floorf(f);  // v_fract_f32
     return f >= 0.5f && __builtin_fabsf(fr - 0.5f) > 0.5f - h * 7.5e-7f;
 }
-// one out-of-line copy of the exact arithmetic for the rare guarded elements (inlined into each of the
-// eight unrolled epilogue slots it triples the kernel's code)
-__device__ __attribute__((noinline)) float amplitude_range_exact_cold(f2 v, float coeff, float scale,
-                                                                      float offset) {
-    return range_f32(amplitude_cf32(v, coeff), scale, offset);
+// One out-of-line copy of the exact arithmetic serves the rare guarded elements (amplitude_range_from_power_cold,
+// above).  Everything from the power p = re^2 + im^2 on is a function of ONE float, identical in both providers up
+// to p, so the guarantee "guarded fast value and exact value fall into the same Spectrogram bin" is checked on
+// every float p, per height, by the exhaustive device sweep (exact_sweep.hip, tests/test_gpu_exact_sweep.py).
+__device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p, float coeff, float scale,
+                                                                         float offset, const BinGuard& g) {
+    float r = range_f32_fast(amplitude_from_power_fast(p, coeff), scale, offset);
+    if (g.h0 > 0.0f) {  // wave-uniform
+        if (near_bin_edge(r, g.h0) || (g.h1 > 0.0f && near_bin_edge(r, g.h1)))
+            r = amplitude_range_from_power_cold(p, coeff, scale, offset);
+    }
+    return r;
 }
 __device__ __forceinline__ float amplitude_range_fast_guarded(f2 v, float coeff, float scale, float offset,
                                                               const BinGuard& g) {
-    float r = range_f32_fast(amplitude_cf32_fast(v, coeff), scale, offset);
-    if (g.h0 > 0.0f) {  // wave-uniform
-        if (near_bin_edge(r, g.h0) || (g.h1 > 0.0f && near_bin_edge(r, g.h1)))
-            r = amplitude_range_exact_cold(v, coeff, scale, offset);
-    }
-    return r;
+    return amplitude_range_fast_guarded_from_power((v.x * v.x) + (v.y * v.y), coeff, scale, offset, g);
 }
 
 }  // namespace jst::dev

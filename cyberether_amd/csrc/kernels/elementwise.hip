@@ -88,7 +88,7 @@ struct MulF32 {
 };
 struct AmpCF32 {
     float coeff;
-    __device__ float operator()(uint64_t, float2 v) const { return amplitude_cf32(v, coeff); }
+    __device__ float operator()(uint64_t, float2 v) const { return amplitude_exact(v, coeff); }
 };
 struct AmpCF32Fast {
     float coeff;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void amplitude_range_probe_kernel(float* __res
                                                                     dev::BinGuard guard) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
         const float2 v = in[i];
-        out_exact[i] = range_f32(amplitude_cf32(v, coeff), scale, offset);
+        out_exact[i] = amplitude_range_exact(v, coeff, scale, offset);  // the fused epilogue's arithmetic
         out_fast[i] = amplitude_range_fast_guarded(v, coeff, scale, offset, guard);
     }
 }

@@ -30,6 +30,11 @@ __device__ __forceinline__ void fft_bases(const FftLayout& L, uint64_t t, int64_
                                           int64_t& out_base) {
     in_base = (int64_t)L.in_offset;
     out_base = (int64_t)L.out_offset;
+    if (L.outer_rank == 1) {  // one batch axis (every dense [B, N] tensor): no 64-bit divisions
+        in_base += (int64_t)t * L.in_outer_stride[0];
+        out_base += (int64_t)t * L.out_outer_stride[0];
+        return;
+    }
     for (int a = L.outer_rank - 1; a >= 0; --a) {
         const uint64_t c = t % L.outer_shape[a];
         t /= L.outer_shape[a];
@@ -183,12 +188,12 @@ struct StoreAmplitudeT {  // Amplitude module fused (amplitude/module_impl_nativ
     static constexpr uint32_t kElemBytes = 4;
     __device__ __forceinline__ const void* row(int64_t base) const { return out + base; }
     __device__ __forceinline__ void store_buf(rsrc_t r, uint32_t voff, uint32_t soff, float2 v) const {
-        buf_store_f1(r, voff, soff, FAST ? amplitude_cf32_fast(v, coeff) : amplitude_cf32(v, coeff));
+        buf_store_f1(r, voff, soff, FAST ? amplitude_cf32_fast(v, coeff) : amplitude_exact(v, coeff));
     }
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
                                           float2 v) const {
-        const float r = FAST ? amplitude_cf32_fast(v, coeff) : amplitude_cf32(v, coeff);
+        const float r = FAST ? amplitude_cf32_fast(v, coeff) : amplitude_exact(v, coeff);
         if constexpr (CONTIG) (out + base)[(unsigned)pos] = r;
         else out[base + (int64_t)pos * axis_stride] = r;
     }
@@ -202,7 +207,11 @@ struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_na
     __device__ __forceinline__ const void* row(int64_t base) const { return out + base; }
     __device__ __forceinline__ float value(float2 v) const {
         if constexpr (FAST) return amplitude_range_fast_guarded(v, coeff, scale, offset, guard);
-        else return range_f32(amplitude_cf32(v, coeff), scale, offset);
+#ifdef JST_EPI_GENERAL  // A/B switch: the class-ladder form of round 1
+        else return range_f32_general(amplitude_cf32(v, coeff), scale, offset);
+#else
+        else return amplitude_range_exact(v, coeff, scale, offset);
+#endif
     }
     __device__ __forceinline__ void store_buf(rsrc_t r, uint32_t voff, uint32_t soff, float2 v) const {
         buf_store_f1(r, voff, soff, value(v));
@@ -265,12 +274,20 @@ __device__ __forceinline__ void run_passes(float2* lds, const float2* __restrict
         const unsigned i = (unsigned)(u & (IDO - 1));
         butterfly<IP, FWD>(x[j]);
         if constexpr (IDO > 1) {
+#ifdef JST_RP_TW_BRANCH  // A/B switch: exec-masked region instead of selects
+            if (i != 0u) {
+                __asm__ volatile("");
+#pragma unroll
+                for (int c = 1; c < IP; ++c) x[j][c] = special_mul<FWD>(x[j][c], W[(unsigned)(c * L1) * i]);
+            }
+#else
 #pragma unroll
             for (int c = 1; c < IP; ++c) {
                 const float2 w = W[(unsigned)(c * L1) * i];
                 const float2 y = special_mul<FWD>(x[j][c], w);
                 x[j][c] = (i != 0u) ? y : x[j][c];
             }
+#endif
         }
         if constexpr (LAST) {
             if (active) {
@@ -350,6 +367,80 @@ constexpr TwPlan make_twplan(int n) {
     return t;
 }
 
+// The output twiddles of one butterfly, IN PLACE under an exec mask that leaves the lanes with i == 0
+// untouched: pocketfft multiplies by WA(c-1,i) only when i > 0 (pocketfft.hh:1141-1225; signed zeros and
+// non-finite values of the i == 0 butterflies survive as they are).  Written as one asm statement per group
+// of outputs because the compiler's own handling of a divergent `if` around the multiplies merges old and new
+// values through a second register set (+16 VGPRs at the join, which spills at the 128 cap), and its
+// if-converted form is fourteen v_cndmask (half rate, plus SGPR hazard nops) per butterfly.  Same operations
+// and order as special_mul<FWD>: four rounded products, one sum, one difference.
+#define JST_TW1(YX, YY, WX, WY)         \
+    "v_mul_f32 %[t0], " YX ", " WX "\n" \
+    "v_mul_f32 %[t1], " YY ", " WY "\n" \
+    "v_mul_f32 %[t2], " YY ", " WX "\n" \
+    "v_mul_f32 %[t3], " YX ", " WY "\n"
+template <bool FWD>
+__device__ __forceinline__ void twiddle_inplace3(unsigned i, float2& y0, float2& y1, float2& y2,
+                                                 float2 w0, float2 w1, float2 w2) {
+    float t0, t1, t2, t3;
+    unsigned long long sv;
+    if constexpr (FWD) {
+        __asm__ volatile(
+            "v_cmp_ne_u32_e32 vcc, 0, %[i]\n"
+            "s_and_saveexec_b64 %[sv], vcc\n"
+            JST_TW1("%[y0x]", "%[y0y]", "%[w0x]", "%[w0y]") "v_add_f32 %[y0x], %[t0], %[t1]\n v_sub_f32 %[y0y], %[t2], %[t3]\n"
+            JST_TW1("%[y1x]", "%[y1y]", "%[w1x]", "%[w1y]") "v_add_f32 %[y1x], %[t0], %[t1]\n v_sub_f32 %[y1y], %[t2], %[t3]\n"
+            JST_TW1("%[y2x]", "%[y2y]", "%[w2x]", "%[w2y]") "v_add_f32 %[y2x], %[t0], %[t1]\n v_sub_f32 %[y2y], %[t2], %[t3]\n"
+            "s_or_b64 exec, exec, %[sv]\n"
+            : [y0x] "+v"(y0.x), [y0y] "+v"(y0.y), [y1x] "+v"(y1.x), [y1y] "+v"(y1.y), [y2x] "+v"(y2.x), [y2y] "+v"(y2.y), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(sv)
+            : [i] "v"(i), [w0x] "v"(w0.x), [w0y] "v"(w0.y), [w1x] "v"(w1.x), [w1y] "v"(w1.y), [w2x] "v"(w2.x), [w2y] "v"(w2.y)
+            : "vcc");
+    } else {
+        __asm__ volatile(
+            "v_cmp_ne_u32_e32 vcc, 0, %[i]\n"
+            "s_and_saveexec_b64 %[sv], vcc\n"
+            JST_TW1("%[y0x]", "%[y0y]", "%[w0x]", "%[w0y]") "v_sub_f32 %[y0x], %[t0], %[t1]\n v_add_f32 %[y0y], %[t3], %[t2]\n"
+            JST_TW1("%[y1x]", "%[y1y]", "%[w1x]", "%[w1y]") "v_sub_f32 %[y1x], %[t0], %[t1]\n v_add_f32 %[y1y], %[t3], %[t2]\n"
+            JST_TW1("%[y2x]", "%[y2y]", "%[w2x]", "%[w2y]") "v_sub_f32 %[y2x], %[t0], %[t1]\n v_add_f32 %[y2y], %[t3], %[t2]\n"
+            "s_or_b64 exec, exec, %[sv]\n"
+            : [y0x] "+v"(y0.x), [y0y] "+v"(y0.y), [y1x] "+v"(y1.x), [y1y] "+v"(y1.y), [y2x] "+v"(y2.x), [y2y] "+v"(y2.y), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(sv)
+            : [i] "v"(i), [w0x] "v"(w0.x), [w0y] "v"(w0.y), [w1x] "v"(w1.x), [w1y] "v"(w1.y), [w2x] "v"(w2.x), [w2y] "v"(w2.y)
+            : "vcc");
+    }
+}
+template <bool FWD>
+__device__ __forceinline__ void twiddle_inplace4(unsigned i, float2& y0, float2& y1, float2& y2, float2& y3,
+                                                 float2 w0, float2 w1, float2 w2, float2 w3) {
+    float t0, t1, t2, t3;
+    unsigned long long sv;
+    if constexpr (FWD) {
+        __asm__ volatile(
+            "v_cmp_ne_u32_e32 vcc, 0, %[i]\n"
+            "s_and_saveexec_b64 %[sv], vcc\n"
+            JST_TW1("%[y0x]", "%[y0y]", "%[w0x]", "%[w0y]") "v_add_f32 %[y0x], %[t0], %[t1]\n v_sub_f32 %[y0y], %[t2], %[t3]\n"
+            JST_TW1("%[y1x]", "%[y1y]", "%[w1x]", "%[w1y]") "v_add_f32 %[y1x], %[t0], %[t1]\n v_sub_f32 %[y1y], %[t2], %[t3]\n"
+            JST_TW1("%[y2x]", "%[y2y]", "%[w2x]", "%[w2y]") "v_add_f32 %[y2x], %[t0], %[t1]\n v_sub_f32 %[y2y], %[t2], %[t3]\n"
+            JST_TW1("%[y3x]", "%[y3y]", "%[w3x]", "%[w3y]") "v_add_f32 %[y3x], %[t0], %[t1]\n v_sub_f32 %[y3y], %[t2], %[t3]\n"
+            "s_or_b64 exec, exec, %[sv]\n"
+            : [y0x] "+v"(y0.x), [y0y] "+v"(y0.y), [y1x] "+v"(y1.x), [y1y] "+v"(y1.y), [y2x] "+v"(y2.x), [y2y] "+v"(y2.y), [y3x] "+v"(y3.x), [y3y] "+v"(y3.y), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(sv)
+            : [i] "v"(i), [w0x] "v"(w0.x), [w0y] "v"(w0.y), [w1x] "v"(w1.x), [w1y] "v"(w1.y), [w2x] "v"(w2.x), [w2y] "v"(w2.y), [w3x] "v"(w3.x), [w3y] "v"(w3.y)
+            : "vcc");
+    } else {
+        __asm__ volatile(
+            "v_cmp_ne_u32_e32 vcc, 0, %[i]\n"
+            "s_and_saveexec_b64 %[sv], vcc\n"
+            JST_TW1("%[y0x]", "%[y0y]", "%[w0x]", "%[w0y]") "v_sub_f32 %[y0x], %[t0], %[t1]\n v_add_f32 %[y0y], %[t3], %[t2]\n"
+            JST_TW1("%[y1x]", "%[y1y]", "%[w1x]", "%[w1y]") "v_sub_f32 %[y1x], %[t0], %[t1]\n v_add_f32 %[y1y], %[t3], %[t2]\n"
+            JST_TW1("%[y2x]", "%[y2y]", "%[w2x]", "%[w2y]") "v_sub_f32 %[y2x], %[t0], %[t1]\n v_add_f32 %[y2y], %[t3], %[t2]\n"
+            JST_TW1("%[y3x]", "%[y3y]", "%[w3x]", "%[w3y]") "v_sub_f32 %[y3x], %[t0], %[t1]\n v_add_f32 %[y3y], %[t3], %[t2]\n"
+            "s_or_b64 exec, exec, %[sv]\n"
+            : [y0x] "+v"(y0.x), [y0y] "+v"(y0.y), [y1x] "+v"(y1.x), [y1y] "+v"(y1.y), [y2x] "+v"(y2.x), [y2y] "+v"(y2.y), [y3x] "+v"(y3.x), [y3y] "+v"(y3.y), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(sv)
+            : [i] "v"(i), [w0x] "v"(w0.x), [w0y] "v"(w0.y), [w1x] "v"(w1.x), [w1y] "v"(w1.y), [w2x] "v"(w2.x), [w2y] "v"(w2.y), [w3x] "v"(w3.x), [w3y] "v"(w3.y)
+            : "vcc");
+    }
+}
+#undef JST_TW1
+
 template <int N, int T, bool FWD, bool CONTIG, int P, class Pro, class Epi>
 __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2* buf1,
                                             const float2 (&twr)[make_twplan(N).regs + 1],
@@ -368,8 +459,28 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
     // the epilogue is a long barrier-free VALU stream.  With both co-resident workgroups at equal
     // priority the epilogue of one delays the passes of the other; passes at priority 3 and the
     // epilogue at 0 gave 30.8 -> 28.9 us (exact) and 21.0 -> 20.1 us (fast) per 1024 x 4096 launch.
-    if constexpr (P == 0) __builtin_amdgcn_s_setprio(3);
-    if constexpr (LAST) __builtin_amdgcn_s_setprio(0);
+#ifndef JST_NO_SETPRIO  // A/B switch
+#ifndef JST_PRIO_PA
+#define JST_PRIO_PA 3
+#define JST_PRIO_PB 3
+#define JST_PRIO_EA 0
+#define JST_PRIO_EB 1
+#endif
+    {
+        // The second workgroup of a CU (dispatched ~1.5-2.5 us after the first: blockIdx >= grid/2 with two resident
+        // workgroups per CU) holds the YOUNGER wavefronts, which lose every VALU arbitration tie against the older
+        // workgroup's: left alone it finishes ~5 us after its neighbour and runs that stretch at half occupancy.
+        const bool young = blockIdx.x >= (gridDim.x >> 1);
+        if constexpr (P == 0) {
+            if (young) __builtin_amdgcn_s_setprio(JST_PRIO_PB);
+            else __builtin_amdgcn_s_setprio(JST_PRIO_PA);
+        }
+        if constexpr (LAST) {
+            if (young) __builtin_amdgcn_s_setprio(JST_PRIO_EB);
+            else __builtin_amdgcn_s_setprio(JST_PRIO_EA);
+        }
+    }
+#endif
     // x[] holds CC(i,b,k) for butterfly j at x[j*IP + b]
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -380,6 +491,10 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
         for (int b = 0; b < IP; ++b) y[b] = x[j * IP + b];
         butterfly<IP, FWD>(y);
         if constexpr (IDO > 1) {
+            // pocketfft multiplies by WA(c-1,i) only when i > 0 (signed zeros and non-finite values survive
+            // the i == 0 butterflies untouched).  One exec-masked region around the seven multiplies instead
+            // of fourteen compare/select pairs: the lanes with i == 0 sit out, everyone else pays nothing.
+#ifdef JST_TW_SELECT  // A/B switch (tools/ubench/fused_bench.hip): the select form
 #pragma unroll
             for (int c = 1; c < IP; ++c) {
                 float2 w;
@@ -388,6 +503,24 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                 const float2 z = special_mul<FWD>(y[c], w);
                 y[c] = (i != 0u) ? z : y[c];
             }
+#else
+            float2 w[IP];
+#pragma unroll
+            for (int c = 1; c < IP; ++c) {
+                if constexpr (tp.reg_off[P] >= 0) w[c] = twr[tp.reg_off[P] + j * (IP - 1) + (c - 1)];
+                else w[c] = twl[tp.lds_off[P] + i * (IP - 1) + (c - 1)];
+            }
+            if constexpr (IP == 8) {
+                twiddle_inplace3<FWD>(i, y[1], y[2], y[3], w[1], w[2], w[3]);  // y[0] takes no twiddle
+                twiddle_inplace4<FWD>(i, y[4], y[5], y[6], y[7], w[4], w[5], w[6], w[7]);
+            } else {
+#pragma unroll
+                for (int c = 1; c < IP; ++c) {
+                    const float2 z = special_mul<FWD>(y[c], w[c]);
+                    y[c] = (i != 0u) ? z : y[c];
+                }
+            }
+#endif
         }
         if constexpr (LAST) {
 #pragma unroll
@@ -399,7 +532,9 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                     epi.template store<CONTIG>(out_base, out_as, u + c * BUT, y[c]);
                 // keep at most two epilogues in flight: interleaving all eight costs ~40 VGPRs
                 // of temporaries and pushes the prefetch registers into scratch
+#ifndef JST_NO_EPI_SCHED_BARRIER  // A/B switch
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 if constexpr (Pro::kHasOperand) {
                     // The per-position operand of the prologue (window taps) is not kept live
                     // across the passes: element e is re-requested from L2 as soon as output e
@@ -465,8 +600,14 @@ __global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 2
     float2* twl = bufB + lds_elems(N);
     const int tid = threadIdx.x;
 
-    // ---- per-workgroup constants ------------------------------------------------------------
+    // ---- per-workgroup constants and the first transform's loads ---------------------------------
+    // Issue order: twiddle loads (L2), then the first transform's operand and input loads (HBM), then the LDS
+    // copy of the small twiddle tables -- the s_waitcnt in front of those LDS writes covers only the (older)
+    // twiddle loads, so the HBM round trip of the first transform overlaps the table set-up.  The table is first
+    // read after the first exchange barrier (unless pass 0 itself reads it), so it needs no barrier of its own.
     float2 twr[tp.regs + 1];
+    constexpr int TWL_PER_THREAD = (tp.lds_entries + T - 1) / T;
+    float2 twv[TWL_PER_THREAD + 1];
 #pragma unroll
     for (int p = 0; p < plan.nf; ++p) {
         if (plan.ido[p] <= 1) continue;
@@ -479,15 +620,22 @@ __global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 2
                     twr[tp.reg_off[p] + j * (plan.ip[p] - 1) + (c - 1)] =
                         W[(unsigned)(c * plan.l1[p]) * i];
             }
-        } else {
-            const int entries = plan.ido[p] * (plan.ip[p] - 1);
-            for (int e = tid; e < entries; e += T) {
-                const unsigned i = (unsigned)(e / (plan.ip[p] - 1)), c = (unsigned)(e % (plan.ip[p] - 1)) + 1u;
-                twl[tp.lds_off[p] + e] = W[c * (unsigned)plan.l1[p] * i];
-            }
         }
     }
-    if constexpr (tp.lds_entries > 0) lds_barrier();
+#pragma unroll
+    for (int q = 0; q < TWL_PER_THREAD; ++q) {
+        const int g = tid + q * T;  // entry of the concatenated LDS table
+        unsigned widx = 0;
+#pragma unroll
+        for (int p = 0; p < plan.nf; ++p) {
+            if (tp.lds_off[p] < 0) continue;
+            const int entries = plan.ido[p] * (plan.ip[p] - 1);
+            const int e = g - tp.lds_off[p];
+            if (e >= 0 && e < entries)
+                widx = ((unsigned)(e % (plan.ip[p] - 1)) + 1u) * (unsigned)plan.l1[p] * (unsigned)(e / (plan.ip[p] - 1));
+        }
+        twv[q] = W[widx];
+    }
 
     // pass-0 element positions of this thread: pos0[j] + IDO0*b
     constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0], NB0 = 8 / IP0;
@@ -521,6 +669,10 @@ __global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 2
             }
         }
     }
+#pragma unroll
+    for (int q = 0; q < TWL_PER_THREAD; ++q)
+        if (tid + q * T < tp.lds_entries) twl[tid + q * T] = twv[q];
+    if constexpr (tp.lds_entries > 0 && tp.lds_off[0] >= 0) lds_barrier();  // pass 0 reads the table
 
     bool flip = false;
 #ifdef JST_FFT_TIMELINE
@@ -555,6 +707,11 @@ __global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 2
         }
         const rsrc_t r_out = make_rsrc(epi.row(out_base), (uint32_t)N * Epi::kElemBytes);
         const rsrc_t r_opnd_next = make_rsrc(pro.operand_row(), more ? (uint32_t)N * 8u : 0u);
+#ifdef JST_FB_SKIP_PASSES  // decomposition experiment (tools/ubench/fused_bench.hip): last pass + epilogue only
+        pipe_passes<N, T, FWD, CONTIG, plan.nf - 1, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
+                                                              L.out_axis_stride, epi, pro, opnd,
+                                                              more, r_out, r_opnd_next JST_TL_PASS);
+#else
         if (flip)
             pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufB, bufA, twr, twl, tid, out_base,
                                                         L.out_axis_stride, epi, pro, opnd,
@@ -563,6 +720,7 @@ __global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 2
             pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
                                                         L.out_axis_stride, epi, pro, opnd,
                                                         more, r_out, r_opnd_next JST_TL_PASS);
+#endif
 #ifdef JST_FFT_TIMELINE
         ++tl_it;
         if (threadIdx.x == 0) jst_tl_base[blockIdx.x * 64 + 63] = wall_clock64();
@@ -625,6 +783,28 @@ __global__ __launch_bounds__(fft_block_threads(N), 4) void fft_lds_kernel(
             lds_barrier();  // LDS reuse by the next transform of this slot
         }
     }
+}
+
+// =============================================================================================
+// One transform per workgroup, EIGHT points per thread (T = N/8: 4096-pt = 512 threads), no
+// persistence and no register prefetch: <= 64 VGPRs -> 8 wavefronts per SIMD, one LDS buffer ->
+// four workgroups (transforms) resident per CU.  A single wavefront issues a VALU instruction
+// only every ~3.4 ns, so the exact epilogue (a ~1000-instruction dependent stream per wavefront)
+// is bound by per-wavefront issue latency unless >= 4 wavefronts per SIMD are in VALU phases at
+// the same time; with four independent workgroups per CU in different phases (waiting for HBM,
+// exchanging through LDS, in the epilogue) the SIMDs stay saturated and the hardware dispatcher
+// does the load/compute/store pipelining that the persistent kernel does by hand.
+template <int N, bool FWD, bool CONTIG, class Pro, class Epi>
+__global__ __launch_bounds__(N / 8, (N / 8) / 64) void fft_wg_kernel(
+    const FftLayout L, const float2* __restrict__ W, const Pro pro, const Epi epi) {
+    constexpr int T = N / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* lds = reinterpret_cast<float2*>(smem_raw);
+    const uint64_t t = blockIdx.x;
+    int64_t in_base = 0, out_base = 0;
+    fft_bases(L, t, in_base, out_base);
+    run_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(lds, W, (int)threadIdx.x, true, in_base,
+                                               L.in_axis_stride, out_base, L.out_axis_stride, pro, epi);
 }
 
 }  // namespace jst::dev

@@ -192,6 +192,11 @@ hipError_t launch_peak_abs(float* peak, const void* in, uint64_t count, bool com
 // ones_tensor: count elements of 1 (elem_bytes 4 = F32, 8 with pair = CF32 (1,0), 8 = F64, 16 = CF64 (1,0))
 hipError_t launch_fill_ones(void* out, uint64_t count, int elem_bytes, bool pair, hipStream_t stream);
 hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipStream_t stream);
+// Exhaustive sweeps over all 2^32 float bit patterns (exact_sweep.hip): which = 0 sqrt of the main path, 1 tanhf
+// main path, 2 amplitude->range from the power (main + bail-out) vs the general form, 3 amplitude alone, 4 fast
+// provider with the bin guard vs exact Spectrogram bins at `height`, 5 the same without the guard.  Synchronous.
+hipError_t launch_exact_sweep(int which, float coeff, float scale, float offset, float height,
+                              uint64_t* mismatches, uint64_t* visited, uint32_t* first_bad);
 
 // ---- Spectrogram (spectrogram.hip) -------------------------------------------------------------
 // bins: F32 [height][width] state, updated in place:

@@ -114,6 +114,38 @@ JST_FN float div_rn_midrange(float a, float b) {
 #else
 JST_FN float div_rn_midrange(float a, float b) { return a / b; }
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// Candidate shorter divides (see the hooks below): v1 drops the last residual correction, v2 the Newton
+// step on the reciprocal, v3 both.
+JST_FN float div_v1(float a, float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e0 = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e0, r, r);
+    float q = a * r;
+    const float e1 = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e1, r, q);
+}
+JST_FN float div_v2(float a, float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    float q = a * r;
+    const float e1 = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e1, r, q);
+    const float e2 = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e2, r, q);
+}
+JST_FN float div_v3(float a, float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    const float e1 = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e1, r, q);
+}
+JST_FN float div_v4(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }  // NOT correctly rounded: sweep sensitivity check
+#else
+JST_FN float div_v4(float a, float b) { return a / b; }
+JST_FN float div_v1(float a, float b) { return a / b; }
+JST_FN float div_v2(float a, float b) { return a / b; }
+JST_FN float div_v3(float a, float b) { return a / b; }
+#endif
 // copysign(|magnitude|, sign_of): one v_bfi_b32 instead of a compare + select pair
 JST_FN float with_sign_of(float magnitude, float sign_of) {
     return u2f((f2u(magnitude) & 0x7fffffffu) | (f2u(sign_of) & 0x80000000u));
@@ -187,5 +219,82 @@ JST_FN float libm_tanhf_branchy(float x) {
     if (ix > 0x7f800000u) r = x + x;           // NaN
     return r;
 }
+
+// Division hooks of the main-path form.  tanhf is a function of ONE float, so is every operand pair its
+// two divisions ever see: a cheaper sequence than the fully general correctly rounded divide is admissible
+// as soon as an exhaustive device sweep (tools/ubench/exact_sweep.hip, tests/test_gpu_exact_sweep.py) shows
+// it returns the correctly rounded quotient on all of them.
+// Result of that sweep on MI355X (all 2^32 arguments, 0 mismatches, round 2): the shortest candidate, div_v3
+// = v_rcp_f32, one product, one exact residual, one fused correction, is correctly rounded on both operand
+// families; the uncorrected product div_v4 is not (93 720 wrong tanhf values), which is how the sweep shows
+// that it can tell.
+#ifndef JST_DIV_EXPM1
+#define JST_DIV_EXPM1(a, b) div_v3(a, b)
+#endif
+#ifndef JST_DIV_TANH
+#define JST_DIV_TANH(a, b) div_v3(a, b)
+#endif
+
+// ---- main-path form ---------------------------------------------------------------------------
+// One straight-line evaluation, free of compare/select pairs, for 2^-26 <= |x| < 7.5 -- every
+// argument the Range module produces for a value inside (or within 1.4 spans of) its display range.
+// On gfx950 a v_cmp -> v_cndmask pair costs two half-rate instructions plus the SGPR-hazard nops
+// between them, and the published ladder of classes turns into a dozen exec-mask regions per
+// element, so the classes are merged arithmetically instead:
+//   * the expm1f argument a = +-2|x| gets its sign by a bit operation;
+//   * ONE argument reduction serves all of them: glibc's |a| <= 0.5 ln2 (k = 0, no reduction) and
+//     0.5 ln2 < |a| < 1.5 ln2 (k = +-1 by the sign) shortcuts compute exactly what the general
+//     formula k = (int)(invln2*a +- 0.5), hi = a - k*ln2_hi, lo = k*ln2_lo computes whenever the
+//     general k agrees (k*ln2_hi, k*ln2_lo are exact for |k| <= 1; k = 0 gives hi = a, lo = c = 0);
+//     it does agree on every float of both intervals (tests/test_libm_float.py sweeps all of them);
+//   * the reconstructions for k <= -2 and 2 <= k < 23 are one formula: 0x1000000 >> (k & 31) is 0
+//     for k in {-7..-1}, i.e. t = 1 - 2^-k degenerates to the `one` of the k <= -2 branch, and the
+//     trailing `- one` of that branch becomes `- (|x| >= 1 ? 0 : 1)` (y - 0 == y bit for bit);
+//   * k == 0 and k == -1 (|x| < 0.52, the middle quarter of the display range) keep their own
+//     three-operation reconstructions, in one exec-masked block that wavefronts without such a
+//     lane skip;
+//   * z = (|x| >= 1 ? 1 : 0) - (|x| >= 1 ? 2 : t) / (t + 2): `0 - q` is `-q` bit for bit (q != 0).
+// Everything else (|x| < 2^-26 incl. 0, |x| >= 7.5 incl. inf, NaN) is reported through `rare` and
+// left to libm_tanhf_branchy.  Same operations in the same order as s_tanhf.c / s_expm1f.c on the
+// taken path, so the bits are glibc's.
+JST_FN float libm_tanhf_main(float x, bool& rare) {
+    constexpr float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f,
+                    invln2 = 1.4426950216e+00f, Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f,
+                    Q3 = -7.9365076090e-05f, Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+    const uint32_t jx = f2u(x);
+    const uint32_t ix = jx & 0x7fffffffu;
+    rare = (ix - 0x32800000u) >= (0x40f00000u - 0x32800000u);
+    const uint32_t mA = (uint32_t)((int32_t)(0x3f7fffffu - ix) >> 31);  // ~0 when |x| >= 1
+    const float a = u2f((ix + 0x00800000u) | (~mA & 0x80000000u));       // +-2|x|
+    const int32_t k = (int32_t)(invln2 * a + with_sign_of(0.5f, a));
+    const float t = (float)k;
+    const float hi = a - t * ln2_hi, lo = t * ln2_lo;
+    const float xr = hi - lo;
+    const float c = (hi - xr) - lo;
+    const float hfx = 0.5f * xr;
+    const float hxs = xr * hfx;
+    const float r1 = 1.0f + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+    const float t3 = 3.0f - r1 * hfx;
+    const float e = hxs * JST_DIV_EXPM1(r1 - t3, 6.0f - xr * t3);
+    float e2 = (xr * (e - c) - c);
+    e2 -= hxs;
+    const float tl = u2f(0x3f800000u - (0x1000000u >> ((uint32_t)k & 31u)));  // 1 - 2^-k (1 for k < 0)
+    const float y = u2f(f2u(tl - (e2 - xr)) + ((uint32_t)k << 23));
+    float em1 = y - u2f(~mA & 0x3f800000u);
+    if ((uint32_t)(k + 1) < 2u) {  // k == 0 or k == -1
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(JST_TANH_KBLOCK_SELECT)
+        __asm__ volatile("");  // keep it a branch (a wavefront without such a lane skips it); if-converted it is
+                               // six operations and two selects for everyone
+#endif
+        const float r0 = xr - (xr * e - hxs);
+        const float rm = 0.5f * (xr - e2) - 0.5f;
+        em1 = (k == 0) ? r0 : rm;
+    }
+    const float num = u2f((mA & 0x40000000u) | (~mA & f2u(em1)));
+    const float q = JST_DIV_TANH(num, em1 + 2.0f);
+    const float z = u2f(mA & 0x3f800000u) - q;
+    return u2f(f2u(z) ^ (jx & 0x80000000u));
+}
+
 
 }  // namespace jst::dev

@@ -134,6 +134,8 @@ _sig("jst_runtime_event_overhead_ms", C.c_double, _h)
 _sig("jst_runtime_reset_timing", R, _h)
 _sig("jst_fft_twiddles", R, C.c_uint64, C.POINTER(C.c_float))
 _sig("jst_probe_tanhf", R, C.c_void_p, C.c_void_p, C.c_uint64)
+_sig("jst_probe_exact_sweep", R, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint64),
+     C.POINTER(C.c_uint64), C.POINTER(C.c_uint32))
 _sig("jst_probe_amplitude_range", R, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_float,
      C.c_float, C.c_float, C.c_float)
 

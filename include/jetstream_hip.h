@@ -204,6 +204,16 @@ jst_result jst_probe_amplitude_range(const float* in_device, float* out_exact_de
                                      uint64_t count, float amplitude_coeff, float range_scale,
                                      float range_offset, float guard_h0, float guard_h1);
 
+/* Exhaustive device sweep over all 2^32 float bit patterns of the one-float functions behind the exact
+ * Amplitude -> Range epilogue (everything from the power re^2+im^2 on): which = 0 the main path's sqrt vs the
+ * correctly rounded one, 1 its tanhf vs the class-ladder restatement of glibc's, 2 amplitude->range (main path
+ * + bail-out) vs the general form, 3 amplitude alone, 4 provider "fast" WITH the Spectrogram bin guard: bin at
+ * `height` equal to the exact provider's on every power, 5 the same WITHOUT the guard (bins move: shows the
+ * sweep can tell).  Returns the number of mismatching arguments, how many the main path answered itself, and
+ * the first mismatching bit pattern.  Synchronous; ~0.1 s per sweep on MI355X. */
+jst_result jst_probe_exact_sweep(int which, float amplitude_coeff, float range_scale, float range_offset,
+                                 float height, uint64_t* mismatches, uint64_t* visited, uint32_t* first_bad);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,8 @@
 
 #include "../../cyberether_amd/csrc/kernels/libm_float.hh"
 
-// variant 0: select form (libm_tanhf); variant 1: branch-structured form (libm_tanhf_branchy)
+// variant 0: select form (libm_tanhf); variant 1: branch-structured form (libm_tanhf_branchy);
+// variant 2: main-path form (libm_tanhf_main) with the branch-structured form for what it reports as rare
 extern "C" uint64_t jst_tanhf_mismatches(uint32_t start, uint32_t stride, uint64_t count,
                                          uint32_t* first_bad, int variant) {
     uint64_t bad = 0;
@@ -13,7 +14,14 @@ extern "C" uint64_t jst_tanhf_mismatches(uint32_t start, uint32_t stride, uint64
     for (uint64_t i = 0; i < count; ++i, u += stride) {
         const float x = jst::dev::u2f(u);
         const float a = tanhf(x);
-        const float b = variant ? jst::dev::libm_tanhf_branchy(x) : jst::dev::libm_tanhf(x);
+        float b;
+        if (variant == 2) {
+            bool rare;
+            b = jst::dev::libm_tanhf_main(x, rare);
+            if (rare) b = jst::dev::libm_tanhf_branchy(x);
+        } else {
+            b = variant ? jst::dev::libm_tanhf_branchy(x) : jst::dev::libm_tanhf(x);
+        }
         if (isnan(a) && isnan(b)) continue;
         if (jst::dev::f2u(a) != jst::dev::f2u(b)) {
             if (bad == 0 && first_bad) *first_bad = u;
@@ -25,3 +33,8 @@ extern "C" uint64_t jst_tanhf_mismatches(uint32_t start, uint32_t stride, uint64
 
 extern "C" float jst_tanhf_select(float x) { return jst::dev::libm_tanhf(x); }
 extern "C" float jst_tanhf_branchy(float x) { return jst::dev::libm_tanhf_branchy(x); }
+extern "C" float jst_tanhf_main(float x) {
+    bool rare;
+    const float r = jst::dev::libm_tanhf_main(x, rare);
+    return rare ? jst::dev::libm_tanhf_branchy(x) : r;
+}

@@ -26,7 +26,7 @@ def checker(tmp_path_factory):
     return lib
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_every_257th_float(checker, variant):
     first = C.c_uint32(0)
     n = (1 << 32) // 257
@@ -34,7 +34,7 @@ def test_every_257th_float(checker, variant):
     assert bad == 0, f"{bad} mismatches, first at bits {first.value:#x}"
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_dense_where_range_lives(checker, variant):
     # the Range module feeds 4*(normalized-0.5): |x| mostly in [2^-10, 8) -> every float there
     first = C.c_uint32(0)
@@ -58,3 +58,24 @@ def test_branch_boundaries(checker, variant):
     assert fn(0.0) == 0.0 and np.signbit(np.float32(fn(-0.0)))
     assert fn(float("inf")) == 1.0 and fn(float("-inf")) == -1.0
     assert np.isnan(fn(float("nan")))
+
+
+def test_main_path_form_on_every_float_of_its_domain(checker):
+    """libm_tanhf_main (the straight-line form the fused epilogue runs) against libm.so.6 on EVERY float it
+    answers itself -- 2^-26 <= |x| < 7.5, both signs, plus a margin into the bail-out region: the unified
+    argument reduction and the merged reconstructions need no patch anywhere."""
+    from concurrent.futures import ThreadPoolExecutor
+    lo, hi = 0x32800000 - 4096, 0x40f00000 + 4096
+    chunk = (hi - lo) // 32 + 1
+
+    def run(job):
+        start, count = job
+        first = C.c_uint32(0)
+        return checker.jst_tanhf_mismatches(start, 1, count, C.byref(first), 2), first.value
+
+    jobs = [((lo + i * chunk) | s, min(chunk, hi - (lo + i * chunk))) for s in (0, 0x80000000) for i in range(32)
+            if lo + i * chunk < hi]
+    with ThreadPoolExecutor(8) as ex:  # ctypes releases the GIL
+        res = list(ex.map(run, jobs))
+    bad = sum(r[0] for r in res)
+    assert bad == 0, f"{bad} mismatches, first at bits {[hex(r[1]) for r in res if r[0]][:4]}"
