@@ -322,14 +322,29 @@ Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
         }
     }
     JST_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
-    JST_CHECK(planOrder(modules));
+    // From here on a failure tears down what was built (stream, initialised modules, events): destroy() does
+    // nothing for a runtime that never reached created_.
+    size_t initialised = 0;
+    auto fail = [&](Result r) {
+        for (size_t i = initialised; i-- > 0;) (void)ordered_[i]->computeDeinitialize();
+        created_ = true;  // let destroy() release units, graphs, streams
+        std::vector<Module*> none;
+        ordered_.swap(none);
+        (void)destroy();
+        return r;
+    };
+    {
+        const Result r = planOrder(modules);
+        if (r != Result::SUCCESS) return fail(r);
+    }
     for (Module* m : ordered_) {
         const Result r = m->computeInitialize();
         if (r != Result::SUCCESS) {
             JST_ERROR("[RUNTIME] computeInitialize failed for module '%s': %s", m->name().c_str(),
                       last_error());
-            return r;
+            return fail(r);
         }
+        ++initialised;
     }
     period_ = 1;
     for (Module* m : ordered_) {  // least common multiple of the modules' host-state periods
@@ -337,8 +352,11 @@ Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
         while (b) { const U64 t = a % b; a = b; b = t; }
         period_ = period_ / a * (m->cyclePeriod() ? m->cyclePeriod() : 1);
     }
-    JST_CHECK(planUnits());
-    if ((flags_ & PIPELINE) && (flags_ & GRAPH)) JST_CHECK(planPipeline());
+    {
+        Result r = planUnits();
+        if (r == Result::SUCCESS && (flags_ & PIPELINE) && (flags_ & GRAPH)) r = planPipeline();
+        if (r != Result::SUCCESS) return fail(r);
+    }
     cycles_ = 0;
     created_ = true;
     return Result::SUCCESS;
@@ -578,6 +596,68 @@ Result Runtime::dropGraphs() {
             lane_graph_[lane][half] = nullptr;
         }
     lane_launches_ = 0;
+    for (auto& kv : span_graphs_) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    span_graphs_.clear();
+    return Result::SUCCESS;
+}
+
+// A failure between hipStreamBeginCapture and hipStreamEndCapture must not leave the stream capturing (every later
+// call on it would fail) nor half-built graphs behind (graphActive() would launch null executables).
+Result Runtime::abortCapture(Result r) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(stream_, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    (void)dropGraphs();
+    return r;
+}
+
+Result Runtime::launchSpan(U64 n, bool timing) {
+    const U64 phase = cycles_ % period_;
+    auto key = std::make_pair(phase, n);
+    auto it = span_graphs_.find(key);
+    if (it == span_graphs_.end()) {
+        if (span_graphs_.size() >= 64) {  // bounded cache: drop the lot rather than grow without limit
+            for (auto& kv : span_graphs_) {
+                if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+                if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+            }
+            span_graphs_.clear();
+        }
+        JST_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+        Result r = Result::SUCCESS;
+        for (U64 c = 0; c < n && r == Result::SUCCESS; ++c) {
+            const U64 slot = (phase + c) % period_;
+            r = submitAll(timing && (slot % timingStride()) == 0, slot, false);  // advances the host cursors
+        }
+        if (r != Result::SUCCESS) return abortCapture(r);
+        SpanGraph sg;
+        if (hipStreamEndCapture(stream_, &sg.graph) != hipSuccess || !sg.graph) return abortCapture(Result::ERROR);
+        if (hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGraphDestroy(sg.graph);
+            JST_ERROR("[RUNTIME] hipGraphInstantiate failed for a %llu-cycle span.", (unsigned long long)n);
+            return Result::ERROR;
+        }
+        captured_generation_ = configGenerations();
+        it = span_graphs_.emplace(key, sg).first;
+    } else {
+        for (Module* m : ordered_) m->advanceHostState(n);  // a replay does not run the host side
+    }
+    JST_HIP_CHECK(hipGraphLaunch(it->second.exec, stream_), "hipGraphLaunch");
+    for (auto& u : units_) {
+        if (u.is_static && u.settled) continue;
+        for (Module* m : u.modules) m->timing.cycles += n;
+        if (timing)
+            for (U64 c = 0; c < n; ++c) {
+                const U64 slot = (phase + c) % period_;
+                if (slot < u.span.recorded.size() && (slot % timingStride()) == 0 && u.timed) u.span.recorded[slot] = true;
+            }
+    }
+    timing_pending_ = timing_pending_ || timing;
+    cycles_ += n;
     return Result::SUCCESS;
 }
 
@@ -586,7 +666,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
         JST_ERROR("[RUNTIME] compute() before create().");
         return Result::ERROR;
     }
-    if (graphActive() && configGenerations() != captured_generation_) JST_CHECK(dropGraphs());
+    if ((graphActive() || !span_graphs_.empty()) && configGenerations() != captured_generation_) JST_CHECK(dropGraphs());
     const bool timing = (flags_ & TIMING) != 0;
     bool needs_sync = sync;
     while (cycles > 0) {
@@ -619,16 +699,16 @@ Result Runtime::compute(U64 cycles, bool sync) {
                 Result r = Result::SUCCESS;
                 for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c)
                     r = submitAll(timing && (c % timingStride()) == 0, c, false);
+                if (r != Result::SUCCESS) return abortCapture(r);
                 hipGraph_t g = nullptr;
-                const hipError_t e = hipStreamEndCapture(stream_, &g);
-                if (r != Result::SUCCESS) {
-                    if (g) (void)hipGraphDestroy(g);
-                    return r;
-                }
-                JST_HIP_CHECK(e, "hipStreamEndCapture");
+                if (hipStreamEndCapture(stream_, &g) != hipSuccess || !g) return abortCapture(Result::ERROR);
                 graph_ = g;
-                JST_HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0),
-                              "hipGraphInstantiate");
+                if (hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0) != hipSuccess) {
+                    graph_exec_ = nullptr;
+                    (void)dropGraphs();
+                    JST_ERROR("[RUNTIME] hipGraphInstantiate failed.");
+                    return Result::ERROR;
+                }
                 captured_generation_ = configGenerations();
                 for (auto& u : units_)  // nothing ran yet: the capture only recorded nodes
                     std::fill(u.span.recorded.begin(), u.span.recorded.end(), false);
@@ -665,6 +745,24 @@ Result Runtime::compute(U64 cycles, bool sync) {
             cycles_ += period_;
             cycles -= period_;
             continue;
+        }
+        if ((flags_ & GRAPH) && !any_unsettled_static && !pipelined() && period_ > 1) {
+            // Not a whole period from here (the head of a call that starts off the captured phase, or its tail):
+            // replay a graph of exactly those cycles instead of running them eagerly.
+            bool capturable = true;
+            for (auto& u : units_)
+                for (Module* m : u.modules) capturable &= (u.is_static || m->capturable());
+            if (capturable) {
+                U64 n = cycles < period_ ? cycles : period_ - 1;
+                if (graphActive()) {
+                    const U64 off = (cycles_ + period_ - capture_phase_) % period_;
+                    if (off) n = std::min<U64>(n, period_ - off);  // up to the next boundary of the period graph
+                }
+                JST_CHECK(launchSpan(n, timing));
+                cycles -= n;
+                continue;
+            }
+            flags_ &= ~GRAPH;
         }
         {
             const Result r = eagerCycle(needs_sync);

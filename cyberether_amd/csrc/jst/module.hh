@@ -16,6 +16,7 @@
 #pragma once
 
 #include <functional>
+#include <map>
 #include <set>
 
 #include "tensor.hh"
@@ -71,6 +72,9 @@ class Module {
     // Number of consecutive cycles after which this module's host-side state repeats (a ring
     // source with R slots: R).  The runtime captures that many cycles into one hipGraph.
     virtual U64 cyclePeriod() const { return 1; }
+    // Moves that host-side state forward by 'cycles' cycles without submitting anything: a cached hipGraph of
+    // those cycles is about to be replayed (a capture advances the state itself, a replay does not).
+    virtual void advanceHostState(U64 /*cycles*/) {}
     // False for view/bookkeeping modules whose computeSubmit enqueues nothing on the stream.
     virtual bool launchesKernels() const { return true; }
     // Named internal state tensors (spectrogram/waterfall "frequencyBins"), for read-back.
@@ -200,6 +204,11 @@ class Runtime {
     Result submitAll(bool record_events, U64 event_slot, bool count_cycles);
     Result harvestTiming();
     Result eagerCycle(bool& needs_sync);
+    // 'n' < period() cycles starting at the current phase as a hipGraph of their own (captured on first use, cached
+    // per (phase, n)): the head and tail of a compute() call that is not a whole number of periods replay like
+    // the periods in between instead of running eagerly.
+    Result launchSpan(U64 n, bool timing);
+    Result abortCapture(Result r);
 
     hipStream_t stream_ = nullptr;
     U32 flags_ = 0;
@@ -214,6 +223,11 @@ class Runtime {
     U64 configGenerations() const;
     Result dropGraphs();
     U64 capture_phase_ = 0;
+    struct SpanGraph {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+    };
+    std::map<std::pair<U64, U64>, SpanGraph> span_graphs_;  // (phase, cycles) -> graph
     std::string calibration_unit_;
     // PIPELINE: SURFACE units run as their own graphs on a second stream (a second hardware queue),
     // one period behind the producers; the tensors in between are rings of two periods.

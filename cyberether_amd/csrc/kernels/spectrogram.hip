@@ -26,6 +26,14 @@ namespace {
 
 constexpr int kThreads = 1024;
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() is a full fence and puts s_waitcnt vmcnt(0)
+// in front of s_barrier, which would drain the input loads in flight across the histogram clear.
+__device__ __forceinline__ void lds_only_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // COPIES: private copies of the tile histogram, one per group of 16 lanes of a wavefront.  The 64
 // lanes of one LDS-atomic instruction cover 4 consecutive batches x 16 columns, and a spectrum's
 // neighbouring batches tend to land in the SAME bin of a column (noise floor): with one copy
@@ -42,36 +50,54 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     const uint32_t cells = height * TW;
     const uint32_t copy_stride = cells + 8u;
 
-    // The state tile does not depend on this cycle's hits: request it first so that its HBM/L2
-    // round trip overlaps the whole accumulate phase (tiles up to kCells*1024 cells; larger
-    // tiles fetch the remainder late).
+    // Tile order: workgroup b runs on XCD b % 8 (observed placement, used for speed only) and every XCD has an L2
+    // of its own.  Tiles t and t+1 share each 128-byte line of a row (TW * 4 = 64 bytes per tile), so they go to
+    // the SAME XCD: XCD k takes the contiguous run of tiles [k * tiles/8, (k+1) * tiles/8) and pulls every line
+    // of its column band from the Infinity Cache once instead of twice.
+    uint32_t tile = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+
+    // Nothing below depends on the histogram until the LDS atomics: the state tile (not touched by this cycle's
+    // hits) and the first kDepth input rows per thread are requested BEFORE the histogram is cleared, and the
+    // barriers order LDS traffic only (no s_waitcnt vmcnt(0)), so the L2 / Infinity-Cache round trips overlap the
+    // clear and each other.
     constexpr uint32_t kCells = 4;
     float state[kCells];
     float* cell[kCells];
 #pragma unroll
     for (uint32_t j = 0; j < kCells; ++j) {
         const uint32_t e = tid + j * kThreads;
-        const uint32_t xx = blockIdx.x * TW + (e % TW);
+        const uint32_t xx = tile * TW + (e % TW);
         cell[j] = (e < cells && xx < width) ? bins + (uint64_t)(e / TW) * width + xx : nullptr;
         state[j] = cell[j] ? *cell[j] : 0.0f;
     }
-    for (uint32_t e = tid; e < copy_stride * COPIES; e += kThreads) hist[e] = 0u;
-    __syncthreads();
 
     const uint32_t c = tid % TW;
-    const uint32_t x = blockIdx.x * TW + c;
+    const uint32_t x = tile * TW + c;
     const float fh = (float)height;
     uint32_t* my_hist = hist + ((tid / TW) % COPIES) * copy_stride;
-    if (x < width) {
-        const float* col = in + in_offset + (int64_t)x * elem_stride;
-        constexpr uint32_t rows_per_iter = kThreads / TW;
-        constexpr uint32_t kDepth = 16;  // loads in flight per thread: the reads are latency bound
-        for (uint32_t b0 = tid / TW; b0 < batches; b0 += rows_per_iter * kDepth) {
-            float v[kDepth];
+    constexpr uint32_t rows_per_iter = kThreads / TW;
+    constexpr uint32_t kDepth = 16;  // loads in flight per thread: the reads are latency bound
+    const float* col = in + in_offset + (int64_t)(x < width ? x : 0) * elem_stride;
+    float v[kDepth];
 #pragma unroll
-            for (uint32_t j = 0; j < kDepth; ++j) {
-                const uint32_t b = b0 + j * rows_per_iter;
-                v[j] = (b < batches) ? col[(int64_t)b * batch_stride] : 0.0f;  // 0 never hits
+    for (uint32_t j = 0; j < kDepth; ++j) {
+        const uint32_t b = tid / TW + j * rows_per_iter;
+        v[j] = (x < width && b < batches) ? col[(int64_t)b * batch_stride] : 0.0f;  // 0 never hits
+    }
+    for (uint32_t e = tid * 4u; e < copy_stride * COPIES; e += kThreads * 4u) {  // copy_stride % 4 == 0
+        *reinterpret_cast<uint4*>(hist + e) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    lds_only_barrier();
+
+    if (x < width) {
+        for (uint32_t b0 = tid / TW; b0 < batches; b0 += rows_per_iter * kDepth) {
+            if (b0 != tid / TW) {  // batches > rows_per_iter * kDepth: later rounds load here
+#pragma unroll
+                for (uint32_t j = 0; j < kDepth; ++j) {
+                    const uint32_t b = b0 + j * rows_per_iter;
+                    v[j] = (b < batches) ? col[(int64_t)b * batch_stride] : 0.0f;
+                }
             }
 #pragma unroll
             for (uint32_t j = 0; j < kDepth; ++j) {
@@ -80,7 +106,7 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
             }
         }
     }
-    __syncthreads();
+    lds_only_barrier();
 
     auto apply = [&](float w, uint32_t e) {
         w *= decay;
@@ -98,7 +124,7 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     for (uint32_t j = 0; j < kCells; ++j)
         if (cell[j]) *cell[j] = apply(state[j], tid + j * kThreads);
     for (uint32_t e = tid + kCells * kThreads; e < cells; e += kThreads) {  // height > 256
-        const uint32_t xx = blockIdx.x * TW + (e % TW);
+        const uint32_t xx = tile * TW + (e % TW);
         if (xx >= width) continue;
         float* p = bins + (uint64_t)(e / TW) * width + xx;
         *p = apply(*p, e);

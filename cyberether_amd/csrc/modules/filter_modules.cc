@@ -1251,6 +1251,13 @@ class SignalGenerator : public Module {
             ConfigF64(previous, "sampleRate", 1.0e6) != sampleRate ||
             ConfigU64(previous, "bufferSize", 8192) != bufferSize)
             return Result::RECREATE;
+        // The reference folds a new `phase` into the running oscillator phase and rescales the chirp clock by a
+        // new `chirpDuration` (signal_generator/module_impl_native_cpu.cc:128-152).  That state lives on the
+        // device here and is not patched in place: ask for a rebuild rather than report a phase the waveform
+        // does not have.
+        if (ConfigF64(previous, "phase", 0.0) != phase ||
+            ConfigF64(previous, "chirpDuration", 1.0) != chirpDuration)
+            return Result::RECREATE;
         return Result::SUCCESS;
     }
     Result define() override { return defineInterfaceOutput("signal"); }

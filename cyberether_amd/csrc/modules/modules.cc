@@ -1073,6 +1073,16 @@ Result RingSource::computeSubmit(hipStream_t) {
     return output.ringSelect(cursor);
 }
 
+void RingSource::advanceHostState(U64 cycles) {
+    if (live || cycles == 0) return;
+    if (first) {  // the first cycle exposes slot 0 without moving
+        first = false;
+        --cycles;
+    }
+    cursor = (cursor + cycles) % slots;
+    (void)output.ringSelect(cursor);
+}
+
 // ---- fusion ------------------------------------------------------------------------------------
 bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string& name,
                      std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,

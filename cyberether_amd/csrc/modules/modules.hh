@@ -229,6 +229,7 @@ class RingSource : public Module {
     Result create() override;
     Result computeSubmit(hipStream_t stream) override;
     U64 cyclePeriod() const override { return live ? 1 : slots; }
+    void advanceHostState(U64 cycles) override;
     bool launchesKernels() const override { return false; }
     bool capturable() const override { return !live; }  // live: every cycle asks the host-side counters
     Result reconfigureImpl(const Config& previous) override;

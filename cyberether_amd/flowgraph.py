@@ -262,8 +262,9 @@ class Flowgraph:
             node.modules, node.outputs = mods, {"buffer": src}
         elif block in _SIMPLE:
             mtype, ports = _SIMPLE[block]
-            if block == "fft":
-                cfg.pop("complexOutput", None)  # only offered for real inputs (fft/block_impl.cc:42-50)
+            # `complexOutput` passes through to the module (fft/block_impl.cc:42-50): it selects the N/2+1
+            # complex bins for a forward transform of REAL input and is ignored for CF32 input, exactly as
+            # the reference's module does (fft/module_impl.cc:33-38).
             kwargs = {"provider": provider} if mtype in ("amplitude", "range") and provider == "fast" else {}
             m = js.Module(mtype, cfg, inputs, name, **kwargs)
             node.modules = [m]

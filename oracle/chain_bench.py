@@ -1,0 +1,63 @@
+"""CPU baseline of the hot path for bench.py (test/bench infrastructure): the spectrum chain
+Window(x)Invert -> Multiply -> FFT -> Amplitude -> Range -> Spectrogram in dense C loops
+(oracle/jst_oracle.c: jst_oracle_chain_bench), the FFT through the reference's own pocketfft
+(oracle/_ref) when that library is present, timed nanobench-style like src/benchmark.cc:100-106,175-186
+(warm-up, epochs of >= 100 ms, median).  Run as a module it prints one JSON line -- bench.py starts one
+process per host core for the `all_cores` replica figure (the reference's compute path is single-threaded,
+fft/module_impl_native_cpu.cc:1-2, so independent replicas over disjoint batch shards are the fair way to
+use every core)."""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+
+import numpy as np
+
+from oracle import oracle
+
+N_FFT, HEIGHT = 4096, 256
+
+
+def run(rows: int, epoch_s: float, epochs: int, use_ref: bool = True, seed: int = 4321) -> dict:
+    lib = oracle.lib()
+    fft_ptr, kind = None, "port"
+    if use_ref and oracle.have_ref():
+        fft_ptr = C.cast(oracle.ref().ref_fft_c2c, C.c_void_p)
+        kind = "reference"
+    rng = np.random.default_rng(seed)
+    n = np.arange(N_FFT, dtype=np.float64)
+    bins_ = (100.25 + np.arange(rows, dtype=np.float64)) % N_FFT
+    phase = 2.0 * np.pi * bins_[:, None] * n[None, :] / N_FFT
+    x = np.empty((rows, N_FFT), np.complex64)
+    x.real = np.cos(phase) + rng.standard_normal((rows, N_FFT)).astype(np.float32) * np.float32(1e-3)
+    x.imag = np.sin(phase) + rng.standard_normal((rows, N_FFT)).astype(np.float32) * np.float32(1e-3)
+    window = oracle.invert(oracle.window(N_FFT))
+    coeff = oracle.amplitude_coeff(N_FFT)
+    scale, offset = oracle.range_coeffs(-100.0, 0.0)
+    product = np.empty((rows, N_FFT), np.complex64)
+    spectrum = np.empty((rows, N_FFT), np.complex64)
+    out = np.empty((rows, N_FFT), np.float32)
+    state = np.zeros(N_FFT * HEIGHT, np.float32)
+    rates = (C.c_double * epochs)()
+    f32p = C.POINTER(C.c_float)
+    fn = lib.jst_oracle_chain_bench
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_void_p, f32p, f32p, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_uint64,
+                   f32p, f32p, f32p, f32p, C.c_double, C.c_uint32, C.POINTER(C.c_double)]
+    p = lambda a: a.ctypes.data_as(f32p)
+    median = fn(fft_ptr, p(x), p(window), rows, N_FFT, coeff, scale, offset, HEIGHT, p(product), p(spectrum),
+                p(out), p(state), epoch_s, epochs, rates)
+    return {"samples_per_s": float(median), "kind": kind, "rows": rows, "epochs": epochs, "epoch_s": epoch_s,
+            "epoch_rates_MSps": [round(r / 1e6, 2) for r in rates]}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=64)
+    ap.add_argument("--epoch-s", type=float, default=0.2)
+    ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--no-ref", action="store_true")
+    ap.add_argument("--seed", type=int, default=4321)
+    a = ap.parse_args()
+    print(json.dumps(run(a.rows, a.epoch_s, a.epochs, not a.no_ref, a.seed)), flush=True)

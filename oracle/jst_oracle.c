@@ -15,6 +15,7 @@
  *   (2) oracle/_ref/libref_pocketfft.so -- the reference's vendored pocketfft.hh compiled
  *       in place from /root/reference (bit-exact comparison of the FFT restatement).
  */
+#define _POSIX_C_SOURCE 199309L /* clock_gettime for the bench driver at the end of this file */
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
@@ -2253,4 +2254,86 @@ void jst_oracle_agc(const float* in, float* out, int complex_in, uint64_t lanes,
             start_gain = end_gain;
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * CPU baseline driver for bench.py's `cpu_baseline` leg (test/bench infrastructure like the rest
+ * of this file).  One pass = the hot path over `rows` batches of n samples with dense loops and
+ * caller-provided buffers (no temporaries): Multiply by the static window (x) invert table,
+ * FFT -- through `fft`, the REFERENCE's own pocketfft (oracle/_ref, SIMD across batches as in
+ * fft/module_impl_native_cpu.cc:125-140) when given, else the restatement above --, Amplitude,
+ * Range, Spectrogram.  Timed the way the reference times its own benchmarks
+ * (src/benchmark.cc:100-106,175-186: nanobench -- warm-up, epochs of >= 100 ms, MEDIAN per op).
+ * ---------------------------------------------------------------------------------------- */
+#include <time.h>
+
+typedef int (*jst_oracle_fft_fn)(uint32_t rank, const uint64_t* shape, const int64_t* stride_in,
+                                 const int64_t* stride_out, uint64_t axis, int forward,
+                                 const float* in, float* out);
+
+void jst_oracle_chain_pass(jst_oracle_fft_fn fft, const float* x, const float* window, uint64_t rows,
+                           uint64_t n, float coeff, float scale, float offset, uint64_t height,
+                           float decay, float* product, float* spectrum, float* out, float* bins) {
+    for (uint64_t r = 0; r < rows; ++r)
+        for (uint64_t i = 0; i < n; ++i)
+            cmul_f32(x[2 * (r * n + i)], x[2 * (r * n + i) + 1], window[2 * i], window[2 * i + 1],
+                     &product[2 * (r * n + i)], &product[2 * (r * n + i) + 1]);
+    if (fft) {
+        const uint64_t shape[2] = {rows, n};
+        const int64_t stride[2] = {(int64_t)(n * 8), 8};
+        (void)fft(2, shape, stride, stride, 1, 1, product, spectrum);
+    } else {
+        (void)jst_oracle_fft_c2c(product, spectrum, n, rows, 1);
+    }
+    const uint64_t total = rows * n;
+    for (uint64_t i = 0; i < total; ++i) {  /* amplitude/module_impl_native_cpu.cc:73-86 + range :67-82 */
+        const float re = spectrum[2 * i], im = spectrum[2 * i + 1];
+        const float mag = sqrtf((re * re) + (im * im));
+        const float db = (mag == 0.0f) ? -INFINITY : 20.0f * jst_oracle_approx_log10(mag) + coeff;
+        if (scale == 0.0f) {
+            out[i] = 0.5f;
+        } else {
+            const float normalized = db * scale + offset;
+            out[i] = 0.5f + 0.5f * tanhf(4.0f * (normalized - 0.5f));
+        }
+    }
+    jst_oracle_spectrogram(bins, out, rows, n, height, n, 1, decay);
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static int cmp_double(const void* a, const void* b) {
+    const double x = *(const double*)a, y = *(const double*)b;
+    return (x > y) - (x < y);
+}
+
+/* Returns the median over `epochs` epochs (each >= min_epoch_s of passes) of samples per second;
+ * rates[e] (if given) receives every epoch's figure. */
+double jst_oracle_chain_bench(jst_oracle_fft_fn fft, const float* x, const float* window, uint64_t rows,
+                              uint64_t n, float coeff, float scale, float offset, uint64_t height,
+                              float* product, float* spectrum, float* out, float* bins,
+                              double min_epoch_s, uint32_t epochs, double* rates) {
+    const float decay = jst_oracle_spectrogram_decay(rows);
+    double local[64];
+    if (epochs == 0 || epochs > 64) return -1.0;
+    jst_oracle_chain_pass(fft, x, window, rows, n, coeff, scale, offset, height, decay, product, spectrum,
+                          out, bins); /* warm-up: pages touched, plans built */
+    for (uint32_t e = 0; e < epochs; ++e) {
+        uint64_t passes = 0;
+        const double t0 = now_s();
+        double t1;
+        do {
+            jst_oracle_chain_pass(fft, x, window, rows, n, coeff, scale, offset, height, decay, product,
+                                  spectrum, out, bins);
+            ++passes;
+            t1 = now_s();
+        } while (t1 - t0 < min_epoch_s);
+        local[e] = (double)(passes * rows * n) / (t1 - t0);
+        if (rates) rates[e] = local[e];
+    }
+    qsort(local, epochs, sizeof(double), cmp_double);
+    return (epochs & 1) ? local[epochs / 2] : 0.5 * (local[epochs / 2 - 1] + local[epochs / 2]);
 }

@@ -113,7 +113,9 @@ def test_ring_source_period_and_graph(js, oracle, pipeline):
     refs = [oracle.spectrum_chain(d, -100.0, 0.0)["range"] for d in data]
     bins = np.zeros(n * h, np.float32)
     total = 0
-    for chunk in (1, 3, 4, 8, 2, 4):  # eager remainder cycles and whole-graph replays mixed
+    # whole-period replays mixed with heads and tails that do not fill a period: those replay as span graphs
+    # (captured per (phase, length), replayed from the cache the second time: the source's host cursor must follow)
+    for chunk in (1, 3, 4, 8, 2, 4, 3, 3, 5, 2, 4, 7, 3, 3):
         rt.compute(chunk)
         for _ in range(chunk):
             oracle.spectrogram(bins, refs[total % slots], h)
