@@ -2,8 +2,8 @@
 // plain elementwise maps: Pad, Unpad, Fold, OverlapAdd, PhaseCorrection, FilterTaps, Arithmetic
 // (axis reduction) and FM.  The reference has CPU implementations only for all of them
 // (SURVEY 2b); every kernel restates the CPU arithmetic in the CPU's order (F64 where the CPU
-// uses F64) so results are bit-identical, except FM whose libm atan2f/sinf/cosf are replaced by
-// the device's (tolerance stated in the tests; the reference's own FM tests use 1e-2).
+// uses F64) so results are bit-identical -- FM included: its atan2f / sinf / cosf are the restatements of
+// the host libm's routines in libm_float.hh (glibc 2.35, swept against libm.so.6 on every float).
 #include <cstdlib>
 
 #include "device_math.hh"
@@ -320,7 +320,7 @@ __device__ __forceinline__ float fm_discriminate(float2 prev, float2 cur, bool h
     if (!has) return 0.0f;
     if (!fin) return __builtin_nanf("");
     const float2 p = cmul_full(mk(prev.x, -prev.y), cur);  // conj(previous) * current
-    return atan2f(p.y, p.x) * ref;
+    return libm_atan2f(p.y, p.x) * ref;
 }
 __global__ __launch_bounds__(64) void fm_kernel(float* __restrict__ out, const float2* __restrict__ in,
                                                 FmState* __restrict__ states, const FmCoeffs k,
@@ -355,14 +355,14 @@ __global__ __launch_bounds__(64) void fm_kernel(float* __restrict__ out, const f
                     out[oo] = st.narrow_deemph;
                 }
             } else {
-                const float pc = cosf(st.pilot_phase), ps = sinf(st.pilot_phase);
+                const float pc = libm_cosf(st.pilot_phase), ps = libm_sinf(st.pilot_phase);
                 st.pilot_cos_stage += k.pilot_alpha * (d * pc - st.pilot_cos_stage);
                 st.pilot_sin_stage += k.pilot_alpha * (d * ps - st.pilot_sin_stage);
                 st.pilot_cos += k.pilot_alpha * (st.pilot_cos_stage - st.pilot_cos);
                 st.pilot_sin += k.pilot_alpha * (st.pilot_sin_stage - st.pilot_sin);
                 const float sum = fm_lowpass(fm_biquad(d, k.notch, st.sum_notch), k, st.sum_filter);
-                const float po = atan2f(st.pilot_cos, st.pilot_sin);
-                const float carrier = sinf(2.0f * (st.pilot_phase + po));
+                const float po = libm_atan2f(st.pilot_cos, st.pilot_sin);
+                const float carrier = libm_sinf(2.0f * (st.pilot_phase + po));
                 const float diff = fm_lowpass(
                     fm_biquad(2.0f * d * carrier, k.notch, st.diff_notch), k, st.diff_filter);
                 float left = sum + diff, right = sum - diff;
@@ -578,8 +578,8 @@ __global__ __launch_bounds__(kFmWideThreads) void fm_wide_kernel(float* __restri
                     const float d = i < cnt ? dch[i] : nan;
                     const bool fin = __builtin_isfinite(d);
                     const float p = fin ? pch[i] : 0.0f;
-                    r_xc[c & 1][i] = fin ? d * cosf(p) : nan;  // non-finite discriminator sample = bubble
-                    r_xs[c & 1][i] = fin ? d * sinf(p) : nan;
+                    r_xc[c & 1][i] = fin ? d * libm_cosf(p) : nan;  // non-finite discriminator sample = bubble
+                    r_xs[c & 1][i] = fin ? d * libm_sinf(p) : nan;
                 }
             }
             // ---- E: chunk s-3 ----
@@ -591,8 +591,8 @@ __global__ __launch_bounds__(kFmWideThreads) void fm_wide_kernel(float* __restri
                     const float d = i < cnt ? dch[i] : nan;
                     float v = nan;
                     if (__builtin_isfinite(d)) {  // D's results sit 1 slot late
-                        const float po = atan2f(r_pcos[c & 1][i + 1], r_psin[c & 1][i + 1]);
-                        const float carrier = sinf(2.0f * (pch[i] + po));
+                        const float po = libm_atan2f(r_pcos[c & 1][i + 1], r_psin[c & 1][i + 1]);
+                        const float carrier = libm_sinf(2.0f * (pch[i] + po));
                         v = 2.0f * d * carrier;
                     }
                     r_xd[c & 1][i] = v;

@@ -297,4 +297,197 @@ JST_FN float libm_tanhf_main(float x, bool& rare) {
 }
 
 
+// =================================================================================================
+// sinf / cosf / atanf / atan2f of the host libm the reference's FM module calls
+// (src/domains/dsp/fm/module_impl_native_cpu.cc:93,123-139), glibc 2.35 on x86-64, restated from the
+// published sources AND checked against the shipped binary (objdump of libm.so.6: constants read back from
+// its tables, the placement of every fused multiply-add read off the instruction stream):
+//   * sinf / cosf are sysdeps/ieee754/flt-32/s_sinf.c / s_cosf.c (ARM's 2018 routines): the argument is
+//     widened to double, reduced by n = round(x * 2/pi) with ONE fused x - n*(pi/2), and a degree-7 / degree-8
+//     polynomial in double gives the result, rounded to float once.  libm resolves them through IFUNC to the
+//     `_fma` build on every CPU with FMA + AVX2 (all current x86 servers), whose polynomial steps are contracted
+//     exactly as written below (fma_d = one rounding).  |x| >= 120 goes through the 192-bit 4/pi table
+//     (reduce_large), integer arithmetic, restated literally.
+//   * atanf / atan2f are FDLIBM's s_atanf.c / e_atan2f.c in float arithmetic; libm ships ONE build of them
+//     (baseline x86-64, no FMA): every operation below is one rounding (-ffp-contract=off), the divisions are
+//     IEEE divisions on both sides.
+// tests/test_libm_float.py sweeps all four against libm.so.6 on the host (sinf/cosf/atanf: every float).
+// =================================================================================================
+JST_FN double fma_d(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+namespace sincosf_data {
+constexpr double kHpiInv = 0x1.45F306DC9C883p+23;  // 2/pi * 2^24
+constexpr double kHpi = 0x1.921FB54442D18p0;       // pi/2
+constexpr double kPi63 = 0x1.921FB54442D18p-62;    // 2 pi / 2^64
+constexpr double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16;
+constexpr double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+}  // namespace sincosf_data
+
+// sinf_poly, (n & 1) == 0 branch: s + x7*s1 with s1 = S2 + x2*S3, s = x + x3*S1 (three fused steps)
+JST_FN double sincosf_sin_poly(double x, double x2) {
+    using namespace sincosf_data;
+    const double s1 = fma_d(x2, S3, S2);
+    const double x3 = x * x2;
+    const double x7 = x3 * x2;
+    const double s = fma_d(x3, S1, x);
+    return fma_d(s1, x7, s);
+}
+// sinf_poly, (n & 1) == 1 branch; `negate` selects __sincosf_table[1], whose cosine coefficients are the negated
+// ones: every step is odd in the coefficients, so the result is exactly the negated value.
+JST_FN double sincosf_cos_poly(double x2, bool negate) {
+    using namespace sincosf_data;
+    const double x4 = x2 * x2;
+    const double c1 = fma_d(x2, C1, C0);
+    const double c2 = fma_d(x2, C4, C3);
+    const double x6 = x2 * x4;
+    const double c = fma_d(x4, C2, c1);
+    const double r = fma_d(c2, x6, c);
+    return negate ? -r : r;
+}
+// reduce_large (sincosf.h): x mod pi/2 from the 4/pi bits, |x| >= 120.  Returns the reduced argument, *np = quadrant.
+JST_FN double sincosf_reduce_large(uint32_t xi, int32_t* np) {
+    const uint32_t inv_pio4[24] = {0xa2,       0xa2f9,     0xa2f983,   0xa2f9836e, 0xf9836e4e, 0x836e4e44,
+                                   0x6e4e4415, 0x4e441529, 0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1,
+                                   0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0, 0x34ddc0db, 0xddc0db62,
+                                   0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+    const uint32_t* arr = &inv_pio4[(xi >> 26) & 15];
+    const int shift = (int)((xi >> 23) & 7);
+    xi = (xi & 0xffffff) | 0x800000;
+    xi <<= shift;
+    uint64_t res0 = (uint32_t)(xi * arr[0]);
+    const uint64_t res1 = (uint64_t)xi * arr[4];
+    const uint64_t res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    *np = (int32_t)n;
+    return (double)(int64_t)res0 * sincosf_data::kPi63;
+}
+// the shared body: COS = false gives sinf, true gives cosf (the two sources differ in the tiny-argument result and
+// in the parity handed to sinf_poly: n for sinf, n ^ 1 for cosf)
+template <bool COS>
+JST_FN float libm_sincosf(float y) {
+    using namespace sincosf_data;
+    const uint32_t bits = f2u(y);
+    const uint32_t top = (bits >> 20) & 0x7ffu;  // abstop12
+    const double x = (double)y;
+    if (top <= 0x3f3u) {  // |y| < pi/4
+        const double x2 = x * x;
+        if (top <= 0x397u) return COS ? 1.0f : y;  // |y| < 2^-12
+        return (float)(COS ? sincosf_cos_poly(x2, false) : sincosf_sin_poly(x, x2));
+    }
+    double xr;
+    int32_t n, q;  // n: quadrant whose parity picks the polynomial; q: quadrant for sign / table
+    if (top <= 0x42eu) {  // |y| < 120: reduce_fast
+        const double r = x * kHpiInv;
+        n = ((int32_t)r + 0x800000) >> 24;
+        xr = fma_d(-(double)n, kHpi, x);
+        q = n;
+    } else if (top <= 0x7f7u) {
+        xr = sincosf_reduce_large(bits, &n);
+        q = n + (int32_t)(bits >> 31);
+    } else {
+        return y - y;  // inf, NaN -> NaN (__math_invalidf)
+    }
+    const double x2 = xr * xr;
+    const bool odd = ((n & 1) != 0) != COS;  // sinf: cosine polynomial when n is odd; cosf: when n is even
+    if (odd) return (float)sincosf_cos_poly(x2, (q & 2) != 0);
+    const double sgn = ((q & 3) == 1 || (q & 3) == 2) ? -1.0 : 1.0;  // sign[] = {1, -1, -1, 1}
+    return (float)sincosf_sin_poly(xr * sgn, x2);
+}
+JST_FN float libm_sinf(float y) { return libm_sincosf<false>(y); }
+JST_FN float libm_cosf(float y) { return libm_sincosf<true>(y); }
+
+// FDLIBM s_atanf.c (float arithmetic; constants as stored in libm.so.6)
+JST_FN float libm_atanf(float x) {
+    const float atanhi[4] = {u2f(0x3eed6338u), u2f(0x3f490fdau), u2f(0x3f7b985eu), u2f(0x3fc90fdau)};
+    const float atanlo[4] = {u2f(0x31ac3769u), u2f(0x33222168u), u2f(0x33140fb4u), u2f(0x33a22168u)};
+    const float aT0 = u2f(0x3eaaaaabu), aT1 = u2f(0xbe4ccccdu), aT2 = u2f(0x3e124925u), aT3 = u2f(0xbde38e38u),
+                aT4 = u2f(0x3dba2e6eu), aT5 = u2f(0xbd9d8795u), aT6 = u2f(0x3d886b35u), aT7 = u2f(0xbd6ef16bu),
+                aT8 = u2f(0x3d4bda59u), aT9 = u2f(0xbd15a221u), aT10 = u2f(0x3c8569d7u);
+    const uint32_t hx = f2u(x);
+    const uint32_t ix = hx & 0x7fffffffu;
+    if (ix >= 0x4c000000u) {  // |x| >= 2^25
+        if (ix > 0x7f800000u) return x + x;  // NaN
+        return ((int32_t)hx > 0) ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    int id;
+    if (ix < 0x3ee00000u) {  // |x| < 0.4375
+        if (ix < 0x31000000u) return x;  // |x| < 2^-29 (huge + x > one always holds)
+        id = -1;
+    } else {
+        x = u2f(ix);  // fabsf
+        if (ix < 0x3f980000u) {      // |x| < 1.1875
+            if (ix < 0x3f300000u) {  // 7/16 <= |x| < 11/16
+                id = 0;
+                x = (2.0f * x - 1.0f) / (2.0f + x);
+            } else {                 // 11/16 <= |x| < 19/16
+                id = 1;
+                x = (x - 1.0f) / (x + 1.0f);
+            }
+        } else {
+            if (ix < 0x401c0000u) {  // |x| < 2.4375
+                id = 2;
+                x = (x - 1.5f) / (1.0f + 1.5f * x);
+            } else {                 // 2.4375 <= |x| < 2^25
+                id = 3;
+                x = -1.0f / x;
+            }
+        }
+    }
+    const float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return ((int32_t)hx < 0) ? -r : r;
+}
+
+// FDLIBM e_atan2f.c
+JST_FN float libm_atan2f(float y, float x) {
+    const float tiny = u2f(0x0da24260u), pi_o_4 = u2f(0x3f490fdbu), pi_o_2 = u2f(0x3fc90fdbu), pi = u2f(0x40490fdbu),
+                pi_lo = u2f(0xb3bbbd2eu);
+    const uint32_t hx = f2u(x), hy = f2u(y);
+    const uint32_t ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    if (ix > 0x7f800000u || iy > 0x7f800000u) return x + y;  // NaN
+    if (hx == 0x3f800000u) return libm_atanf(y);             // x = 1.0
+    const uint32_t m = (hy >> 31) | ((hx >> 30) & 2u);       // 2*sign(x) + sign(y)
+    if (iy == 0) {                                           // y = +-0
+        if (m < 2) return y;
+        return m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (ix == 0) return ((int32_t)hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000u) {
+        if (iy == 0x7f800000u) {
+            switch (m) {
+                case 0: return pi_o_4 + tiny;
+                case 1: return -pi_o_4 - tiny;
+                case 2: return 3.0f * pi_o_4 + tiny;
+                default: return -3.0f * pi_o_4 - tiny;
+            }
+        }
+        switch (m) {
+            case 0: return 0.0f;
+            case 1: return -0.0f;
+            case 2: return pi + tiny;
+            default: return -pi - tiny;
+        }
+    }
+    if (iy == 0x7f800000u) return ((int32_t)hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int32_t k = ((int32_t)iy - (int32_t)ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                   // |y/x| > 2^60
+    else if ((int32_t)hx < 0 && k < -60) z = 0.0f;           // |y|/x < -2^60
+    else z = libm_atanf(u2f(f2u(y / x) & 0x7fffffffu));      // atanf(fabsf(y / x))
+    switch (m) {
+        case 0: return z;
+        case 1: return u2f(f2u(z) ^ 0x80000000u);
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
 }  // namespace jst::dev

@@ -150,9 +150,12 @@ def fm_signal(rng, n, sr, dev, wide):
     return x.astype(np.complex64)
 
 
-@pytest.mark.parametrize("mode,deemph,tol", [("narrow", "none", 2e-6), ("narrow", "75us", 2e-6),
-                                            ("wide", "none", 2e-4), ("wide", "50us", 2e-4)])
-def test_fm_against_oracle_across_submissions(js, oracle, mode, deemph, tol):
+@pytest.mark.parametrize("mode,deemph", [("narrow", "none"), ("narrow", "75us"), ("wide", "none"), ("wide", "50us")])
+def test_fm_against_oracle_across_submissions(js, oracle, mode, deemph):
+    """BIT-EXACT (round 2; 2e-6 / 2e-4 absolute before): atan2f / sinf / cosf inside the kernels are the
+    restatements of the host libm's routines (kernels/libm_float.hh, swept against libm.so.6 on every float by
+    tests/test_libm_float.py), so the discriminator, the pilot tracker and every recurrence behind them see the
+    operands the reference's CPU path sees (fm/module_impl_native_cpu.cc:93,123-139)."""
     rng = np.random.default_rng(6)
     sr, lanes, batches, samples = 240e3, 3, 2, 1500
     wide = mode == "wide"
@@ -174,7 +177,8 @@ def test_fm_against_oracle_across_submissions(js, oracle, mode, deemph, tol):
             g = got[:, lane].reshape(-1, 2) if wide else got[:, lane].reshape(-1)
             assert np.array_equal(np.isnan(g), np.isnan(ref))
             ok = ~np.isnan(ref)
-            assert np.max(np.abs(g[ok] - ref[ok])) <= tol, (cycle, lane)
+            assert np.array_equal(g[ok].view(np.uint32), np.asarray(ref, np.float32)[ok].view(np.uint32)), \
+                (cycle, lane, float(np.max(np.abs(g[ok] - ref[ok]))))
     if cycle == 0:
         assert got.reshape(-1)[0] == 0.0  # first-ever sample demodulates to exactly 0
 

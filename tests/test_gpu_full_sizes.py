@@ -81,7 +81,7 @@ def test_config4_wbfm_chain_full_rate(js, oracle):
     lane = oracle.FmLane("wide", "75us", 200e3)
     stereo = np.asarray(lane(np.ascontiguousarray(base[:, 0, :]))).reshape(b, 2024, 2)
     got_fm = fm.output("signal").numpy()
-    assert np.max(np.abs(got_fm - stereo)) <= 2e-4          # device sinf/cosf/atan2f vs libm
+    assert_bit_equal(got_fm, np.asarray(stereo, np.float32), "wide FM decode (libm sinf/cosf/atan2f restated)")
     ref_dec = oracle.arithmetic_add(np.ascontiguousarray(got_fm.reshape(b, 506, 4, 2)), 2).reshape(b, 506, 2)
     assert_bit_equal(dec.buffer.numpy(), ref_dec, "integrate-and-dump /4 of the device FM output")
     rt.destroy()

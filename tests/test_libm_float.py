@@ -23,6 +23,10 @@ def checker(tmp_path_factory):
     lib.jst_tanhf_branchy.argtypes = [C.c_float]
     lib.jst_tanhf_select.restype = C.c_float
     lib.jst_tanhf_select.argtypes = [C.c_float]
+    lib.jst_trig_mismatches.restype = C.c_uint64
+    lib.jst_trig_mismatches.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32), C.c_int]
+    lib.jst_atan2f_mismatches.restype = C.c_uint64
+    lib.jst_atan2f_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
     return lib
 
 
@@ -79,3 +83,46 @@ def test_main_path_form_on_every_float_of_its_domain(checker):
         res = list(ex.map(run, jobs))
     bad = sum(r[0] for r in res)
     assert bad == 0, f"{bad} mismatches, first at bits {[hex(r[1]) for r in res if r[0]][:4]}"
+
+
+@pytest.mark.parametrize("which,name", [(0, "sinf"), (1, "cosf"), (2, "atanf")])
+def test_fm_trig_restatements_on_every_float(checker, which, name):
+    """libm_sinf / libm_cosf / libm_atanf (kernels/libm_float.hh, what the FM kernels call) against this host's
+    libm.so.6 on ALL 2^32 floats.  sinf / cosf follow the `_fma` build libm selects on CPUs with FMA + AVX2 (every
+    current x86 server): on a CPU without FMA libm runs its non-contracted build, whose double-precision
+    intermediate can differ in the last place and, once in ~2^29 arguments, round to the other float -- hence the
+    skip there."""
+    from concurrent.futures import ThreadPoolExecutor
+    if which < 2:
+        flags = open("/proc/cpuinfo").read()
+        if " fma" not in flags or " avx2" not in flags:
+            pytest.skip("host libm runs its non-FMA sinf/cosf build")
+    chunk = 1 << 26
+
+    def run(i):
+        first = C.c_uint32(0)
+        return checker.jst_trig_mismatches(i * chunk, 1, chunk, C.byref(first), which), first.value
+
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(run, range(64)))
+    bad = sum(r[0] for r in res)
+    assert bad == 0, f"{name}: {bad} mismatches, first at bits {[hex(r[1]) for r in res if r[0]][:4]}"
+
+
+def test_fm_atan2f_restatement(checker):
+    """libm_atan2f: random bit patterns (every special-case branch), Gaussian IQ at three scales (the discriminator's
+    operands) and the axes / infinities / signed zeros explicitly."""
+    rng = np.random.default_rng(1)
+    n = 1 << 22
+    first = C.c_uint64(0)
+    cases = [(rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32),
+              rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32))]
+    for scale in (1e-3, 1.0, 1e3):
+        cases.append(((rng.standard_normal(n) * scale).astype(np.float32), rng.standard_normal(n).astype(np.float32)))
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-38, -1e-38, 3e38, -3e38, 1e-45, 2.0**61, 2.0**-61],
+                       np.float32)
+    cases.append((np.repeat(special, special.size), np.tile(special, special.size)))
+    for ys, xs in cases:
+        ys, xs = np.ascontiguousarray(ys), np.ascontiguousarray(xs)
+        bad = checker.jst_atan2f_mismatches(ys.ctypes.data, xs.ctypes.data, ys.size, C.byref(first))
+        assert bad == 0, f"{bad} mismatches, first at index {first.value}: atan2f({ys[first.value]}, {xs[first.value]})"
