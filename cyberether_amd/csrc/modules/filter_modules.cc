@@ -680,12 +680,36 @@ class FilterTaps : public Module {
         produced("coeffs", coeffs);
         return Result::SUCCESS;
     }
+    // STATIC table: evaluated on the host with the host libm, the sin()/cos() the reference's CPU module calls
+    // (dsp/filter_taps/module_impl_native_cpu.cc:46-80), and uploaded -- see Window::computeSubmit.
     Result computeSubmit(hipStream_t s) override {
-        return hip_result(kernels::launch_filter_taps(ptr<float2>(coeffs), sampleRate, bandwidth,
-                                                      ptr<const double>(devCenter), center.size(),
-                                                      taps, s),
-                          "filter_taps kernel");
+        const U64 heads = center.size();
+        hostCoeffs.assign(2 * heads * taps, 0.0f);
+        const double pi = 3.14159265358979323846;
+        const double filter_width = (bandwidth / sampleRate) / 2.0;
+        for (U64 c = 0; c < heads; ++c) {
+            const double filter_offset = center[c] / sampleRate;
+            for (U64 i = 0; i < taps; ++i) {
+                const double fi = (double)i, half = (double)(taps - 1) / 2.0, n = fi - half;
+                const double sinc =
+                    (n == 0.0) ? (2.0 * filter_width) : std::sin(2.0 * pi * filter_width * n) / (pi * n);
+                const double win = (taps == 1) ? 1.0
+                                               : 0.42 - 0.50 * std::cos(2.0 * pi * fi / (double)(taps - 1)) +
+                                                     0.08 * std::cos(4.0 * pi * fi / (double)(taps - 1));
+                const double theta = ((2.0 * pi) * n) * filter_offset;
+                const double sw = sinc * win;
+                hostCoeffs[2 * (c * taps + i)] = (float)(sw * std::cos(theta));
+                hostCoeffs[2 * (c * taps + i) + 1] = (float)(sw * std::sin(theta));
+            }
+        }
+        JST_HIP_CHECK(hipMemcpyAsync(ptr<float2>(coeffs), hostCoeffs.data(), hostCoeffs.size() * sizeof(float),
+                                     hipMemcpyHostToDevice, s),
+                      "filter_taps upload");
+        JST_HIP_CHECK(hipStreamSynchronize(s), "hipStreamSynchronize");
+        return Result::SUCCESS;
     }
+    bool capturable() const override { return false; }
+    std::vector<float> hostCoeffs;
     Tensor coeffs, devCenter;
     F64 sampleRate = 2.0e6, bandwidth = 1.0e6;
     std::vector<F64> center;

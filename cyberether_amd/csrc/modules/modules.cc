@@ -215,9 +215,28 @@ Result Window::create() {
     produced("window", output);
     return Result::SUCCESS;
 }
+// The taps are a STATIC table (computed in the first cycle, never again): they are evaluated on the HOST with the
+// host libm -- the very cos() the reference's CPU module calls (window/module_impl_native_cpu.cc:20-37) -- and
+// uploaded, like the FFT twiddles.  A device evaluation would lean on the device math library's double cos being
+// bit-equal to glibc's; one differing double that straddles a float rounding boundary would cost the whole chain
+// its bit-exactness for that size.
 Result Window::computeSubmit(hipStream_t stream) {
-    return hip_result(kernels::launch_window(ptr<float2>(output) + output.offset(), size, stream),
-                      "window kernel");
+    hostTaps.assign(2 * size, 0.0f);
+    if (size == 1) {
+        hostTaps[0] = 1.0f;
+    } else {
+        const double pi = 3.14159265358979323846;
+        for (U64 i = 0; i < size; ++i) {
+            const double tap = 0.42 - 0.50 * std::cos(2.0 * pi * (double)i / (double)(size - 1)) +
+                               0.08 * std::cos(4.0 * pi * (double)i / (double)(size - 1));
+            hostTaps[2 * i] = (float)tap;
+        }
+    }
+    JST_HIP_CHECK(hipMemcpyAsync(ptr<float2>(output) + output.offset(), hostTaps.data(),
+                                 hostTaps.size() * sizeof(float), hipMemcpyHostToDevice, stream),
+                  "window upload");
+    JST_HIP_CHECK(hipStreamSynchronize(stream), "hipStreamSynchronize");  // pageable source: done before we return
+    return Result::SUCCESS;
 }
 
 // ---- Invert ------------------------------------------------------------------------------------

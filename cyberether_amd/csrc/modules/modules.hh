@@ -43,8 +43,10 @@ class Window : public Module {
     Result define() override;
     Result create() override;
     Result computeSubmit(hipStream_t stream) override;
+    bool capturable() const override { return false; }  // host evaluation + upload (runs once: STATIC_OUTPUT)
     Tensor output;
     U64 size = 1024;
+    std::vector<float> hostTaps;
 };
 
 // src/domains/dsp/invert/{module_impl.cc, module_impl_native_cpu.cc:79-103}
