@@ -540,7 +540,7 @@ Result Runtime::harvestTiming() {
     return Result::SUCCESS;
 }
 
-Result Runtime::eagerCycle(bool& needs_sync) {
+Result Runtime::eagerCycle(bool& needs_sync, bool overwrite_samples) {
     const bool timing = (flags_ & TIMING) != 0;
     bool any_unsettled_static = false;
     for (auto& u : units_) any_unsettled_static |= (u.is_static && !u.settled);
@@ -550,7 +550,7 @@ Result Runtime::eagerCycle(bool& needs_sync) {
     if (timing) {
         bool busy = false;
         for (auto& u : units_) busy |= (slot < u.span.recorded.size() && u.span.recorded[slot]);
-        if (busy) {
+        if (busy && !overwrite_samples) {
             JST_HIP_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
             timing_pending_ = true;
             JST_CHECK(harvestTiming());
@@ -629,10 +629,10 @@ Result Runtime::launchSpan(U64 n, bool timing) {
         }
         JST_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
         Result r = Result::SUCCESS;
-        for (U64 c = 0; c < n && r == Result::SUCCESS; ++c) {
-            const U64 slot = (phase + c) % period_;
-            r = submitAll(timing && (slot % timingStride()) == 0, slot, false);  // advances the host cursors
-        }
+        // No event-record nodes in span graphs: the unit timers live in the period graph (every timingStride()-th
+        // cycle) and in eager cycles; a span is a head or a tail of at most period - 1 cycles.
+        for (U64 c = 0; c < n && r == Result::SUCCESS; ++c)
+            r = submitAll(false, (phase + c) % period_, false);  // advances the host cursors
         if (r != Result::SUCCESS) return abortCapture(r);
         SpanGraph sg;
         if (hipStreamEndCapture(stream_, &sg.graph) != hipSuccess || !sg.graph) return abortCapture(Result::ERROR);
@@ -650,13 +650,8 @@ Result Runtime::launchSpan(U64 n, bool timing) {
     for (auto& u : units_) {
         if (u.is_static && u.settled) continue;
         for (Module* m : u.modules) m->timing.cycles += n;
-        if (timing)
-            for (U64 c = 0; c < n; ++c) {
-                const U64 slot = (phase + c) % period_;
-                if (slot < u.span.recorded.size() && (slot % timingStride()) == 0 && u.timed) u.span.recorded[slot] = true;
-            }
     }
-    timing_pending_ = timing_pending_ || timing;
+    (void)timing;
     cycles_ += n;
     return Result::SUCCESS;
 }
@@ -666,14 +661,26 @@ Result Runtime::compute(U64 cycles, bool sync) {
         JST_ERROR("[RUNTIME] compute() before create().");
         return Result::ERROR;
     }
-    if ((graphActive() || !span_graphs_.empty()) && configGenerations() != captured_generation_) JST_CHECK(dropGraphs());
+    if (graphActive() && configGenerations() != captured_generation_) JST_CHECK(dropGraphs());
     const bool timing = (flags_ & TIMING) != 0;
     bool needs_sync = sync;
     while (cycles > 0) {
         bool any_unsettled_static = false;
         for (auto& u : units_) any_unsettled_static |= (u.is_static && !u.settled);
-        bool use_graph = (flags_ & GRAPH) && !any_unsettled_static && cycles >= period_;
-        if (use_graph && !graphActive()) {
+        // TIMING: a hipEventRecord issued under stream capture is only a dependency edge of the capture -- nothing is
+        // recorded when the graph replays (and hipEventRecordExternal is rejected by this ROCm) -- so a timed runtime
+        // does not capture whole periods: the first cycle of every period runs EAGERLY between real event records
+        // (same kernels, same stream, back to back with the graphs) and the other period - 1 cycles replay as a
+        // span graph.  (Round 1's "in-graph" unit timers were in fact fed by the eager cycles between replays.)
+        // Every kTimedPeriodStride-th period is timed that way (the eager cycle costs ~1.5 us of launch gaps); the
+        // periods in between replay as one graph, captured from phase 0 without event records.
+        const U64 kTimedPeriodStride = period_ > 1 ? 4 : 16;
+        const bool timed_periods = timing && !pipelined();
+        const bool aligned0 = (cycles_ % period_) == 0;
+        const bool timed_now = timed_periods && aligned0 && untimed_run_ + 1 >= kTimedPeriodStride;
+        bool use_graph = (flags_ & GRAPH) && !any_unsettled_static && cycles >= period_ &&
+                         (!timed_periods || (aligned0 && !timed_now));
+        if (use_graph && !periodGraphActive()) {
             bool capturable = true;
             for (auto& u : units_)
                 for (Module* m : u.modules) capturable &= (u.is_static || m->capturable());
@@ -698,7 +705,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
                               "hipStreamBeginCapture");
                 Result r = Result::SUCCESS;
                 for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c)
-                    r = submitAll(timing && (c % timingStride()) == 0, c, false);
+                    r = submitAll(false, c, false);  // event records under capture record nothing on replay (see above)
                 if (r != Result::SUCCESS) return abortCapture(r);
                 hipGraph_t g = nullptr;
                 if (hipStreamEndCapture(stream_, &g) != hipSuccess || !g) return abortCapture(Result::ERROR);
@@ -710,8 +717,6 @@ Result Runtime::compute(U64 cycles, bool sync) {
                     return Result::ERROR;
                 }
                 captured_generation_ = configGenerations();
-                for (auto& u : units_)  // nothing ran yet: the capture only recorded nodes
-                    std::fill(u.span.recorded.begin(), u.span.recorded.end(), false);
             }
         }
         if (use_graph && (cycles_ % period_) == capture_phase_) {
@@ -733,20 +738,31 @@ Result Runtime::compute(U64 cycles, bool sync) {
             } else {
                 JST_HIP_CHECK(hipGraphLaunch(graph_exec_, stream_), "hipGraphLaunch");
             }
-            const bool events_ran = !pipelined() || (lane_launches_ % 2) == 1;  // the half-0 graphs carry them
-            for (auto& u : units_) {  // (the in-graph nodes overwrite any unread eager samples)
+            for (auto& u : units_) {
                 if (u.is_static && u.settled) continue;
                 for (Module* m : u.modules) m->timing.cycles += period_;
-                if (timing && events_ran)  // event nodes sit on every timingStride()-th cycle only
-                    for (size_t c = 0; c < u.span.recorded.size(); ++c)
-                        u.span.recorded[c] = (c % timingStride()) == 0;
             }
             timing_pending_ = timing_pending_ || timing;
             cycles_ += period_;
             cycles -= period_;
+            ++untimed_run_;
             continue;
         }
-        if ((flags_ & GRAPH) && !any_unsettled_static && !pipelined() && period_ > 1) {
+        static const bool no_spans = getenv("JST_RUNTIME_NO_SPANS") != nullptr;  // A/B switch: eager heads and tails
+        if (timed_now && (!no_spans || period_ == 1) && (flags_ & GRAPH) && !any_unsettled_static && cycles >= period_) {
+            bool capturable = true;
+            for (auto& u : units_)
+                for (Module* m : u.modules) capturable &= (u.is_static || m->capturable());
+            if (capturable) {
+                const Result r = eagerCycle(needs_sync, true);  // the timed cycle: real event records
+                if (r != Result::SUCCESS) return r;
+                untimed_run_ = 0;
+                if (period_ > 1) JST_CHECK(launchSpan(period_ - 1, timing));
+                cycles -= period_;
+                continue;
+            }
+        }
+        if (!no_spans && (flags_ & GRAPH) && !any_unsettled_static && !pipelined() && period_ > 1) {
             // Not a whole period from here (the head of a call that starts off the captured phase, or its tail):
             // replay a graph of exactly those cycles instead of running them eagerly.
             bool capturable = true;
@@ -754,9 +770,10 @@ Result Runtime::compute(U64 cycles, bool sync) {
                 for (Module* m : u.modules) capturable &= (u.is_static || m->capturable());
             if (capturable) {
                 U64 n = cycles < period_ ? cycles : period_ - 1;
-                if (graphActive()) {
-                    const U64 off = (cycles_ + period_ - capture_phase_) % period_;
-                    if (off) n = std::min<U64>(n, period_ - off);  // up to the next boundary of the period graph
+                if (periodGraphActive() || timed_periods) {
+                    const U64 base = timed_periods ? 0 : capture_phase_;
+                    const U64 off = (cycles_ + period_ - base) % period_;
+                    if (off) n = std::min<U64>(n, period_ - off);  // up to the next period boundary
                 }
                 JST_CHECK(launchSpan(n, timing));
                 cycles -= n;
@@ -765,7 +782,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
             flags_ &= ~GRAPH;
         }
         {
-            const Result r = eagerCycle(needs_sync);
+            const Result r = eagerCycle(needs_sync, false);
             if (r == Result::YIELD || r == Result::TIMEOUT) {  // quiet end: what was queued still completes
                 if (sync) {
                     JST_CHECK(joinLanes());

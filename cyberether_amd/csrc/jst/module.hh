@@ -175,7 +175,8 @@ class Runtime {
     hipStream_t stream() const { return stream_; }
     const std::vector<std::string>& order() const { return order_names_; }
     const std::vector<std::string>& units() const { return unit_names_; }
-    bool graphActive() const { return graph_exec_ != nullptr || lane_exec_[0][0] != nullptr; }
+    bool graphActive() const { return periodGraphActive() || !span_graphs_.empty(); }
+    bool periodGraphActive() const { return graph_exec_ != nullptr || lane_exec_[0][0] != nullptr; }
     // Mean device time (ms) of the named unit over the cycles run with TIMING; <0 if unknown.
     F64 unitMeanMs(const std::string& name);
     // Mean duration of an EMPTY event pair recorded in the same graph/stream (one kernel-less
@@ -203,7 +204,7 @@ class Runtime {
     U64 timingStride() const { return period_ >= 8 ? 4 : 1; }
     Result submitAll(bool record_events, U64 event_slot, bool count_cycles);
     Result harvestTiming();
-    Result eagerCycle(bool& needs_sync);
+    Result eagerCycle(bool& needs_sync, bool overwrite_samples);
     // 'n' < period() cycles starting at the current phase as a hipGraph of their own (captured on first use, cached
     // per (phase, n)): the head and tail of a compute() call that is not a whole number of periods replay like
     // the periods in between instead of running eagerly.
@@ -244,6 +245,7 @@ class Runtime {
     Result captureLane(int lane, int half, bool timing);
     Result joinLanes();
     bool timing_pending_ = false;
+    U64 untimed_run_ = ~0ull >> 1;  // periods replayed since the last timed (eager) one
     bool created_ = false;
 };
 

@@ -17,6 +17,8 @@
 // bin's hits can come from), so no inter-workgroup communication exists.  Rows of the F32[B,N]
 // input are read TW*4 bytes at a time (64 B at TW = 16) -- they were just written by the
 // spectrum kernel and sit in L2 / Infinity Cache.  The state tile is read-modified-written once.
+#include <cstdlib>
+
 #include "device_math.hh"
 #include "kernels.hh"
 
@@ -24,7 +26,7 @@ namespace jst::kernels {
 
 namespace {
 
-constexpr int kThreads = 1024;
+constexpr int kThreadsDefault = 1024;
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() is a full fence and puts s_waitcnt vmcnt(0)
 // in front of s_barrier, which would drain the input loads in flight across the histogram clear.
@@ -39,7 +41,7 @@ __device__ __forceinline__ void lds_only_barrier() {
 // neighbouring batches tend to land in the SAME bin of a column (noise floor): with one copy
 // that is a 4-way same-address collision on nearly every instruction.  Copies are offset by 8
 // words so the four lanes of a column fall on different banks.
-template <int TW, int COPIES>
+template <int TW, int COPIES, int kThreads = kThreadsDefault, int kDepthT = 16>
 __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     float* __restrict__ bins, const float* __restrict__ in, uint64_t in_offset, uint32_t batches,
     uint32_t width, uint32_t height, int64_t batch_stride, int64_t elem_stride, float decay) {
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     // hits) and the first kDepth input rows per thread are requested BEFORE the histogram is cleared, and the
     // barriers order LDS traffic only (no s_waitcnt vmcnt(0)), so the L2 / Infinity-Cache round trips overlap the
     // clear and each other.
-    constexpr uint32_t kCells = 4;
+    constexpr uint32_t kCells = 4 * (kThreadsDefault / kThreads);  // 4096 cells (height 256 x 16 columns) in registers
     float state[kCells];
     float* cell[kCells];
 #pragma unroll
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     const float fh = (float)height;
     uint32_t* my_hist = hist + ((tid / TW) % COPIES) * copy_stride;
     constexpr uint32_t rows_per_iter = kThreads / TW;
-    constexpr uint32_t kDepth = 16;  // loads in flight per thread: the reads are latency bound
+    constexpr uint32_t kDepth = kDepthT;  // loads in flight per thread: the reads are latency bound
     const float* col = in + in_offset + (int64_t)(x < width ? x : 0) * elem_stride;
     float v[kDepth];
 #pragma unroll
@@ -151,24 +153,32 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
     const size_t lds = spectrogram_lds_bytes(height);
     const unsigned tiles16 = (unsigned)((width + 15) / 16), tiles8 = (unsigned)((width + 7) / 8);
     (void)hipGetLastError();  // drop any stale error: only this launch is judged
-#define JST_SPEC_LAUNCH(TW, COPIES, TILES)                                                        \
+#define JST_SPEC_LAUNCH(TW, COPIES, THREADS, DEPTH, TILES)                                         \
     do {                                                                                          \
         static bool raised = false;                                                               \
         if (!raised) { /* the padded copies can exceed the 64 KiB default by a few words */       \
             const hipError_t e = hipFuncSetAttribute(                                             \
-                reinterpret_cast<const void*>(spectrogram_kernel<TW, COPIES>),                    \
+                reinterpret_cast<const void*>(spectrogram_kernel<TW, COPIES, THREADS, DEPTH>),    \
                 hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                           \
             if (e != hipSuccess) return e;                                                        \
             raised = true;                                                                        \
         }                                                                                         \
-        hipLaunchKernelGGL((spectrogram_kernel<TW, COPIES>), dim3(TILES), dim3(kThreads), lds,    \
-                           stream, bins, in, in_offset, (uint32_t)batches, (uint32_t)width,       \
-                           (uint32_t)height, batch_stride, elem_stride, decay);                   \
+        hipLaunchKernelGGL((spectrogram_kernel<TW, COPIES, THREADS, DEPTH>), dim3(TILES),         \
+                           dim3(THREADS), lds, stream, bins, in, in_offset, (uint32_t)batches,    \
+                           (uint32_t)width, (uint32_t)height, batch_stride, elem_stride, decay);  \
     } while (0)
-    if (height <= 256) JST_SPEC_LAUNCH(16, 4, tiles16);
-    else if (height <= 512) JST_SPEC_LAUNCH(16, 2, tiles16);
-    else if (height <= 1024) JST_SPEC_LAUNCH(16, 1, tiles16);
-    else JST_SPEC_LAUNCH(8, 1, tiles8);
+    if (height <= 256) {
+        static const int threads = [] {  // A/B switch: JST_SPEC_THREADS=512|256 (fewer wavefronts to dispatch)
+            const char* e = getenv("JST_SPEC_THREADS");
+            return e ? atoi(e) : 1024;
+        }();
+        if (threads == 512) JST_SPEC_LAUNCH(16, 4, 512, 32, tiles16);
+        else if (threads == 256) JST_SPEC_LAUNCH(16, 4, 256, 32, tiles16);
+        else JST_SPEC_LAUNCH(16, 4, 1024, 16, tiles16);
+    }
+    else if (height <= 512) JST_SPEC_LAUNCH(16, 2, 1024, 16, tiles16);
+    else if (height <= 1024) JST_SPEC_LAUNCH(16, 1, 1024, 16, tiles16);
+    else JST_SPEC_LAUNCH(8, 1, 1024, 16, tiles8);
 #undef JST_SPEC_LAUNCH
     return hipGetLastError();
 }
