@@ -18,6 +18,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md
+
+
+def roofline(bytes_per_sample, samples_per_cycle, seconds_per_cycle, what):
+    """Whole-chain HBM roofline of a config: SURVEY 8(d)'s ALGORITHMIC bytes per input sample x the samples one cycle
+    processes / the measured cycle time, against the 8 TB/s spec peak."""
+    achieved = bytes_per_sample * samples_per_cycle / seconds_per_cycle / 1e9
+    return {"bound": "hbm", "bytes_per_sample": bytes_per_sample, "what": what, "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS}
+
+
 def timed(rt, cycles, warmup):
     import torch
     rt.compute(warmup, sync=True)
@@ -87,7 +98,8 @@ def run_c3(js, out, rng):
     dt = timed(rt, 20, 3)
     out.append({"config": "C3: Filter block 251 taps, /10, CF32[100,159750] (conv 160000 = 8*8*4*5^4)",
                 "ms_per_cycle": dt * 1e3, "MS_per_s_in": b * s / dt / 1e6, "plan": blk.plan,
-                "units": rt.units, "note": "FFT overlap-add: tiled 160000-pt FFT with the pad fused in, fold of the never-materialised product"})
+                "units": rt.units, "note": "FFT overlap-add: tiled 160000-pt FFT with the pad fused in, fold of the never-materialised product",
+                "roofline": roofline(32.0, b * s, dt, "FFT overlap-add view: forward transform 8 r + 8 w + 8 r, product/fold/inverse/overlap 8 (SURVEY 8d)")})
     exact = blk.buffer.numpy()
     rt.destroy()
     blk = js.Filter(src, sr, bw, [0.0], taps, 1, provider="fast")
@@ -99,7 +111,8 @@ def run_c3(js, out, rng):
     out.append({"config": "C3-fast: Filter block, provider fast = one direct-form polyphase FIR + /10 kernel",
                 "ms_per_cycle": dt * 1e3, "MS_per_s_in": b * s / dt / 1e6, "units": rt.units,
                 "max_err_vs_fft_chain_rel_peak": err,
-                "algorithmic_GBps": (b * s * 8 + b * s // 10 * 8) / dt / 1e9})
+                "algorithmic_GBps": (b * s * 8 + b * s // 10 * 8) / dt / 1e9,
+                "roofline": roofline(8.8, b * s, dt, "time-domain view: 8 B read + 0.8 B written per input sample (SURVEY 8d)")})
     rt.destroy()
 
 
@@ -120,6 +133,8 @@ def run_c4(js, out):
     out.append({"config": "C4: WBFM 20 MS/s -> Filter(/100) -> FM wide 75us -> Decimator(/4)",
                 "ms_per_cycle": dt * 1e3, "MS_per_s_in": b * s / dt / 1e6,
                 "audio_shape": list(dec.buffer.shape),
+                "roofline": roofline(8.0 + 0.08 * 32.0, b * s, dt, "channel filter 8 B read per input sample + the /100 chain; the FM "
+                                                                     "decode is latency bound (serial recurrences), not HBM bound"),
                 "note": "FM stereo decode = serial recurrences per lane (1 lane here), run as software-pipelined wavefront stages with DPP lane pipelines inside (fm_wide_kernel); 17.9 ms with the one-thread walk (JST_FM_SERIAL=1)"})
     rt.destroy()
     # the same decoder on many stations at once: lanes are independent workgroups
@@ -176,8 +191,10 @@ def run_c5(js, out, rng):
     dt = timed(rt, 50, 5)
     out.append({"config": "C5 (per GPU): Window -> 65536-pt FFT -> Amplitude -> Range -> Lineplot avg, 16 batches",
                 "us_per_cycle": dt * 1e6, "MS_per_s": b * n / dt / 1e6, "units": rt.units,
-                "note": "65536-pt FFT = 6 Stockham passes through HBM (not fused); PSD all-reduce is one "
-                        "256 KiB RCCL all-reduce per reporting interval (cyberether_amd/distributed.py)"})
+                "note": "65536-pt FFT = two LDS-tiled kernels (columns + blocks) with window / amplitude / range fused in; PSD "
+                        "all-reduce is one 256 KiB RCCL all-reduce per reporting interval (cyberether_amd/distributed.py)",
+                "roofline": roofline(28.0, b * n, dt, "two HBM passes: 8 r + 8 w + 8 r + 4 w per sample (SURVEY 8d); 1 Mi samples "
+                                                     "per cycle: launch/occupancy bound")})
     rt.destroy()
 
 
