@@ -172,6 +172,24 @@ jst_result jst_module_compute_submit(jst_module m, void* hip_stream);
 jst_result jst_module_compute_deinitialize(jst_module m);
 
 /* ---- runtime (src/runtime/native/cuda/impl.cc + src/scheduler_synchronous.cc) ------------ */
+/* Blocks are wiring: a C/C++ consumer of this header creates the MODULES a reference block expands to and hands
+ * them to one runtime (any order: the runtime orders them by data flow).  With JST_RUNTIME_FUSE the runtime
+ * replaces these module patterns by one kernel each -- only when the intermediates have no other consumer, the
+ * modules share a provider and follow each other in the data-flow order; otherwise the modules run one by one,
+ * with the same results:
+ *   spectrum_engine (spectrum_engine/block_impl.cc:120-217):
+ *       window{size=N} -> invert -> reshape{shape=[1,..,N]}            (STATIC: run once, then settled)
+ *       multiply{a = signal CF32[.., N], b = that window}  ->  fft{forward=true}  ->  amplitude  [-> range]
+ *     fused unit "spectrum_fused(multiply+fft+amplitude[+range])": needs multiply.b STATIC and broadcast along every
+ *     axis but the sample axis, fft forward on CF32, N a power of two in [256, 16384] or any length whose pocketfft
+ *     plan uses radices <= 11 (tiled kernels); a Spectrogram consuming the range output passes its height to the
+ *     "fast" provider's bin guard.
+ *   filter (filter/block_impl.cc:350-582), per the plan of CalculateCandidatePlan (:40-168):
+ *       pad -> fft                      fused: the zeros are synthesised in the transform's first load
+ *       multiply{fft output, taps spectrum} -> fold     fused: the broadcast product is never materialised
+ *       then fft{forward=false} -> unpad -> overlap_add -> multiply_constant [-> phase_correction]
+ *     provider "fast" on a single head centred on 0 Hz replaces the whole chain by fir_taps + fir_decimate.
+ * jst_runtime_units reports what was fused. */
 jst_result jst_runtime_create(const jst_module* modules, uint32_t n, uint32_t flags,
                               jst_runtime* out);
 jst_result jst_runtime_destroy(jst_runtime r);
