@@ -31,6 +31,9 @@ using namespace jst::dev;
 
 namespace {
 
+#ifndef JST_TILED_MIN_WAVES
+#define JST_TILED_MIN_WAVES 6  // wavefronts per SIMD the register budget must allow (80 VGPRs)
+#endif
 constexpr int kMaxThreads = 1024;  // workgroup size follows the tile: about 4 elements per thread
 constexpr uint32_t kTileElems = 8192;  // upper bound of a tile (64 KiB of LDS, one buffer: passes run in place)
 constexpr uint64_t kWantGroups = 1024; // enough workgroups to cover 256 CUs several times
@@ -138,6 +141,15 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
     return true;
 }
 
+// Workgroup b runs on XCD b % 8 (observed placement, used for speed only) and every XCD has an L2 of its own.
+// Neighbouring tiles share cache lines (a column tile's 128-byte runs start 8 bytes off the line grid whenever the
+// row length is odd in elements; a block tile writes 64-byte halves of 128-byte lines), so XCD k takes a CONTIGUOUS
+// run of tiles: the second touch of a line is an L2 hit / an L2 merge instead of a second HBM transaction.
+__device__ __forceinline__ uint32_t xcd_contiguous_tile(uint32_t b, uint32_t grid) {
+    const uint32_t q = grid >> 3, r = grid & 7u, k = b & 7u;
+    return k * q + (k < r ? k : r) + (b >> 3);
+}
+
 __device__ __forceinline__ void outer_bases(const FftLayout& L, uint64_t t, int64_t& in_base,
                                             int64_t& out_base) {
     in_base = (int64_t)L.in_offset;
@@ -231,7 +243,7 @@ __device__ __forceinline__ void tile_pass_any(uint32_t ip, float2* buf, const fl
 
 // ---- kernel A: passes 0..g-1 on CA adjacent columns ---------------------------------------------
 template <bool FWD, class Pro>
-__global__ __launch_bounds__(kMaxThreads, 6) void fft_tile_columns_kernel(const FftLayout L,
+__global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_columns_kernel(const FftLayout L,
                                                                     const TiledPlan P,
                                                                     const float2* __restrict__ W,
                                                                     const Pro pro,
@@ -239,16 +251,30 @@ __global__ __launch_bounds__(kMaxThreads, 6) void fft_tile_columns_kernel(const 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* buf0 = reinterpret_cast<float2*>(smem_raw);
     const uint32_t tiles_per_t = (P.S + P.CA - 1) >> P.ca_shift;
-    const uint64_t t = blockIdx.x / tiles_per_t;
-    const uint32_t c0 = (blockIdx.x % tiles_per_t) << P.ca_shift;
+    const uint32_t bid = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const uint64_t t = bid / tiles_per_t;
+    const uint32_t c0 = (bid % tiles_per_t) << P.ca_shift;
     const uint32_t live = (P.S - c0 < P.CA) ? (P.S - c0) : P.CA;
     const uint32_t tile = P.R1 << P.ca_shift;
     int64_t in_base, out_base;
     outer_bases(L, t, in_base, out_base);
-    for (uint32_t idx = threadIdx.x; idx < tile; idx += blockDim.x) {
-        const uint32_t r = idx >> P.ca_shift, col = idx & (P.CA - 1u);
-        if (col < live)
-            buf0[idx] = pro.template load<false>(in_base, L.in_axis_stride, (int)(c0 + col + P.S * r));
+    // Eight loads in flight per thread (a tile is at most 8 elements per thread): written as a plain loop, hipcc
+    // waits for every load before the LDS write that consumes it -- eight serial HBM round trips per workgroup
+    // (round 1: ~10 of the ~20 us a column workgroup lived).
+    for (uint32_t i0 = threadIdx.x; i0 < tile; i0 += 8 * blockDim.x) {
+        float2 v[8];
+        bool ok[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t idx = i0 + (uint32_t)k * blockDim.x;
+            const uint32_t r = idx >> P.ca_shift, col = idx & (P.CA - 1u);
+            ok[k] = idx < tile && col < live;
+            v[k] = mk(0.0f, 0.0f);
+            if (ok[k]) v[k] = pro.template load<false>(in_base, L.in_axis_stride, (int)(c0 + col + P.S * r));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (ok[k]) buf0[i0 + (uint32_t)k * blockDim.x] = v[k];
     }
     __syncthreads();
     uint32_t l1 = 1, m = P.R1;
@@ -268,7 +294,7 @@ __global__ __launch_bounds__(kMaxThreads, 6) void fft_tile_columns_kernel(const 
 
 // ---- kernel B: passes g..nf-1 on CB adjacent blocks (or whole transforms when g == 0) -----------
 template <bool FWD, class Pro, class Epi>
-__global__ __launch_bounds__(kMaxThreads, 6) void fft_tile_blocks_kernel(const FftLayout L,
+__global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blocks_kernel(const FftLayout L,
                                                                    const TiledPlan P,
                                                                    const float2* __restrict__ W,
                                                                    const Pro pro, const Epi epi,
@@ -280,13 +306,14 @@ __global__ __launch_bounds__(kMaxThreads, 6) void fft_tile_blocks_kernel(const F
     // R1 > 1: a tile is CB adjacent blocks of ONE transform; R1 == 1: CB adjacent transforms
     uint64_t t0;
     uint32_t k0, live;
+    const uint32_t bid = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     if (P.R1 > 1) {
         const uint32_t tiles_per_t = (P.R1 + P.CB - 1) >> P.cb_shift;
-        t0 = blockIdx.x / tiles_per_t;
-        k0 = (blockIdx.x % tiles_per_t) << P.cb_shift;
+        t0 = bid / tiles_per_t;
+        k0 = (bid % tiles_per_t) << P.cb_shift;
         live = (P.R1 - k0 < P.CB) ? (P.R1 - k0) : P.CB;
     } else {
-        t0 = (uint64_t)blockIdx.x << P.cb_shift;
+        t0 = (uint64_t)bid << P.cb_shift;
         k0 = 0;
         live = (uint32_t)((L.transforms - t0 < P.CB) ? (L.transforms - t0) : P.CB);
     }
