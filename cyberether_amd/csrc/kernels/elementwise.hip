@@ -5,6 +5,10 @@
 // Traversal: one thread per output element, grid-stride; flat index -> coordinates by a
 // mixed-radix decode over the common shape (row-major, like AutomaticIterator's odometer,
 // include/jetstream/tools/automatic_iterator.hh:207-231); dense operands skip the decode.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "device_math.hh"
 #include "kernels.hh"
 
@@ -350,6 +354,20 @@ hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipSt
     L.contiguous = 1;
     L.shape[0] = count;
     return run_unary(L, out, in, TanhProbe{}, s);
+}
+
+hipError_t raise_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> raised;  // (kernel, device) -> bytes granted
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = raised.find({kernel, dev});
+    if (it != raised.end() && it->second >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) raised[{kernel, dev}] = bytes;
+    return e;
 }
 
 }  // namespace jst::kernels

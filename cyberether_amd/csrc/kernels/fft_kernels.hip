@@ -34,12 +34,9 @@ hipError_t launch_pipe(const FftLayout& L, const float2* W, const Pro& pro, cons
     constexpr size_t lds = fft_pipe_lds_bytes(N);
     const bool contig = L.in_axis_stride == 1 && L.out_axis_stride == 1 && window_contig(pro);
     auto kernel = contig ? fft_pipe_kernel<N, FWD, true, Pro, Epi> : fft_pipe_kernel<N, FWD, false, Pro, Epi>;
-    static bool raised[2] = {false, false};
-    if (lds > 64 * 1024 && !raised[contig]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) {
+        const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
         if (e != hipSuccess) return e;
-        raised[contig] = true;
     }
     if (L.transforms == 0) return hipSuccess;
     // Resident workgroups: LDS allows floor(160 KiB / lds) per CU.  Give every resident
@@ -64,14 +61,8 @@ hipError_t launch_one(const FftLayout& L, const float2* W, const Pro& pro, const
     const bool contig = L.in_axis_stride == 1 && L.out_axis_stride == 1 && window_contig(pro);
     auto kernel = contig ? fft_lds_kernel<N, FWD, true, Pro, Epi> : fft_lds_kernel<N, FWD, false, Pro, Epi>;
     if constexpr (lds > 64 * 1024) {
-        static bool raised[2] = {false, false};  // per instantiation; the attribute is sticky
-        if (!raised[contig]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)lds);
-            if (e != hipSuccess) return e;
-            raised[contig] = true;
-        }
+        const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
+        if (e != hipSuccess) return e;
     }
     const uint64_t blocks_needed = (L.transforms + TPB - 1) / TPB;
     // Enough workgroups to occupy every CU several times over, grid-stride beyond that.

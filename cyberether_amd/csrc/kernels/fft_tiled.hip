@@ -391,13 +391,9 @@ hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W,
         if (!scratch) return hipErrorInvalidValue;
         const size_t lds_a = (size_t)P.R1 * P.CA * sizeof(float2);
         auto ka = fft_tile_columns_kernel<FWD, Pro>;
-        static bool raised_a = false;  // once per instantiation: tiles never exceed kTileElems
-        if (!raised_a) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ka),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)(kTileElems * sizeof(float2)));
+        {  // tiles never exceed kTileElems
+            const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(ka), (int)(kTileElems * sizeof(float2)));
             if (e != hipSuccess) return e;
-            raised_a = true;
         }
         const uint64_t blocks = L.transforms * ((P.S + P.CA - 1) / P.CA);
         if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
@@ -406,13 +402,9 @@ hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W,
     }
     const size_t lds_b = (size_t)P.S * (P.CB | 1u) * sizeof(float2);
     auto kb = fft_tile_blocks_kernel<FWD, Pro, Epi>;
-    static bool raised_b = false;  // pitch CB|1 adds at most one lane of padding per row
-    if (!raised_b) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kb),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)(2 * kTileElems * sizeof(float2)));
+    {  // pitch CB|1 adds at most one lane of padding per row
+        const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kb), (int)(2 * kTileElems * sizeof(float2)));
         if (e != hipSuccess) return e;
-        raised_b = true;
     }
     if (lds_b > 2 * kTileElems * sizeof(float2)) return hipErrorInvalidValue;
     const uint64_t blocks = P.R1 > 1 ? L.transforms * ((P.R1 + P.CB - 1) / P.CB)

@@ -306,12 +306,9 @@ hipError_t launch_fir_decimate(float2* out, const float2* in, const float* table
     const dim3 grid((unsigned)(rows * d.tiles_per_row));
 #define JST_FIR(JJ)                                                                                   \
     do {                                                                                              \
-        static bool raised = false;                                                                   \
-        if (!raised) {                                                                                \
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fir_decimate_kernel<JJ>), \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        {                                                                                             \
+            const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(fir_decimate_kernel<JJ>), 160 * 1024); \
             if (e != hipSuccess) return e;                                                            \
-            raised = true;                                                                            \
         }                                                                                             \
         hipLaunchKernelGGL((fir_decimate_kernel<JJ>), grid, dim3(threads), lds, s, out, in,           \
                            (const float2*)history, table, d);                           \

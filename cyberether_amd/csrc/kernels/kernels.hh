@@ -277,4 +277,8 @@ size_t fm_state_bytes();
 hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
                      hipStream_t s);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: remember it per (function,
+// device), not per process (a process that drives several GPUs raises it once on each).
+hipError_t raise_dynamic_lds(const void* kernel, int bytes);
+
 }  // namespace jst::kernels

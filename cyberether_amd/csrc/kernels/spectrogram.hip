@@ -155,13 +155,10 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
     (void)hipGetLastError();  // drop any stale error: only this launch is judged
 #define JST_SPEC_LAUNCH(TW, COPIES, THREADS, DEPTH, TILES)                                         \
     do {                                                                                          \
-        static bool raised = false;                                                               \
-        if (!raised) { /* the padded copies can exceed the 64 KiB default by a few words */       \
-            const hipError_t e = hipFuncSetAttribute(                                             \
-                reinterpret_cast<const void*>(spectrogram_kernel<TW, COPIES, THREADS, DEPTH>),    \
-                hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                           \
+        { /* the padded copies can exceed the 64 KiB default by a few words */                    \
+            const hipError_t e = raise_dynamic_lds(                                               \
+                reinterpret_cast<const void*>(spectrogram_kernel<TW, COPIES, THREADS, DEPTH>), 80 * 1024); \
             if (e != hipSuccess) return e;                                                        \
-            raised = true;                                                                        \
         }                                                                                         \
         hipLaunchKernelGGL((spectrogram_kernel<TW, COPIES, THREADS, DEPTH>), dim3(TILES),         \
                            dim3(THREADS), lds, stream, bins, in, in_offset, (uint32_t)batches,    \
