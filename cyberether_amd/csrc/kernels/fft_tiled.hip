@@ -24,6 +24,7 @@
 #include "kernels.hh"
 
 #include <cstring>
+#include <type_traits>
 
 namespace jst::kernels {
 
@@ -45,7 +46,11 @@ struct LoadCF32Padded {
     uint32_t valid;
     template <bool CONTIG>
     __device__ __forceinline__ float2 load(int64_t base, int64_t axis_stride, int pos) const {
-        return (uint32_t)pos < valid ? in[base + (int64_t)pos * axis_stride] : mk(0.0f, 0.0f);
+        // branch-free: a conditional load is a branch, and hipcc drains vmcnt at every such branch when eight of them
+        // are unrolled back to back (one HBM round trip per element); load a clamped position, select afterwards
+        const uint32_t p = (uint32_t)pos < valid ? (uint32_t)pos : (valid ? valid - 1u : 0u);
+        const float2 v = in[base + (int64_t)p * axis_stride];
+        return (uint32_t)pos < valid ? v : mk(0.0f, 0.0f);
     }
 };
 
@@ -265,12 +270,12 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_col
         float2 v[8];
         bool ok[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 8; ++k) {  // unconditional loads from clamped positions: no branch between them
             const uint32_t idx = i0 + (uint32_t)k * blockDim.x;
             const uint32_t r = idx >> P.ca_shift, col = idx & (P.CA - 1u);
             ok[k] = idx < tile && col < live;
-            v[k] = mk(0.0f, 0.0f);
-            if (ok[k]) v[k] = pro.template load<false>(in_base, L.in_axis_stride, (int)(c0 + col + P.S * r));
+            const uint32_t rc = r < P.R1 ? r : P.R1 - 1u, cc = col < live ? col : live - 1u;
+            v[k] = pro.template load<false>(in_base, L.in_axis_stride, (int)(c0 + cc + P.S * rc));
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k)
@@ -327,24 +332,28 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
     const uint32_t tile = P.S * live;
     // load: x fastest (contiguous in memory for both the dense scratch and a dense input row)
     const float2* blk = scratch + (t0 * P.R1 + k0) * P.S;  // only dereferenced when g > 0
-    for (uint32_t i0 = threadIdx.x; i0 < tile; i0 += 8 * blockDim.x) {  // eight loads in flight per thread
-        float2 v[8];
-        uint32_t slot[8];
+    // eight loads in flight per thread: unconditional loads from clamped indices (a conditional load is a branch and
+    // hipcc drains vmcnt at each of them), the g == 0 / g > 0 choice hoisted out of the unrolled body
+    auto load_tile = [&](auto from_scratch) {
+        for (uint32_t i0 = threadIdx.x; i0 < tile; i0 += 8 * blockDim.x) {
+            float2 v[8];
+            uint32_t slot[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t idx = i0 + (uint32_t)k * blockDim.x;
-            slot[k] = 0xffffffffu;
-            if (idx < tile) {
-                const uint32_t kb = idx / P.S, x = idx - kb * P.S;
-                if (P.g == 0) v[k] = pro.template load<false>(lane_in[kb], L.in_axis_stride, (int)x);
-                else v[k] = blk[idx];
-                slot[k] = x * pitch + kb;
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t idx = i0 + (uint32_t)k * blockDim.x;
+                const uint32_t cidx = idx < tile ? idx : tile - 1u;
+                const uint32_t kb = cidx / P.S, x = cidx - kb * P.S;
+                if constexpr (decltype(from_scratch)::value) v[k] = blk[cidx];
+                else v[k] = pro.template load<false>(lane_in[kb], L.in_axis_stride, (int)x);
+                slot[k] = idx < tile ? x * pitch + kb : 0xffffffffu;
             }
-        }
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (slot[k] != 0xffffffffu) buf0[slot[k]] = v[k];
-    }
+            for (int k = 0; k < 8; ++k)
+                if (slot[k] != 0xffffffffu) buf0[slot[k]] = v[k];
+        }
+    };
+    if (P.g == 0) load_tile(std::false_type{});
+    else load_tile(std::true_type{});
     __syncthreads();
     const float2* src = buf0;
     uint32_t l1 = P.R1, ido = P.S;
