@@ -41,7 +41,13 @@ __device__ __forceinline__ void lds_only_barrier() {
 // neighbouring batches tend to land in the SAME bin of a column (noise floor): with one copy
 // that is a 4-way same-address collision on nearly every instruction.  Copies are offset by 8
 // words so the four lanes of a column fall on different banks.
-template <int TW, int COPIES, int kThreads = kThreadsDefault, int kDepthT = 16>
+// BUF: the input rows are addressed through ONE buffer descriptor (SGPRs), one 32-bit per-lane offset shared by all
+// of a thread's loads and a wave-uniform row offset per load.  With flat 64-bit addresses the 16 loads in flight need
+// 32 address VGPRs on top of their 16 destinations -- more than a 1024-thread workgroup's 64-register budget leaves, so
+// hipcc recycled destination registers as addresses and drained vmcnt in front of the last four loads.  Rows at or
+// beyond `batches` and the columns of a ragged last tile fall outside the descriptor's range and read as 0 (which never
+// hits).  Used when the tensor spans < 2 GiB and its rows do not interleave; the flat form stays for everything else.
+template <int TW, int COPIES, int kThreads = kThreadsDefault, int kDepthT = 16, bool BUF = false>
 __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     float* __restrict__ bins, const float* __restrict__ in, uint64_t in_offset, uint32_t batches,
     uint32_t width, uint32_t height, int64_t batch_stride, int64_t elem_stride, float decay) {
@@ -82,10 +88,22 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     constexpr uint32_t kDepth = kDepthT;  // loads in flight per thread: the reads are latency bound
     const float* col = in + in_offset + (int64_t)(x < width ? x : 0) * elem_stride;
     float v[kDepth];
+    const uint32_t extent = BUF ? (uint32_t)(((int64_t)(batches - 1) * batch_stride + (int64_t)(width - 1) * elem_stride + 1) * 4) : 0u;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t r_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + in_offset), 0, extent, 0x00020000);
+    [[maybe_unused]] uint32_t voff = 0, row_step = 0;
+    if constexpr (BUF) {
+        voff = x < width ? (uint32_t)(((int64_t)x * elem_stride + (int64_t)(tid / TW) * batch_stride) * 4) : 0x7ffffff0u;
+        row_step = (uint32_t)((int64_t)rows_per_iter * batch_stride * 4);
 #pragma unroll
-    for (uint32_t j = 0; j < kDepth; ++j) {
-        const uint32_t b = tid / TW + j * rows_per_iter;
-        v[j] = (x < width && b < batches) ? col[(int64_t)b * batch_stride] : 0.0f;  // 0 never hits
+        for (uint32_t j = 0; j < kDepth; ++j)
+            v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_in, voff, j * row_step, 0));
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < kDepth; ++j) {
+            const uint32_t b = tid / TW + j * rows_per_iter;
+            v[j] = (x < width && b < batches) ? col[(int64_t)b * batch_stride] : 0.0f;  // 0 never hits
+        }
     }
     for (uint32_t e = tid * 4u; e < copy_stride * COPIES; e += kThreads * 4u) {  // copy_stride % 4 == 0
         *reinterpret_cast<uint4*>(hist + e) = make_uint4(0u, 0u, 0u, 0u);
@@ -95,10 +113,17 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     if (x < width) {
         for (uint32_t b0 = tid / TW; b0 < batches; b0 += rows_per_iter * kDepth) {
             if (b0 != tid / TW) {  // batches > rows_per_iter * kDepth: later rounds load here
+                if constexpr (BUF) {
+                    voff += kDepth * row_step;
 #pragma unroll
-                for (uint32_t j = 0; j < kDepth; ++j) {
-                    const uint32_t b = b0 + j * rows_per_iter;
-                    v[j] = (b < batches) ? col[(int64_t)b * batch_stride] : 0.0f;
+                    for (uint32_t j = 0; j < kDepth; ++j)
+                        v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_in, voff, j * row_step, 0));
+                } else {
+#pragma unroll
+                    for (uint32_t j = 0; j < kDepth; ++j) {
+                        const uint32_t b = b0 + j * rows_per_iter;
+                        v[j] = (b < batches) ? col[(int64_t)b * batch_stride] : 0.0f;
+                    }
                 }
             }
 #pragma unroll
@@ -153,16 +178,25 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
     const size_t lds = spectrogram_lds_bytes(height);
     const unsigned tiles16 = (unsigned)((width + 15) / 16), tiles8 = (unsigned)((width + 7) / 8);
     (void)hipGetLastError();  // drop any stale error: only this launch is judged
-#define JST_SPEC_LAUNCH(TW, COPIES, THREADS, DEPTH, TILES)                                         \
+#define JST_SPEC_LAUNCH_B(TW, COPIES, THREADS, DEPTH, TILES, BUFV)                                  \
     do {                                                                                          \
         { /* the padded copies can exceed the 64 KiB default by a few words */                    \
             const hipError_t e = raise_dynamic_lds(                                               \
-                reinterpret_cast<const void*>(spectrogram_kernel<TW, COPIES, THREADS, DEPTH>), 80 * 1024); \
+                reinterpret_cast<const void*>(spectrogram_kernel<TW, COPIES, THREADS, DEPTH, BUFV>), 80 * 1024); \
             if (e != hipSuccess) return e;                                                        \
         }                                                                                         \
-        hipLaunchKernelGGL((spectrogram_kernel<TW, COPIES, THREADS, DEPTH>), dim3(TILES),         \
+        hipLaunchKernelGGL((spectrogram_kernel<TW, COPIES, THREADS, DEPTH, BUFV>), dim3(TILES),   \
                            dim3(THREADS), lds, stream, bins, in, in_offset, (uint32_t)batches,    \
                            (uint32_t)width, (uint32_t)height, batch_stride, elem_stride, decay);  \
+    } while (0)
+    // dense-enough input for the one-descriptor form: non-negative strides, rows that do not interleave, < 2 GiB
+    const int64_t span = (int64_t)(batches ? batches - 1 : 0) * batch_stride + (int64_t)(width - 1) * elem_stride + 1;
+    const bool buf_ok = elem_stride >= 0 && batch_stride >= (int64_t)(width - 1) * elem_stride + 1 && batches > 0 &&
+                        span * 4 < (int64_t)0x7fff0000 && getenv("JST_SPEC_FLAT") == nullptr;
+#define JST_SPEC_LAUNCH(TW, COPIES, THREADS, DEPTH, TILES)                          \
+    do {                                                                            \
+        if (buf_ok) JST_SPEC_LAUNCH_B(TW, COPIES, THREADS, DEPTH, TILES, true);     \
+        else JST_SPEC_LAUNCH_B(TW, COPIES, THREADS, DEPTH, TILES, false);           \
     } while (0)
     if (height <= 256) {
         static const int threads = [] {  // A/B switch: JST_SPEC_THREADS=512|256 (fewer wavefronts to dispatch)
@@ -177,6 +211,7 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
     else if (height <= 1024) JST_SPEC_LAUNCH(16, 1, 1024, 16, tiles16);
     else JST_SPEC_LAUNCH(8, 1, 1024, 16, tiles8);
 #undef JST_SPEC_LAUNCH
+#undef JST_SPEC_LAUNCH_B
     return hipGetLastError();
 }
 
