@@ -94,8 +94,8 @@ def test_spectrogram_state_over_cycles_with_graph(js, oracle, pipeline):
     assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), ref_bins, "bins after new input")
 
 
-@pytest.mark.parametrize("pipeline", [False, True])
-def test_ring_source_period_and_graph(js, oracle, pipeline):
+@pytest.mark.parametrize("pipeline,timing", [(False, False), (True, False), (False, True)])
+def test_ring_source_period_and_graph(js, oracle, pipeline, timing):
     n, b, h, slots = 1024, 8, 64, 4
     src = js.Module("ring_source", {"batches": b, "samples": n, "slots": slots}, {}, "source")
     out = src.output("buffer")
@@ -107,7 +107,8 @@ def test_ring_source_period_and_graph(js, oracle, pipeline):
     eng = js.SpectrumEngine(out)
     spec = js.Module("spectrogram", {"height": h}, {"signal": eng.buffer}, "spectrogram")
     water = js.Module("waterfall", {"height": 16}, {"signal": eng.buffer}, "waterfall")
-    rt = js.Runtime([src] + eng.modules + [spec, water], graph=True, fuse=True, pipeline=pipeline)
+    # timing=True: one cycle of every fourth period runs eagerly between real event records, the rest as span graphs
+    rt = js.Runtime([src] + eng.modules + [spec, water], graph=True, fuse=True, pipeline=pipeline, timing=timing)
     assert rt.period == slots
     ring, wstate = np.zeros((16, n), np.float32), (0, 0)
     refs = [oracle.spectrum_chain(d, -100.0, 0.0)["range"] for d in data]
@@ -115,7 +116,7 @@ def test_ring_source_period_and_graph(js, oracle, pipeline):
     total = 0
     # whole-period replays mixed with heads and tails that do not fill a period: those replay as span graphs
     # (captured per (phase, length), replayed from the cache the second time: the source's host cursor must follow)
-    for chunk in (1, 3, 4, 8, 2, 4, 3, 3, 5, 2, 4, 7, 3, 3):
+    for chunk in (1, 3, 4, 8, 2, 4, 3, 3, 5, 2, 4, 7, 3, 3, 16, 9, 40):
         rt.compute(chunk)
         for _ in range(chunk):
             oracle.spectrogram(bins, refs[total % slots], h)
@@ -125,6 +126,8 @@ def test_ring_source_period_and_graph(js, oracle, pipeline):
         assert_bit_equal(eng.buffer.numpy(), refs[(total - 1) % slots], f"after {total} cycles")
         assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins, f"bins after {total}")
     assert rt.graph_active
+    if timing:
+        assert 0.0 < rt.unit_mean_ms("spectrum_fused") < 5.0 and spec.timing["cycles"] == total
 
 
 def test_full_size_properties(js, oracle):
