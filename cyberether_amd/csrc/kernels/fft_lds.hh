@@ -574,7 +574,18 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
             const int i = u & (IDO2 - 1), k = u / IDO2;
             const float2* rd = buf0 + phys(i + IDO2 * IP2 * k);
 #pragma unroll
-            for (int b = 0; b < IP2; ++b) x[j * IP2 + b] = rd[cphys(IDO2 * b)];
+            for (int b = 0; b < IP2; ++b) {
+#ifdef JST_LDS_READ2  // A/B switch: let the compiler pair the reads into ds_read2_b64
+                x[j * IP2 + b] = rd[cphys(IDO2 * b)];
+#else
+                // One ds_read_b64 per element: the load/store optimiser would pair these into ds_read2_b64, which the
+                // LDS serves at 128 B/clk against 256 B/clk for the single form (tools/ubench/lds_rate.hip: 27 vs 16
+                // clocks per wavefront for the eight elements of a butterfly).  A volatile access is never merged.
+                typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_u64_ptr;
+                const unsigned long long bits = *(lds_u64_ptr)(rd + cphys(IDO2 * b));
+                x[j * IP2 + b] = __builtin_bit_cast(float2, bits);
+#endif
+            }
         }
         pipe_passes<N, T, FWD, CONTIG, P + 1, Pro, Epi>(x, buf1, buf0, twr, twl, tid, out_base,
                                                         out_as, epi, pro, opnd, more, r_out,

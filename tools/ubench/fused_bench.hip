@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <vector>
 using namespace jst::dev;
 
@@ -144,6 +145,37 @@ int main(int argc, char** argv) {
     for (int i = 0; i < reps; ++i) launch(i % SLOTS);
     CK(hipEventRecord(b2, st)); CK(hipStreamSynchronize(st));
     float msbb; CK(hipEventElapsedTime(&msbb, a, b2));
+    // two (three) streams, alternating launches with no dependencies between them: does the tail of one launch overlap
+    // the ramp of the next when they sit on different hardware queues?  (outputs of their own; host clock)
+    for (int ns : {2, 3}) {
+        hipStream_t ss[3] = {st, nullptr, nullptr};
+        float* outs[3] = {out, nullptr, nullptr};
+        for (int q = 1; q < ns; ++q) { CK(hipStreamCreate(&ss[q])); CK(hipMalloc(&outs[q], B * N * 4)); }
+        auto launch_on = [&](int slot, int q) {
+            LoadCF32TimesWindow pro{in + (size_t)slot * B * N, win, 1};
+#ifdef FB_TRIVIAL_EPI
+            Epi epi{outs[q]};
+#else
+            Epi epi{outs[q], coeff, scale, offset, BinGuard{(FB_FAST && guard) ? 256.0f : 0.0f, 0.0f}};
+#endif
+            k<<<grid, N / 8, lds, ss[q]>>>(L, W, pro, epi);
+        };
+        for (int i = 0; i < 30; ++i) launch_on(i % SLOTS, i % ns);
+        CK(hipDeviceSynchronize());
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps * 4; ++i) launch_on(i % SLOTS, i % ns);
+        CK(hipDeviceSynchronize());
+        const double us_total = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        printf("%-28s %d streams alternating, no dependencies: %.2f us per launch (host clock, %d launches)\n", name, ns,
+               us_total / (reps * 4), reps * 4);
+    }
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps * 4; ++i) launch(i % SLOTS);
+        CK(hipDeviceSynchronize());
+        const double us_total = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        printf("%-28s 1 stream: %.2f us per launch (host clock, %d launches)\n", name, us_total / (reps * 4), reps * 4);
+    }
     // checksum of the output for slot 3 (fixed), order independent
     launch(3); CK(hipStreamSynchronize(st));
     checksum_kernel<<<1024, 256, 0, st>>>((const uint32_t*)out, B * N, acc);
