@@ -23,6 +23,7 @@
 #include "fft_radix.hh"
 #include "kernels.hh"
 
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -31,6 +32,19 @@ namespace jst::kernels {
 using namespace jst::dev;
 
 namespace {
+
+#ifdef JST_TILED_TIMELINE  // tools/ubench/tiled_timeline.hip: wall-clock stamps of workgroup phases
+__device__ unsigned long long* jst_tiled_tl = nullptr;
+// stamps go to LDS and reach memory in one piece at the end: a global store per stamp would sit in front of the next
+// __syncthreads (which waits for vmcnt(0)) and stretch every phase by a store round trip
+__shared__ unsigned long long jst_tiled_stamps[16];
+#define JST_TSTAMP(i) do { if (threadIdx.x == 0) jst_tiled_stamps[(i)] = wall_clock64(); } while (0)
+#define JST_TSTAMP_FLUSH() do { if (threadIdx.x == 0) { jst_tiled_stamps[15] = wall_clock64(); \
+    for (int q_ = 0; q_ < 16; ++q_) jst_tiled_tl[(size_t)blockIdx.x * 16 + q_] = jst_tiled_stamps[q_]; } } while (0)
+#else
+#define JST_TSTAMP(i) do {} while (0)
+#define JST_TSTAMP_FLUSH() do {} while (0)
+#endif
 
 #ifndef JST_TILED_MIN_WAVES
 #define JST_TILED_MIN_WAVES 6  // wavefronts per SIMD the register budget must allow (80 VGPRs)
@@ -58,6 +72,9 @@ struct TiledPlan {
     uint32_t n, nf, g, R1, S;
     uint32_t CA, CB;        // columns / blocks per workgroup: powers of two (ragged last tile)
     uint32_t ca_shift, cb_shift;
+    // kernel B's lanes as `CB / grp_w` groups of grp_w adjacent blocks, the groups grp_stride blocks apart (one group
+    // of CB adjacent blocks unless a fold epilogue needs the aliases of a bin in one workgroup: plan_fold_groups)
+    uint32_t grp_w, grp_stride, grp_shift;  // grp_w = 1 << grp_shift
     uint32_t fact[20];
     uint32_t magic[20];     // ceil(2^32 / local ido of pass p): exact quotients for x < 2^16
     uint32_t tw_off[20];    // start of pass p in the per-pass twiddle table (fft_pass_twiddle_*)
@@ -125,6 +142,9 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
     }
     p.ca_shift = ilog2(p.CA ? p.CA : 1);
     p.cb_shift = ilog2(p.CB);
+    p.grp_w = p.CB;
+    p.grp_stride = p.R1;
+    p.grp_shift = p.cb_shift;
     // local ido of every pass: passes < g run on R1-point columns, the rest on S-point blocks
     uint32_t m = p.R1;
     for (uint32_t q = 0; q < p.g; ++q) {
@@ -143,6 +163,46 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
         off += (uint64_t)(p.fact[q] - 1) * ido;
         l1 *= p.fact[q];
     }
+    return true;
+}
+
+// ---- Multiply -> Fold behind the last pass (filter/block_impl.cc:444-497: fftSignal -> multiply -> fold) -----------
+// fold (dsp/fold/module_impl_native_cpu.cc:103-172) sums the `decim` aliases idx = (m - off + g * fold) mod n of output
+// bin m, in F64, g ascending, and divides by decim; the addends are products spectrum[idx] * h[idx] formed with the
+// Multiply module's arithmetic.  Result q of block k of the second kernel sits at idx = k + R1 * q, so the aliases of a
+// bin live in the blocks k + g * (fold mod R1) (mod R1): an orbit of o = R1 / gcd(R1, fold mod R1) blocks, R1 / o apart.
+// A workgroup that holds whole orbits (CB / o adjacent blocks from each of the o groups) has every addend of its bins
+// in LDS: the spectrum (8 B per sample written and read again) and the product are never materialised.
+struct FoldProductEpi {
+    static constexpr bool kTile = true;
+    float2* out;             // dense [transforms, fold]
+    const float2* h;         // the other Multiply operand along the transform axis (broadcast over transforms)
+    int64_t h_stride;
+    uint32_t fold, decim;
+    uint32_t off;            // scalar offset (mod n) when chan_offsets == nullptr
+    const uint64_t* chan_offsets;
+    uint32_t chan_count, chan_div;  // channel of transform t = (t / chan_div) % chan_count
+    bool spectrum_first;     // operand order of the product
+    // idx += fold in tile coordinates (filled by the launcher from the plan): row += dq, block += dk (carry into the
+    // row at R1), lane group += grp_step (mod the number of groups); idx -= n is row -= nq
+    uint32_t dq, dk, nq, grp_step;
+};
+template <class E>
+constexpr bool is_tile_epilogue = requires { E::kTile; };
+
+bool plan_fold_groups(TiledPlan& p, uint64_t fold) {
+    if (fold == 0 || p.n % fold != 0 || p.n / fold > 64) return false;
+    if (p.R1 == 1) return true;  // whole transforms per lane: every alias is in the lane's own column
+    const uint32_t d = (uint32_t)(fold % p.R1);
+    uint32_t a = p.R1, b = d;
+    while (b) { const uint32_t t = a % b; a = b; b = t; }  // a = gcd(R1, d), gcd(R1, 0) = R1
+    const uint32_t o = p.R1 / a;
+    if (o > p.CB || p.CB % o != 0) return false;
+    const uint32_t w = p.CB / o, stride = p.R1 / o;
+    if (stride % w != 0) return false;  // every tile full, no group runs into the next
+    p.grp_w = w;
+    p.grp_stride = stride;
+    p.grp_shift = ilog2(w);
     return true;
 }
 
@@ -255,6 +315,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_col
                                                                     float2* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* buf0 = reinterpret_cast<float2*>(smem_raw);
+    JST_TSTAMP(0);
     const uint32_t tiles_per_t = (P.S + P.CA - 1) >> P.ca_shift;
     const uint32_t bid = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     const uint64_t t = bid / tiles_per_t;
@@ -282,6 +343,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_col
             if (ok[k]) buf0[i0 + (uint32_t)k * blockDim.x] = v[k];
     }
     __syncthreads();
+    JST_TSTAMP(1);  // tile loaded
     uint32_t l1 = 1, m = P.R1;
     for (uint32_t p = 0; p < P.g; ++p) {
         const uint32_t ip = P.fact[p];
@@ -289,12 +351,14 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_col
         tile_pass_any<FWD>(ip, buf0, W + P.tw_off[p], P.R1, P.ca_shift, live, P.CA, m, P.magic[p], l1,
                            m * P.S, P.S, c0, 1u);
         l1 *= ip;
+        JST_TSTAMP(2 + p);  // pass p done
     }
     float2* o = scratch + t * P.n;
     for (uint32_t idx = threadIdx.x; idx < tile; idx += blockDim.x) {
         const uint32_t r = idx >> P.ca_shift, col = idx & (P.CA - 1u);
         if (col < live) o[c0 + col + P.S * r] = buf0[idx];
     }
+    JST_TSTAMP_FLUSH();  // stores issued
 }
 
 // ---- kernel B: passes g..nf-1 on CB adjacent blocks (or whole transforms when g == 0) -----------
@@ -306,8 +370,10 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
                                                                    const float2* __restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ int64_t lane_in[32], lane_out[32];  // per lane of the tile: tensor row bases
+    __shared__ uint32_t lane_off[32];              // fold epilogue: per lane, the fold offset of its transform (mod n)
     const uint32_t pitch = P.CB | 1u;  // odd pitch: the x-major global loops stay conflict-free
     float2* buf0 = reinterpret_cast<float2*>(smem_raw);
+    JST_TSTAMP(0);
     // R1 > 1: a tile is CB adjacent blocks of ONE transform; R1 == 1: CB adjacent transforms
     uint64_t t0;
     uint32_t k0, live;
@@ -315,8 +381,8 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
     if (P.R1 > 1) {
         const uint32_t tiles_per_t = (P.R1 + P.CB - 1) >> P.cb_shift;
         t0 = bid / tiles_per_t;
-        k0 = (bid % tiles_per_t) << P.cb_shift;
-        live = (P.R1 - k0 < P.CB) ? (P.R1 - k0) : P.CB;
+        k0 = (bid % tiles_per_t) * P.grp_w;  // grp_w == CB unless the lanes are split into alias groups
+        live = P.grp_w != P.CB ? P.CB : ((P.R1 - k0 < P.CB) ? (P.R1 - k0) : P.CB);
     } else {
         t0 = (uint64_t)bid << P.cb_shift;
         k0 = 0;
@@ -327,9 +393,17 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
         outer_bases(L, P.R1 > 1 ? t0 : t0 + threadIdx.x, ib, ob);
         lane_in[threadIdx.x] = ib;
         lane_out[threadIdx.x] = ob;
+        if constexpr (is_tile_epilogue<Epi>) {  // 64-bit divisions: once per lane, not once per output bin
+            const uint64_t t = P.R1 > 1 ? t0 : t0 + threadIdx.x;
+            lane_off[threadIdx.x] = epi.chan_offsets
+                ? (uint32_t)(epi.chan_offsets[(t / epi.chan_div) % epi.chan_count] % P.n) : epi.off;
+        }
     }
     __syncthreads();
     const uint32_t tile = P.S * live;
+    // block of lane kb: CB adjacent blocks, or CB / grp_w groups of grp_w adjacent blocks grp_stride apart
+    const uint32_t grp_gap = P.grp_stride - P.grp_w;  // blocks skipped between two groups
+    auto block_of = [&](uint32_t kb) { return k0 + kb + (kb >> P.grp_shift) * grp_gap; };
     // load: x fastest (contiguous in memory for both the dense scratch and a dense input row)
     const float2* blk = scratch + (t0 * P.R1 + k0) * P.S;  // only dereferenced when g > 0
     // eight loads in flight per thread: unconditional loads from clamped indices (a conditional load is a branch and
@@ -343,7 +417,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
                 const uint32_t idx = i0 + (uint32_t)k * blockDim.x;
                 const uint32_t cidx = idx < tile ? idx : tile - 1u;
                 const uint32_t kb = cidx / P.S, x = cidx - kb * P.S;
-                if constexpr (decltype(from_scratch)::value) v[k] = blk[cidx];
+                if constexpr (decltype(from_scratch)::value) v[k] = blk[cidx + (kb >> P.grp_shift) * grp_gap * P.S];
                 else v[k] = pro.template load<false>(lane_in[kb], L.in_axis_stride, (int)x);
                 slot[k] = idx < tile ? x * pitch + kb : 0xffffffffu;
             }
@@ -355,6 +429,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
     if (P.g == 0) load_tile(std::false_type{});
     else load_tile(std::true_type{});
     __syncthreads();
+    JST_TSTAMP(1);  // tile loaded
     const float2* src = buf0;
     uint32_t l1 = P.R1, ido = P.S;
     for (uint32_t p = P.g; p < P.nf; ++p) {
@@ -363,7 +438,95 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
         tile_pass_any<FWD>(ip, buf0, W + P.tw_off[p], P.S, P.cb_shift, live, pitch, ido, P.magic[p],
                            l1 / P.R1, ido, 1u, 0u, 0u);
         l1 *= ip;
+        JST_TSTAMP(2 + (p - P.g));  // pass done
     }
+    if constexpr (is_tile_epilogue<Epi>) {
+        // Multiply -> Fold.  Phase 1: every element of the tile becomes its product with h, in place (all of a
+        // thread's h loads in flight before the first multiply).  Phase 2: one thread per output bin walks the bin's
+        // aliases through LDS -- idx += fold is (block group + grp_step, q + dq [+ carry]) with no division.
+        const uint32_t F = epi.fold, N = P.n;
+        const uint32_t elems = P.S << P.cb_shift;
+        for (uint32_t e0 = threadIdx.x; e0 < elems; e0 += 8 * blockDim.x) {
+            float2 hv[8];
+            uint32_t slot[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t e = e0 + (uint32_t)k * blockDim.x;
+                const uint32_t ec = e < elems ? e : elems - 1u;
+                const uint32_t kb = ec & (P.CB - 1u), q = ec >> P.cb_shift;
+                const uint32_t idx = P.R1 > 1 ? block_of(kb) + P.R1 * q : q;
+                hv[k] = epi.h[(int64_t)idx * epi.h_stride];
+                slot[k] = (e < elems && kb < live) ? q * pitch + kb : 0xffffffffu;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (slot[k] != 0xffffffffu)
+#ifdef JST_FOLD_EPI_PLAIN_CMUL
+                    buf0[slot[k]] = cmul(buf0[slot[k]], hv[k]);
+#else
+                    buf0[slot[k]] = epi.spectrum_first ? cmul_full(buf0[slot[k]], hv[k]) : cmul_full(hv[k], buf0[slot[k]]);
+#endif
+        }
+        __syncthreads();
+        const double divisor = (double)epi.decim;
+        const uint32_t per_lane = P.R1 > 1 ? (F + P.R1 - 1) / P.R1 : F;
+        const uint32_t total = per_lane << P.cb_shift;
+        const uint32_t groups = P.CB >> P.grp_shift;
+        for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+            const uint32_t kb = e & (P.CB - 1u), q = e >> P.cb_shift;
+            if (kb >= live) continue;
+            const uint32_t r = P.R1 > 1 ? block_of(kb) + P.R1 * q : q;
+            if (r >= F) continue;
+            const uint64_t t = P.R1 > 1 ? t0 : t0 + kb;
+            const uint32_t off = lane_off[kb];
+            const uint32_t off_q = off / F, off_r = off - off_q * F;
+            uint32_t m = r + off_r;  // output bin whose addends are the alias class of r
+            uint32_t steps = epi.decim - off_q;  // r is alias number `decim - steps` of bin m ...
+            if (m >= F) { m -= F; steps -= 1u; }
+            if (steps >= epi.decim) steps -= epi.decim;  // ... so the first addend (m - off) mod n is `steps` aliases on
+            uint32_t idx = m + N - off;
+            if (idx >= N) idx -= N;
+            // position of idx in the tile: row qq, block kk_low, lane group grp (lane `within` of the group never changes)
+            uint32_t qq = idx, grp = 0, kk_low = 0;
+            const uint32_t within = kb & (P.grp_w - 1u);
+            if (P.R1 > 1) {
+                qq = idx / P.R1;
+                kk_low = idx - qq * P.R1;
+                grp = ((kb >> P.grp_shift) + steps * epi.grp_step) & (groups - 1u);  // groups is a power of two
+            }
+            double sr = 0.0, si = 0.0;
+            auto advance = [&]() {  // (idx, qq, grp) of the next alias; returns the LDS slot of the current one
+                const uint32_t at = qq * pitch + (grp << P.grp_shift) + within;
+                idx += F;
+                qq += epi.dq;
+                if (P.R1 > 1) {
+                    kk_low += epi.dk;
+                    if (kk_low >= P.R1) { kk_low -= P.R1; qq += 1u; }
+                    grp += epi.grp_step;
+                    if (grp >= groups) grp -= groups;
+                }
+                if (idx >= N) { idx -= N; qq -= epi.nq; }
+                return at;
+            };
+            uint32_t g = 0;
+            for (; g + 5u <= epi.decim; g += 5u) {  // five LDS reads in flight, added in order
+                float2 pr[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) pr[u] = src[advance()];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    sr += (double)pr[u].x;
+                    si += (double)pr[u].y;
+                }
+            }
+            for (; g < epi.decim; ++g) {
+                const float2 pr = src[advance()];
+                sr += (double)pr.x;
+                si += (double)pr.y;
+            }
+            epi.out[t * F + m] = mk((float)(sr / divisor), (float)(si / divisor));
+        }
+    } else
     // store result q of block (t, k) at k + R1*q: block index fastest when R1 > 1 (adjacent k are
     // adjacent in memory), q fastest for whole transforms
     if (P.R1 > 1) {
@@ -372,7 +535,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
             const uint32_t kb = idx & (P.CB - 1u), q = idx >> P.cb_shift;
             if (kb < live)
                 epi.template store<false>(lane_out[kb], L.out_axis_stride,
-                                          (int)(k0 + kb + P.R1 * q), src[q * pitch + kb]);
+                                          (int)(block_of(kb) + P.R1 * q), src[q * pitch + kb]);
         }
     } else {
         for (uint32_t idx = threadIdx.x; idx < tile; idx += blockDim.x) {
@@ -380,6 +543,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
             epi.template store<false>(lane_out[kb], L.out_axis_stride, (int)q, src[q * pitch + kb]);
         }
     }
+    JST_TSTAMP_FLUSH();  // stores issued
 }
 
 // at least tile/8 threads (the in-place passes hold <= 8 points per thread); a multiple of 256 so
@@ -484,6 +648,30 @@ hipError_t launch_fft_c2c_tiled_padded(uint64_t n, uint64_t valid, bool forward,
     TiledPlan p;
     if (valid > n || !make_tiled_plan(n, L.transforms, p)) return hipErrorInvalidValue;
     return dispatch_dir(forward, p, L, W, LoadCF32Padded{in, (uint32_t)valid}, StoreCF32{out}, scratch, s);
+}
+
+bool fft_tiled_fold_supported(uint64_t n, uint64_t transforms, uint64_t fold) {
+    TiledPlan p;
+    return make_tiled_plan(n, transforms, p) && plan_fold_groups(p, fold);
+}
+
+hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,
+                                            const float2* W, const float2* in, float2* scratch,
+                                            const FoldProductArgs& f, hipStream_t s) {
+    TiledPlan p;
+    if (valid > n || !make_tiled_plan(n, L.transforms, p) || !plan_fold_groups(p, f.fold)) return hipErrorInvalidValue;
+    FoldProductEpi epi{f.out, f.h, f.h_stride, (uint32_t)f.fold, (uint32_t)(n / f.fold), (uint32_t)(f.offset % n),
+                       f.chan_offsets, (uint32_t)f.chan_count, (uint32_t)f.chan_div, f.spectrum_first, 0, 0, 0, 0};
+    if (p.R1 > 1) {
+        epi.dq = (uint32_t)(f.fold / p.R1);
+        epi.dk = (uint32_t)(f.fold % p.R1);
+        epi.nq = p.n / p.R1;
+        epi.grp_step = epi.dk / p.grp_stride;  // dk is a multiple of grp_stride = gcd(R1, dk) (0 when dk == 0)
+    } else {
+        epi.dq = (uint32_t)f.fold;
+        epi.nq = p.n;
+    }
+    return dispatch_dir(forward, p, L, W, LoadCF32Padded{in, (uint32_t)valid}, epi, scratch, s);
 }
 
 hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const float2* W,

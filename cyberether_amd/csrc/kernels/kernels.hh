@@ -94,6 +94,25 @@ hipError_t launch_fft_c2c_tiled(uint64_t n, bool forward, const FftLayout& L, co
 hipError_t launch_fft_c2c_tiled_padded(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,
                                        const float2* W, const float2* in, float2* out,
                                        float2* scratch, hipStream_t stream);
+// The same transform with Multiply -> Fold behind its last pass (filter/block_impl.cc:444-497): bin m of the output
+// is the F64 mean of the `n / fold` products spectrum[idx] * h[idx], idx = (m - offset + g * fold) mod n, g ascending
+// (dsp/fold/module_impl_native_cpu.cc:103-172); neither the spectrum nor the product is written.  `out` is dense
+// [transforms, fold]; `h` is addressed along the transform axis only (an operand broadcast over the transforms).
+// chan_offsets (device, optional): per-channel offsets, channel of transform t = (t / chan_div) % chan_count.
+struct FoldProductArgs {
+    float2* out;
+    const float2* h;
+    int64_t h_stride;
+    uint64_t fold, offset;
+    const uint64_t* chan_offsets;
+    uint64_t chan_count, chan_div;
+    bool spectrum_first;
+};
+bool fft_tiled_fold_supported(uint64_t n, uint64_t transforms, uint64_t fold);
+hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,
+                                            const float2* W, const float2* in, float2* scratch,
+                                            const FoldProductArgs& f, hipStream_t s);
+
 hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const float2* W,
                                        const float2* in, const float2* window,
                                        int64_t window_stride, float* out, float amp_coeff,

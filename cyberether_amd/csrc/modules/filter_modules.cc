@@ -1345,6 +1345,79 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
             !fft->input.contiguous() || fft->input.offset() != 0)
             return false;
         if (!fft->useTiled || fft->bluesteinSize != 0) return false;  // decided in computeInitialize
+        // ... -> multiply(spectrum, operand broadcast over the transforms) -> fold(last axis): the aliases of a bin
+        // meet in one workgroup of the transform's second kernel (kernels::FoldProductArgs); the spectrum and the
+        // product are never written
+        if (at + 3 < ordered.size()) {
+            auto* mul = dynamic_cast<Multiply*>(ordered[at + 2]);
+            auto* fold = dynamic_cast<Fold*>(ordered[at + 3]);
+            const auto whole_spectrum = [&](const Tensor& v) {
+                return v.storageId() == fft->output.storageId() && v.offset() == 0 && v.contiguous() &&
+                       v.shape() == fft->output.shape();
+            };
+            const auto broadcast_row = [&](const Tensor& v) {
+                if (v.dtype() != DataType::CF32 || v.rank() != fft->output.rank()) return false;
+                for (Index ax = 0; ax + 1 < v.rank(); ++ax)
+                    if (v.stride(ax) != 0 && v.shape(ax) != 1) return false;
+                return true;
+            };
+            bool ok = mul && fold && std::string(mul->type()) == "multiply" && fft->forward &&
+                      fft->output.contiguous() && fft->output.offset() == 0 &&
+                      sole_consumer(ordered, fft->output, mul) &&
+                      fold->input.storageId() == mul->c.storageId() && sole_consumer(ordered, mul->c, fold) &&
+                      mul->c.dtype() == DataType::CF32 && mul->c.shape() == fft->output.shape() &&
+                      fold->resolvedAxis + 1 == mul->c.rank() && fold->output.contiguous() &&
+                      std::getenv("JST_NO_FOLD_EPILOGUE") == nullptr;
+            bool spectrum_first = true;
+            if (ok) {
+                if (whole_spectrum(mul->a) && broadcast_row(mul->b)) spectrum_first = true;
+                else if (whole_spectrum(mul->b) && broadcast_row(mul->a)) spectrum_first = false;
+                else ok = false;
+            }
+            U64 chanCount = 1, chanDiv = 1;
+            if (ok && fold->channelAxis) {
+                U64 chanInner = 1;
+                chanCount = fold->output.shape(*fold->channelAxis);
+                for (Index i = *fold->channelAxis + 1; i < fold->output.rank(); ++i) chanInner *= fold->output.shape(i);
+                ok = chanInner % fold->size == 0;  // the channel of an output element depends on its transform only
+                chanDiv = ok ? chanInner / fold->size : 1;
+            }
+            const U64 n = fft->input.shape(axis);
+            ok = ok && kernels::fft_tiled_fold_supported(n, fft->input.size() / n, fold->size);
+            if (ok) {
+                members = {pad, fft, mul, fold};
+                consumed = 4;
+                name = "fft_padded_fold(" + pad->name() + "+" + fft->name() + "+" + mul->name() + "+" + fold->name() + ")";
+                submit = [pad, fft, mul, fold, axis, spectrum_first, chanCount, chanDiv, n](hipStream_t stream) -> Result {
+                    dev::FftLayout L;
+                    JST_CHECK(fft->layout(L));
+                    int r = 0;
+                    for (Index ax = 0; ax < pad->input.rank(); ++ax) {
+                        if (ax == axis) continue;
+                        L.in_outer_stride[r++] = (int64_t)pad->input.stride(ax);
+                    }
+                    L.in_axis_stride = (int64_t)pad->input.stride(axis);
+                    L.in_offset = pad->input.offset();
+                    const Tensor& h = spectrum_first ? mul->b : mul->a;
+                    kernels::FoldProductArgs f{};
+                    f.out = ptr<float2>(fold->output) + fold->output.offset();
+                    f.h = ptr<const float2>(h) + h.offset();
+                    f.h_stride = (int64_t)h.stride(axis);
+                    f.fold = fold->size;
+                    f.offset = fold->offset % n;
+                    f.chan_offsets = fold->channelAxis ? ptr<const uint64_t>(fold->devOffsets) : nullptr;
+                    f.chan_count = chanCount;
+                    f.chan_div = chanDiv;
+                    f.spectrum_first = spectrum_first;
+                    return hip_result(
+                        kernels::launch_fft_c2c_tiled_padded_fold(n, pad->input.shape(axis), true, L, fft->twiddles,
+                                                                  ptr<const float2>(pad->input),
+                                                                  ptr<float2>(fft->scratchA), f, stream),
+                        "fft (tiled, padded, multiply + fold epilogue) kernel");
+                };
+                return true;
+            }
+        }
         members = {pad, fft};
         consumed = 2;
         name = "fft_padded(" + pad->name() + "+" + fft->name() + ")";

@@ -34,10 +34,12 @@ def test_filter_block_matches_oracle_chain(js, oracle, case, fuse):
     assert plan == js.filter_plan(sr, bw, center, taps, heads, s)
     rt = js.Runtime(blk.modules, graph=True, fuse=fuse)
     units = rt.units
-    if fuse:  # pad -> fft and multiply -> fold collapse into one launch each (mixed-radix sizes)
+    if fuse:  # pad -> fft (-> multiply -> fold with one head) collapse into the tiled transform (mixed-radix sizes)
         conv_is_pow2 = plan["convolutionSize"] & (plan["convolutionSize"] - 1) == 0
-        assert any(u.startswith("fft_padded(") for u in units) == (not conv_is_pow2), units
-        assert any(u.startswith("fold_product(") for u in units) == plan["resample"], units
+        one_unit = plan["resample"] and heads == 1 and not conv_is_pow2
+        assert any(u.startswith("fft_padded_fold(") for u in units) == one_unit, units
+        assert any(u.startswith("fft_padded(") for u in units) == (not conv_is_pow2 and not one_unit), units
+        assert any(u.startswith("fold_product(") for u in units) == (plan["resample"] and not one_unit), units
     else:
         assert not any("(" in u for u in units)
     state = {}
@@ -87,3 +89,41 @@ def test_decimator_block(js, oracle, ratio):
     blk = js.Decimator(js.Tensor.from_numpy(c, batch=0, sample=1), ratio)
     js.Runtime(blk.modules).compute()
     assert_bit_equal(blk.buffer.numpy(), oracle.arithmetic_add(c.reshape(5, 120 // ratio, ratio), 2).reshape(5, -1))
+
+
+@pytest.mark.parametrize("n,valid,fold,offset,b", [
+    (2000, 1750, 200, 0, 5),        # one kernel (whole transforms per lane), /10
+    (2000, 1990, 500, 137, 3),      # /4 with a scalar offset
+    (6000, 5000, 6000, 17, 2),      # decimation 1: a pure rotation
+    (16000, 15750, 1600, 0, 3),     # two kernels: R1 = 128, 1600 mod 128 = 64 -> alias orbit of two block groups
+    (16000, 15000, 4000, 4321, 2),  # 4000 mod 128 = 32 -> orbit of four
+    (16000, 15000, 3200, 0, 2),     # 3200 mod 128 = 0 -> aliases in the bin's own block
+    (160000, 159750, 16000, 0, 2),  # SURVEY C3's transform: R1 = 256, orbit of two
+    (160000, 159750, 32000, 77777, 1),
+])
+@pytest.mark.parametrize("spectrum_first", [True, False])
+def test_fft_with_multiply_fold_epilogue(js, oracle, n, valid, fold, offset, b, spectrum_first):
+    """pad -> fft -> multiply -> fold as ONE unit (the fold's aliases meet in one workgroup of the tiled transform's
+    last kernel) against the oracle's composition of the four modules and against the unfused runtime."""
+    rng = np.random.default_rng(n + fold + offset)
+    x = csignal(rng, (b, valid))
+    h = csignal(rng, (1, n))
+    outs = {}
+    for fuse in (True, False):
+        src = js.Tensor.from_numpy(x, batch=0, sample=1)
+        hh = js.Tensor.from_numpy(h, batch=0, sample=1)
+        pad = js.Module("pad", {"size": n - valid, "axis": 1}, {"unpadded": src}, "pad")
+        fft = js.Module("fft", {"forward": True}, {"signal": pad.output("padded")}, "fft")
+        spec = fft.output("signal")
+        mul = js.Module("multiply", {}, {"a": spec, "b": hh} if spectrum_first else {"a": hh, "b": spec}, "mul")
+        fld = js.Module("fold", {"offset": offset, "size": fold},
+                        {"buffer": mul.output("product").set_axes(batch=0, sample=1)}, "fold")
+        rt = js.Runtime([pad, fft, mul, fld], graph=False, fuse=fuse)
+        assert any(u.startswith("fft_padded_fold(") for u in rt.units) == fuse, rt.units
+        rt.compute()
+        outs[fuse] = fld.output("buffer").numpy()
+    spec_ref = oracle.fft_c2c(oracle.pad(x, n - valid, 1))
+    prod = oracle.multiply(spec_ref, h) if spectrum_first else oracle.multiply(h, spec_ref)
+    ref = oracle.fold(prod, 1, fold, offset)
+    assert_bit_equal(outs[True], ref, "fused vs oracle")
+    assert_bit_equal(outs[False], ref, "unfused vs oracle")
