@@ -139,6 +139,8 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
         p.CA = pick_lanes(p.R1, transforms * p.S);
         p.CB = pick_lanes(p.S, transforms * p.R1);
         if (!p.CA || !p.CB) return false;
+        if (const char* e = getenv("JST_TILED_CB")) p.CB = (uint32_t)atoi(e);  // A/B switch
+        if (const char* e = getenv("JST_TILED_CA")) p.CA = (uint32_t)atoi(e);
     }
     p.ca_shift = ilog2(p.CA ? p.CA : 1);
     p.cb_shift = ilog2(p.CB);
@@ -189,6 +191,24 @@ struct FoldProductEpi {
 };
 template <class E>
 constexpr bool is_tile_epilogue = requires { E::kTile; };
+
+// ---- multiply_constant -> unpad behind the last pass (filter/block_impl.cc:499-560: ifft -> normalize -> unpad) -----
+// The launcher's layout makes `base` the transform index (unit stride over the flattened outer axes): positions below
+// body_len go to row `base` of the dense body tensor, the rest to row `base` of the dense tail tensor, each scaled
+// like core/multiply_constant (complex x real: two products).
+struct StoreScaledUnpad {
+    float2* body;
+    float2* tail;
+    float c;
+    uint32_t body_len, tail_len;
+    static constexpr uint32_t kElemBytes = 8;
+    template <bool CONTIG>
+    __device__ __forceinline__ void store(int64_t base, int64_t, int pos, float2 v) const {
+        const float2 r = mk(v.x * c, v.y * c);
+        if ((uint32_t)pos < body_len) body[base * (int64_t)body_len + pos] = r;
+        else tail[base * (int64_t)tail_len + ((uint32_t)pos - body_len)] = r;
+    }
+};
 
 bool plan_fold_groups(TiledPlan& p, uint64_t fold) {
     if (fold == 0 || p.n % fold != 0 || p.n / fold > 64) return false;
@@ -672,6 +692,23 @@ hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool for
         epi.nq = p.n;
     }
     return dispatch_dir(forward, p, L, W, LoadCF32Padded{in, (uint32_t)valid}, epi, scratch, s);
+}
+
+hipError_t launch_fft_c2c_tiled_scaled_unpad(uint64_t n, bool forward, const FftLayout& L, const float2* W,
+                                             const float2* in, float2* scratch, float2* body, float2* tail,
+                                             float constant, uint64_t body_len, hipStream_t s) {
+    TiledPlan p;
+    if (body_len > n || !make_tiled_plan(n, L.transforms, p)) return hipErrorInvalidValue;
+    FftLayout T = L;  // output side: `base` = transform index
+    int64_t stride = 1;
+    for (int a = T.outer_rank - 1; a >= 0; --a) {
+        T.out_outer_stride[a] = stride;
+        stride *= (int64_t)T.outer_shape[a];
+    }
+    T.out_offset = 0;
+    T.out_axis_stride = 0;
+    return dispatch_dir(forward, p, T, W, LoadCF32{in},
+                        StoreScaledUnpad{body, tail, constant, (uint32_t)body_len, (uint32_t)(n - body_len)}, scratch, s);
 }
 
 hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const float2* W,

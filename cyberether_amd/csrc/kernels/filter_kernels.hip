@@ -186,6 +186,40 @@ __global__ __launch_bounds__(kBlock) void overlap_state_kernel(T* __restrict__ p
     }
 }
 
+// The overlap region only: `out` already holds the buffer values (the fused inverse transform wrote them there).
+// One thread per overlap element; the thread of a first-batch element is the only one that touches its state entry,
+// so it reads it for the sum and then replaces it with the last batch's overlap.
+template <class T>
+__global__ __launch_bounds__(kBlock) void overlap_heads_kernel(T* __restrict__ out, const T* __restrict__ ovl,
+                                                               T* __restrict__ prev, const OlaLayout L,
+                                                               uint64_t total) {
+    JST_GRID_STRIDE(e, total) {  // e indexes the overlap tensor
+        uint64_t c[kMaxRank], rem = e;
+        for (int d = (int)L.rank - 1; d >= 0; --d) {
+            c[d] = rem % L.ovl_shape[d];
+            rem /= L.ovl_shape[d];
+        }
+        uint64_t bi = 0;  // the same coordinates in the buffer
+        for (uint32_t d = 0; d < L.rank; ++d) bi = bi * L.buf_shape[d] + c[d];
+        const bool first = L.batch_axis < 0 || c[L.batch_axis] == 0;
+        uint64_t idx = 0;
+        if (first) {
+            uint64_t last = 0;  // the last batch's overlap element with these coordinates
+            for (uint32_t d = 0; d < L.rank; ++d) {
+                const bool is_batch = (int)d == L.batch_axis;
+                idx = idx * (is_batch ? 1 : L.ovl_shape[d]) + (is_batch ? 0 : c[d]);
+                last = last * L.ovl_shape[d] + (is_batch ? L.ovl_shape[d] - 1 : c[d]);
+            }
+            out[bi] = add_t(out[bi], prev[idx]);
+            prev[idx] = ovl[last];
+        } else {
+            for (uint32_t d = 0; d < L.rank; ++d)
+                idx = idx * L.ovl_shape[d] + (((int)d == L.batch_axis) ? c[d] - 1 : c[d]);
+            out[bi] = add_t(out[bi], ovl[idx]);
+        }
+    }
+}
+
 // ---- PhaseCorrection (dsp/phase_correction/module_impl_native_cpu.cc:60-115) -----------------
 __global__ void phase_table_kernel(float2* __restrict__ corr, double* __restrict__ phases,
                                    const double* __restrict__ increments, uint64_t channels,
@@ -1162,6 +1196,28 @@ hipError_t launch_overlap_add(void* out, const void* buf, const void* ovl, void*
         hipLaunchKernelGGL(overlap_state_kernel<float>, dim3(grid_for(prev_total)), dim3(kBlock), 0,
                            s, (float*)prev, (const float*)ovl, L, prev_total);
     }
+    return hipGetLastError();
+}
+hipError_t launch_overlap_heads(void* out, const void* ovl, void* prev, bool complex, uint32_t rank,
+                                int32_t batch_axis, const uint64_t* buf_shape, const uint64_t* ovl_shape,
+                                hipStream_t s) {
+    OlaLayout L{};
+    L.rank = rank;
+    L.batch_axis = batch_axis;
+    uint64_t total = 1;
+    for (uint32_t d = 0; d < rank; ++d) {
+        L.buf_shape[d] = buf_shape[d];
+        L.ovl_shape[d] = ovl_shape[d];
+        total *= ovl_shape[d];
+    }
+    (void)hipGetLastError();
+    if (total == 0) return hipSuccess;
+    if (complex)
+        hipLaunchKernelGGL(overlap_heads_kernel<float2>, dim3(grid_for(total)), dim3(kBlock), 0, s, (float2*)out,
+                           (const float2*)ovl, (float2*)prev, L, total);
+    else
+        hipLaunchKernelGGL(overlap_heads_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (float*)out,
+                           (const float*)ovl, (float*)prev, L, total);
     return hipGetLastError();
 }
 hipError_t launch_phase_correction(const EwLayout& L, float2* out, const float2* in, float2* corr,

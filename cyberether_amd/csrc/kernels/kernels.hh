@@ -112,6 +112,13 @@ bool fft_tiled_fold_supported(uint64_t n, uint64_t transforms, uint64_t fold);
 hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,
                                             const float2* W, const float2* in, float2* scratch,
                                             const FoldProductArgs& f, hipStream_t s);
+// The transform with multiply_constant -> unpad behind its last pass (filter/block_impl.cc:499-560): element `pos` of
+// transform t, times `constant` (complex x real), goes to body[t * body_len + pos] when pos < body_len and to
+// tail[t * (n - body_len) + pos - body_len] otherwise; t counts the outer axes of L row-major.  L's output side is ignored.
+hipError_t launch_fft_c2c_tiled_scaled_unpad(uint64_t n, bool forward, const FftLayout& L, const float2* W,
+                                             const float2* in, float2* scratch, float2* body, float2* tail,
+                                             float constant, uint64_t body_len, hipStream_t s);
+
 
 hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const float2* W,
                                        const float2* in, const float2* window,
@@ -268,6 +275,13 @@ hipError_t launch_fir_decimate(float2* out, const float2* in, const float* table
 hipError_t launch_overlap_add(void* out, const void* buf, const void* ovl, void* prev, bool complex,
                               uint32_t rank, int32_t batch_axis, const uint64_t* buf_shape,
                               const uint64_t* ovl_shape, hipStream_t s);
+// overlap_add when `out` already holds the buffer (written there by the producer): only the overlap region is touched
+// -- out += previous overlap (first batch) / the previous batch's overlap -- and the state takes the last batch's
+// overlap, by the thread that read it.
+hipError_t launch_overlap_heads(void* out, const void* ovl, void* prev, bool complex, uint32_t rank,
+                                int32_t batch_axis, const uint64_t* buf_shape, const uint64_t* ovl_shape,
+                                hipStream_t s);
+
 hipError_t launch_phase_correction(const EwLayout& L, float2* out, const float2* in, float2* corr,
                                    double* phases, const double* increments, uint64_t batches,
                                    uint64_t batch_inner, uint64_t channels, uint64_t channel_inner,

@@ -1440,6 +1440,50 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
         };
         return true;
     }
+    // fft(inverse, tiled) -> multiply_constant -> unpad(same axis) -> overlap_add: the scale and the body / tail split
+    // ride on the transform's last store (the body lands in overlap_add's output), one small kernel then patches the
+    // overlap region and rolls the state
+    if (auto* fft = dynamic_cast<Fft*>(ordered[at])) {
+        if (at + 3 >= ordered.size()) return false;
+        auto* norm = dynamic_cast<MultiplyConstant*>(ordered[at + 1]);
+        auto* unpad = dynamic_cast<Unpad*>(ordered[at + 2]);
+        auto* ola = dynamic_cast<OverlapAdd*>(ordered[at + 3]);
+        if (!norm || !unpad || !ola || std::getenv("JST_NO_UNPAD_EPILOGUE")) return false;
+        const Index axis = fft->resolvedAxis;
+        if (fft->realInput || !fft->useTiled || fft->bluesteinSize != 0 || axis + 1 != fft->input.rank()) return false;
+        if (fft->input.dtype() != DataType::CF32 || fft->output.dtype() != DataType::CF32) return false;
+        if (norm->input.storageId() != fft->output.storageId() || !sole_consumer(ordered, fft->output, norm)) return false;
+        if (norm->input.shape() != fft->output.shape() || norm->input.offset() != fft->output.offset() ||
+            !norm->input.contiguous() || norm->output.dtype() != DataType::CF32)
+            return false;
+        if (unpad->input.storageId() != norm->output.storageId() || !sole_consumer(ordered, norm->output, unpad)) return false;
+        if (unpad->resolvedAxis != axis || unpad->input.shape() != fft->output.shape() || !unpad->input.contiguous()) return false;
+        if (ola->buffer.storageId() != unpad->body.storageId() || ola->overlap.storageId() != unpad->tail.storageId()) return false;
+        if (!sole_consumer(ordered, unpad->body, ola) || !sole_consumer(ordered, unpad->tail, ola)) return false;
+        if (ola->buffer.shape() != unpad->body.shape() || ola->overlap.shape() != unpad->tail.shape() ||
+            ola->buffer.offset() != 0 || ola->overlap.offset() != 0 || !ola->buffer.contiguous() ||
+            !ola->overlap.contiguous() || !ola->output.contiguous() || ola->output.offset() != 0)
+            return false;
+        members = {fft, norm, unpad, ola};
+        consumed = 4;
+        name = "ifft_unpad_overlap(" + fft->name() + "+" + norm->name() + "+" + unpad->name() + "+" + ola->name() + ")";
+        submit = [fft, norm, unpad, ola, axis](hipStream_t stream) -> Result {
+            dev::FftLayout L;
+            JST_CHECK(fft->layout(L));
+            const U64 n = fft->input.shape(axis);
+            JST_CHECK(hip_result(kernels::launch_fft_c2c_tiled_scaled_unpad(
+                                     n, fft->forward, L, fft->twiddles, ptr<const float2>(fft->input),
+                                     ptr<float2>(fft->scratchA), ptr<float2>(ola->output), ptr<float2>(unpad->tail),
+                                     norm->constant, unpad->body.shape(axis), stream),
+                                 "fft (tiled, multiply_constant + unpad epilogue) kernel"));
+            return hip_result(kernels::launch_overlap_heads(
+                                  ptr<char>(ola->output), ptr<char>(ola->overlap), ptr<char>(ola->previousOverlap), true,
+                                  (uint32_t)ola->buffer.rank(), ola->batchAxis ? (int32_t)*ola->batchAxis : -1,
+                                  ola->buffer.shape().data(), ola->overlap.shape().data(), stream),
+                              "overlap_add (overlap region) kernel");
+        };
+        return true;
+    }
     // multiply(CF32, broadcast) -> fold(last axis): fold reads the operands and forms the product
     if (auto* mul = dynamic_cast<Multiply*>(ordered[at])) {
         auto* fold = dynamic_cast<Fold*>(ordered[at + 1]);

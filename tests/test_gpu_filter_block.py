@@ -40,6 +40,11 @@ def test_filter_block_matches_oracle_chain(js, oracle, case, fuse):
         assert any(u.startswith("fft_padded_fold(") for u in units) == one_unit, units
         assert any(u.startswith("fft_padded(") for u in units) == (not conv_is_pow2 and not one_unit), units
         assert any(u.startswith("fold_product(") for u in units) == (plan["resample"] and not one_unit), units
+        # ifft -> normalize -> unpad -> overlap_add ride on the inverse transform's last store (no phase correction
+        # in between, mixed-radix length)
+        n_ifft = plan["resamplerSize"] if plan["resample"] else plan["convolutionSize"]
+        tail_unit = all(c == 0.0 for c in center) and n_ifft & (n_ifft - 1) != 0
+        assert any(u.startswith("ifft_unpad_overlap(") for u in units) == tail_unit, units
     else:
         assert not any("(" in u for u in units)
     state = {}
