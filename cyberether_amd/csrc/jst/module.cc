@@ -672,9 +672,10 @@ Result Runtime::compute(U64 cycles, bool sync) {
         // does not capture whole periods: the first cycle of every period runs EAGERLY between real event records
         // (same kernels, same stream, back to back with the graphs) and the other period - 1 cycles replay as a
         // span graph.  (Round 1's "in-graph" unit timers were in fact fed by the eager cycles between replays.)
-        // Every kTimedPeriodStride-th period is timed that way (the eager cycle costs ~1.5 us of launch gaps); the
+        // Every kTimedPeriodStride-th period is timed that way (the eager cycle costs ~1.5 us of launch gaps and a
+        // pair of event packets per unit: at every fourth period that was 1.5 % of the step); the
         // periods in between replay as one graph, captured from phase 0 without event records.
-        const U64 kTimedPeriodStride = period_ > 1 ? 4 : 16;
+        const U64 kTimedPeriodStride = period_ > 1 ? 16 : 64;
         const bool timed_periods = timing && !pipelined();
         const bool aligned0 = (cycles_ % period_) == 0;
         const bool timed_now = timed_periods && aligned0 && untimed_run_ + 1 >= kTimedPeriodStride;

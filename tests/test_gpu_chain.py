@@ -107,7 +107,7 @@ def test_ring_source_period_and_graph(js, oracle, pipeline, timing):
     eng = js.SpectrumEngine(out)
     spec = js.Module("spectrogram", {"height": h}, {"signal": eng.buffer}, "spectrogram")
     water = js.Module("waterfall", {"height": 16}, {"signal": eng.buffer}, "waterfall")
-    # timing=True: one cycle of every fourth period runs eagerly between real event records, the rest as span graphs
+    # timing=True: one cycle of every sixteenth period runs eagerly between real event records, the rest as span graphs
     rt = js.Runtime([src] + eng.modules + [spec, water], graph=True, fuse=True, pipeline=pipeline, timing=timing)
     assert rt.period == slots
     ring, wstate = np.zeros((16, n), np.float32), (0, 0)
