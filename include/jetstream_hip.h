@@ -187,7 +187,14 @@ jst_result jst_module_compute_deinitialize(jst_module m);
  *   filter (filter/block_impl.cc:350-582), per the plan of CalculateCandidatePlan (:40-168):
  *       pad -> fft                      fused: the zeros are synthesised in the transform's first load
  *       multiply{fft output, taps spectrum} -> fold     fused: the broadcast product is never materialised
- *       then fft{forward=false} -> unpad -> overlap_add -> multiply_constant [-> phase_correction]
+ *       pad -> fft -> multiply -> fold  ONE unit "fft_padded_fold(..)" when the transform runs on the LDS-tiled kernels
+ *                                       (mixed-radix length), one head (the taps spectrum is broadcast over the
+ *                                       transforms) and the fold's aliases fit one workgroup: neither the spectrum
+ *                                       nor the product is written
+ *       fft{forward=false} -> multiply_constant -> unpad -> overlap_add     ONE unit "ifft_unpad_overlap(..)" (tiled
+ *                                       transform, no phase_correction in between): scale and body / tail split on
+ *                                       the transform's last store, one small kernel for the overlap region + state
+ *       [multiply_constant -> phase_correction ->] unpad -> overlap_add otherwise
  *     provider "fast" on a single head centred on 0 Hz replaces the whole chain by fir_taps + fir_decimate.
  * jst_runtime_units reports what was fused. */
 jst_result jst_runtime_create(const jst_module* modules, uint32_t n, uint32_t flags,
