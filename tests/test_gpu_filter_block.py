@@ -132,3 +132,48 @@ def test_fft_with_multiply_fold_epilogue(js, oracle, n, valid, fold, offset, b, 
     ref = oracle.fold(prod, 1, fold, offset)
     assert_bit_equal(outs[True], ref, "fused vs oracle")
     assert_bit_equal(outs[False], ref, "unfused vs oracle")
+
+
+@pytest.mark.parametrize("shape,axes,size", [
+    ((3, 2, 2000), dict(batch=0, channel=1, sample=2), 250),   # one kernel (whole transforms per lane)
+    ((2, 1, 16000), dict(batch=0, channel=1, sample=2), 25),   # two kernels (columns + blocks)
+    ((3, 600), dict(channel=0, sample=1), 40),                 # no batch axis: every row adds its own state
+    ((1, 6000), dict(batch=0, sample=1), 2999),                # overlap nearly as long as the body
+])
+def test_inverse_fft_with_unpad_overlap_epilogue(js, oracle, shape, axes, size):
+    """fft(inverse) -> multiply_constant -> unpad -> overlap_add as ONE unit (scale and body / tail split on the tiled
+    transform's last store, one kernel over the overlap region that also rolls the state) against the oracle's
+    composition and the unfused runtime, over cycles (state carried across submissions and batches)."""
+    rng = np.random.default_rng(sum(shape) + size)
+    n = shape[-1]
+    batch_axis = axes.get("batch")
+    c = float(np.float32(1.0) / np.float32(n))
+    runs = {}
+    for fuse in (True, False):
+        src = js.Tensor.create("hip", "CF32", shape).set_axes(**axes)
+        ifft = js.Module("fft", {"forward": False}, {"signal": src}, "ifft")
+        norm = js.Module("multiply_constant", {"constant": c}, {"factor": ifft.output("signal")}, "normalize")
+        unp = js.Module("unpad", {"size": size, "axis": len(shape) - 1},
+                        {"padded": norm.output("product").set_axes(**axes)}, "unpad")
+        ola = js.Module("overlap_add", {}, {"buffer": unp.output("unpadded").set_axes(**axes),
+                                            "overlap": unp.output("pad").set_axes(**axes)}, "overlap")
+        rt = js.Runtime([ifft, norm, unp, ola], graph=True, fuse=fuse)
+        assert any(u.startswith("ifft_unpad_overlap(") for u in rt.units) == fuse, rt.units
+        runs[fuse] = (src, ola, rt)
+    pshape = list(shape)
+    pshape[-1] = size
+    if batch_axis is not None:
+        pshape[batch_axis] = 1
+    prev = np.zeros(pshape, np.complex64)
+    for cycle in range(3):
+        x = csignal(rng, shape)
+        y = oracle.fft_c2c(x, forward=False)
+        y = (y.view(np.float32) * np.float32(c)).view(np.complex64)   # complex x real: two products
+        body, tail = oracle.unpad(y, size, len(shape) - 1)
+        ref, prev = oracle.overlap_add(body, tail, prev, batch_axis)
+        for fuse in (True, False):
+            src, ola, rt = runs[fuse]
+            src.copy_from(x)
+            rt.compute()
+            assert_bit_equal(ola.output("buffer").numpy(), ref, f"cycle {cycle} fuse={fuse}")
+            assert_bit_equal(ola.state("previousOverlap").numpy(), prev, f"state, cycle {cycle} fuse={fuse}")
