@@ -230,6 +230,22 @@ using StoreAmplitudeRange = StoreAmplitudeRangeT<false>;
 
 constexpr int cphys(int q) { return q + (q >> 3); }
 
+// The pipelined kernel's exchange layout: TWO pad elements per 16 (same footprint).  Its writes are 16-lane groups of
+// consecutive butterflies (ds_write_b64: four groups of 16 lanes, banks = element mod 16): with one pad per 8 a group
+// straddles a pad slot and its first and last lane meet on a bank -- every group of every write took two LDS cycles
+// (96 of the 112 conflict cycles per wavefront and transform that SQ_LDS_BANK_CONFLICT counted for N = 4096).  With
+// the pads at multiples of 16 an aligned group of 16 is contiguous: writes and the ido = 8 reads are conflict-free,
+// the contiguous reads keep their one extra cycle per 32-lane group and the ido = 1 reads (stride 8) gain one:
+// 32 conflict cycles instead of 112, no extra instruction (base + compile-time offsets as before: no carry into
+// bit 4 between a base and its in-butterfly offsets for power-of-two plans).
+#ifdef JST_LDS_PAD8  // A/B switch: the one-pad-per-8 layout
+__device__ __forceinline__ int pphys(int p) { return p + (p >> 3); }
+constexpr int pcphys(int q) { return q + (q >> 3); }
+#else
+__device__ __forceinline__ int pphys(int p) { return p + ((p >> 4) << 1); }
+constexpr int pcphys(int q) { return q + ((q >> 4) << 1); }
+#endif
+
 // ---- one Stockham pass -----------------------------------------------------------------------
 // Butterfly u in [0, N/IP): i = u % IDO, k = u / IDO.
 //   reads  CC(i,b,k) = src[i + IDO*(b + IP*k)]         (pocketfft.hh CC macro)
@@ -557,9 +573,9 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                 }
             }
         } else {
-            float2* wr = buf0 + phys(u);
+            float2* wr = buf0 + pphys(u);
 #pragma unroll
-            for (int c = 0; c < IP; ++c) wr[cphys(c * BUT)] = y[c];
+            for (int c = 0; c < IP; ++c) wr[pcphys(c * BUT)] = y[c];
         }
     }
     JST_STAMP(2 + 2 * P);  // pass P computed, results issued to LDS / HBM
@@ -572,17 +588,17 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
         for (int j = 0; j < NB2; ++j) {
             const int u = tid + j * T;
             const int i = u & (IDO2 - 1), k = u / IDO2;
-            const float2* rd = buf0 + phys(i + IDO2 * IP2 * k);
+            const float2* rd = buf0 + pphys(i + IDO2 * IP2 * k);
 #pragma unroll
             for (int b = 0; b < IP2; ++b) {
 #ifdef JST_LDS_READ2  // A/B switch: let the compiler pair the reads into ds_read2_b64
-                x[j * IP2 + b] = rd[cphys(IDO2 * b)];
+                x[j * IP2 + b] = rd[pcphys(IDO2 * b)];
 #else
                 // One ds_read_b64 per element: the load/store optimiser would pair these into ds_read2_b64, which the
                 // LDS serves at 128 B/clk against 256 B/clk for the single form (tools/ubench/lds_rate.hip: 27 vs 16
                 // clocks per wavefront for the eight elements of a butterfly).  A volatile access is never merged.
                 typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_u64_ptr;
-                const unsigned long long bits = *(lds_u64_ptr)(rd + cphys(IDO2 * b));
+                const unsigned long long bits = *(lds_u64_ptr)(rd + pcphys(IDO2 * b));
                 x[j * IP2 + b] = __builtin_bit_cast(float2, bits);
 #endif
             }
