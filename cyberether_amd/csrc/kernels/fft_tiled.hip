@@ -481,11 +481,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (slot[k] != 0xffffffffu)
-#ifdef JST_FOLD_EPI_PLAIN_CMUL
-                    buf0[slot[k]] = cmul(buf0[slot[k]], hv[k]);
-#else
                     buf0[slot[k]] = epi.spectrum_first ? cmul_full(buf0[slot[k]], hv[k]) : cmul_full(hv[k], buf0[slot[k]]);
-#endif
         }
         __syncthreads();
         const double divisor = (double)epi.decim;
