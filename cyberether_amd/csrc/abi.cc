@@ -422,6 +422,24 @@ jst_result jst_runtime_synchronize(jst_runtime r) {
 void* jst_runtime_stream(jst_runtime r) { return r ? r->rt.stream() : nullptr; }
 uint64_t jst_runtime_period(jst_runtime r) { return r ? r->rt.period() : 0; }
 int jst_runtime_graph_active(jst_runtime r) { return r && r->rt.graphActive() ? 1 : 0; }
+jst_result jst_filter_plan(float sample_rate, float bandwidth, const float* center, uint64_t centers,
+                           uint64_t taps, uint64_t heads, uint64_t signal_size, jst_filter_plan_desc* plan,
+                           uint64_t* offsets) {
+    JST_ARG(plan && (center || centers == 0) && (offsets || heads == 0) && taps > 0, "invalid filter plan arguments");
+    jst::modules::FilterPlan p;
+    const Result r = jst::modules::CalculateFilterPlan(sample_rate, bandwidth,
+                                                       std::vector<float>(center, center + centers), taps, heads,
+                                                       signal_size, p);
+    if (r != Result::SUCCESS) return R(r);
+    plan->pad_size = p.padSize;
+    plan->convolution_size = p.convolutionSize;
+    plan->resampler_size = p.resamplerSize;
+    plan->resample = p.resample ? 1 : 0;
+    plan->resampled_sample_rate = p.resampledSampleRate;
+    for (uint64_t h = 0; h < heads; ++h) offsets[h] = h < p.resamplerOffsets.size() ? p.resamplerOffsets[h] : 0;
+    return R(Result::SUCCESS);
+}
+
 size_t jst_runtime_order(jst_runtime r, char* buffer, size_t capacity) {
     return r ? join_lines(r->rt.order(), buffer, capacity) : 0;
 }

@@ -1318,6 +1318,55 @@ class SignalGenerator : public Module {
     U64 bufferSize = 8192;
 };
 
+// ---- the Filter block's plan (filter/block_impl.cc:40-168) -------------------------------------------
+Result CalculateFilterPlan(F32 sampleRate, F32 bandwidth, const std::vector<F32>& center, U64 taps, U64 heads,
+                           U64 signalSize, FilterPlan& plan) {
+    plan = FilterPlan{};
+    plan.padSize = taps - 1;
+    // taps + (signalSize - 1) must fit U64 (the block refuses the configuration otherwise)
+    if (signalSize == 0 || taps > ~0ull - (signalSize - 1)) {
+        JST_ERROR("[BLOCK_FILTER] Combined signal and filter extent exceeds the supported range.");
+        return Result::ERROR;
+    }
+    const U64 conv = taps + (signalSize - 1);
+    plan.convolutionSize = conv;
+    // resampling needs an integer ratio that divides both the pad and the convolution; anything else is a bypass
+    const F64 sr = sampleRate, bw = bandwidth;
+    const F64 ratio = sr / bw;
+    const F64 two64 = std::ldexp(1.0, 64);
+    if (!std::isfinite(ratio) || !(ratio > 0.0) || ratio >= two64 || ratio != std::floor(ratio)) return Result::SUCCESS;
+    const U64 r = (U64)ratio;
+    if (plan.padSize % r != 0 || conv % r != 0) return Result::SUCCESS;
+    // per head: the fold starts at minus the centre bin, wrapped into [0, conv)
+    plan.resamplerOffsets.assign(heads, 0);
+    const F64 binWidth = sr / (F64)conv;
+    for (U64 h = 0; h < heads; ++h) {
+        const F64 ct = h < center.size() ? (F64)center[h] : 0.0;
+        if (ct == 0.0) continue;
+        const F64 bin = ct / binWidth;
+        if (!std::isfinite(bin)) {
+            JST_ERROR("[BLOCK_FILTER] Center frequency (%g) cannot be mapped to a finite resampler bin.", ct);
+            return Result::ERROR;
+        }
+        const F64 start = -std::round(bin);  // half away from zero
+        if (std::fabs(start) >= two64) {
+            JST_ERROR("[BLOCK_FILTER] Center frequency (%g) cannot be mapped to a representable resampler bin.", ct);
+            return Result::ERROR;
+        }
+        if (start < 0.0) {
+            const U64 rem = (U64)(-start) % conv;
+            plan.resamplerOffsets[h] = rem ? conv - rem : 0;
+        } else {
+            plan.resamplerOffsets[h] = (U64)std::fmod((long double)start, (long double)conv);
+        }
+    }
+    plan.resamplerSize = conv / r;
+    plan.padSize /= r;
+    plan.resampledSampleRate = (F32)(sr / (F64)r);
+    plan.resample = true;
+    return Result::SUCCESS;
+}
+
 // ---- fusion hooks for the Filter block's chain (filter/block_impl.cc:350-582) --------------------
 namespace {
 bool sole_consumer(const std::vector<Module*>& ordered, const Tensor& t, const Module* consumer) {

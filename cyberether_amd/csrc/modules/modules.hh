@@ -35,6 +35,18 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
                    std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
                    size_t& consumed);
 
+// The Filter block's plan (src/domains/dsp/filter/block_impl.cc:40-168, CalculateCandidatePlan): how long the
+// convolution is, whether the block resamples by spectral folding and, if so, each head's fold offset.  Host logic of
+// the block, kept next to the modules it wires so that a C / C++ consumer of the C ABI does not have to re-derive it.
+struct FilterPlan {
+    U64 padSize = 0, convolutionSize = 0, resamplerSize = 0;
+    bool resample = false;
+    F32 resampledSampleRate = 0.0f;
+    std::vector<U64> resamplerOffsets;  // one per head when resample
+};
+Result CalculateFilterPlan(F32 sampleRate, F32 bandwidth, const std::vector<F32>& center, U64 taps, U64 heads,
+                           U64 signalSize, FilterPlan& plan);
+
 // src/domains/dsp/window/{module_impl.cc, module_impl_native_cpu.cc, module_impl_native_cuda.cc}
 class Window : public Module {
  public:

@@ -550,41 +550,28 @@ class SpectrumEngine:
         return ms
 
 
+class _FilterPlanDesc(C.Structure):
+    _fields_ = [("pad_size", C.c_uint64), ("convolution_size", C.c_uint64), ("resampler_size", C.c_uint64),
+                ("resample", C.c_int32), ("resampled_sample_rate", C.c_float)]
+
+
+_sig("jst_filter_plan", C.c_uint16, C.c_float, C.c_float, C.POINTER(C.c_float), C.c_uint64, C.c_uint64, C.c_uint64,
+     C.c_uint64, C.POINTER(_FilterPlanDesc), C.POINTER(C.c_uint64))
+
+
 def filter_plan(sample_rate: float, bandwidth: float, center: Sequence[float], taps: int,
                 heads: int, signal_size: int) -> dict:
-    """CalculateCandidatePlan (src/domains/dsp/filter/block_impl.cc:40-168): convolution size,
-    whether the block resamples (fold), per-head fold offsets (integers), pad size."""
-    import math
-    sr = float(np.float32(sample_rate))  # the block config holds F32 (filter/block.hh)
-    bw = float(np.float32(bandwidth))
-    plan = {"padSize": taps - 1, "convolutionSize": taps + signal_size - 1, "resample": False,
-            "resamplerOffsets": [], "resamplerSize": 0, "resampledSampleRate": 0.0}
-    conv = plan["convolutionSize"]
-    ratio = sr / bw
-    if not math.isfinite(ratio) or ratio <= 0 or ratio >= 2.0 ** 64 or ratio != math.floor(ratio):
-        return plan
-    r = int(ratio)
-    if plan["padSize"] % r != 0 or conv % r != 0:
-        return plan
-    offsets = [0] * heads
-    per_bin = sr / float(conv)
-    for head in range(heads):
-        ct = float(np.float32(center[head])) if head < len(center) else 0.0
-        if ct == 0.0:
-            continue
-        center_bin = ct / per_bin
-        rounded = float(np.round(center_bin))  # std::round: half away from zero
-        if abs(center_bin - math.trunc(center_bin)) == 0.5:
-            rounded = math.trunc(center_bin) + math.copysign(1.0, center_bin)
-        fold_offset_bin = -rounded
-        if fold_offset_bin < 0.0:
-            rem = int(-fold_offset_bin) % conv
-            offsets[head] = 0 if rem == 0 else conv - rem
-        else:
-            offsets[head] = int(math.fmod(fold_offset_bin, float(conv)))
-    plan.update(resamplerOffsets=offsets, resamplerSize=conv // r, padSize=plan["padSize"] // r,
-                resampledSampleRate=float(np.float32(sr / float(r))), resample=True)
-    return plan
+    """CalculateCandidatePlan (src/domains/dsp/filter/block_impl.cc:40-168): convolution size, whether the block
+    resamples (fold), per-head fold offsets (integers), pad size -- computed by the library (jst_filter_plan; host
+    logic in csrc/modules/filter_modules.cc), this is only the ctypes call."""
+    ctr = (C.c_float * max(len(center), 1))(*[float(c) for c in center])
+    offs = (C.c_uint64 * max(heads, 1))()
+    d = _FilterPlanDesc()
+    _check(_lib.jst_filter_plan(float(sample_rate), float(bandwidth), ctr, len(center), int(taps), int(heads),
+                                int(signal_size), C.byref(d), offs))
+    return {"padSize": int(d.pad_size), "convolutionSize": int(d.convolution_size), "resample": bool(d.resample),
+            "resamplerOffsets": [int(offs[h]) for h in range(heads)] if d.resample else [],
+            "resamplerSize": int(d.resampler_size), "resampledSampleRate": float(d.resampled_sample_rate)}
 
 
 class Filter:

@@ -171,6 +171,21 @@ jst_result jst_module_compute_initialize(jst_module m);
 jst_result jst_module_compute_submit(jst_module m, void* hip_stream);
 jst_result jst_module_compute_deinitialize(jst_module m);
 
+/* ---- block plans ----------------------------------------------------------------------------- */
+/* The Filter block's plan (src/domains/dsp/filter/block_impl.cc:40-168, CalculateCandidatePlan): convolution size,
+ * whether the block resamples by spectral folding, the pad size after resampling and one fold offset per head.  A
+ * consumer wiring the block's modules itself (see the runtime notes below) configures pad / fold / unpad from it.
+ * sample_rate, bandwidth and center are F32 like the block's config (filter/block.hh); offsets: `heads` entries
+ * (all 0 when the plan does not resample). */
+typedef struct jst_filter_plan_desc {
+    uint64_t pad_size, convolution_size, resampler_size;
+    int32_t resample;
+    float resampled_sample_rate;
+} jst_filter_plan_desc;
+jst_result jst_filter_plan(float sample_rate, float bandwidth, const float* center, uint64_t centers,
+                           uint64_t taps, uint64_t heads, uint64_t signal_size, jst_filter_plan_desc* plan,
+                           uint64_t* offsets);
+
 /* ---- runtime (src/runtime/native/cuda/impl.cc + src/scheduler_synchronous.cc) ------------ */
 /* Blocks are wiring: a C/C++ consumer of this header creates the MODULES a reference block expands to and hands
  * them to one runtime (any order: the runtime orders them by data flow).  With JST_RUNTIME_FUSE the runtime

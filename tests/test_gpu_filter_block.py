@@ -69,16 +69,6 @@ def test_filter_block_matches_oracle_chain(js, oracle, case, fuse):
             assert np.max(np.abs(got_stream - full)) <= 1e-5 * max(1.0, np.max(np.abs(full)))
 
 
-def test_resampling_plan_integers():
-    import cyberether_amd.jetstream as js
-    p = js.filter_plan(20e6, 2e6, [0.0], 251, 1, 159750)
-    assert (p["convolutionSize"], p["resample"], p["resamplerSize"], p["padSize"]) == (160000, True, 16000, 25)
-    p = js.filter_plan(20e6, 2e6, [0.0, 3.0e6, -5.0e6], 101, 3, 900)
-    assert p["resamplerOffsets"] == [0, 850, 250] and p["resamplerSize"] == 100
-    assert not js.filter_plan(2e6, 0.7e6, [0.0], 65, 1, 960)["resample"]     # non-integer ratio
-    assert not js.filter_plan(20e6, 2e6, [0.0], 101, 1, 905)["resample"]     # conv % 10 != 0
-
-
 @pytest.mark.parametrize("ratio", [2, 4, 10])
 def test_decimator_block(js, oracle, ratio):
     rng = np.random.default_rng(ratio)
