@@ -463,7 +463,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                                             const float2* twl, int tid, int64_t out_base,
                                             int64_t out_as, const Epi& epi, const Pro& pro,
                                             float2 (&opnd)[8], bool more, rsrc_t r_out,
-                                            rsrc_t r_opnd JST_TL_ARG) {
+                                            rsrc_t r_opnd, bool young JST_TL_ARG) {
     constexpr Plan plan = make_plan(N);
     constexpr TwPlan tp = make_twplan(N);
     constexpr int IP = plan.ip[P], IDO = plan.ido[P];
@@ -486,7 +486,6 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
         // The second workgroup of a CU (dispatched ~1.5-2.5 us after the first: blockIdx >= grid/2 with two resident
         // workgroups per CU) holds the YOUNGER wavefronts, which lose every VALU arbitration tie against the older
         // workgroup's: left alone it finishes ~5 us after its neighbour and runs that stretch at half occupancy.
-        const bool young = blockIdx.x >= (gridDim.x >> 1);
         if constexpr (P == 0) {
             if (young) __builtin_amdgcn_s_setprio(JST_PRIO_PB);
             else __builtin_amdgcn_s_setprio(JST_PRIO_PA);
@@ -605,7 +604,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
         }
         pipe_passes<N, T, FWD, CONTIG, P + 1, Pro, Epi>(x, buf1, buf0, twr, twl, tid, out_base,
                                                         out_as, epi, pro, opnd, more, r_out,
-                                                        r_opnd JST_TL_PASS);
+                                                        r_opnd, young JST_TL_PASS);
     }
 }
 
@@ -614,9 +613,11 @@ constexpr size_t fft_pipe_lds_bytes(int n) {
     return (2 * (size_t)lds_elems(n) + (size_t)make_twplan(n).lds_entries) * sizeof(float2);
 }
 
+// The kernel's body as a device function of (workgroup index, workgroup count): the plain kernel below passes
+// blockIdx.x / gridDim.x, a launch that carries other work beside the transforms passes its own numbering.
 template <int N, bool FWD, bool CONTIG, class Pro, class Epi>
-__global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 256) void fft_pipe_kernel(
-    const FftLayout L, const float2* __restrict__ W, const Pro pro, const Epi epi) {
+__device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* __restrict__ W, const Pro& pro,
+                                              const Epi& epi, const uint32_t bid, const uint32_t grid) {
     constexpr int T = N / 8;
     constexpr Plan plan = make_plan(N);
     constexpr TwPlan tp = make_twplan(N);
@@ -673,8 +674,9 @@ __global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 2
         pos0[j] = (u & (IDO0 - 1)) + IDO0 * IP0 * (u / IDO0);
     }
 
-    uint64_t t = blockIdx.x;
+    uint64_t t = bid;
     if (t >= L.transforms) return;
+    const bool young = bid >= (grid >> 1);
     int64_t in_base, out_base;
     fft_bases(L, t, in_base, out_base);
     float2 raw[8], opnd[8];
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 2
         for (int e = 0; e < 8; ++e) x[e] = pro.apply(raw[e], opnd[e]);
         JST_STAMP(1);  // input arrived + prologue applied
         // prefetch the next transform of this workgroup while this one is computed
-        const uint64_t tn = t + gridDim.x;
+        const uint64_t tn = t + grid;
         const bool more = tn < L.transforms;
         int64_t nin = 0, nout = 0;
         if constexpr (CONTIG) {
@@ -737,16 +739,16 @@ __global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 2
 #ifdef JST_FB_SKIP_PASSES  // decomposition experiment (tools/ubench/fused_bench.hip): last pass + epilogue only
         pipe_passes<N, T, FWD, CONTIG, plan.nf - 1, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
                                                               L.out_axis_stride, epi, pro, opnd,
-                                                              more, r_out, r_opnd_next JST_TL_PASS);
+                                                              more, r_out, r_opnd_next, young JST_TL_PASS);
 #else
         if (flip)
             pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufB, bufA, twr, twl, tid, out_base,
                                                         L.out_axis_stride, epi, pro, opnd,
-                                                        more, r_out, r_opnd_next JST_TL_PASS);
+                                                        more, r_out, r_opnd_next, young JST_TL_PASS);
         else
             pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
                                                         L.out_axis_stride, epi, pro, opnd,
-                                                        more, r_out, r_opnd_next JST_TL_PASS);
+                                                        more, r_out, r_opnd_next, young JST_TL_PASS);
 #endif
 #ifdef JST_FFT_TIMELINE
         ++tl_it;
@@ -757,6 +759,12 @@ __global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 2
         t = tn;
         out_base = nout;
     }
+}
+
+template <int N, bool FWD, bool CONTIG, class Pro, class Epi>
+__global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 256) void fft_pipe_kernel(
+    const FftLayout L, const float2* __restrict__ W, const Pro pro, const Epi epi) {
+    fft_pipe_body<N, FWD, CONTIG, Pro, Epi>(L, W, pro, epi, blockIdx.x, gridDim.x);
 }
 
 constexpr int fft_threads_per_transform(int n) { return n >= 16 ? n / 16 : 1; }

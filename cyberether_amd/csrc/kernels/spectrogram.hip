@@ -47,10 +47,12 @@ __device__ __forceinline__ void lds_only_barrier() {
 // hipcc recycled destination registers as addresses and drained vmcnt in front of the last four loads.  Rows at or
 // beyond `batches` and the columns of a ragged last tile fall outside the descriptor's range and read as 0 (which never
 // hits).  Used when the tensor spans < 2 GiB and its rows do not interleave; the flat form stays for everything else.
+// The body as a device function of (workgroup index, workgroup count), see fft_pipe_body.
 template <int TW, int COPIES, int kThreads = kThreadsDefault, int kDepthT = 16, bool BUF = false>
-__global__ __launch_bounds__(kThreads) void spectrogram_kernel(
+__device__ __forceinline__ void spectrogram_body(
     float* __restrict__ bins, const float* __restrict__ in, uint64_t in_offset, uint32_t batches,
-    uint32_t width, uint32_t height, int64_t batch_stride, int64_t elem_stride, float decay) {
+    uint32_t width, uint32_t height, int64_t batch_stride, int64_t elem_stride, float decay,
+    const uint32_t bid, const uint32_t grid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);  // [height][TW]
 
@@ -62,8 +64,8 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
     // of its own.  Tiles t and t+1 share each 128-byte line of a row (TW * 4 = 64 bytes per tile), so they go to
     // the SAME XCD: XCD k takes the contiguous run of tiles [k * tiles/8, (k+1) * tiles/8) and pulls every line
     // of its column band from the Infinity Cache once instead of twice.
-    uint32_t tile = blockIdx.x;
-    if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    uint32_t tile = bid;
+    if ((grid & 7u) == 0u) tile = (bid & 7u) * (grid >> 3) + (bid >> 3);
 
     // Nothing below depends on the histogram until the LDS atomics: the state tile (not touched by this cycle's
     // hits) and the first kDepth input rows per thread are requested BEFORE the histogram is cleared, and the
@@ -169,6 +171,14 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
         float* p = bins + (uint64_t)(e / TW) * width + xx;
         *p = apply(*p, hits(e));
     }
+}
+
+template <int TW, int COPIES, int kThreads = kThreadsDefault, int kDepthT = 16, bool BUF = false>
+__global__ __launch_bounds__(kThreads) void spectrogram_kernel(
+    float* __restrict__ bins, const float* __restrict__ in, uint64_t in_offset, uint32_t batches,
+    uint32_t width, uint32_t height, int64_t batch_stride, int64_t elem_stride, float decay) {
+    spectrogram_body<TW, COPIES, kThreads, kDepthT, BUF>(bins, in, in_offset, batches, width, height, batch_stride,
+                                                        elem_stride, decay, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
