@@ -93,6 +93,10 @@ def test_decimator_block(js, oracle, ratio):
     (16000, 15750, 1600, 0, 3),     # two kernels: R1 = 128, 1600 mod 128 = 64 -> alias orbit of two block groups
     (16000, 15000, 4000, 4321, 2),  # 4000 mod 128 = 32 -> orbit of four
     (16000, 15000, 3200, 0, 2),     # 3200 mod 128 = 0 -> aliases in the bin's own block
+    (20000, 19000, 2000, 0, 2),     # R1 = 8*4*5 = 160 (not a power of two): 2000 mod 160 = 80 -> orbit of two
+    (20000, 19990, 5000, 1234, 2),  # 5000 mod 160 = 40 -> orbit of four, offset
+    (20000, 19000, 1000, 7, 3),     # 1000 mod 160 = 40, /20
+    (50000, 49000, 5000, 49999, 1), # R1 = 400: 5000 mod 400 = 200 -> orbit of two, offset n - 1
     (160000, 159750, 16000, 0, 2),  # SURVEY C3's transform: R1 = 256, orbit of two
     (160000, 159750, 32000, 77777, 1),
 ])
