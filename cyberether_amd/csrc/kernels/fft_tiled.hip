@@ -139,8 +139,11 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
         p.CA = pick_lanes(p.R1, transforms * p.S);
         p.CB = pick_lanes(p.S, transforms * p.R1);
         if (!p.CA || !p.CB) return false;
-        if (const char* e = getenv("JST_TILED_CB")) p.CB = (uint32_t)atoi(e);  // A/B switch
-        if (const char* e = getenv("JST_TILED_CA")) p.CA = (uint32_t)atoi(e);
+        // A/B switches (read once): lanes per workgroup of the two kernels, powers of two
+        static const uint32_t force_cb = [] { const char* e = getenv("JST_TILED_CB"); return e ? (uint32_t)atoi(e) : 0u; }();
+        static const uint32_t force_ca = [] { const char* e = getenv("JST_TILED_CA"); return e ? (uint32_t)atoi(e) : 0u; }();
+        if (force_cb) p.CB = force_cb;
+        if (force_ca) p.CA = force_ca;
     }
     p.ca_shift = ilog2(p.CA ? p.CA : 1);
     p.cb_shift = ilog2(p.CB);
@@ -201,7 +204,6 @@ struct StoreScaledUnpad {
     float2* tail;
     float c;
     uint32_t body_len, tail_len;
-    static constexpr uint32_t kElemBytes = 8;
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t, int pos, float2 v) const {
         const float2 r = mk(v.x * c, v.y * c);

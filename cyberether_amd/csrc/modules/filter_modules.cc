@@ -1382,6 +1382,9 @@ bool sole_consumer(const std::vector<Module*>& ordered, const Tensor& t, const M
 bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& name,
                    std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
                    size_t& consumed) {
+    // A/B switches (read once): keep the two-kernel forms of the forward / inverse side
+    static const bool no_fold_epilogue = std::getenv("JST_NO_FOLD_EPILOGUE") != nullptr;
+    static const bool no_unpad_epilogue = std::getenv("JST_NO_UNPAD_EPILOGUE") != nullptr;
     if (at + 1 >= ordered.size()) return false;
     // pad(last axis) -> fft(same axis): the padded tensor is only ever read by the transform
     if (auto* pad = dynamic_cast<Pad*>(ordered[at])) {
@@ -1416,7 +1419,7 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
                       fold->input.storageId() == mul->c.storageId() && sole_consumer(ordered, mul->c, fold) &&
                       mul->c.dtype() == DataType::CF32 && mul->c.shape() == fft->output.shape() &&
                       fold->resolvedAxis + 1 == mul->c.rank() && fold->output.contiguous() &&
-                      std::getenv("JST_NO_FOLD_EPILOGUE") == nullptr;
+                      !no_fold_epilogue;
             bool spectrum_first = true;
             if (ok) {
                 if (whole_spectrum(mul->a) && broadcast_row(mul->b)) spectrum_first = true;
@@ -1497,7 +1500,7 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
         auto* norm = dynamic_cast<MultiplyConstant*>(ordered[at + 1]);
         auto* unpad = dynamic_cast<Unpad*>(ordered[at + 2]);
         auto* ola = dynamic_cast<OverlapAdd*>(ordered[at + 3]);
-        if (!norm || !unpad || !ola || std::getenv("JST_NO_UNPAD_EPILOGUE")) return false;
+        if (!norm || !unpad || !ola || no_unpad_epilogue) return false;
         const Index axis = fft->resolvedAxis;
         if (fft->realInput || !fft->useTiled || fft->bluesteinSize != 0 || axis + 1 != fft->input.rank()) return false;
         if (fft->input.dtype() != DataType::CF32 || fft->output.dtype() != DataType::CF32) return false;
