@@ -93,6 +93,15 @@ constexpr int lds_elems(int n) { return n + (n >> 3); }
 // wave-uniform (SGPR/immediate) offset per access.  With flat addressing hipcc materialises a
 // 64-bit VGPR address pair per access and carries them through the transform loop.
 using rsrc_t = __amdgpu_buffer_rsrc_t;
+// Cache policy of the kernels' output stores (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1).  sc1 = AGENT scope: the
+// store is written through to the device-coherent level as it is issued.  With the default (wave scope) the 16 MiB of
+// a launch's output sit dirty in the eight per-XCD L2s until the end-of-kernel release writes them back, and that
+// write-back is serial time at the end of every launch: 24.0 -> 22.3 us per 1024 x 4096 launch by events, step
+// 29.3 -> 27.5 us, same box (profiles/r02_experiments/r_store_policy.log).  nt (streaming) shortens the kernel as
+// much but evicts the lines, and the Spectrogram that reads them next pays it back (9.6 -> 11.0 us).
+#ifndef JST_STORE_AUX
+#define JST_STORE_AUX 16
+#endif
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
@@ -103,10 +112,10 @@ __device__ __forceinline__ float2 buf_load_f2(rsrc_t r, uint32_t voff_bytes, uin
 }
 __device__ __forceinline__ void buf_store_f2(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, float2 v) {
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b64(v2u{f2u(v.x), f2u(v.y)}, r, voff_bytes, soff_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(v2u{f2u(v.x), f2u(v.y)}, r, voff_bytes, soff_bytes, JST_STORE_AUX);
 }
 __device__ __forceinline__ void buf_store_f1(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(f2u(v), r, voff_bytes, soff_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(f2u(v), r, voff_bytes, soff_bytes, JST_STORE_AUX);
 }
 
 // ---- prologues (how pass 0 obtains CC(i,b,k)) -------------------------------------------------
