@@ -102,6 +102,19 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 #ifndef JST_STORE_AUX
 #define JST_STORE_AUX 16
 #endif
+// The same policy for plain global stores: a relaxed atomic store at agent scope is `global_store ... sc1`, nothing else.
+#ifndef JST_PLAIN_STORES  // A/B switch
+__device__ __forceinline__ void store_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_agent(float2* p, float2 v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+__device__ __forceinline__ void store_agent(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_agent(float2* p, float2 v) { *p = v; }
+#endif
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
@@ -186,8 +199,8 @@ struct StoreCF32 {
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
                                           float2 v) const {
-        if constexpr (CONTIG) (out + base)[(unsigned)pos] = v;
-        else out[base + (int64_t)pos * axis_stride] = v;
+        if constexpr (CONTIG) store_agent(out + base + (unsigned)pos, v);
+        else store_agent(out + (base + (int64_t)pos * axis_stride), v);
     }
 };
 template <bool FAST>
@@ -203,8 +216,8 @@ struct StoreAmplitudeT {  // Amplitude module fused (amplitude/module_impl_nativ
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
                                           float2 v) const {
         const float r = FAST ? amplitude_cf32_fast(v, coeff) : amplitude_exact(v, coeff);
-        if constexpr (CONTIG) (out + base)[(unsigned)pos] = r;
-        else out[base + (int64_t)pos * axis_stride] = r;
+        if constexpr (CONTIG) store_agent(out + base + (unsigned)pos, r);
+        else store_agent(out + (base + (int64_t)pos * axis_stride), r);
     }
 };
 template <bool FAST>
@@ -229,8 +242,8 @@ struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_na
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
                                           float2 v) const {
         const float r = value(v);
-        if constexpr (CONTIG) (out + base)[(unsigned)pos] = r;
-        else out[base + (int64_t)pos * axis_stride] = r;
+        if constexpr (CONTIG) store_agent(out + base + (unsigned)pos, r);
+        else store_agent(out + (base + (int64_t)pos * axis_stride), r);
     }
 };
 

@@ -207,6 +207,8 @@ struct StoreScaledUnpad {
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t, int pos, float2 v) const {
         const float2 r = mk(v.x * c, v.y * c);
+        // plain stores: these land in 64-byte runs that neighbouring workgroups complete to full lines in L2; written
+        // through at agent scope (like the dense outputs of the spectrum kernels) config 3 lost 2-3 %
         if ((uint32_t)pos < body_len) body[base * (int64_t)body_len + pos] = r;
         else tail[base * (int64_t)tail_len + ((uint32_t)pos - body_len)] = r;
     }
@@ -378,6 +380,8 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_col
     float2* o = scratch + t * P.n;
     for (uint32_t idx = threadIdx.x; idx < tile; idx += blockDim.x) {
         const uint32_t r = idx >> P.ca_shift, col = idx & (P.CA - 1u);
+        // plain store: the scratch image is re-read at once by the second kernel and L2 / MALL absorb most of it; written
+        // through at agent scope (see JST_STORE_AUX in fft_lds.hh) config 3 lost 3 % (128 MB per cycle)
         if (col < live) o[c0 + col + P.S * r] = buf0[idx];
     }
     JST_TSTAMP_FLUSH();  // stores issued
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
                 sr += (double)pr.x;
                 si += (double)pr.y;
             }
-            epi.out[t * F + m] = mk((float)(sr / divisor), (float)(si / divisor));
+            epi.out[t * F + m] = mk((float)(sr / divisor), (float)(si / divisor));  // 32-byte runs: plain store, merged in L2
         }
     } else
     // store result q of block (t, k) at k + R1*q: block index fastest when R1 > 1 (adjacent k are

@@ -24,6 +24,16 @@
 
 namespace jst::kernels {
 
+// State stores written through at agent scope (`global_store ... sc1`), like the spectrum kernel's output (fft_lds.hh,
+// JST_STORE_AUX): nothing dirty is left for the end-of-kernel release.
+#ifndef JST_PLAIN_STORES  // A/B switch
+__device__ __forceinline__ void store_state(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#else
+__device__ __forceinline__ void store_state(float* p, float v) { *p = v; }
+#endif
+
 namespace {
 
 constexpr int kThreadsDefault = 1024;
@@ -164,12 +174,12 @@ __device__ __forceinline__ void spectrogram_body(
     for (uint32_t j = 0; j < kCells; ++j) k[j] = hits(tid + j * kThreads < cells ? tid + j * kThreads : 0u);
 #pragma unroll
     for (uint32_t j = 0; j < kCells; ++j)
-        if (cell[j]) *cell[j] = apply(state[j], k[j]);
+        if (cell[j]) store_state(cell[j], apply(state[j], k[j]));
     for (uint32_t e = tid + kCells * kThreads; e < cells; e += kThreads) {  // height > 256
         const uint32_t xx = tile * TW + (e % TW);
         if (xx >= width) continue;
         float* p = bins + (uint64_t)(e / TW) * width + xx;
-        *p = apply(*p, hits(e));
+        store_state(p, apply(*p, hits(e)));
     }
 }
 
