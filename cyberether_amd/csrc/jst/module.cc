@@ -720,6 +720,17 @@ Result Runtime::compute(U64 cycles, bool sync) {
                 captured_generation_ = configGenerations();
             }
         }
+        if (use_graph && !pipelined() && period_ > 1 && cycles > period_ && cycles < 2 * period_ &&
+            (cycles_ % period_) == capture_phase_ && getenv("JST_RUNTIME_NO_SPANS") == nullptr) {
+            // One period and a tail: ONE graph of exactly these cycles (cached per (phase, cycles) like every span)
+            // instead of the period graph followed by a span graph -- a launch less per call, which is what a short
+            // timed region (bench.py --steps 20 with 16 ring slots) is made of.
+            const U64 n = cycles;
+            JST_CHECK(launchSpan(n, timing));
+            ++untimed_run_;
+            cycles -= n;
+            continue;
+        }
         if (use_graph && (cycles_ % period_) == capture_phase_) {
             // No harvest between replays: the in-graph event nodes are simply re-recorded, and the
             // final synchronise reads the last replay's period_ samples per unit.  Replays
