@@ -113,6 +113,9 @@ def main() -> None:
     ap.add_argument("--no-alt", action="store_true",
                     help="skip the informational alt_provider / alt_pipelined measurements (profiling runs: "
                          "one kernel variant, one launch pattern per trace)")
+    ap.add_argument("--combine", action="store_true",
+                    help="JST_RUNTIME_COMBINE: the spectrogram of cycle k - 1 rides on the fused spectrum launch of cycle k "
+                         "(one kernel per cycle); default off: reported as alt_combined beside the headline")
     ap.add_argument("--pipeline", action="store_true",
                     help="run the spectrogram as its own graph on a second stream, one ring period behind "
                          "the spectrum graph (two hardware queues: +6 %% throughput, the spectrum kernel "
@@ -168,7 +171,7 @@ def main() -> None:
         if world > 1:
             dist.barrier()
 
-    def measure(provider: str, seed_offset: int = 0, pipeline: bool = args.pipeline):
+    def measure(provider: str, seed_offset: int = 0, pipeline: bool = args.pipeline, combine: bool = args.combine):
         """Builds ring_source -> spectrum_engine -> spectrogram with the given amplitude/range
         provider, runs W untimed + K timed steps; returns (runtime, elapsed seconds over ranks)."""
         source = js.Module("ring_source", {"batches": BATCHES, "samples": N_FFT, "slots": args.slots},
@@ -184,7 +187,7 @@ def main() -> None:
                                 "spectrogram")
         rt = js.Runtime([source] + engine.modules + [spectrogram], graph=not args.no_graph,
                         fuse=not args.no_fuse, timing=not args.no_timing,
-                        pipeline=pipeline)
+                        pipeline=pipeline, combine=combine and not pipeline)
         rt._keep = (source, engine, spectrogram)  # module handles must outlive the runtime
         # Initialisation, not measurement: the first replays of a freshly instantiated hipGraph carry its
         # one-time upload (milliseconds inside the first in-graph kernel's event pair), and a timed region
@@ -325,7 +328,7 @@ def main() -> None:
                                    "1024 batches cf32 per step, hipGraph capture",
                        "batches": BATCHES, "fft_size": N_FFT, "ring_slots": args.slots,
                        "graph": rt.graph_active, "fused": not args.no_fuse,
-                       "provider": args.provider, "pipelined": args.pipeline,
+                       "provider": args.provider, "pipelined": args.pipeline, "combined": args.combine,
                        "untimed_init_steps": 2 * max(rt.period, 1) + (-args.warmup) % max(rt.period, 1)
                                              + args.steps + (-args.steps) % max(rt.period, 1),
                        "repeats": repeats_main, "region_ms_min_max": [round(spread_main[0] * 1e3, 4),
@@ -361,6 +364,14 @@ def main() -> None:
                                      "ms_per_step": elapsed3 / args.steps * 1e3, "kernel_ms": ms3,
                                      "roofline_frac": (ach3 / HBM_PEAK_GBS) if ach3 else None}
             rt3.destroy()
+        if world == 1 and not args.pipeline and not args.combine and not args.no_graph and not args.no_fuse and not args.no_alt:
+            # informational fourth measurement: one kernel per cycle (spectrum of cycle k + spectrogram of cycle k - 1);
+            # kernel_ms is then the combined kernel's and is not comparable with the 12 B/sample roofline above
+            rt4, elapsed4 = measure(args.provider, seed_offset=0, pipeline=False, combine=True)
+            line["alt_combined"] = {"value": samples / elapsed4 / 1e6, "unit": "MS/s",
+                                    "ms_per_step": elapsed4 / args.steps * 1e3,
+                                    "units": [u.split("(")[0] for u in rt4.units if not u.startswith("spectrum.")]}
+            rt4.destroy()
         if world == 1 and not args.no_host_fed and not args.no_alt:
             try:
                 line["host_fed"] = host_fed(args.provider)

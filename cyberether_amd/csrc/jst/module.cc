@@ -241,8 +241,25 @@ Result Runtime::planOrder(const std::vector<Module*>& modules) {
     return Result::SUCCESS;
 }
 
+void Runtime::computePeriod() {
+    period_ = 1;
+    for (Module* m : ordered_) {  // least common multiple of the modules' host-state periods
+        U64 a = period_, b = m->cyclePeriod() ? m->cyclePeriod() : 1;
+        while (b) { const U64 t = a % b; a = b; b = t; }
+        period_ = period_ / a * (m->cyclePeriod() ? m->cyclePeriod() : 1);
+    }
+}
+
+Result Runtime::flushUnits() {
+    for (auto& u : units_)
+        if (u.flush) JST_CHECK(u.flush(stream_));
+    return Result::SUCCESS;
+}
+
 Result Runtime::planUnits() {
     units_.clear();
+    for (Module* m : ordered_)  // a decision of an earlier runtime does not outlive it
+        if (auto* spec = dynamic_cast<modules::Spectrogram*>(m)) spec->combined = false;
     // Static settlement: a STATIC_OUTPUT module with no inputs, or a STATELESS/STATIC module
     // whose inputs all come from settled producers, runs once
     // (src/scheduler_synchronous.cc:534-546,670-693).
@@ -277,6 +294,7 @@ Result Runtime::planUnits() {
         units_.push_back(std::move(u));
         ++i;
     }
+    computePeriod();  // a Spectrogram taken into the spectrum unit alternates between two output slots
     // Event pairs go around the units that launch kernels, plus ONE kernel-less dynamic unit
     // whose (empty) pair measures what the pair itself costs on this stream.
     calibration_unit_.clear();
@@ -308,7 +326,8 @@ Result Runtime::planUnits() {
 // [-> range] laid out consecutively in the order, with no other consumer of the intermediates
 // (the block wiring of src/domains/dsp/spectrum_engine/block_impl.cc:120-217).
 bool Runtime::tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed) {
-    return modules::TryFuseSpectrum(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
+    return modules::TryFuseSpectrum(ordered_, at, unit.name, unit.modules, unit.submit, consumed,
+                                    (flags_ & COMBINE) != 0 && (flags_ & PIPELINE) == 0, &unit.flush) ||
            modules::TryFuseFilter(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
 }
 
@@ -346,12 +365,7 @@ Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
         }
         ++initialised;
     }
-    period_ = 1;
-    for (Module* m : ordered_) {  // least common multiple of the modules' host-state periods
-        U64 a = period_, b = m->cyclePeriod() ? m->cyclePeriod() : 1;
-        while (b) { const U64 t = a % b; a = b; b = t; }
-        period_ = period_ / a * (m->cyclePeriod() ? m->cyclePeriod() : 1);
-    }
+    computePeriod();
     {
         Result r = planUnits();
         if (r == Result::SUCCESS && (flags_ & PIPELINE) && (flags_ & GRAPH)) r = planPipeline();
@@ -750,6 +764,9 @@ Result Runtime::compute(U64 cycles, bool sync) {
             } else {
                 JST_HIP_CHECK(hipGraphLaunch(graph_exec_, stream_), "hipGraphLaunch");
             }
+            // a replay does not run the host side: a whole period brings every cursor back to where it was, but a
+            // module may still need to know that cycles went by (Spectrogram riding on the spectrum launches)
+            for (Module* m : ordered_) m->advanceHostState(period_);
             for (auto& u : units_) {
                 if (u.is_static && u.settled) continue;
                 for (Module* m : u.modules) m->timing.cycles += period_;
@@ -796,6 +813,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
         {
             const Result r = eagerCycle(needs_sync, false);
             if (r == Result::YIELD || r == Result::TIMEOUT) {  // quiet end: what was queued still completes
+                JST_CHECK(flushUnits());
                 if (sync) {
                     JST_CHECK(joinLanes());
                     JST_CHECK(harvestTiming());
@@ -806,6 +824,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
         }
         --cycles;
     }
+    JST_CHECK(flushUnits());  // work a unit deferred past its cycle (a spectrogram riding on the next launch)
     if (needs_sync) {
         JST_CHECK(joinLanes());
         JST_CHECK(harvestTiming());

@@ -154,7 +154,7 @@ struct KernelSpan {  // hipEvent pairs around one execution unit, for live per-k
 
 class Runtime {
  public:
-    enum Flags : U32 { NONE = 0, GRAPH = 1 << 0, FUSE = 1 << 1, TIMING = 1 << 2, PIPELINE = 1 << 3 };
+    enum Flags : U32 { NONE = 0, GRAPH = 1 << 0, FUSE = 1 << 1, TIMING = 1 << 2, PIPELINE = 1 << 3, COMBINE = 1 << 4 };
 
     Runtime();
     ~Runtime();
@@ -189,6 +189,7 @@ class Runtime {
         std::string name;
         std::vector<Module*> modules;      // 1 module, or the fused chain
         std::function<Result(hipStream_t)> submit;
+        std::function<Result(hipStream_t)> flush;  // optional: work the unit defers to the end of a compute call
         bool is_static = false;            // STATIC_OUTPUT with settled inputs: runs once
         bool has_kernels = true;           // false: nothing reaches the stream
         bool timed = true;                 // carries an event pair
@@ -198,6 +199,8 @@ class Runtime {
     };
     Result planOrder(const std::vector<Module*>& modules);
     Result planUnits();
+    void computePeriod();
+    Result flushUnits();
     bool tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed);
     // In a captured period only every timingStride()-th cycle carries event-record nodes: a pair
     // costs ~2 us of queue time, sampling keeps Module::Timing live at a quarter of that cost.

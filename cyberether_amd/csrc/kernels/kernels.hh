@@ -228,6 +228,15 @@ hipError_t launch_exact_sweep(int which, float coeff, float scale, float offset,
 // bins: F32 [height][width] state, updated in place:
 //   bins *= decay; for every (batch, x): f = in*height; if 1 <= f < height: bins[x + (u64)f*width]
 //   = min(bins + 0.02, 1)   (spectrogram/module_impl_native_cpu.cc:61-87)
+// The fused spectrum kernel of cycle k and the Spectrogram of cycle k - 1 in one launch (fft_kernels.hip): `out` is the
+// half of the two-slot output ring this cycle writes, `spec_in` the other half (read only while ctrl[0] != 0), `bins` the
+// spectrogram state, ctrl two zero-initialised device words {pending, ticket}.  4096-point dense batches only.
+bool spectrum_spectrogram_supported(uint64_t n, const FftLayout& L, int64_t window_stride, uint64_t height);
+hipError_t launch_spectrum_spectrogram_fused(const FftLayout& L, const float2* W, const float2* in, const float2* window,
+                                             float* out, float amp_coeff, bool with_range, float range_scale,
+                                             float range_offset, bool fast, float guard_h0, float guard_h1, float* bins,
+                                             const float* spec_in, uint64_t height, float decay, uint32_t* ctrl,
+                                             hipStream_t stream);
 size_t spectrogram_lds_bytes(uint64_t height);
 hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, uint64_t batches,
                               uint64_t width, uint64_t height, int64_t batch_stride,

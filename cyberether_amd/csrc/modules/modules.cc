@@ -1105,7 +1105,7 @@ void RingSource::advanceHostState(U64 cycles) {
 // ---- fusion ------------------------------------------------------------------------------------
 bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string& name,
                      std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
-                     size_t& consumed) {
+                     size_t& consumed, bool allow_combine, std::function<Result(hipStream_t)>* flush) {
     if (at + 2 >= ordered.size()) return false;
     auto* mul = dynamic_cast<Multiply*>(ordered[at]);
     auto* fft = dynamic_cast<Fft*>(ordered[at + 1]);
@@ -1177,6 +1177,91 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     consumed = members.size();
     name = "spectrum_fused(" + mul->name() + "+" + fft->name() + "+" + amp->name() +
            (rng ? "+" + rng->name() : "") + ")";
+
+    // A Spectrogram that follows in the order and is the ONLY reader of the fused output rides on the next cycle's
+    // launch (kernels::launch_spectrum_spectrogram_fused): the output becomes a ring of two slots, this unit takes the
+    // module in, and `flush` runs the spectrogram that is still waiting when a compute call ends.
+    static const bool no_combine = std::getenv("JST_NO_SPECTROGRAM_COMBINE") != nullptr;
+    if (allow_combine && flush && !tiled && !no_combine && at + consumed < ordered.size()) {
+        auto* spec = dynamic_cast<Spectrogram*>(ordered[at + consumed]);
+        Tensor& out = rng ? rng->output : amp->output;
+        FftLayout L;
+        std::memset(&L, 0, sizeof(L));
+        if (spec && sig.rank() == 2 && axis == 1) {
+            L.transforms = sig.shape(0);
+            L.outer_rank = 1;
+            L.outer_shape[0] = sig.shape(0);
+            L.in_outer_stride[0] = (int64_t)sig.stride(0);
+            L.out_outer_stride[0] = (int64_t)out.stride(0);
+            L.in_axis_stride = (int64_t)sig.stride(1);
+            L.out_axis_stride = (int64_t)out.stride(1);
+        }
+        if (spec && sig.rank() == 2 && axis == 1 && spec->input.storageId() == out.storageId() &&
+            sole_consumer(out, spec) && out.offset() == 0 && spec->input.offset() == 0 &&
+            spec->numberOfElements == n && spec->numberOfBatches == sig.shape(0) && spec->inputElementStride == 1 &&
+            spec->inputBatchStride == n && (out.ringSlots() == 1 || out.ringSlots() == 2) &&
+            kernels::spectrum_spectrogram_supported(n, L, (int64_t)win.stride(axis), spec->height)) {
+            bool ok = out.ringSlots() == 2 || out.promoteToRing(2) == Result::SUCCESS;
+            ok = ok && spec->combineCtrl.create(DeviceType::HIP, DataType::U64, {1}) == Result::SUCCESS;
+            if (ok) {
+                spec->combined = true;
+                spec->combinedPending = false;
+                spec->combinedCycle = 0;
+                members.push_back(spec);
+                consumed = members.size();
+                name = "spectrum_fused_spectrogram(" + mul->name() + "+" + fft->name() + "+" + amp->name() +
+                       (rng ? "+" + rng->name() : "") + "+" + spec->name() + ")";
+                submit = [mul, fft, amp, rng, spec, n, fast, guard0, guard1](hipStream_t stream) -> Result {
+                    const Tensor& sig = mul->a;
+                    const Tensor& win = mul->b;
+                    Tensor& out = rng ? rng->output : amp->output;
+                    const U64 k = spec->combinedCycle;  // cycle k writes slot k & 1, the spectrogram part reads the other
+                    JST_CHECK(out.ringSelect(0));
+                    float* const slot0 = static_cast<float*>(out.data());
+                    JST_CHECK(out.ringSelect(1));
+                    float* const slot1 = static_cast<float*>(out.data());
+                    JST_CHECK(out.ringSelect(k & 1));
+                    FftLayout L;
+                    std::memset(&L, 0, sizeof(L));
+                    L.transforms = sig.shape(0);
+                    L.outer_rank = 1;
+                    L.outer_shape[0] = sig.shape(0);
+                    L.in_outer_stride[0] = (int64_t)sig.stride(0);
+                    L.out_outer_stride[0] = (int64_t)out.stride(0);
+                    L.in_axis_stride = (int64_t)sig.stride(1);
+                    L.out_axis_stride = (int64_t)out.stride(1);
+                    L.in_offset = sig.offset();
+                    L.out_offset = 0;
+                    const Result r = hip_result(
+                        kernels::launch_spectrum_spectrogram_fused(
+                            L, fft->twiddles, static_cast<const float2*>(sig.data()),
+                            static_cast<const float2*>(win.data()) + win.offset(), (k & 1) ? slot1 : slot0,
+                            amp->scalingCoeff, rng != nullptr, rng ? rng->scalingCoeff : 0.0f,
+                            rng ? rng->offsetCoeff : 0.0f, fast, guard0, guard1, ptr<float>(spec->frequencyBins),
+                            (k & 1) ? slot0 : slot1, spec->height, spec->decayFactor,
+                            static_cast<uint32_t*>(spec->combineCtrl.data()), stream),
+                        "fused spectrum + spectrogram kernel");
+                    spec->combinedCycle = k + 1;
+                    spec->combinedPending = true;
+                    return r;
+                };
+                *flush = [rng, amp, spec, n](hipStream_t stream) -> Result {
+                    if (!spec->combinedPending) return Result::SUCCESS;
+                    Tensor& out = rng ? rng->output : amp->output;
+                    JST_CHECK(out.ringSelect((spec->combinedCycle - 1) & 1));  // the handle shows the latest cycle
+                    JST_CHECK(hip_result(kernels::launch_spectrogram(ptr<float>(spec->frequencyBins),
+                                                                     static_cast<const float*>(out.data()), 0,
+                                                                     spec->numberOfBatches, n, spec->height, (int64_t)n, 1,
+                                                                     spec->decayFactor, stream),
+                                         "spectrogram kernel (flush)"));
+                    JST_HIP_CHECK(hipMemsetAsync(spec->combineCtrl.data(), 0, sizeof(uint32_t), stream), "hipMemsetAsync");
+                    spec->combinedPending = false;
+                    return Result::SUCCESS;
+                };
+                return true;
+            }
+        }
+    }
 
     submit = [mul, fft, amp, rng, axis, n, fast, tiled, guard0, guard1](hipStream_t stream) -> Result {
         const Tensor& sig = mul->a;

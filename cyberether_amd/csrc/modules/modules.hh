@@ -25,9 +25,12 @@ void ComputeTwiddles(U64 n, float* interleaved);
 bool MakeEwLayout(const Tensor& out, const Tensor* a, const Tensor* b, dev::EwLayout& L);
 
 // Scheduler hook: recognise multiply -> fft -> amplitude [-> range] starting at ordered[at].
+// allow_combine: a Spectrogram that is the only consumer of the fused output may ride on the next cycle's launch
+// (then `flush` is set: the runtime calls it at the end of every compute call to run the waiting spectrogram).
 bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string& name,
                      std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
-                     size_t& consumed);
+                     size_t& consumed, bool allow_combine = false,
+                     std::function<Result(hipStream_t)>* flush = nullptr);
 
 // Filter-chain fusions (filter_modules.cc): pad -> fft (zeros synthesised in the FFT's first load)
 // and multiply -> fold (the broadcast product is never materialised).  Same contract.
@@ -206,6 +209,19 @@ class Spectrogram : public Module {
     U64 height = 256, numberOfElements = 0, numberOfBatches = 0;
     U64 inputElementStride = 0, inputBatchStride = 0;
     F32 decayFactor = 1.0f;
+    // Carried by the NEXT cycle's fused spectrum launch (TryFuseSpectrum, kernels::launch_spectrum_spectrogram_fused):
+    // the spectrum output is then a ring of two slots, cycle k writes slot k & 1, and this module keeps the count of
+    // cycles submitted or replayed that way (host side of the ring) and whether one is still waiting for its
+    // spectrogram (the flush at the end of a compute call runs it).
+    bool combined = false, combinedPending = false;
+    U64 combinedCycle = 0;
+    Tensor combineCtrl;  // two zeroed device words {pending, ticket}
+    U64 cyclePeriod() const override { return combined ? 2 : 1; }
+    void advanceHostState(U64 cycles) override {
+        if (!combined || cycles == 0) return;
+        combinedCycle += cycles;
+        combinedPending = true;
+    }
 };
 
 // src/domains/visualization/waterfall/{module_impl.cc, ring_state.hh:16-56,

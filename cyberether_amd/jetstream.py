@@ -47,7 +47,7 @@ DTYPE_OF_NP = {np.dtype(v): k for k, v in NP_DTYPE.items()}
 RESULT_NAMES = ["SUCCESS", "ERROR", "WARNING", "FATAL", "SKIP", "YIELD", "RELOAD", "RECREATE",
                 "TIMEOUT", "INCOMPLETE"]
 
-RUNTIME_GRAPH, RUNTIME_FUSE, RUNTIME_TIMING, RUNTIME_PIPELINE = 1, 2, 4, 8
+RUNTIME_GRAPH, RUNTIME_FUSE, RUNTIME_TIMING, RUNTIME_PIPELINE, RUNTIME_COMBINE = 1, 2, 4, 8, 16
 
 TAINT = {"IN_PLACE": 1, "DISCONTIGUOUS": 2, "SURFACE": 4, "CROSS_DEVICE": 16,
          "STATIC_OUTPUT": 64, "STATELESS": 128}
@@ -425,10 +425,11 @@ class Runtime:
     """One device segment: ordered modules on one HIP stream, optionally as a hipGraph."""
 
     def __init__(self, modules: Iterable[Module], graph: bool = False, fuse: bool = False,
-                 timing: bool = False, pipeline: bool = False):
+                 timing: bool = False, pipeline: bool = False, combine: bool = False):
         self.modules = list(modules)
         flags = (RUNTIME_GRAPH if graph else 0) | (RUNTIME_FUSE if fuse else 0) | \
-                (RUNTIME_TIMING if timing else 0) | (RUNTIME_PIPELINE if pipeline else 0)
+                (RUNTIME_TIMING if timing else 0) | (RUNTIME_PIPELINE if pipeline else 0) | \
+                (RUNTIME_COMBINE if combine else 0)
         arr = (C.c_void_p * max(len(self.modules), 1))(*[m._h for m in self.modules])
         out = C.c_void_p()
         self._h = None

@@ -64,9 +64,13 @@ enum {
     JST_RUNTIME_GRAPH = 1 << 0,  /* capture the steady-state cycle(s) into a hipGraph */
     JST_RUNTIME_FUSE = 1 << 1,   /* submit Multiply->FFT->Amplitude[->Range] as one kernel */
     JST_RUNTIME_TIMING = 1 << 2, /* hipEvent pair around every execution unit */
-    JST_RUNTIME_PIPELINE = 1 << 3 /* with GRAPH: SURFACE units (spectrogram, waterfall, lineplot) run on
+    JST_RUNTIME_PIPELINE = 1 << 3, /* with GRAPH: SURFACE units (spectrogram, waterfall, lineplot) run on
                                      a second captured stream beside the NEXT cycle's producers; the
                                      tensors they read are double-buffered */
+    JST_RUNTIME_COMBINE = 1 << 4  /* with FUSE: a Spectrogram that is the only reader of the fused spectrum unit's
+                                     output rides on the NEXT cycle's spectrum launch (one kernel per cycle, output a
+                                     ring of two slots); the one still waiting when a compute call ends is run then,
+                                     so results and their visibility after jst_runtime_compute are unchanged */
 };
 
 typedef struct jst_tensor_s* jst_tensor;

@@ -47,7 +47,10 @@ def test_graph_replay_equals_eager_and_timing_reports(js):
         outs.append((eng.buffer.numpy(), spec.state("frequencyBins").numpy()))
         ms = rt.unit_mean_ms("spectrum_fused")
         assert 0.0 < ms < 50.0, ms
-        assert rt.unit_mean_ms("spectrogram") > 0.0
+        if any(u.startswith("spectrogram") for u in rt.units):  # else it rides on the spectrum launches (one unit)
+            assert rt.unit_mean_ms("spectrogram") > 0.0
+        else:
+            assert any(u.startswith("spectrum_fused_spectrogram(") for u in rt.units) and spec.timing["computeTime"] > 0.0
         assert eng.fft.timing["computeTime"] > 0.0
     assert_bit_equal(outs[0][0], outs[1][0])
     assert_bit_equal(outs[0][1], outs[1][1])

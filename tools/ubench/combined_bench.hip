@@ -36,12 +36,21 @@ __global__ __launch_bounds__(512, 4) void combined_kernel(const FftLayout L, con
                                                           const LoadCF32TimesWindow pro, const Epi epi,
                                                           float* __restrict__ bins, const float* __restrict__ spec_in,
                                                           uint32_t batches, uint32_t width, uint32_t height, float decay) {
+#ifdef CB_SPEC_FIRST  // spectrogram tiles take the first slot of every CU: they overlap the spectrum kernel's start-up
+    if (blockIdx.x >= 256u) {
+        fft_pipe_body<N, true, true, LoadCF32TimesWindow, Epi>(L, W, pro, epi, blockIdx.x - 256u, 512u);
+    } else {
+        spectrogram_body<16, 4, SPEC_THREADS, SPEC_DEPTH, true>(bins, spec_in, 0, batches, width, height, (int64_t)width, 1,
+                                                              decay, blockIdx.x, 256u);
+    }
+#else
     if (blockIdx.x < 512u) {
         fft_pipe_body<N, true, true, LoadCF32TimesWindow, Epi>(L, W, pro, epi, blockIdx.x, 512u);
     } else {
         spectrogram_body<16, 4, SPEC_THREADS, SPEC_DEPTH, true>(bins, spec_in, 0, batches, width, height, (int64_t)width, 1,
                                                               decay, blockIdx.x - 512u, 256u);
     }
+#endif
 }
 
 static float gauss() {
@@ -128,6 +137,28 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < b0.size(); ++i) { diff += (b0[i] != b1[i]); sum += b0[i]; }
         printf("%s: separate %.2f us per cycle, combined %.2f us per cycle (%d cycles); spectrogram states differ in %zu cells (sum %.1f)\n",
                CB_FAST ? "fast" : "exact", us_sep, us_comb, reps, diff, sum);
+    }
+    // the same comparison under hipGraph replay (16 cycles per graph, like the runtime's period graphs)
+    {
+        hipGraph_t g[2]; hipGraphExec_t ge[2];
+        for (int v = 0; v < 2; ++v) {
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            for (int k = 0; k < 16; ++k) { if (v == 0) separate(k); else combined(k); }
+            CK(hipStreamEndCapture(st, &g[v]));
+            CK(hipGraphInstantiate(&ge[v], g[v], nullptr, nullptr, 0));
+        }
+        for (int rep = 0; rep < 3; ++rep) {
+            double us[2];
+            for (int v = 0; v < 2; ++v) {
+                for (int i = 0; i < 4; ++i) CK(hipGraphLaunch(ge[v], st));
+                CK(hipDeviceSynchronize());
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int i = 0; i < 40; ++i) CK(hipGraphLaunch(ge[v], st));
+                CK(hipDeviceSynchronize());
+                us[v] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (40 * 16);
+            }
+            printf("%s, graph replay: separate %.2f us per cycle, combined %.2f us per cycle\n", CB_FAST ? "fast" : "exact", us[0], us[1]);
+        }
     }
     return 0;
 }
