@@ -20,6 +20,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                   src/benchmark.cc:100-106,175-186 (warm-up, epochs, median), on 1 core (the reference's
                   compute path is single-threaded, fft/module_impl_native_cpu.cc:1-2) plus an `all_cores`
                   figure from one independent replica per host core.
+  parity       -- AFTER the timed region, outside it: the very runtime that was timed (same graphs, same ring data)
+                  runs one more ring period cycle by cycle, then a whole-period graph replay and a tail; a sample of
+                  rows of every slot's range output and the full spectrogram state are recomputed by the oracle
+                  (the checker; the timed leg never touches it) and compared bit for bit.
   host_fed     -- the same chain fed from PINNED HOST memory: every cycle's batch is uploaded with
                   jst_tensor_copy_from_host_async on the library's side stream into the next ring slot while
                   the previous slot computes (the HBM replacement of the Soapy CircularBuffer hand-over,
@@ -47,6 +51,7 @@ BATCHES = 1024
 HEIGHT = 256
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALGO_BYTES_PER_SAMPLE = 12.0    # 8 B cf32 in + 4 B f32 out (SURVEY 8d / DESIGN.md section 4)
+STEP_BYTES_PER_SAMPLE = 14.0    # + the spectrogram's state read-modify-write, 2*4*N*H per cycle = 2 B/sample at B = 1024
 
 
 def synth_slot(rng: np.random.Generator, slot: int) -> np.ndarray:
@@ -81,7 +86,12 @@ def cpu_baseline() -> dict:
             total += json.loads(out.strip().splitlines()[-1])["samples_per_s"]
         except (ValueError, IndexError, KeyError):
             pass
+    c0 = chain_bench.run_configs0(epoch_s=0.1, epochs=11)
     return {"value": one["samples_per_s"] / 1e6, "unit": "MS/s", "cores": 1, "kind": one["kind"],
+            "configs0": {"value": c0["samples_per_s"] / 1e6, "unit": "MS/s", "us_per_op": c0["us_per_op"], "cores": 1,
+                         "kind": c0["kind"],
+                         "sample": f"BASELINE configs[0]: 1 batch x {N_FFT}-pt CW tone, FFT -> Amplitude per op, median of "
+                                   f"{c0['epochs']} epochs of >= {c0['epoch_s']} s (src/benchmark.cc:100-106,175-186 shape)"},
             "sample": f"64 batches x {N_FFT}-pt per pass through multiply/FFT/amplitude/range/spectrogram, "
                       f"FFT = {'the reference pocketfft (oracle/_ref)' if one['kind'] == 'reference' else 'C restatement'}, "
                       f"median of {one['epochs']} epochs of >= {one['epoch_s']} s (nanobench-style)",
@@ -111,7 +121,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timing", action="store_true", help="no hipEvent nodes in the graph")
     ap.add_argument("--no-alt", action="store_true",
-                    help="skip the informational alt_provider / alt_pipelined measurements (profiling runs: "
+                    help="skip the informational alt_provider / alt_combined / host_fed measurements (profiling runs: "
                          "one kernel variant, one launch pattern per trace)")
     ap.add_argument("--combine", action="store_true",
                     help="JST_RUNTIME_COMBINE: the spectrogram of cycle k - 1 rides on the fused spectrum launch of cycle k "
@@ -125,6 +135,8 @@ def main() -> None:
                          "path; fast = hardware transcendentals (floats within 3e-7 of it, spectrogram "
                          "bins identical through the fused kernel's bin guard)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the pinned-host -> async H2D -> chain measurement")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the post-measurement parity leg (profiling runs: nothing but the timed workload in the trace)")
     ap.add_argument("--min-time", type=float, default=0.25,
                     help="repeat the K-step timed region until this many seconds have been timed (0: once)")
     args = ap.parse_args()
@@ -189,6 +201,7 @@ def main() -> None:
                         fuse=not args.no_fuse, timing=not args.no_timing,
                         pipeline=pipeline, combine=combine and not pipeline)
         rt._keep = (source, engine, spectrogram)  # module handles must outlive the runtime
+        rt._seed = 1234 + rank + seed_offset
         # Initialisation, not measurement: the first replays of a freshly instantiated hipGraph carry its
         # one-time upload (milliseconds inside the first in-graph kernel's event pair), and a timed region
         # that starts off a period boundary runs its first cycles eagerly.  Two periods prime the graph;
@@ -301,16 +314,72 @@ def main() -> None:
         ms = raw - 0.5 * pair if raw > 0 else -1.0
         return raw, pair, ms, (algo_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None)
 
+    def parity_check(rt, provider: str) -> dict:
+        """The checker leg (never inside a timed region): the runtime that was just timed -- same graphs, same ring
+        data -- runs one more ring period cycle by cycle (a sample of rows of EVERY slot's range output is compared),
+        then a whole-period graph replay plus a 3-cycle tail; the full spectrogram state the device ends with must
+        equal, bit for bit, the oracle's replay of the same cycles from the state the device started this leg with."""
+        t0 = time.perf_counter()
+        from oracle import oracle  # the checker; only this leg and cpu_baseline() import it
+        oracle.build()
+        source, engine, spectrogram = rt._keep
+        period, slots = max(rt.period, 1), args.slots
+        rt.compute((-args.steps) % period, sync=True)  # every region starts at ring phase 0: back there
+        rng = np.random.default_rng(rt._seed)
+        data = [synth_slot(rng, s) for s in range(slots)]  # the generator that filled the ring, replayed
+        state = spectrogram.state("frequencyBins").numpy().reshape(-1).copy()
+        rows = np.unique(np.linspace(0, BATCHES - 1, 64).astype(np.int64))
+        refs, out_equal, max_err, bad_words = [], True, 0.0, 0
+        for s in range(slots):
+            rt.compute(1, sync=True)
+            ref = oracle.chain_pass(data[s % len(data)], state, HEIGHT)  # also advances the oracle's state
+            refs.append(ref)
+            got = engine.buffer.numpy()[rows]
+            same = np.array_equal(got.view(np.uint32), ref[rows].view(np.uint32))
+            out_equal &= bool(same)
+            if not same:
+                bad_words += int(np.count_nonzero(got.view(np.uint32) != ref[rows].view(np.uint32)))
+                max_err = max(max_err, float(np.max(np.abs(got.astype(np.float64) - ref[rows]))))
+        tail_cycles = period + 3
+        rt.compute(tail_cycles, sync=True)  # a whole-period graph replay and a span graph
+        for c in range(tail_cycles):
+            oracle.spectrogram(state, refs[c % slots], HEIGHT)
+        dev = spectrogram.state("frequencyBins").numpy().reshape(-1)
+        state_equal = bool(np.array_equal(dev.view(np.uint32), state.view(np.uint32)))
+        exact_provider = provider == "generic"
+        return {"checked": True, "against": "oracle/jst_oracle.c chain pass (FFT restatement pinned to the reference's pocketfft)",
+                "slots": slots, "rows_per_slot": int(rows.size), "output_rows": int(rows.size) * slots,
+                "cycles": slots + tail_cycles, "graph_replayed": bool(rt.graph_active),
+                "output_bit_exact": bool(out_equal), "output_max_abs_err": max_err, "output_words_differing": bad_words,
+                "spectrogram_state_bit_exact": state_equal, "spectrogram_state_words": int(state.size),
+                # provider generic promises bits; provider fast promises exact bins (the state) and floats within 1e-5
+                "bit_exact": bool(state_equal and (out_equal if exact_provider else max_err <= 1e-5)),
+                "seconds": round(time.perf_counter() - t0, 2)}
+
     rt, elapsed = measure(args.provider)
     repeats_main, spread_main = measure.repeats, measure.spread
     samples = float(args.steps) * BATCHES * N_FFT * world
     kernel_ms_raw, pair_ms, kernel_ms, achieved = kernel_time(rt)
 
+    line = None
     if rank == 0:
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from a --pmc pass
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written by tools/pmc_summary.py from --pmc passes
         if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("spectrum_fused_hbm_bytes_per_launch")
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from kernel_hash import kernel_sources_sha256
+            rec = json.load(open(pmc))
+            if rec.get("kernel_sources_sha256") == kernel_sources_sha256() and args.provider == "generic":
+                traffic = rec.get("spectrum_fused_hbm_bytes_per_launch")
+                traffic_src = {"source": rec.get("source"), "kernel": rec.get("kernel"),
+                               "kernel_sources_sha256": rec.get("kernel_sources_sha256"),
+                               "fetch_size_kib_mean": rec.get("fetch_size_kib_mean"),
+                               "write_size_kib_mean": rec.get("write_size_kib_mean"), "correction": rec.get("correction")}
+            else:
+                traffic_src = {"source": None, "stale": "profiles/pmc_traffic.json was measured on other kernel sources "
+                                                         "(or another provider): not quoted"}
+        step_ms = elapsed / args.steps * 1e3
+        step_bytes = STEP_BYTES_PER_SAMPLE * BATCHES * N_FFT
         line = {
             "metric": baseline_metric(),
             "value": samples / elapsed / 1e6,
@@ -318,7 +387,7 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -340,11 +409,26 @@ def main() -> None:
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": traffic, "kernel_ms": kernel_ms,
+                         "traffic": traffic, "traffic_provenance": traffic_src, "kernel_ms": kernel_ms,
+                         "kernel_ms_method": "hipEvent pair on the runtime's stream around the kernel's eager launches "
+                                             "inside the timed region (one cycle of every 16th ring period), minus half "
+                                             "of an empty pair measured the same way; rocprofv3's per-dispatch mean "
+                                             "(profiles/) is the cross-check, not this number's source",
                          "kernel_ms_event_pair_raw": kernel_ms_raw,
                          "event_pair_overhead_ms": pair_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes},
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         # the whole step on SURVEY 8(d)'s 14 B/sample (spectrum 12 + spectrogram state 2), per rank
+                         "step_bytes": step_bytes,
+                         "step_achieved": step_bytes / (step_ms * 1e-3) / 1e9,
+                         "step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if not args.no_parity and not args.no_fuse and not args.pipeline:
+            try:
+                line["parity"] = parity_check(rt, args.provider)
+            except Exception as exc:  # a missing compiler for the checker must not lose the measurement
+                line["parity"] = {"checked": False, "error": repr(exc)}
+        else:
+            line["parity"] = {"checked": False, "reason": "--no-parity / unfused / pipelined run"}
         if world == 1 and args.provider == "generic" and not args.no_fuse and not args.no_alt:
             # informational second measurement: same chain with provider "fast" (hardware
             # transcendentals for amplitude/range: floats within 3e-7 of the CPU path -- BASELINE allows
@@ -354,18 +438,14 @@ def main() -> None:
             line["alt_provider"] = {"provider": "fast", "value": samples / elapsed2 / 1e6, "unit": "MS/s",
                                     "ms_per_step": elapsed2 / args.steps * 1e3, "kernel_ms": ms2,
                                     "roofline_frac": (ach2 / HBM_PEAK_GBS) if ach2 else None}
+            if not args.no_parity:
+                try:
+                    line["alt_provider"]["parity"] = parity_check(rt2, "fast")
+                except Exception as exc:
+                    line["alt_provider"]["parity"] = {"checked": False, "error": repr(exc)}
             rt2.destroy()
-        if world == 1 and not args.pipeline and not args.no_graph and not args.no_alt:
-            # informational third measurement: the spectrogram as a graph of its own on a second stream
-            # (second hardware queue), one period behind the spectrum graph -- see --pipeline
-            rt3, elapsed3 = measure(args.provider, seed_offset=0, pipeline=True)
-            raw3, pair3, ms3, ach3 = kernel_time(rt3)
-            line["alt_pipelined"] = {"value": samples / elapsed3 / 1e6, "unit": "MS/s",
-                                     "ms_per_step": elapsed3 / args.steps * 1e3, "kernel_ms": ms3,
-                                     "roofline_frac": (ach3 / HBM_PEAK_GBS) if ach3 else None}
-            rt3.destroy()
         if world == 1 and not args.pipeline and not args.combine and not args.no_graph and not args.no_fuse and not args.no_alt:
-            # informational fourth measurement: one kernel per cycle (spectrum of cycle k + spectrogram of cycle k - 1);
+            # informational third measurement: one kernel per cycle (spectrum of cycle k + spectrogram of cycle k - 1);
             # kernel_ms is then the combined kernel's and is not comparable with the 12 B/sample roofline above
             rt4, elapsed4 = measure(args.provider, seed_offset=0, pipeline=False, combine=True)
             line["alt_combined"] = {"value": samples / elapsed4 / 1e6, "unit": "MS/s",
@@ -377,15 +457,15 @@ def main() -> None:
                 line["host_fed"] = host_fed(args.provider)
             except Exception as exc:  # the headline must not depend on it
                 line["host_fed"] = {"error": repr(exc)}
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline()
-        else:
-            line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
 
     rt.destroy()
     if world > 1:
+        barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # after the process group is gone (N > 1: the other ranks have left), so a SCALE line carries it too
+        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -334,6 +334,10 @@ bool Runtime::tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed) {
 Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
     if (created_) JST_CHECK(destroy());
     flags_ = flags;
+    span_graphs_.clear();  // destroy() released them; a runtime object never carries graphs across create()
+    span_clock_ = 0;
+    timed_once_ = false;
+    last_timed_cycle_ = 0;
     for (Module* m : modules) {
         if (!m || !m->created()) {
             JST_ERROR("[RUNTIME] Every module must be created before Runtime::create.");
@@ -427,8 +431,10 @@ Result Runtime::captureLane(int lane, int half, bool timing) {
         for (Tensor& t : pipelined_) JST_CHECK(t.ringSelect((U64)half * period_ + c));
         for (auto& u : units_) {
             if (u.lane != lane || (u.is_static && u.settled)) continue;
-            // event nodes only in the half-0 graphs (the same events cannot sit in two graphs)
-            const bool rec = timing && half == 0 && (c % timingStride()) == 0 && c < u.span.begin.size();
+            // No event records: one issued under capture is a dependency edge, nothing is recorded when the graph
+            // replays.  A PIPELINE runtime's unit timers are fed by its eager cycles only (settling, non-period tails).
+            const bool rec = false;
+            (void)timing;
             if (rec) JST_HIP_CHECK(hipEventRecord(u.span.begin[c], s), "hipEventRecord");
             r = u.submit(s);
             if (r != Result::SUCCESS && r != Result::RELOAD) {
@@ -464,6 +470,10 @@ Result Runtime::joinLanes() {
 Result Runtime::destroy() {
     if (!created_) return Result::SUCCESS;
     created_ = false;
+    // Every captured graph -- period, lane and the span cache -- goes while the streams still exist (dropGraphs joins
+    // both lanes first): a span graph that outlived destroy() held the previous modules' kernel arguments and a
+    // create() on the same object would have replayed it for a matching (phase, length).
+    if (stream_) (void)dropGraphs();
     (void)hipStreamSynchronize(stream_);
     if (side_stream_) {
         (void)hipStreamSynchronize(side_stream_);
@@ -634,12 +644,16 @@ Result Runtime::launchSpan(U64 n, bool timing) {
     auto key = std::make_pair(phase, n);
     auto it = span_graphs_.find(key);
     if (it == span_graphs_.end()) {
-        if (span_graphs_.size() >= 64) {  // bounded cache: drop the lot rather than grow without limit
-            for (auto& kv : span_graphs_) {
-                if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-                if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
-            }
-            span_graphs_.clear();
+        if (span_graphs_.size() >= 64) {
+            // Bounded cache: the least recently used entry goes, and only behind a stream fence -- after an
+            // unsynchronised compute() its executable may still be in flight.
+            auto victim = span_graphs_.begin();
+            for (auto j = span_graphs_.begin(); j != span_graphs_.end(); ++j)
+                if (j->second.last_use < victim->second.last_use) victim = j;
+            JST_HIP_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+            if (victim->second.exec) (void)hipGraphExecDestroy(victim->second.exec);
+            if (victim->second.graph) (void)hipGraphDestroy(victim->second.graph);
+            span_graphs_.erase(victim);
         }
         JST_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
         Result r = Result::SUCCESS;
@@ -660,6 +674,7 @@ Result Runtime::launchSpan(U64 n, bool timing) {
     } else {
         for (Module* m : ordered_) m->advanceHostState(n);  // a replay does not run the host side
     }
+    it->second.last_use = ++span_clock_;
     JST_HIP_CHECK(hipGraphLaunch(it->second.exec, stream_), "hipGraphLaunch");
     for (auto& u : units_) {
         if (u.is_static && u.settled) continue;
@@ -692,7 +707,10 @@ Result Runtime::compute(U64 cycles, bool sync) {
         const U64 kTimedPeriodStride = period_ > 1 ? 16 : 64;
         const bool timed_periods = timing && !pipelined();
         const bool aligned0 = (cycles_ % period_) == 0;
-        const bool timed_now = timed_periods && aligned0 && untimed_run_ + 1 >= kTimedPeriodStride;
+        // (counted in cycles, not in whole-period replays: a caller that submits fewer cycles than a period per call
+        // still gets its unit timers sampled every kTimedPeriodStride periods)
+        const bool timed_now = timed_periods && aligned0 &&
+                               (!timed_once_ || cycles_ - last_timed_cycle_ >= kTimedPeriodStride * period_);
         bool use_graph = (flags_ & GRAPH) && !any_unsettled_static && cycles >= period_ &&
                          (!timed_periods || (aligned0 && !timed_now));
         if (use_graph && !periodGraphActive()) {
@@ -741,7 +759,6 @@ Result Runtime::compute(U64 cycles, bool sync) {
             // timed region (bench.py --steps 20 with 16 ring slots) is made of.
             const U64 n = cycles;
             JST_CHECK(launchSpan(n, timing));
-            ++untimed_run_;
             cycles -= n;
             continue;
         }
@@ -774,20 +791,22 @@ Result Runtime::compute(U64 cycles, bool sync) {
             timing_pending_ = timing_pending_ || timing;
             cycles_ += period_;
             cycles -= period_;
-            ++untimed_run_;
             continue;
         }
         static const bool no_spans = getenv("JST_RUNTIME_NO_SPANS") != nullptr;  // A/B switch: eager heads and tails
-        if (timed_now && (!no_spans || period_ == 1) && (flags_ & GRAPH) && !any_unsettled_static && cycles >= period_) {
+        if (timed_now && (!no_spans || period_ == 1) && (flags_ & GRAPH) && !any_unsettled_static) {
             bool capturable = true;
             for (auto& u : units_)
                 for (Module* m : u.modules) capturable &= (u.is_static || m->capturable());
             if (capturable) {
+                last_timed_cycle_ = cycles_;
                 const Result r = eagerCycle(needs_sync, true);  // the timed cycle: real event records
                 if (r != Result::SUCCESS) return r;
-                untimed_run_ = 0;
-                if (period_ > 1) JST_CHECK(launchSpan(period_ - 1, timing));
-                cycles -= period_;
+                timed_once_ = true;
+                // the rest of the period (or of the call, when it is shorter) replays as a span graph
+                const U64 rest = std::min<U64>(cycles - 1, period_ - 1);
+                if (rest) JST_CHECK(launchSpan(rest, timing));
+                cycles -= 1 + rest;
                 continue;
             }
         }

@@ -230,6 +230,7 @@ class Runtime {
     struct SpanGraph {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
+        U64 last_use = 0;  // LRU stamp
     };
     std::map<std::pair<U64, U64>, SpanGraph> span_graphs_;  // (phase, cycles) -> graph
     std::string calibration_unit_;
@@ -248,7 +249,9 @@ class Runtime {
     Result captureLane(int lane, int half, bool timing);
     Result joinLanes();
     bool timing_pending_ = false;
-    U64 untimed_run_ = ~0ull >> 1;  // periods replayed since the last timed (eager) one
+    bool timed_once_ = false;       // an eager timed cycle has run since create()
+    U64 last_timed_cycle_ = 0;      // cycle index of the last eager timed cycle (phase 0 of its period)
+    U64 span_clock_ = 0;            // LRU stamp source of the span-graph cache
     bool created_ = false;
 };
 

@@ -130,6 +130,42 @@ __device__ __forceinline__ void buf_store_f2(rsrc_t r, uint32_t voff_bytes, uint
 __device__ __forceinline__ void buf_store_f1(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(f2u(v), r, voff_bytes, soff_bytes, JST_STORE_AUX);
 }
+// 16-byte forms.  A wavefront's 4-byte store is one 256-byte request per instruction and the epilogue issues eight of
+// them per transform and thread; MI355X_MICROARCH.md prices a scalar sc1 store at ~6x the dwordx4 time per byte and
+// calls such store tails issue-bound, not bandwidth-bound.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f buf_load_f4(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes) {
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
+}
+__device__ __forceinline__ void buf_store_f4(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, v4f v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, voff_bytes, soff_bytes, JST_STORE_AUX);
+}
+// Lane exchanges inside a quad (DPP quad_perm: no LDS, full rate).  xor1 = [1,0,3,2], xor2 = [2,3,0,1].
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;
+// 4 x 4 transpose across the lanes of a quad: in, lane q holds M[q][0..3]; out, lane q holds M[0..3][q].
+__device__ __forceinline__ void quad_transpose4(float (&a)[4], bool odd, bool hi) {
+    const float n0 = dpp_quad<kQuadXor1>(a[0]), n1 = dpp_quad<kQuadXor1>(a[1]);
+    const float n2 = dpp_quad<kQuadXor1>(a[2]), n3 = dpp_quad<kQuadXor1>(a[3]);
+    const float b0 = odd ? n1 : a[0], b1 = odd ? a[1] : n0;
+    const float b2 = odd ? n3 : a[2], b3 = odd ? a[3] : n2;
+    const float m0 = dpp_quad<kQuadXor2>(b0), m1 = dpp_quad<kQuadXor2>(b1);
+    const float m2 = dpp_quad<kQuadXor2>(b2), m3 = dpp_quad<kQuadXor2>(b3);
+    a[0] = hi ? m2 : b0;
+    a[1] = hi ? m3 : b1;
+    a[2] = hi ? b2 : m0;
+    a[3] = hi ? b3 : m1;
+}
+#ifndef JST_STORE16
+#define JST_STORE16 1
+#endif
+#ifndef JST_LOAD16
+#define JST_LOAD16 1
+#endif
 
 // ---- prologues (how pass 0 obtains CC(i,b,k)) -------------------------------------------------
 // operator()(base, axis_stride, pos): element 'pos' along the transform axis of the transform
@@ -209,8 +245,11 @@ struct StoreAmplitudeT {  // Amplitude module fused (amplitude/module_impl_nativ
     float coeff;
     static constexpr uint32_t kElemBytes = 4;
     __device__ __forceinline__ const void* row(int64_t base) const { return out + base; }
+    __device__ __forceinline__ float value(float2 v) const {
+        return FAST ? amplitude_cf32_fast(v, coeff) : amplitude_exact(v, coeff);
+    }
     __device__ __forceinline__ void store_buf(rsrc_t r, uint32_t voff, uint32_t soff, float2 v) const {
-        buf_store_f1(r, voff, soff, FAST ? amplitude_cf32_fast(v, coeff) : amplitude_exact(v, coeff));
+        buf_store_f1(r, voff, soff, value(v));
     }
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos,
@@ -479,6 +518,21 @@ __device__ __forceinline__ void twiddle_inplace4(unsigned i, float2& y0, float2&
 }
 #undef JST_TW1
 
+// Which wide-access forms a pipe-kernel instantiation uses: 16-byte input loads when pass 0 is a radix-8 pass on a dense
+// row (one butterfly per thread: the two lanes of a pair split its eight 16-byte pieces and swap halves), 16-byte
+// stores when the epilogue produces one float per output on a dense row and the last pass is radix 4 or 8.
+template <int N, bool CONTIG>
+constexpr bool pipe_load16() {
+    return JST_LOAD16 && CONTIG && make_plan(N).ip[0] == 8;
+}
+template <int N, bool CONTIG, class Epi>
+constexpr bool pipe_store16() {
+    if constexpr (JST_STORE16 && CONTIG && Epi::kElemBytes == 4 && (make_plan(N).ip[make_plan(N).nf - 1] % 4) == 0)
+        return requires(const Epi& e, float2 v) { e.value(v); };
+    else
+        return false;
+}
+
 template <int N, int T, bool FWD, bool CONTIG, int P, class Pro, class Epi>
 __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2* buf1,
                                             const float2 (&twr)[make_twplan(N).regs + 1],
@@ -559,7 +613,51 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
             }
 #endif
         }
-        if constexpr (LAST) {
+        if constexpr (LAST && pipe_store16<N, CONTIG, Epi>()) {
+            // Wide stores: the eight outputs of a butterfly sit 4 * BUT bytes apart, one float each.  A 4 x 4 transpose
+            // inside every quad of lanes (two DPP stages) gives lane q the four CONSECUTIVE outputs u0..u0+3 of
+            // segment c = 4g + q: two 16-byte stores per thread and transform instead of eight 4-byte ones.
+            const bool odd = (tid & 1) != 0, hi2 = (tid & 2) != 0;
+            const uint32_t voff = (uint32_t)(((tid & ~3) + (tid & 3) * BUT) * 4);
+#pragma unroll
+            for (int g = 0; g < IP / 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = epi.value(y[4 * g + q]);
+#ifndef JST_NO_EPI_SCHED_BARRIER
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+                quad_transpose4(v, odd, hi2);
+                buf_store_f4(r_out, voff, (uint32_t)((4 * g * BUT + j * T) * 4), v4f{v[0], v[1], v[2], v[3]});
+#ifndef JST_NO_EPI_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                if constexpr (Pro::kHasOperand) {
+                    constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
+                    if constexpr (pipe_load16<N, CONTIG>()) {
+                        const uint32_t vo = (uint32_t)(((tid & ~1) + 4 * IDO0 * (tid & 1)) * 8);
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            const int k = (j * IP + 4 * g) / 2 + k2;
+                            const v4f w = buf_load_f4(r_opnd, vo, (uint32_t)(IDO0 * k) * 8u);
+                            opnd[2 * k] = mk(w.x, w.y);
+                            opnd[2 * k + 1] = mk(w.z, w.w);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int e = j * IP + 4 * g + q;
+                            const int u0 = tid + (e / IP0) * T;
+                            const int l0 = (u0 & (IDO0 - 1)) + IDO0 * IP0 * (u0 / IDO0);
+                            opnd[e] = buf_load_f2(r_opnd, (uint32_t)l0 * 8u, (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else if constexpr (LAST) {
 #pragma unroll
             for (int c = 0; c < IP; ++c) {
                 if constexpr (CONTIG)
@@ -582,13 +680,23 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                     if (CONTIG || more) {
                         constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
                         const int e = j * IP + c;  // constant after unrolling
-                        const int u0 = tid + (e / IP0) * T;
-                        const int l0 = (u0 & (IDO0 - 1)) + IDO0 * IP0 * (u0 / IDO0);
-                        if constexpr (CONTIG)
-                            opnd[e] = buf_load_f2(r_opnd, (uint32_t)l0 * 8u,
-                                                  (uint32_t)(IDO0 * (e % IP0)) * 8u);
-                        else
-                            opnd[e] = pro.template load_operand<CONTIG>(IDO0 * (e % IP0), l0);
+                        if constexpr (pipe_load16<N, CONTIG>()) {
+                            if ((e & 1) == 1) {  // a 16-byte request once both halves have retired (folds after unrolling)
+                                const int k = e >> 1;
+                                const uint32_t vo = (uint32_t)(((tid & ~1) + 4 * IDO0 * (tid & 1)) * 8);
+                                const v4f w = buf_load_f4(r_opnd, vo, (uint32_t)(IDO0 * k) * 8u);
+                                opnd[2 * k] = mk(w.x, w.y);
+                                opnd[2 * k + 1] = mk(w.z, w.w);
+                            }
+                        } else {
+                            const int u0 = tid + (e / IP0) * T;
+                            const int l0 = (u0 & (IDO0 - 1)) + IDO0 * IP0 * (u0 / IDO0);
+                            if constexpr (CONTIG)
+                                opnd[e] = buf_load_f2(r_opnd, (uint32_t)l0 * 8u,
+                                                      (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                            else
+                                opnd[e] = pro.template load_operand<CONTIG>(IDO0 * (e % IP0), l0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -703,8 +811,25 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
     fft_bases(L, t, in_base, out_base);
     float2 raw[8], opnd[8];
     const rsrc_t r_opnd = make_rsrc(pro.operand_row(), (uint32_t)N * 8u);
+    // 16-byte loads (pipe_load16): the even lane of a pair requests {i, i+1} x b = 0..3, the odd lane {i-1, i} x b = 4..7
+    // (i = tid: its own butterfly index); raw[2k] / raw[2k+1] hold the two elements of piece k until the halves are swapped.
+    constexpr bool L16 = pipe_load16<N, CONTIG>();
+    const uint32_t voff16 = (uint32_t)(((tid & ~1) + 4 * IDO0 * (tid & 1)) * 8);
     {
         const rsrc_t r_in = make_rsrc(pro.row(in_base), (uint32_t)N * 8u);
+        if constexpr (L16) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (Pro::kHasOperand) {
+                    const v4f w = buf_load_f4(r_opnd, voff16, (uint32_t)(IDO0 * k) * 8u);
+                    opnd[2 * k] = mk(w.x, w.y);
+                    opnd[2 * k + 1] = mk(w.z, w.w);
+                }
+                const v4f v = buf_load_f4(r_in, voff16, (uint32_t)(IDO0 * k) * 8u);
+                raw[2 * k] = mk(v.x, v.y);
+                raw[2 * k + 1] = mk(v.z, v.w);
+            }
+        } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if constexpr (CONTIG) {
@@ -718,6 +843,7 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
                 raw[e] = pro.template load_raw<CONTIG>(in_base, L.in_axis_stride,
                                                        IDO0 * (e % IP0), pos0[e / IP0]);
             }
+        }
         }
     }
 #pragma unroll
@@ -733,8 +859,23 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
     while (true) {
         JST_STAMP(0);  // iteration start
         float2 x[8];
+        if constexpr (L16) {
+            // products on the pieces as loaded, then the pair swaps halves: the even lane keeps the first element of
+            // every piece (b = 0..3 of butterfly i) and receives the odd lane's first elements (b = 4..7); the odd lane
+            // keeps its second elements (b = 4..7 of butterfly i) and receives the even lane's (b = 0..3).
+            const bool odd = (tid & 1) != 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = pro.apply(raw[e], opnd[e]);
+            for (int k = 0; k < 4; ++k) {
+                const float2 lo = pro.apply(raw[2 * k], opnd[2 * k]), hi = pro.apply(raw[2 * k + 1], opnd[2 * k + 1]);
+                const float2 nlo = mk(dpp_quad<kQuadXor1>(lo.x), dpp_quad<kQuadXor1>(lo.y));
+                const float2 nhi = mk(dpp_quad<kQuadXor1>(hi.x), dpp_quad<kQuadXor1>(hi.y));
+                x[k] = odd ? nhi : lo;
+                x[4 + k] = odd ? hi : nlo;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = pro.apply(raw[e], opnd[e]);
+        }
         JST_STAMP(1);  // input arrived + prologue applied
         // prefetch the next transform of this workgroup while this one is computed
         const uint64_t tn = t + grid;
@@ -747,9 +888,18 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
             // zero records: the loads return 0 without touching memory.
             fft_bases(L, more ? tn : t, nin, nout);
             const rsrc_t r_in = make_rsrc(pro.row(nin), more ? (uint32_t)N * 8u : 0u);
+            if constexpr (L16) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                raw[e] = buf_load_f2(r_in, (uint32_t)pos0[e / IP0] * 8u, (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                for (int k = 0; k < 4; ++k) {
+                    const v4f v = buf_load_f4(r_in, voff16, (uint32_t)(IDO0 * k) * 8u);
+                    raw[2 * k] = mk(v.x, v.y);
+                    raw[2 * k + 1] = mk(v.z, v.w);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    raw[e] = buf_load_f2(r_in, (uint32_t)pos0[e / IP0] * 8u, (uint32_t)(IDO0 * (e % IP0)) * 8u);
+            }
         } else if (more) {
             fft_bases(L, tn, nin, nout);
 #pragma unroll

@@ -90,9 +90,14 @@ __device__ __forceinline__ void spectrogram_body(
     if constexpr (BUF) {
         voff = x < width ? (uint32_t)(((int64_t)x * elem_stride + (int64_t)(tid / TW) * batch_stride) * 4) : 0x7ffffff0u;
         row_step = (uint32_t)((int64_t)rows_per_iter * batch_stride * 4);
+        // Rows past the last batch must read as 0 (0 never hits).  The descriptor's range check covers the per-lane
+        // voffset only -- LLVM documents soffset as excluded from it -- so the tail is NOT left to the wave-uniform
+        // row offset: a lane whose row does not exist gets an out-of-range voffset (one compare on a row index).
 #pragma unroll
-        for (uint32_t j = 0; j < kDepth; ++j)
-            v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_in, voff, j * row_step, 0));
+        for (uint32_t j = 0; j < kDepth; ++j) {
+            const bool row_ok = tid / TW + j * rows_per_iter < batches;
+            v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_in, row_ok ? voff : 0x7ffffff0u, row_ok ? j * row_step : 0u, 0));
+        }
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < kDepth; ++j) {
@@ -111,8 +116,10 @@ __device__ __forceinline__ void spectrogram_body(
                 if constexpr (BUF) {
                     voff += kDepth * row_step;
 #pragma unroll
-                    for (uint32_t j = 0; j < kDepth; ++j)
-                        v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_in, voff, j * row_step, 0));
+                    for (uint32_t j = 0; j < kDepth; ++j) {
+                        const bool row_ok = b0 + j * rows_per_iter < batches;
+                        v[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_in, row_ok ? voff : 0x7ffffff0u, row_ok ? j * row_step : 0u, 0));
+                    }
                 } else {
 #pragma unroll
                     for (uint32_t j = 0; j < kDepth; ++j) {

@@ -52,6 +52,31 @@ def run(rows: int, epoch_s: float, epochs: int, use_ref: bool = True, seed: int 
             "epoch_rates_MSps": [round(r / 1e6, 2) for r in rates]}
 
 
+def run_configs0(epoch_s: float = 0.1, epochs: int = 11, use_ref: bool = True) -> dict:
+    """BASELINE configs[0], like for like: ONE batch of 4096 cf32 (an off-bin CW tone) through
+    FFT -> Amplitude, one op per compute(), nanobench-style (epochs >= 100 ms, median) as src/benchmark.cc:100-106,
+    175-186 does; the FFT is the reference's own pocketfft when oracle/_ref is present."""
+    lib = oracle.lib()
+    fft_ptr, kind = None, "port"
+    if use_ref and oracle.have_ref():
+        fft_ptr = C.cast(oracle.ref().ref_fft_c2c, C.c_void_p)
+        kind = "reference"
+    x, _ = oracle.signal_cosine(N_FFT, 1.0, 100.25 * 2.0e6 / N_FFT, 2.0e6)
+    x = np.ascontiguousarray(x)
+    spectrum = np.empty(N_FFT, np.complex64)
+    out = np.empty(N_FFT, np.float32)
+    per_op = (C.c_double * epochs)()
+    f32p = C.POINTER(C.c_float)
+    fn = lib.jst_oracle_fft_amplitude_bench
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_void_p, f32p, C.c_uint64, C.c_float, f32p, f32p, C.c_double, C.c_uint32, C.POINTER(C.c_double)]
+    p = lambda a: a.ctypes.data_as(f32p)
+    median = fn(fft_ptr, p(x.view(np.float32)), N_FFT, oracle.amplitude_coeff(N_FFT), p(spectrum.view(np.float32)),
+                p(out), epoch_s, epochs, per_op)
+    return {"us_per_op": median * 1e6, "samples_per_s": N_FFT / median, "kind": kind, "epochs": epochs,
+            "epoch_s": epoch_s, "epoch_us_per_op": [round(v * 1e6, 3) for v in per_op]}
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=64)

@@ -2337,3 +2337,37 @@ double jst_oracle_chain_bench(jst_oracle_fft_fn fft, const float* x, const float
     qsort(local, epochs, sizeof(double), cmp_double);
     return (epochs & 1) ? local[epochs / 2] : 0.5 * (local[epochs / 2 - 1] + local[epochs / 2]);
 }
+
+/* BASELINE configs[0]: the reference's `benchmark` shape -- ONE batch, FFT -> Amplitude, timed per compute() like
+ * src/benchmark.cc:100-106,175-186 drives nanobench (warm-up, epochs of >= min_epoch_s, MEDIAN elapsed per op).
+ * One op = fft/module_impl_native_cpu.cc:125-140 (pocketfft c2c, forward) + amplitude/module_impl_native_cpu.cc:73-86
+ * on CF32[n].  Returns the median seconds per op over `epochs` epochs; per_op[e] (if given) receives each epoch's. */
+double jst_oracle_fft_amplitude_bench(jst_oracle_fft_fn fft, const float* x, uint64_t n, float coeff, float* spectrum,
+                                      float* out, double min_epoch_s, uint32_t epochs, double* per_op) {
+    double local[64];
+    if (epochs == 0 || epochs > 64) return -1.0;
+    const uint64_t shape[1] = {n};
+    const int64_t stride[1] = {8};
+    for (uint32_t e = 0; e <= epochs; ++e) { /* epoch 0 is the warm-up (plan built, pages touched) */
+        uint64_t ops = 0;
+        const double t0 = now_s();
+        double t1;
+        do {
+            if (fft) (void)fft(1, shape, stride, stride, 0, 1, x, spectrum);
+            else (void)jst_oracle_fft_c2c(x, spectrum, n, 1, 1);
+            for (uint64_t i = 0; i < n; ++i) {
+                const float re = spectrum[2 * i], im = spectrum[2 * i + 1];
+                const float mag = sqrtf((re * re) + (im * im));
+                out[i] = (mag == 0.0f) ? -INFINITY : 20.0f * jst_oracle_approx_log10(mag) + coeff;
+            }
+            ++ops;
+            t1 = now_s();
+        } while (t1 - t0 < (e ? min_epoch_s : 0.02));
+        if (e) {
+            local[e - 1] = (t1 - t0) / (double)ops;
+            if (per_op) per_op[e - 1] = local[e - 1];
+        }
+    }
+    qsort(local, epochs, sizeof(double), cmp_double);
+    return (epochs & 1) ? local[epochs / 2] : 0.5 * (local[epochs / 2 - 1] + local[epochs / 2]);
+}

@@ -347,6 +347,30 @@ def spectrum_chain(x: np.ndarray, range_min=None, range_max=None):
     return out
 
 
+
+def chain_pass(x: np.ndarray, bins: np.ndarray, height: int, range_min: float = -100.0, range_max: float = 0.0,
+               use_ref: bool = False) -> np.ndarray:
+    """One compute cycle of the headline chain on a dense CF32[rows, n] batch in dense C loops
+    (jst_oracle.c: jst_oracle_chain_pass = multiply by the inverted window -> FFT -> amplitude -> range ->
+    spectrogram update of `bins` in place): the same arithmetic as spectrum_chain() + spectrogram(), ~50 MS/s,
+    so the FULL configs[1] batch (1024 x 4096) is checked in 80 ms per cycle.  Returns the range output."""
+    assert x.dtype == np.complex64 and x.ndim == 2 and x.flags.c_contiguous
+    assert bins.dtype == np.float32 and bins.flags.c_contiguous and bins.size == x.shape[1] * height
+    rows, n = x.shape
+    w = np.ascontiguousarray(invert(window(n)))
+    scale, offset = range_coeffs(range_min, range_max)
+    product = np.empty((rows, n), np.complex64)
+    spectrum = np.empty((rows, n), np.complex64)
+    out = np.empty((rows, n), np.float32)
+    fn = lib().jst_oracle_chain_pass
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, _f32p, _f32p, C.c_uint64, C.c_uint64, C.c_float, C.c_float, C.c_float, C.c_uint64,
+                   C.c_float, _f32p, _f32p, _f32p, _f32p]
+    fft_ptr = C.cast(ref().ref_fft_c2c, C.c_void_p) if (use_ref and have_ref()) else None
+    fn(fft_ptr, _p(x.view(np.float32)), _p(w.view(np.float32)), rows, n, amplitude_coeff(n), scale, offset, height,
+       spectrogram_decay(rows), _p(product.view(np.float32)), _p(spectrum.view(np.float32)), _p(out), _p(bins))
+    return out
+
 # ------------------------------------------------------------- filter / FM side chains
 def pad(x: np.ndarray, size: int, axis: int = -1) -> np.ndarray:
     """core/pad/module_impl_native_cpu.cc:75-140: zeros appended along axis."""

@@ -154,6 +154,62 @@ def test_full_size_properties(js, oracle):
     assert_bit_equal(bins.reshape(-1), ref_bins, "full-size spectrogram")
 
 
+def test_c2_literal_full_batch_three_cycles(js, oracle):
+    """BASELINE configs[1] exactly as SURVEY 8(d) C2 writes it: CF32[1024, 4096], row b = unit tone at bin
+    100.25 + b (signal_generator arithmetic) + complex AWGN sigma 1e-3 from default_rng(1234), 1024 DISTINCT
+    rows, window 4096, range -100..0 dB, spectrogram height 256, three cycles under graph replay.  The range
+    output of the WHOLE batch and the whole spectrogram state are compared bit for bit with the oracle's dense
+    chain pass (oracle/jst_oracle.c: jst_oracle_chain_pass, ~50 MS/s) after every cycle."""
+    n, b, h = 4096, 1024, 256
+    x = tone_batch(oracle, b, n, 1234)
+    src, eng, spec, rt = build(js, x, h=h, fuse=True, graph=True)
+    assert any(u.startswith("spectrum_fused") for u in rt.units), rt.units
+    bins = np.zeros(n * h, np.float32)
+    for cycle in range(1, 4):
+        rt.compute(1)
+        ref = oracle.chain_pass(x, bins, h)
+        assert_bit_equal(eng.buffer.numpy(), ref, f"range output, cycle {cycle}")
+        assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins, f"spectrogram state, cycle {cycle}")
+    assert rt.graph_active
+    # every row's peak sits at the centred bin n/2 + 100 + b (mod n): no row was dropped or duplicated
+    peaks = np.argmax(eng.buffer.numpy(), axis=1)
+    assert np.array_equal(peaks, (n // 2 + 100 + np.arange(b)) % n)
+    rt.destroy()
+
+
+def test_c2_bench_ring_two_graph_periods_full_size(js, oracle):
+    """The data bench.py times: its 16-slot ring of synth_slot() batches (1024 x 4096 each, 512 MiB), the runtime
+    built like bench.py builds it (ring_source, fused, graph, TIMING), run through two whole graph periods plus a
+    tail; after every chunk the last cycle's range output (all 1024 rows) and the spectrogram state are bit-equal
+    to the oracle's.  This is the parity the bench line's `parity` stamp re-checks on its own run."""
+    import bench
+    n, b, h, slots = bench.N_FFT, bench.BATCHES, bench.HEIGHT, 16
+    source = js.Module("ring_source", {"batches": b, "samples": n, "slots": slots}, {}, "source")
+    buf = source.output("buffer")
+    rng = np.random.default_rng(1234)
+    data = [bench.synth_slot(rng, s) for s in range(slots)]
+    for s in range(slots):
+        buf.ring_select(s).copy_from(data[s])
+    buf.ring_select(0)
+    eng = js.SpectrumEngine(buf, enable_scale=True, range_min=-100.0, range_max=0.0)
+    spec = js.Module("spectrogram", {"height": h}, {"signal": eng.buffer}, "spectrogram")
+    rt = js.Runtime([source] + eng.modules + [spec], graph=True, fuse=True, timing=True)
+    assert rt.period == slots
+    scratch = np.zeros(n * h, np.float32)
+    refs = [oracle.chain_pass(d, scratch.copy(), h) for d in data]   # range output per slot (state-free)
+    bins = np.zeros(n * h, np.float32)
+    total = 0
+    for chunk in (1, 15, 16, 16, 5):   # settle cycle, rest of period 0, two whole periods, a tail span
+        rt.compute(chunk)
+        for _ in range(chunk):
+            oracle.spectrogram(bins, refs[total % slots], h)
+            total += 1
+        assert_bit_equal(eng.buffer.numpy(), refs[(total - 1) % slots], f"range output after {total} cycles")
+        assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins, f"state after {total} cycles")
+    assert rt.graph_active and 0.0 < rt.unit_mean_ms("spectrum_fused") < 5.0
+    rt.destroy()
+
+
 def test_golden_fixture(js):
     import os
     path = os.path.join(os.path.dirname(__file__), "golden", "spectrum_chain_c1.npz")

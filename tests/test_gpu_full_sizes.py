@@ -62,6 +62,39 @@ def test_config3_filter_block_full_size(js, oracle, fuse):
     rt.destroy()
 
 
+@pytest.mark.parametrize("fuse", [False, True])
+def test_config3_literal_distinct_rows_two_cycles(js, oracle, fuse):
+    """SURVEY 8(d) C3 as written: CF32[100, 159750], two tones (0.3 MHz in band, 4 MHz out of band) + complex AWGN
+    from default_rng(1235) -- every row DISTINCT -- 251 taps, /10, two compute cycles with a second distinct batch,
+    so that the overlap state crosses rows AND the compute boundary at the 160000-point size.  Rows 0..7 and
+    92..99 of both cycles are compared bit for bit with the oracle; overlap-add state is sequential along the
+    batch axis and depends on the previous row only, so the oracle walks rows 91..99 to hand the carried tail
+    to the next cycle's row 0."""
+    b, s, taps, sr, bw = 100, 159750, 251, 20e6, 2e6
+    rng = np.random.default_rng(1235)
+    t = np.arange(s) / sr
+    tones = (np.exp(2j * np.pi * 0.3e6 * t) + 0.5 * np.exp(2j * np.pi * 4.0e6 * t)).astype(np.complex64)
+    batches = [(tones[None, :] + csignal(rng, (b, s), 0.01)).astype(np.complex64) for _ in range(2)]
+    src = js.Tensor.from_numpy(batches[0], batch=0, sample=1)
+    blk = js.Filter(src, sr, bw, [0.0], taps, 1)
+    assert blk.plan["convolutionSize"] == 160000 and blk.plan["resamplerSize"] == 16000
+    rt = js.Runtime(blk.modules, graph=True, fuse=fuse)
+    state = {}   # the oracle's carried overlap tail: what the row before the rows under test left behind
+    for cycle, x in enumerate(batches):
+        if cycle:
+            src.copy_from(x)
+        rt.compute(1)
+        got = blk.buffer.numpy()
+        assert got.shape == (b, 1, 15975)
+        head = oracle.filter_block(x[:8], blk.plan, sr, bw, [0.0], taps, state)
+        assert_bit_equal(got[:8], head, f"cycle {cycle}: rows 0..7 (carried state from the previous cycle's last row)")
+        state = {}
+        tail = oracle.filter_block(x[91:], blk.plan, sr, bw, [0.0], taps, state)   # row 91 primes the tail
+        assert_bit_equal(got[92:], tail[1:], f"cycle {cycle}: rows 92..99")
+        assert len({got[r].tobytes() for r in range(0, b, 9)}) == len(range(0, b, 9))   # rows really are distinct
+    rt.destroy()
+
+
 def test_config4_wbfm_chain_full_rate(js, oracle):
     """20 MS/s -> Filter(/100) -> FM (wide, 75 us) -> Decimator(/4): one stereo lane, 10 batches."""
     b, s, taps, sr, bw = 10, 202400, 101, 20e6, 200e3   # conv 202500 = 2^2 * 3^4 * 5^4

@@ -1,0 +1,63 @@
+"""The multi-rank launch paths, exercised unattended: `python bench.py --gpus 2` re-executes itself
+under torch.distributed.run (two ranks; on a one-GPU box they share the device and the control plane runs on gloo),
+and tools/bench_c5_multi.py under torchrun with two ranks.  Asserted: the JSON contract of the bench line (n_gpus,
+roofline, cpu_baseline, parity) and that config 5's cross-rank PSD mean does not overwrite a rank's own IIR state."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def _last_json(text: str) -> dict:
+    lines = [ln for ln in text.strip().splitlines() if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_two_ranks_contract():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+                          "--no-alt"], cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _last_json(out.stdout)
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak"
+    assert line["unit"] == "MS/s" and line["value"] > 0 and line["higher_is_better"] is True
+    assert line["config"]["workload"].startswith("configs[1]")
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and 0.0 < roof["frac"] < 1.0 and roof["kernel_ms"] > 0 and "step_frac" in roof
+    assert "kernel_ms_method" in roof
+    cpu = line["cpu_baseline"]   # present for N > 1 too (measured on rank 0 after the process group is gone)
+    assert cpu and cpu["value"] > 0 and cpu["cores"] == 1 and cpu["configs0"]["value"] > 0
+    par = line["parity"]
+    assert par["checked"] and par["bit_exact"] and par["output_rows"] >= 64 * 16 and par["cycles"] >= 16
+
+
+def test_config5_two_ranks_psd_reduce_keeps_rank_state():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = _env()
+    env["JST_BENCH_BACKEND"] = "gloo"   # two ranks on one device: control plane on gloo, trace through the host
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "tools", "bench_c5_multi.py"), "--cycles", "50", "--interval", "25"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _last_json(out.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["backend"] == "gloo"
+    assert line["merged_trace_is_mean_of_rank_traces"] is True

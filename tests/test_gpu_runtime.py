@@ -82,3 +82,62 @@ def test_borrowed_torch_memory(js, oracle):
     rt = js.Runtime([m])
     rt.compute()
     assert_bit_equal(m.output("signal").numpy(), oracle.fft_c2c(x))
+
+
+def test_timing_keeps_sampling_when_calls_are_shorter_than_a_period(js, oracle):
+    """TIMING | GRAPH with a ring period > 1 and a caller that submits fewer cycles than a period per call: the
+    eager timed cycle must still run at every sixteenth period boundary (it used to need a whole period inside
+    one call, so Module::Timing froze on the cold settle sample while timing.cycles kept growing), the rest of
+    the call replays as span graphs, and the results stay those of the oracle."""
+    n, b, h, slots = 1024, 8, 64, 4
+    src = js.Module("ring_source", {"batches": b, "samples": n, "slots": slots}, {}, "source")
+    out = src.output("buffer")
+    rng = np.random.default_rng(11)
+    data = [csignal(rng, (b, n), 0.05) for _ in range(slots)]
+    for s in range(slots):
+        out.ring_select(s).copy_from(data[s])
+    out.ring_select(0)
+    eng = js.SpectrumEngine(out)
+    spec = js.Module("spectrogram", {"height": h}, {"signal": eng.buffer}, "spectrogram")
+    rt = js.Runtime([src] + eng.modules + [spec], graph=True, fuse=True, timing=True)
+    assert rt.period == slots
+    refs = [oracle.spectrum_chain(d, -100.0, 0.0)["range"] for d in data]
+    bins = np.zeros(n * h, np.float32)
+    seen, total = [], 0
+    for chunk in [1] * 70 + [3] * 44 + [2] * 40:   # never a whole period in one call
+        rt.compute(chunk)
+        for _ in range(chunk):
+            oracle.spectrogram(bins, refs[total % slots], h)
+            total += 1
+        if total in (1, 70, 202, 282):
+            seen.append(eng.fft.timing["computeTime"])
+    assert eng.fft.timing["cycles"] == total == 282
+    assert 0.0 < seen[0] < seen[1] < seen[2] < seen[3], seen   # a new sample at least every 16 periods = 64 cycles
+    assert_bit_equal(eng.buffer.numpy(), refs[(total - 1) % slots], "range output")
+    assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins, "spectrogram state")
+    assert rt.graph_active
+    rt.destroy()
+
+
+def test_runtime_recreate_drops_span_graphs(js, oracle):
+    """destroy() releases the span-graph cache with everything else: a second runtime over NEW modules that reaches
+    the same (phase, length) keys must capture its own graphs, not replay stale ones."""
+    n, b, slots = 512, 4, 4
+    outs = []
+    for seed in (1, 2):
+        src = js.Module("ring_source", {"batches": b, "samples": n, "slots": slots}, {}, "source")
+        buf = src.output("buffer")
+        rng = np.random.default_rng(seed)
+        data = [csignal(rng, (b, n), 0.05) for _ in range(slots)]
+        for s in range(slots):
+            buf.ring_select(s).copy_from(data[s])
+        buf.ring_select(0)
+        eng = js.SpectrumEngine(buf)
+        rt = js.Runtime([src] + eng.modules, graph=True, fuse=True)
+        for chunk in (1, 2, 3, 2, 3, 1):   # spans at several (phase, length) keys
+            rt.compute(chunk)
+        outs.append(eng.buffer.numpy())
+        assert_bit_equal(outs[-1], oracle.spectrum_chain(data[(12 - 1) % slots], -100.0, 0.0)["range"], f"runtime {seed}")
+        rt.destroy()
+        rt.destroy()   # idempotent
+    assert not np.array_equal(outs[0], outs[1])

@@ -67,13 +67,20 @@ def main() -> None:
     if backend != "gloo":
         dev_trace = torch.as_tensor(_View(), device="cuda")
 
+    merged = None if backend == "gloo" else torch.empty(n, dtype=torch.float32, device="cuda")
+    reduced = {}
+
     def reduce_psd() -> float:
+        """The cross-rank mean of the averaged PSD goes into a SEPARATE trace: the lineplot's averagingBuffer is the
+        state of each rank's own IIR recursion (lineplot/module_impl_native_cpu.cc:80-118) and must not be
+        overwritten by the mean -- every rank keeps averaging ITS stream, the merged trace is what is displayed."""
         t0 = time.perf_counter()
         if backend == "gloo":
             host = torch.from_numpy(trace.numpy().copy())
-            D.allreduce_average(host)
+            reduced["trace"] = D.allreduce_average(host)
         else:
-            D.allreduce_average(dev_trace)   # in place on the module's own state tensor
+            merged.copy_(dev_trace)          # 256 KiB device copy; the module's state stays this rank's own
+            reduced["trace"] = D.allreduce_average(merged)
             torch.cuda.synchronize()
         return time.perf_counter() - t0
 
@@ -92,13 +99,17 @@ def main() -> None:
         done += step
     torch.cuda.synchronize()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, "cpu" if backend == "gloo" else "cuda")
+    # the merged trace is the mean of the ranks' own (untouched) traces: check it on the way out
+    own = torch.from_numpy(trace.numpy().copy()).to("cpu" if backend == "gloo" else "cuda")
+    mean_check = D.allreduce_average(own.clone())
+    merged_ok = bool(torch.allclose(reduced["trace"].cpu(), mean_check.cpu(), rtol=0, atol=1e-6))
     if rank == 0:
         print(json.dumps({
             "config": "C5: %d independent 65536-pt spectrum streams, PSD all-reduce every %d cycles" % (world, args.interval),
             "n_gpus": world, "cycles": args.cycles, "value": world * b * n * args.cycles / elapsed / 1e6,
             "unit": "MS/s", "us_per_cycle": elapsed / args.cycles * 1e6,
             "allreduce_ms_each": spent / max(1, (args.cycles + args.interval - 1) // args.interval) * 1e3,
-            "backend": backend}), flush=True)
+            "merged_trace_is_mean_of_rank_traces": merged_ok, "backend": backend}), flush=True)
     rt.destroy()
     if world > 1:
         dist.destroy_process_group()

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/${1:-prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-alt --steps 96 --warmup 17 ${BENCH_ARGS:-}"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-alt --no-parity --steps 96 --warmup 17 ${BENCH_ARGS:-}"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1

@@ -24,8 +24,9 @@ struct StorePower {
     float* out;
     static constexpr uint32_t kElemBytes = 4;
     __device__ __forceinline__ const void* row(int64_t base) const { return out + base; }
+    __device__ __forceinline__ float value(float2 v) const { return v.x * v.x + v.y * v.y; }
     __device__ __forceinline__ void store_buf(rsrc_t r, uint32_t voff, uint32_t soff, float2 v) const {
-        buf_store_f1(r, voff, soff, v.x * v.x + v.y * v.y);
+        buf_store_f1(r, voff, soff, value(v));
     }
     template <bool CONTIG>
     __device__ __forceinline__ void store(int64_t base, int64_t axis_stride, int pos, float2 v) const {
