@@ -339,21 +339,69 @@ __device__ __forceinline__ bool near_bin_edge(float r, float h) {
     return f >= 0.5f && __builtin_fabsf(fr - 0.5f) > 0.5f - h * 7.5e-7f;
 }
 // One out-of-line copy of the exact arithmetic serves the rare guarded elements (amplitude_range_from_power_cold,
-// above).  Everything from the power p = re^2 + im^2 on is a function of ONE float, identical in both providers up
-// to p, so the guarantee "guarded fast value and exact value fall into the same Spectrogram bin" is checked on
+// above).  Everything from the power p = re^2 + im^2 on is a function of ONE float, identical in both providers up to
+// p, so the guarantee "guarded fast value and exact value fall into the same Spectrogram bin" is checked on
 // every float p, per height, by the exhaustive device sweep (exact_sweep.hip, tests/test_gpu_exact_sweep.py).
+//
+// Round 3: the fast value itself is the LEAN form.  Amplitude -> Range is affine in (P(F) + E) up to the tanh --
+//   arg = 4 * ((20 * L * (P(F) + E) + coeff) * scale + offset - 0.5),  0.5 + 0.5 * tanh(arg) = 1 / (1 + 2^z),
+//   z = -2 log2(e) * arg  --
+// so every constant folds into the four coefficients of ApproxLog10's cubic and one exponent weight (computed once per
+// launch in double, FastRangePoly), the chain runs as four fused multiply-adds and the logistic form needs one v_exp_f32
+// and one v_rcp_f32: 17 VALU instructions from the power on, against ~50 for the round-2 fast form and ~105 for the
+// exact one.  Its deviation from the exact provider stays below 3e-7 (every float p, WHICH = 6 of the sweep).
+struct FastRangePoly {
+    float k3 = 0.0f, k2 = 0.0f, k1 = 0.0f, k0 = 0.0f, ke = 0.0f;
+};
+__host__ __device__ inline FastRangePoly make_fast_range_poly(float coeff, float scale, float offset) {
+    const double L = 0.3010299956639812, M = -2.885390081777926814719849362003784;  // log10(2), -2 log2(e)
+    const double A = 80.0 * L * (double)scale;                                      // d arg / d (P + E)
+    const double B = 4.0 * ((double)coeff * (double)scale + (double)offset - 0.5);
+    FastRangePoly q;
+    q.k3 = (float)(M * A * 1.23149591368684);
+    q.k2 = (float)(M * A * -4.11852516267426);
+    q.k1 = (float)(M * A * 6.02197014179219);
+    q.k0 = (float)(M * (A * -3.13396450166353 + B));
+    q.ke = (float)(M * A);
+    return q;
+}
+// Domain: power in [2^-100, 2^100] (the caller bails out to the exact arithmetic for anything else).
+__device__ __forceinline__ float amplitude_range_lean(float p, const FastRangePoly& q) {
+    const float mag = __builtin_amdgcn_sqrtf(p);
+    const float f = __builtin_amdgcn_frexp_mantf(mag);
+    const float e = (float)__builtin_amdgcn_frexp_expf(mag);
+    const float tail = __builtin_fmaf(q.ke, e, q.k0);
+    const float z = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(q.k3, f, q.k2), f, q.k1), f, tail);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));  // 2^z = inf -> 0, 2^z = 0 -> 1
+}
+__device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p, float coeff, float scale,
+                                                                         float offset, const BinGuard& g,
+                                                                         const FastRangePoly& q) {
+    if (scale == 0.0f) return 0.5f;  // wave-uniform
+    float r = amplitude_range_lean(p, q);
+    bool cold = (f2u(p) - kPowerLo) > (kPowerHi - kPowerLo);  // zero, subnormal, huge, inf, NaN: the exact ladder
+    if (g.h0 > 0.0f) {  // wave-uniform
+        cold |= near_bin_edge(r, g.h0);
+        if (g.h1 > 0.0f) cold |= near_bin_edge(r, g.h1);
+    }
+    if (__builtin_expect(cold, 0)) r = amplitude_range_from_power_cold(p, coeff, scale, offset);
+    return r;
+}
 __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p, float coeff, float scale,
                                                                          float offset, const BinGuard& g) {
-    float r = range_f32_fast(amplitude_from_power_fast(p, coeff), scale, offset);
-    if (g.h0 > 0.0f) {  // wave-uniform
-        if (near_bin_edge(r, g.h0) || (g.h1 > 0.0f && near_bin_edge(r, g.h1)))
-            r = amplitude_range_from_power_cold(p, coeff, scale, offset);
-    }
-    return r;
+    return amplitude_range_fast_guarded_from_power(p, coeff, scale, offset, g, make_fast_range_poly(coeff, scale, offset));
 }
 __device__ __forceinline__ float amplitude_range_fast_guarded(f2 v, float coeff, float scale, float offset,
                                                               const BinGuard& g) {
     return amplitude_range_fast_guarded_from_power((v.x * v.x) + (v.y * v.y), coeff, scale, offset, g);
+}
+__device__ __forceinline__ float amplitude_range_fast_guarded(f2 v, float coeff, float scale, float offset,
+                                                              const BinGuard& g, const FastRangePoly& q) {
+    return amplitude_range_fast_guarded_from_power((v.x * v.x) + (v.y * v.y), coeff, scale, offset, g, q);
+}
+// the round-2 fast form (v_sqrt + restated cubic + tanh through v_exp / v_rcp), kept for the A/B in the sweep
+__device__ __forceinline__ float amplitude_range_fast_r02_from_power(float p, float coeff, float scale, float offset) {
+    return range_f32_fast(amplitude_from_power_fast(p, coeff), scale, offset);
 }
 
 }  // namespace jst::dev

@@ -66,10 +66,19 @@ __global__ __launch_bounds__(256) void sweep_kernel(float coeff, float scale, fl
             const float got = amplitude_range_fast_guarded_from_power(a, coeff, scale, offset, BinGuard{height, 0.0f});
             if (f2u(got) != f2u(ref)) ++main_hits;  // elements that kept the fast value
             if (bin_of(ref, height) != bin_of(got, height)) note(res, bits);
-        } else {  // WHICH == 5: fast provider WITHOUT the guard (shows the sweep can tell: bins do move)
+        } else if constexpr (WHICH == 5) {  // fast provider WITHOUT the guard (shows the sweep can tell: bins do move)
             const float ref = range_f32_general(amplitude_from_power(a, coeff), scale, offset);
-            const float got = range_f32_fast(amplitude_from_power_fast(a, coeff), scale, offset);
+            float got = amplitude_range_lean(a, make_fast_range_poly(coeff, scale, offset));
+            if ((bits - kPowerLo) > (kPowerHi - kPowerLo)) got = ref;
             if (bin_of(ref, height) != bin_of(got, height)) note(res, bits);
+        } else {  // WHICH == 6: largest |lean fast value - exact value| over the lean form's domain (bits of it in `first`)
+            if ((bits - kPowerLo) > (kPowerHi - kPowerLo)) continue;
+            ++main_hits;
+            const float ref = range_f32_general(amplitude_from_power(a, coeff), scale, offset);
+            const float got = amplitude_range_lean(a, make_fast_range_poly(coeff, scale, offset));
+            const float d = __builtin_fabsf(got - ref);
+            if (!(d <= 1.0f)) note(res, bits);              // NaN or nonsense: counted as bad
+            else atomicMax(&res->pad, f2u(d));              // non-negative floats order like their bits
         }
     }
     if (main_hits) atomicAdd(&res->visited, main_hits);
@@ -92,6 +101,7 @@ hipError_t launch_exact_sweep(int which, float coeff, float scale, float offset,
         case 3: hipLaunchKernelGGL(sweep_kernel<3>, grid, block, 0, nullptr, coeff, scale, offset, height, d); break;
         case 4: hipLaunchKernelGGL(sweep_kernel<4>, grid, block, 0, nullptr, coeff, scale, offset, height, d); break;
         case 5: hipLaunchKernelGGL(sweep_kernel<5>, grid, block, 0, nullptr, coeff, scale, offset, height, d); break;
+        case 6: hipLaunchKernelGGL(sweep_kernel<6>, grid, block, 0, nullptr, coeff, scale, offset, height, d); break;
         default: (void)hipFree(d); return hipErrorInvalidValue;
     }
     e = hipGetLastError();
@@ -102,7 +112,7 @@ hipError_t launch_exact_sweep(int which, float coeff, float scale, float offset,
     if (e != hipSuccess) return e;
     if (mismatches) *mismatches = h.bad;
     if (visited) *visited = h.visited;
-    if (first_bad) *first_bad = h.first;
+    if (first_bad) *first_bad = which == 6 ? h.pad : h.first;  // WHICH 6 reports the largest deviation's float bits
     return hipSuccess;
 }
 

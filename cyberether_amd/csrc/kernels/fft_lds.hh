@@ -161,10 +161,18 @@ __device__ __forceinline__ void quad_transpose4(float (&a)[4], bool odd, bool hi
     a[3] = hi ? b3 : m1;
 }
 #ifndef JST_STORE16
-#define JST_STORE16 1
+#define JST_STORE16 0
 #endif
 #ifndef JST_LOAD16
 #define JST_LOAD16 1
+#endif
+// The Multiply operand of the prologue (the window taps of this thread's eight pass-0 positions) stays in VGPRs across
+// the transforms of a workgroup instead of being re-requested from L2 behind every retired output: a thread visits
+// the same positions in every transform.  Round 2 could not afford the 16 registers (127 VGPRs); the in-place twiddles
+// left room (104).  In the memory-only skeleton the re-requests cost 2.4 us per launch and their L2 round trip is
+// exposed at the top of every transform (profiles/r03_experiments/a_floor_bisect.log, rows D2 -> E1).
+#ifndef JST_OPND_RESIDENT
+#define JST_OPND_RESIDENT 1
 #endif
 
 // ---- prologues (how pass 0 obtains CC(i,b,k)) -------------------------------------------------
@@ -264,10 +272,11 @@ struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_na
     float* out;
     float coeff, scale, offset;
     BinGuard guard;  // FAST only: heights of the Spectrogram consumers (device_math.hh)
+    FastRangePoly poly = make_fast_range_poly(coeff, scale, offset);  // FAST only: folded constants, computed on the host
     static constexpr uint32_t kElemBytes = 4;
     __device__ __forceinline__ const void* row(int64_t base) const { return out + base; }
     __device__ __forceinline__ float value(float2 v) const {
-        if constexpr (FAST) return amplitude_range_fast_guarded(v, coeff, scale, offset, guard);
+        if constexpr (FAST) return amplitude_range_fast_guarded(v, coeff, scale, offset, guard, poly);
 #ifdef JST_EPI_GENERAL  // A/B switch: the class-ladder form of round 1
         else return range_f32_general(amplitude_cf32(v, coeff), scale, offset);
 #else
@@ -634,7 +643,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
 #ifndef JST_NO_EPI_SCHED_BARRIER
                 __builtin_amdgcn_sched_barrier(0);
 #endif
-                if constexpr (Pro::kHasOperand) {
+                if constexpr (Pro::kHasOperand && !(JST_OPND_RESIDENT && CONTIG)) {
                     constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
                     if constexpr (pipe_load16<N, CONTIG>()) {
                         const uint32_t vo = (uint32_t)(((tid & ~1) + 4 * IDO0 * (tid & 1)) * 8);
@@ -670,7 +679,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
 #ifndef JST_NO_EPI_SCHED_BARRIER  // A/B switch
                 __builtin_amdgcn_sched_barrier(0);
 #endif
-                if constexpr (Pro::kHasOperand) {
+                if constexpr (Pro::kHasOperand && !(JST_OPND_RESIDENT && CONTIG)) {
                     // The per-position operand of the prologue (window taps) is not kept live
                     // across the passes: element e is re-requested from L2 as soon as output e
                     // has retired, into the registers that output just freed.

@@ -241,6 +241,13 @@ size_t spectrogram_lds_bytes(uint64_t height);
 hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, uint64_t batches,
                               uint64_t width, uint64_t height, int64_t batch_stride,
                               int64_t elem_stride, float decay, hipStream_t stream);
+// The exact multi-GPU merge of spectrograms: this cycle's hit COUNTS as a U32[height][width] tensor
+// (no state touched) -- all-reduce(sum) them over the ranks -- then one shared decay and the count-times update.
+hipError_t launch_spectrogram_counts(uint32_t* counts, const float* in, uint64_t in_offset, uint64_t batches,
+                                     uint64_t width, uint64_t height, int64_t batch_stride, int64_t elem_stride,
+                                     hipStream_t stream);
+hipError_t launch_spectrogram_apply_counts(float* bins, const uint32_t* counts, uint64_t cells, float decay,
+                                           hipStream_t stream);
 
 // ---- Waterfall (waterfall.hip) -----------------------------------------------------------------
 // ring: F32 [height][width]; state: device u64[4] = {writeIndex, dirtyRows, ticket, pad}.

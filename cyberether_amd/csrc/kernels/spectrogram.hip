@@ -36,6 +36,32 @@ __global__ __launch_bounds__(kThreads) void spectrogram_kernel(
                                                         elem_stride, decay, blockIdx.x, gridDim.x);
 }
 
+// The same histogram with the COUNTS as the result (U32[height][width], written over `counts`): the device half of
+// the exact multi-GPU spectrogram merge -- spectrogram/module_impl_native_cpu.cc:61-87 applies min(v + 0.02f, 1.0f)
+// once per hit, so the update depends on the hit count per bin only, and integer counts add exactly across ranks.
+template <int TW, int COPIES>
+__global__ __launch_bounds__(kThreadsDefault) void spectrogram_counts_kernel(
+    uint32_t* __restrict__ counts, const float* __restrict__ in, uint64_t in_offset, uint32_t batches,
+    uint32_t width, uint32_t height, int64_t batch_stride, int64_t elem_stride) {
+    spectrogram_body<TW, COPIES, kThreadsDefault, 16, false, true>(reinterpret_cast<float*>(counts), in, in_offset, batches,
+                                                                   width, height, batch_stride, elem_stride, 1.0f,
+                                                                   blockIdx.x, gridDim.x);
+}
+
+// bins = decay * bins, then min(v + 0.02f, 1.0f) applied counts[i] times: what spectrogram_body does per tile, on
+// counts that were summed over the ranks first.  decay = 0.999^(total batches of all ranks) (module_impl.cc:104).
+__global__ __launch_bounds__(256) void spectrogram_apply_counts_kernel(float* __restrict__ bins,
+                                                                       const uint32_t* __restrict__ counts,
+                                                                       uint64_t cells, float decay) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (uint64_t)gridDim.x * 256) {
+        float w = bins[i] * decay;
+        uint32_t k = counts[i];
+        k = k < 64u ? k : 64u;  // 0.02 * 51 > 1: pinned at 1.0f long before 64 hits
+        for (uint32_t n = 0; n < k && w < 1.0f; ++n) w = fminf(w + 0.02f, 1.0f);
+        store_state(bins + i, w);
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -90,6 +116,40 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
     else JST_SPEC_LAUNCH(8, 1, 1024, 16, tiles8);
 #undef JST_SPEC_LAUNCH
 #undef JST_SPEC_LAUNCH_B
+    return hipGetLastError();
+}
+
+hipError_t launch_spectrogram_counts(uint32_t* counts, const float* in, uint64_t in_offset, uint64_t batches,
+                                     uint64_t width, uint64_t height, int64_t batch_stride, int64_t elem_stride,
+                                     hipStream_t stream) {
+    if (width == 0 || height == 0) return hipSuccess;
+    if (height > 2048 || batches > 0xffffffffull || width > 0xffffffffull) return hipErrorInvalidValue;
+    const size_t lds = spectrogram_lds_bytes(height);
+    const unsigned tiles16 = (unsigned)((width + 15) / 16), tiles8 = (unsigned)((width + 7) / 8);
+    (void)hipGetLastError();
+#define JST_SPEC_COUNTS(TW, COPIES, TILES)                                                                          \
+    do {                                                                                                            \
+        const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(spectrogram_counts_kernel<TW, COPIES>), \
+                                               80 * 1024);                                                          \
+        if (e != hipSuccess) return e;                                                                              \
+        hipLaunchKernelGGL((spectrogram_counts_kernel<TW, COPIES>), dim3(TILES), dim3(kThreadsDefault), lds, stream, \
+                           counts, in, in_offset, (uint32_t)batches, (uint32_t)width, (uint32_t)height,             \
+                           batch_stride, elem_stride);                                                              \
+    } while (0)
+    if (height <= 256) JST_SPEC_COUNTS(16, 4, tiles16);
+    else if (height <= 512) JST_SPEC_COUNTS(16, 2, tiles16);
+    else if (height <= 1024) JST_SPEC_COUNTS(16, 1, tiles16);
+    else JST_SPEC_COUNTS(8, 1, tiles8);
+#undef JST_SPEC_COUNTS
+    return hipGetLastError();
+}
+
+hipError_t launch_spectrogram_apply_counts(float* bins, const uint32_t* counts, uint64_t cells, float decay,
+                                           hipStream_t stream) {
+    if (cells == 0) return hipSuccess;
+    (void)hipGetLastError();
+    const unsigned grid = (unsigned)((cells + 255) / 256 < 4096 ? (cells + 255) / 256 : 4096);
+    hipLaunchKernelGGL(spectrogram_apply_counts_kernel, dim3(grid), dim3(256), 0, stream, bins, counts, cells, decay);
     return hipGetLastError();
 }
 

@@ -41,7 +41,10 @@ __device__ __forceinline__ void lds_only_barrier() {
 // beyond `batches` and the columns of a ragged last tile fall outside the descriptor's range and read as 0 (which never
 // hits).  Used when the tensor spans < 2 GiB and its rows do not interleave; the flat form stays for everything else.
 // The body as a device function of (workgroup index, workgroup count), see fft_pipe_body.
-template <int TW, int COPIES, int kThreads = kThreadsDefault, int kDepthT = 16, bool BUF = false>
+// COUNTS: the hit counts of this cycle are the RESULT -- `bins` then points at a U32[height][width] tensor that receives
+// them (unclamped) and no state is read or updated: the device half of the exact multi-GPU merge (all-reduce the
+// integer counts over the ranks, then spectrogram_apply_counts_kernel: one shared decay and the count-times update).
+template <int TW, int COPIES, int kThreads = kThreadsDefault, int kDepthT = 16, bool BUF = false, bool COUNTS = false>
 __device__ __forceinline__ void spectrogram_body(
     float* __restrict__ bins, const float* __restrict__ in, uint64_t in_offset, uint32_t batches,
     uint32_t width, uint32_t height, int64_t batch_stride, int64_t elem_stride, float decay,
@@ -72,7 +75,7 @@ __device__ __forceinline__ void spectrogram_body(
         const uint32_t e = tid + j * kThreads;
         const uint32_t xx = tile * TW + (e % TW);
         cell[j] = (e < cells && xx < width) ? bins + (uint64_t)(e / TW) * width + xx : nullptr;
-        state[j] = cell[j] ? *cell[j] : 0.0f;
+        if constexpr (!COUNTS) state[j] = cell[j] ? *cell[j] : 0.0f;
     }
 
     const uint32_t c = tid % TW;
@@ -141,8 +144,16 @@ __device__ __forceinline__ void spectrogram_body(
         uint32_t k = 0;
 #pragma unroll
         for (int cp = 0; cp < COPIES; ++cp) k += hist[cp * copy_stride + e];
+        if constexpr (COUNTS) return k;
         return k < 64u ? k : 64u;  // 0.02 * 51 > 1: the value is pinned at 1.0f long before 64 hits
     };
+    if constexpr (COUNTS) {
+        for (uint32_t e = tid; e < cells; e += kThreads) {
+            const uint32_t xx = tile * TW + (e % TW);
+            if (xx < width) reinterpret_cast<uint32_t*>(bins)[(uint64_t)(e / TW) * width + xx] = hits(e);
+        }
+        return;
+    }
     auto apply = [&](float w, uint32_t k) {
         w *= decay;
         // std::min(val + 0.02f, 1.0f), k times.  1.0f is a fixed point of the update, so the early exit only has to be

@@ -995,27 +995,78 @@ Result validate_surface_input(const char* tag, const Config& cfg, U64 default_he
 }  // namespace
 
 Result Spectrogram::validate() {
+    const std::string merge = ConfigStr(config_, "merge", "local");
+    if (merge != "local" && merge != "counts") {
+        JST_ERROR("[MODULE_SPECTROGRAM] Invalid merge mode '%s', must be 'local' or 'counts'.", merge.c_str());
+        return Result::ERROR;
+    }
+    countsOnly = merge == "counts";
     return validate_surface_input("MODULE_SPECTROGRAM", config_, 256, inputs_, height,
                                   numberOfElements, numberOfBatches, inputElementStride,
                                   inputBatchStride);
 }
 Result Spectrogram::define() {
     JST_CHECK(defineTaint(SURFACE));
-    return defineInterfaceInput("signal");
+    JST_CHECK(defineInterfaceInput("signal"));
+    if (ConfigStr(config_, "merge", "local") == "counts") return defineInterfaceOutput("counts");
+    return Result::SUCCESS;
 }
 Result Spectrogram::create() {
     input = inputs_.at("signal");
     decayFactor = std::pow(0.999f, static_cast<F32>(numberOfBatches));  // module_impl.cc:104
     JST_CHECK(frequencyBins.create(device(), DataType::F32, {numberOfElements, height}));
+    if (countsOnly) {
+        JST_CHECK(hitCounts.create(device(), DataType::U32, {numberOfElements, height}));
+        produced("counts", hitCounts);
+    }
     return Result::SUCCESS;
 }
 Result Spectrogram::computeSubmit(hipStream_t stream) {
+    if (countsOnly)
+        return hip_result(
+            kernels::launch_spectrogram_counts(ptr<uint32_t>(hitCounts), ptr<const float>(input), input.offset(),
+                                               numberOfBatches, numberOfElements, height, (int64_t)inputBatchStride,
+                                               (int64_t)inputElementStride, stream),
+            "spectrogram counts kernel");
     return hip_result(
         kernels::launch_spectrogram(ptr<float>(frequencyBins), ptr<const float>(input),
                                     input.offset(), numberOfBatches, numberOfElements, height,
                                     (int64_t)inputBatchStride, (int64_t)inputElementStride,
                                     decayFactor, stream),
         "spectrogram kernel");
+}
+
+Result SpectrogramMerge::validate() {
+    bool ok = true;
+    totalBatches = ConfigU64(config_, "batches", 0, &ok);
+    if (!ok || totalBatches == 0) {
+        JST_ERROR("[MODULE_SPECTROGRAM_MERGE] Invalid batches value '%s': the batch count of ALL merged ranks.",
+                  ConfigStr(config_, "batches", "?").c_str());
+        return Result::ERROR;
+    }
+    if (!inputs_.count("counts")) return Result::SUCCESS;
+    const Tensor& in = inputs_.at("counts");
+    if (!in.validShape() || in.size() == 0) return Result::SUCCESS;
+    if (in.dtype() != DataType::U32 || in.rank() != 2 || !in.contiguous()) {
+        JST_ERROR("[MODULE_SPECTROGRAM_MERGE] Input must be a contiguous U32 {width, height} hit-count tensor.");
+        return Result::ERROR;
+    }
+    return Result::SUCCESS;
+}
+Result SpectrogramMerge::define() {
+    JST_CHECK(defineTaint(SURFACE));
+    return defineInterfaceInput("counts");
+}
+Result SpectrogramMerge::create() {
+    counts = inputs_.at("counts");
+    decayFactor = std::pow(0.999f, static_cast<F32>(totalBatches));  // module_impl.cc:104 on the merged batch count
+    JST_CHECK(frequencyBins.create(device(), DataType::F32, {counts.shape(0), counts.shape(1)}));
+    return Result::SUCCESS;
+}
+Result SpectrogramMerge::computeSubmit(hipStream_t stream) {
+    return hip_result(kernels::launch_spectrogram_apply_counts(ptr<float>(frequencyBins), ptr<const uint32_t>(counts) + counts.offset(),
+                                                               counts.size(), decayFactor, stream),
+                      "spectrogram merge kernel");
 }
 
 Result Waterfall::validate() {
@@ -1322,6 +1373,7 @@ using RangeFast = Range;
 JST_REGISTER_MODULE(AmplitudeFast, "amplitude", DeviceType::HIP, RuntimeType::NATIVE, "fast");
 JST_REGISTER_MODULE(RangeFast, "range", DeviceType::HIP, RuntimeType::NATIVE, "fast");
 JST_REGISTER_MODULE(Spectrogram, "spectrogram", DeviceType::HIP, RuntimeType::NATIVE, "generic");
+JST_REGISTER_MODULE(SpectrogramMerge, "spectrogram_merge", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Waterfall, "waterfall", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(RingSource, "ring_source", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 

@@ -206,6 +206,11 @@ class Spectrogram : public Module {
         return key == "frequencyBins" ? &frequencyBins : nullptr;
     }
     Tensor input, frequencyBins;  // state: F32 {width, height}, laid out [height][width]
+    // config merge = "counts" (not in the reference, whose display is per process): the module publishes this cycle's
+    // integer hit counts as output "counts" (U32 {width, height}, laid out like the state) and leaves the state
+    // alone -- the counts of all ranks are summed (RCCL all-reduce) and applied by a spectrogram_merge module.
+    bool countsOnly = false;
+    Tensor hitCounts;
     U64 height = 256, numberOfElements = 0, numberOfBatches = 0;
     U64 inputElementStride = 0, inputBatchStride = 0;
     F32 decayFactor = 1.0f;
@@ -222,6 +227,25 @@ class Spectrogram : public Module {
         combinedCycle += cycles;
         combinedPending = true;
     }
+};
+
+// The second half of the exact multi-GPU spectrogram: input "counts" = U32 {width, height} hit counts already
+// summed over the ranks; state frequencyBins decays by 0.999^batches (config: the batches of ALL ranks, the `decayFactor`
+// of spectrogram/module_impl.cc:104 for the merged batch) and takes min(v + 0.02f, 1.0f) count-times per bin
+// (module_impl_native_cpu.cc:61-87 applies it once per hit): bit-identical to one Spectrogram over the union of the batches.
+class SpectrogramMerge : public Module {
+ public:
+    const char* type() const override { return "spectrogram_merge"; }
+    Result validate() override;
+    Result define() override;
+    Result create() override;
+    Result computeSubmit(hipStream_t stream) override;
+    const Tensor* state(const std::string& key) const override {
+        return key == "frequencyBins" ? &frequencyBins : nullptr;
+    }
+    Tensor counts, frequencyBins;
+    U64 totalBatches = 0;
+    F32 decayFactor = 1.0f;
 };
 
 // src/domains/visualization/waterfall/{module_impl.cc, ring_state.hh:16-56,

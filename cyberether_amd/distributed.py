@@ -48,6 +48,41 @@ def merge_hit_counts(counts: torch.Tensor) -> torch.Tensor:
     return counts
 
 
+_TORCH_OF = {"F32": (torch.float32, "<f4"), "U32": (torch.int32, "<i4"), "I32": (torch.int32, "<i4")}
+
+
+def device_view(tensor) -> torch.Tensor:
+    """Zero-copy torch view of a dense HIP jetstream Tensor (F32 / U32) for a collective: the collective then runs
+    in place on the module's own HBM.  U32 hit counts travel as int32 (sums stay far below 2^31)."""
+    if tensor.device != "hip":
+        raise ValueError("device_view needs a HIP tensor")
+    tdtype, typestr = _TORCH_OF[tensor.dtype]
+    shape = tuple(int(v) for v in tensor.shape)
+
+    class _View:
+        __cuda_array_interface__ = {"shape": shape, "typestr": typestr,
+                                    "data": (int(tensor.data_ptr) + int(tensor.offset) * 4, False), "version": 2}
+    view = torch.as_tensor(_View(), device="cuda")
+    view._jst_keep = tensor   # the jetstream tensor owns the memory
+    return view
+
+
+def merge_spectrogram_counts(counts_tensor, via_host: bool = False) -> None:
+    """The exchange step of the exact multi-GPU spectrogram: sum the U32[H, N] hit counts a
+    `spectrogram{merge=counts}` module wrote this cycle over all ranks, in place on the device (RCCL all-reduce of
+    4 MiB at H = 256, N = 4096); a `spectrogram_merge{batches = all ranks' batches}` module then applies them.
+    via_host: bounce through the host (gloo dry runs where ranks share a device)."""
+    if _world() == 1:
+        return
+    if via_host:
+        host = torch.from_numpy(counts_tensor.numpy().astype(np.int32))
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        counts_tensor.copy_from(host.numpy().astype(np.uint32))
+    else:
+        merge_hit_counts(device_view(counts_tensor))
+        torch.cuda.synchronize()
+
+
 def max_over_ranks(seconds: float, device: str = "cpu") -> float:
     """The bench contract's timing rule: the slowest rank defines the step time."""
     if _world() == 1:

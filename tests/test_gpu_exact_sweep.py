@@ -74,3 +74,16 @@ def test_fast_provider_bins_are_exact_with_the_guard_on_every_power(js, coeff, s
 def test_without_the_guard_bins_do_move(js):
     bad, _, _ = sweep(js, 5, *PARAMS[0], 256.0)
     assert bad > 0  # the sweep can tell
+
+
+@pytest.mark.parametrize("coeff,scale,offset", PARAMS)
+def test_lean_fast_value_deviates_less_than_3e7_on_every_power(js, coeff, scale, offset):
+    """Round 3's lean fast form (folded cubic as four fused multiply-adds, logistic through v_exp / v_rcp): its largest
+    deviation from the exact provider over EVERY power of its domain.  The bin guard's width (height x 7.5e-7) is twice
+    this bound plus the two roundings of the value x height product; BASELINE's float tolerance is 1e-5."""
+    bad, visited, dev_bits = sweep(js, 6, coeff, scale, offset)
+    assert visited == 0x71800000 - 0x0d800000 + 1 and bad == 0
+    import struct
+    dev = struct.unpack("<f", struct.pack("<I", dev_bits))[0]
+    print(f"largest |lean - exact| = {dev:.3e} (coeff {coeff:.2f}, scale {scale:.4f})")
+    assert 0.0 < dev <= 3.0e-7, dev

@@ -144,3 +144,48 @@ def test_lineplot_compute_and_averaging(js, oracle):
             assert_bit_equal(m.state("signalPoints").numpy()[:, 1], avg)
     with pytest.raises(js.JetstreamError, match="Averaging must be greater than zero"):
         js.Module("lineplot", {"averaging": 0}, {"signal": t})
+
+
+def test_spectrogram_counts_merge_equals_one_spectrogram_over_all_batches(js, oracle):
+    """The device path of the exact multi-GPU merge (SURVEY 8e): two shards of a batch run spectrogram{merge=counts}
+    (integer hit counts out, no state), the counts are summed -- what the RCCL all-reduce does across ranks --
+    and spectrogram_merge{batches = total} applies them; over several cycles the merged display must equal, bit for
+    bit, ONE Spectrogram (and the oracle) over the union of the batches
+    (spectrogram/module_impl_native_cpu.cc:61-87: the update runs once per hit, so only the count matters)."""
+    n, b, h = 1024, 48, 256
+    rng = np.random.default_rng(31)
+    xs = [rng.random((b, n), dtype=np.float32) * np.float32(1.2) - np.float32(0.1) for _ in range(4)]   # some outside [0, 1)
+    for x in xs:
+        x[:, 100:110] = np.float32(0.5)      # a hot column band: > 51 hits per bin saturate at 1.0
+    t_all = js.Tensor.from_numpy(xs[0], batch=0, sample=1)
+    t_a = js.Tensor.from_numpy(xs[0][:20], batch=0, sample=1)      # shards of unequal size
+    t_b = js.Tensor.from_numpy(xs[0][20:], batch=0, sample=1)
+    one = js.Module("spectrogram", {"height": h}, {"signal": t_all}, "one")
+    sa = js.Module("spectrogram", {"height": h, "merge": "counts"}, {"signal": t_a}, "shard_a")
+    sb = js.Module("spectrogram", {"height": h, "merge": "counts"}, {"signal": t_b}, "shard_b")
+    ca, cb = sa.output("counts"), sb.output("counts")
+    assert ca.dtype == "U32" and tuple(ca.shape) == (n, h)
+    merge = js.Module("spectrogram_merge", {"batches": b}, {"counts": ca}, "merge")
+    rt_one = js.Runtime([one], graph=True)
+    rt_sh = js.Runtime([sa, sb], graph=True)
+    rt_m = js.Runtime([merge], graph=True)
+    ref = np.zeros(n * h, np.float32)
+    for cyc, x in enumerate(xs):
+        t_all.copy_from(x)
+        t_a.copy_from(x[:20])
+        t_b.copy_from(x[20:])
+        rt_one.compute(1)
+        rt_sh.compute(1)
+        total = ca.numpy() + cb.numpy()           # the all-reduce(sum) of the ranks' counts
+        assert total.sum() == np.count_nonzero((x * np.float32(h) >= 1) & (x * np.float32(h) < h))
+        ca.copy_from(total)
+        rt_m.compute(1)
+        oracle.spectrogram(ref, x, h)
+        assert_bit_equal(one.state("frequencyBins").numpy().reshape(-1), ref, f"one spectrogram, cycle {cyc}")
+        assert_bit_equal(merge.state("frequencyBins").numpy().reshape(-1), ref, f"merged display, cycle {cyc}")
+    assert np.all(sa.state("frequencyBins").numpy() == 0)   # counts mode leaves its own state alone
+    assert ref.max() == 1.0
+    with pytest.raises(js.JetstreamError):
+        js.Module("spectrogram", {"height": h, "merge": "sum"}, {"signal": t_a})
+    with pytest.raises(js.JetstreamError):
+        js.Module("spectrogram_merge", {"batches": 0}, {"counts": ca})

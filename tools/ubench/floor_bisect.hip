@@ -90,8 +90,8 @@ __global__ __launch_bounds__(512, 2) void skel(const float2* __restrict__ in, fl
     const rsrc_t r_w = make_rsrc(win, 4096u * 8u);
     {
         const rsrc_t r_in = make_rsrc(in + (size_t)r * 4096, 4096u * 8u);
-        if constexpr (WINDOW) load_row<(LOADK == 0 ? 1 : LOADK)>(opnd, win, r_w, tid);
-        load_row<LOADK>(cur, in + (size_t)r * 4096, r_in, tid);
+        if constexpr (WINDOW) load_row<((LOADK == 0 || LOADK == 4) ? 1 : LOADK)>(opnd, win, r_w, tid);
+        load_row<(LOADK == 4 ? 1 : LOADK)>(cur, in + (size_t)r * 4096, r_in, tid);
     }
     bool flip = false;
     while (true) {
@@ -102,6 +102,8 @@ __global__ __launch_bounds__(512, 2) void skel(const float2* __restrict__ in, fl
         const bool more = rn < nrows;
         if constexpr (LOADK == 0) {
             if (more) load_row<0>(cur, in + (size_t)rn * 4096, r_w, tid);
+        } else if constexpr (LOADK == 4) {  // buffer loads under a condition (the form the product kernel avoids)
+            if (more) load_row<1>(cur, nullptr, make_rsrc(in + (size_t)rn * 4096, 4096u * 8u), tid);
         } else {
             const rsrc_t r_in = make_rsrc(in + (size_t)(more ? rn : r) * 4096, more ? 4096u * 8u : 0u);
             load_row<LOADK>(cur, nullptr, r_in, tid);
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(512, 2) void skel(const float2* __restrict__ in, fl
         float* orow = out + (size_t)r * 4096;
         const rsrc_t r_out = make_rsrc(orow, 4096u * 4u);
         const rsrc_t r_wn = make_rsrc(win, more ? 4096u * 8u : 0u);
+        constexpr bool REQ = WINDOW == 1;  // WINDOW == 2: the operand stays in registers, nothing is re-requested
         if constexpr (STOREK == 0 || STOREK == 1 || STOREK == 2 || STOREK == 6) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void skel(const float2* __restrict__ in, fl
                 else if constexpr (STOREK == 1) __hip_atomic_store(orow + tid + 512 * j, f[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else if constexpr (STOREK == 2) buf_store_f1x<16>(r_out, (uint32_t)tid * 4u, (uint32_t)(2048 * j), f[j]);
                 else buf_store_f1x<0>(r_out, (uint32_t)tid * 4u, (uint32_t)(2048 * j), f[j]);
-                if constexpr (WINDOW) {
+                if constexpr (REQ) {
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (LOADK == 2 || LOADK == 3) {
                         if (j & 1) {  // a 16-byte operand request behind every second output
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void skel(const float2* __restrict__ in, fl
                 const uint32_t voff = (STOREK == 4) ? (uint32_t)tid * 16u : (uint32_t)(((tid & ~3) + 512 * (tid & 3)) * 4);
                 if constexpr (STOREK == 5) buf_store_f4x<0>(r_out, voff, (uint32_t)(8192 * h), q);
                 else buf_store_f4x<16>(r_out, voff, (uint32_t)(8192 * h), q);
-                if constexpr (WINDOW) {
+                if constexpr (REQ) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int k2 = 0; k2 < 2; ++k2) {
@@ -355,6 +358,14 @@ int main(int argc, char** argv) {
     // ---- window operand --------------------------------------------------------------------------
     variant<1, 2, 1, 0, 104>(c, "E1 D2 + window (8-byte L2 re-requests)", 512, L73, true);
     variant<2, 3, 1, 0, 104>(c, "E2 D5 + window (16-byte L2 re-requests)", 512, L73, true);
+    variant<1, 2, 2, 0, 104>(c, "E3 D2 + window RESIDENT in VGPRs", 512, L73, true);
+    variant<2, 3, 2, 0, 104>(c, "E4 D5 + window RESIDENT in VGPRs", 512, L73, true);
+    variant<2, 2, 2, 0, 104>(c, "E5 buf16 pairs / buf4 sc1 + window RESIDENT", 512, L73, true);
+    // ---- flat versus buffer addressing (A3 9.0 us vs B2 10.3 us) --------------------------------------
+    variant<0, 6, 0, 0, 0>(c, "G1 flat8 (conditional) / buf4 plain", 512, 0, true);
+    variant<1, 0, 0, 0, 0>(c, "G2 buf8 (unconditional) / flat4 plain", 512, 0, true);
+    variant<4, 6, 0, 0, 0>(c, "G3 buf8 (conditional) / buf4 plain", 512, 0, true);
+    variant<4, 0, 0, 0, 0>(c, "G4 buf8 (conditional) / flat4 plain", 512, 0, true);
     // ---- LDS exchanges ---------------------------------------------------------------------------
     variant<1, 2, 1, 1, 104>(c, "F1 E1 + 1 exchange", 512, L73, true);
     variant<1, 2, 1, 2, 104>(c, "F2 E1 + 2 exchanges", 512, L73, true);
