@@ -485,7 +485,7 @@ jst_result jst_probe_tanhf(const float* in, float* out, uint64_t count) {
 
 jst_result jst_probe_exact_sweep(int which, float amplitude_coeff, float range_scale, float range_offset,
                                  float height, uint64_t* mismatches, uint64_t* visited, uint32_t* first_bad) {
-    JST_ARG(which >= 0 && which <= 5, "unknown sweep");
+    JST_ARG(which >= 0 && which <= 6, "unknown sweep");
     JST_HIP_CHECK(kernels::launch_exact_sweep(which, amplitude_coeff, range_scale, range_offset, height,
                                               mismatches, visited, first_bad),
                   "exact sweep");

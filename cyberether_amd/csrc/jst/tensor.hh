@@ -48,6 +48,11 @@ class Tensor {
     // tensor between a producer kernel and a consumer that runs concurrently with the NEXT cycle.
     Result promoteToRing(U64 slots);
     U64 ringSlots() const { return buffer_ ? buffer_->slots : 0; }
+    // Address of ring slot 'slot' of this (dense, offset-free) tensor, independent of the selected slot: the
+    // producer side of a live source uploads into slots the compute side is not reading.
+    void* ringSlotData(U64 slot) const {
+        return buffer_ && slot < buffer_->slots ? static_cast<char*>(buffer_->ptr) + slot * buffer_->slot_bytes : nullptr;
+    }
     U64 ringSlot() const { return buffer_ ? buffer_->slot : 0; }
     // Borrow external memory (no ownership): stride empty = dense row-major.
     Result wrap(void* ptr, size_t bytes, DeviceType device, DataType dtype, const Shape& shape,

@@ -3,6 +3,7 @@
 #include "modules.hh"
 
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 
@@ -1105,36 +1106,94 @@ Result RingSource::validate() {
     }
     bool o4 = true, o5 = true;
     live = ConfigBool(config_, "live", false, &o4);
-    published = ConfigU64(config_, "published", 0, &o5);
+    publishedConfig = ConfigU64(config_, "published", 0, &o5);
     if (!o4 || !o5) {
         JST_ERROR("[MODULE_RING_SOURCE] Invalid live / published value.");
         return Result::ERROR;
     }
+    const std::string dt = ConfigStr(config_, "dtype", "CF32");
+    if (dt == "CF32") sampleType = DataType::CF32;
+    else if (dt == "CI16") sampleType = DataType::CI16;
+    else if (dt == "CI8") sampleType = DataType::CI8;
+    else if (dt == "CU8") sampleType = DataType::CU8;
+    else {
+        JST_ERROR("[MODULE_RING_SOURCE] Unsupported sample format '%s' (CF32, CI16, CI8, CU8).", dt.c_str());
+        return Result::ERROR;
+    }
+    const std::string policy = ConfigStr(config_, "overflow", "overwrite");
+    if (policy != "overwrite" && policy != "reject") {
+        JST_ERROR("[MODULE_RING_SOURCE] Invalid overflow policy '%s' (overwrite, reject).", policy.c_str());
+        return Result::ERROR;
+    }
+    rejectOnOverflow = policy == "reject";
     return Result::SUCCESS;
 }
 Result RingSource::reconfigureImpl(const Config& previous) {  // the counters move in place, the geometry does not
     if (ConfigU64(previous, "batches", 8) != batches || ConfigU64(previous, "samples", 2048) != samples ||
-        ConfigU64(previous, "slots", 1) != slots || ConfigBool(previous, "live", false) != live)
+        ConfigU64(previous, "slots", 1) != slots || ConfigBool(previous, "live", false) != live ||
+        ConfigStr(previous, "dtype", "CF32") != ConfigStr(config_, "dtype", "CF32") ||
+        ConfigStr(previous, "overflow", "overwrite") != ConfigStr(config_, "overflow", "overwrite"))
         return Result::RECREATE;
     return Result::SUCCESS;
 }
 Result RingSource::define() { return defineInterfaceOutput("buffer"); }
 Result RingSource::create() {
-    JST_CHECK(output.createRing(device(), DataType::CF32, {batches, samples}, slots));
+    JST_CHECK(output.createRing(device(), sampleType, {batches, samples}, slots));
     JST_CHECK(SetSignalAxes(output, {.sample = Index{1}, .batch = Index{0}}));
     output.setAttribute("sampleRate", AttrValue{ConfigF64(config_, "sampleRate", 2.0e6)});
     output.setAttribute("frequency", AttrValue{ConfigF64(config_, "frequency", 96.9e6)});
+    elementBytes = DataTypeSize(sampleType);
     cursor = 0;
     consumed = 0;
+    pushed = 0;
     first = true;
+    overflowCount = 0;
+    stagingIndex = stagingFill = 0;
+    pendingFreeSlot = -1;
+    lastComputeStream = nullptr;
     produced("buffer", output);
     return Result::SUCCESS;
 }
-Result RingSource::computeSubmit(hipStream_t) {
+RingSource::~RingSource() { (void)destroy(); }
+Result RingSource::destroy() {
+    std::lock_guard<std::mutex> lock(mu);
+    if (uploadStream) (void)hipStreamSynchronize(uploadStream);
+    for (U64 i = 0; i < kStaging; ++i) {
+        if (staging[i]) (void)hipHostFree(staging[i]);
+        if (stagingFree[i]) (void)hipEventDestroy(stagingFree[i]);
+        staging[i] = nullptr;
+        stagingFree[i] = nullptr;
+        stagingBusy[i] = false;
+    }
+    for (hipEvent_t e : slotUploaded) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : slotFree) if (e) (void)hipEventDestroy(e);
+    slotUploaded.clear();
+    slotFree.clear();
+    slotUploadValid.clear();
+    slotFreeValid.clear();
+    if (uploadStream) (void)hipStreamDestroy(uploadStream);
+    uploadStream = nullptr;
+    return Result::SUCCESS;
+}
+Result RingSource::computeSubmit(hipStream_t stream) {
     if (live) {
-        if (consumed >= published) return Result::YIELD;  // nothing new from the host: no cycle
+        std::lock_guard<std::mutex> lock(mu);
+        lastComputeStream = stream;
+        if (pendingFreeSlot >= 0 && !slotFree.empty()) {
+            // everything the previous cycle enqueued precedes this point of the stream: its slot is free behind it
+            JST_HIP_CHECK(hipEventRecord(slotFree[(size_t)pendingFreeSlot], stream), "hipEventRecord");
+            slotFreeValid[(size_t)pendingFreeSlot] = 1;
+            pendingFreeSlot = -1;
+        }
+        if (consumed >= published()) return Result::YIELD;  // nothing new from the host: no cycle
         const U64 slot = consumed % slots;
+        if (!slotUploaded.empty() && slotUploadValid[slot])  // the batch's H2D copy (upload stream) before its readers
+            JST_HIP_CHECK(hipStreamWaitEvent(stream, slotUploaded[slot], 0), "hipStreamWaitEvent");
         ++consumed;
+        if (!slotFree.empty()) {
+            slotFreeValid[slot] = 0;
+            pendingFreeSlot = (I64)slot;
+        }
         return output.ringSelect(slot);
     }
     // First cycle exposes slot 0, then round-robin; no data moves.
@@ -1151,6 +1210,147 @@ void RingSource::advanceHostState(U64 cycles) {
     }
     cursor = (cursor + cycles) % slots;
     (void)output.ringSelect(cursor);
+}
+
+// ---- RingSource: producer side -------------------------------------------------------------------
+Result RingSource::ensureProducer() {  // mu held
+    if (!live) {
+        JST_ERROR("[MODULE_RING_SOURCE] The producer interface needs a live source (config live = true).");
+        return Result::ERROR;
+    }
+    if (uploadStream) return Result::SUCCESS;
+    JST_HIP_CHECK(hipStreamCreateWithFlags(&uploadStream, hipStreamNonBlocking), "hipStreamCreate");
+    const size_t batch_bytes = (size_t)(batches * samples) * elementBytes;
+    for (U64 i = 0; i < kStaging; ++i) {
+        JST_HIP_CHECK(hipHostMalloc(&staging[i], batch_bytes, hipHostMallocDefault), "hipHostMalloc");
+        JST_HIP_CHECK(hipEventCreateWithFlags(&stagingFree[i], hipEventDisableTiming), "hipEventCreate");
+        stagingBusy[i] = false;
+    }
+    slotUploaded.assign(slots, nullptr);
+    slotFree.assign(slots, nullptr);
+    slotUploadValid.assign(slots, 0);
+    slotFreeValid.assign(slots, 0);
+    for (U64 s = 0; s < slots; ++s) {
+        JST_HIP_CHECK(hipEventCreateWithFlags(&slotUploaded[s], hipEventDisableTiming), "hipEventCreate");
+        JST_HIP_CHECK(hipEventCreateWithFlags(&slotFree[s], hipEventDisableTiming), "hipEventCreate");
+    }
+    return Result::SUCCESS;
+}
+
+Result RingSource::ringAcquire(void** ptr, U64* max_elements) {
+    if (!ptr || !max_elements) return Result::ERROR;
+    std::lock_guard<std::mutex> lock(mu);
+    JST_CHECK(ensureProducer());
+    if (stagingFill == 0 && stagingBusy[stagingIndex]) {  // the copy that last left this staging buffer must be done
+        JST_HIP_CHECK(hipEventSynchronize(stagingFree[stagingIndex]), "hipEventSynchronize");
+        stagingBusy[stagingIndex] = false;
+    }
+    *ptr = static_cast<char*>(staging[stagingIndex]) + stagingFill * elementBytes;
+    *max_elements = batches * samples - stagingFill;
+    return Result::SUCCESS;
+}
+
+Result RingSource::publishStagedBatch() {  // mu held; the current staging buffer holds one whole batch
+    if (published() - consumed >= slots) {
+        // every slot holds a published batch no cycle has consumed
+        ++overflowCount;
+        if (rejectOnOverflow) return Result::INCOMPLETE;
+        ++consumed;  // OverwriteOldest (circular_buffer.cc:151-161): the oldest unconsumed batch is dropped
+    }
+    const U64 slot = published() % slots;
+    // The cycle that consumed this slot last must have finished before the copy lands.
+    if (pendingFreeSlot == (I64)slot && lastComputeStream) {  // consumed by the latest cycle: record its completion now
+        JST_HIP_CHECK(hipEventRecord(slotFree[slot], lastComputeStream), "hipEventRecord");
+        slotFreeValid[slot] = 1;
+        pendingFreeSlot = -1;
+    }
+    if (slotFreeValid[slot]) JST_HIP_CHECK(hipStreamWaitEvent(uploadStream, slotFree[slot], 0), "hipStreamWaitEvent");
+    const size_t batch_bytes = (size_t)(batches * samples) * elementBytes;
+    JST_HIP_CHECK(hipMemcpyAsync(output.ringSlotData(slot), staging[stagingIndex], batch_bytes, hipMemcpyHostToDevice,
+                                 uploadStream),
+                  "hipMemcpyAsync(H2D)");
+    JST_HIP_CHECK(hipEventRecord(stagingFree[stagingIndex], uploadStream), "hipEventRecord");
+    JST_HIP_CHECK(hipEventRecord(slotUploaded[slot], uploadStream), "hipEventRecord");
+    stagingBusy[stagingIndex] = true;
+    slotUploadValid[slot] = 1;
+    ++pushed;
+    stagingIndex = (stagingIndex + 1) % kStaging;
+    stagingFill = 0;
+    return Result::SUCCESS;
+}
+
+Result RingSource::ringCommit(U64 elements) {
+    Result r = Result::SUCCESS;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        JST_CHECK(ensureProducer());
+        const U64 batch = batches * samples;
+        if (elements > batch - stagingFill) {
+            JST_ERROR("[MODULE_RING_SOURCE] commit of %llu elements exceeds the %llu acquired.",
+                      (unsigned long long)elements, (unsigned long long)(batch - stagingFill));
+            return Result::ERROR;
+        }
+        stagingFill += elements;
+        if (stagingFill == batch) {
+            r = publishStagedBatch();
+            if (r == Result::INCOMPLETE) stagingFill = batch - elements;  // rejected: the chunk was not taken
+        }
+    }
+    dataAvailable.notify_all();
+    return r;
+}
+
+Result RingSource::ringPush(const void* data, U64 elements) {
+    if (elements > 0 && !data) return Result::ERROR;
+    const U64 batch = batches * samples;
+    if (rejectOnOverflow) {  // Reject takes all of a push or nothing (circular_buffer.cc:143-149)
+        std::lock_guard<std::mutex> lock(mu);
+        JST_CHECK(ensureProducer());
+        const U64 completing = (stagingFill + elements) / batch;
+        if (published() - consumed + completing > slots) {
+            ++overflowCount;
+            return elements > ringCapacity() ? Result::ERROR : Result::INCOMPLETE;
+        }
+    }
+    const char* src = static_cast<const char*>(data);
+    while (elements > 0) {
+        void* dst = nullptr;
+        U64 room = 0;
+        JST_CHECK(ringAcquire(&dst, &room));
+        const U64 n = elements < room ? elements : room;
+        std::memcpy(dst, src, (size_t)n * elementBytes);
+        const Result r = ringCommit(n);
+        if (r != Result::SUCCESS) return r;
+        src += (size_t)n * elementBytes;
+        elements -= n;
+    }
+    return Result::SUCCESS;
+}
+
+U64 RingSource::ringSize() {
+    std::lock_guard<std::mutex> lock(mu);
+    return (published() - consumed) * batches * samples + stagingFill;
+}
+U64 RingSource::ringOverflows() {
+    std::lock_guard<std::mutex> lock(mu);
+    return overflowCount;
+}
+Result RingSource::ringWait(U64 elements, U32 timeout_ms) {  // circular_buffer.cc waitForSize
+    std::unique_lock<std::mutex> lock(mu);
+    if (elements > ringCapacity() + batches * samples) return Result::ERROR;
+    const bool ok = dataAvailable.wait_for(lock, std::chrono::milliseconds(timeout_ms), [&] {
+        return (published() - consumed) * batches * samples + stagingFill >= elements;
+    });
+    return ok ? Result::SUCCESS : Result::TIMEOUT;
+}
+Result RingSource::ringClear() {
+    std::lock_guard<std::mutex> lock(mu);
+    if (uploadStream) JST_HIP_CHECK(hipStreamSynchronize(uploadStream), "hipStreamSynchronize");
+    consumed = published();
+    stagingFill = 0;
+    overflowCount = 0;
+    for (U64 i = 0; i < kStaging; ++i) stagingBusy[i] = false;
+    return Result::SUCCESS;
 }
 
 // ---- fusion ------------------------------------------------------------------------------------

@@ -4,6 +4,9 @@
 // and error texts follow the reference so a flowgraph node only has to switch `device:`.
 #pragma once
 
+#include <condition_variable>
+#include <mutex>
+
 #include "../jst/module.hh"
 #include "../kernels/kernels.hh"
 
@@ -278,9 +281,11 @@ class Waterfall : public Module {
 class RingSource : public Module {
  public:
     const char* type() const override { return "ring_source"; }
+    ~RingSource() override;
     Result validate() override;
     Result define() override;
     Result create() override;
+    Result destroy() override;
     Result computeSubmit(hipStream_t stream) override;
     U64 cyclePeriod() const override { return live ? 1 : slots; }
     void advanceHostState(U64 cycles) override;
@@ -288,12 +293,56 @@ class RingSource : public Module {
     bool capturable() const override { return !live; }  // live: every cycle asks the host-side counters
     Result reconfigureImpl(const Config& previous) override;
     Tensor output;
+    DataType sampleType = DataType::CF32;  // config dtype: CF32 | CI16 | CI8 | CU8 (raw SDR sample formats, cast downstream)
     U64 batches = 8, samples = 2048, slots = 1, cursor = 0;
     // live: the host fills slot (published % slots), then raises `published` by reconfigure(); a cycle
     // consumes one published slot, or YIELDs when there is none (io/soapy/module_impl_native_cpu.cc:47-60)
     bool live = false;
-    U64 published = 0, consumed = 0;
+    // batches made available so far: raised from the host through reconfigure("published") by a caller that fills the
+    // slots itself (round-1 interface), and by the producer interface below (ringPush / ringCommit)
+    U64 publishedConfig = 0, pushed = 0, consumed = 0;
+    U64 published() const { return publishedConfig + pushed; }
     bool first = true;
+
+    // ---- producer side of a live source: the HBM replacement of the Soapy thread's CircularBuffer --------------------
+    // (include/jetstream/tools/circular_buffer.hh:31-48, src/tools/circular_buffer.cc, the 8192-sample pushes of
+    // soapy/module_impl.cc:375-399 and the waitForSize of module_impl_native_cpu.cc:39-45.)  Samples arrive in chunks of
+    // ANY size; they are assembled into batches in PINNED staging memory (acquire / commit hands the producer the
+    // staging memory itself, so a driver can read straight into it; push() is acquire + memcpy + commit); every
+    // completed batch goes to ring slot (published % slots) with an asynchronous H2D copy on the source's own upload
+    // stream.  The library -- not the caller -- keeps an upload from overwriting a slot whose consuming cycle has not
+    // finished: a cycle's completion is an event on the compute stream, recorded when the NEXT cycle is submitted (or
+    // on demand), and the upload stream waits for it.  A full ring (every slot published and unconsumed) follows the
+    // overflow policy of the reference's buffer: "overwrite" (default, OverwriteOldest: the oldest unconsumed batch is
+    // dropped) or "reject" (the push returns INCOMPLETE and nothing of it is taken); both count an overflow.
+    Result ringAcquire(void** ptr, U64* max_elements);
+    Result ringCommit(U64 elements);
+    Result ringPush(const void* samples, U64 elements);
+    Result ringWait(U64 elements, U32 timeout_ms);
+    Result ringClear();
+    U64 ringSize();      // elements published and not yet consumed, plus the partial batch in staging
+    U64 ringCapacity() const { return slots * batches * samples; }
+    U64 ringOverflows();
+
+ private:
+    Result ensureProducer();
+    Result publishStagedBatch();  // mu held
+    static constexpr U64 kStaging = 4;
+    std::mutex mu;
+    std::condition_variable dataAvailable;
+    bool rejectOnOverflow = false;
+    hipStream_t uploadStream = nullptr;
+    void* staging[kStaging] = {};
+    hipEvent_t stagingFree[kStaging] = {};   // the H2D copy out of staging buffer i has finished
+    bool stagingBusy[kStaging] = {};
+    U64 stagingIndex = 0, stagingFill = 0;   // current staging buffer, elements already in it
+    std::vector<hipEvent_t> slotUploaded;    // per ring slot: its latest H2D has finished (compute waits for it)
+    std::vector<hipEvent_t> slotFree;        // per ring slot: the cycle that consumed it has finished (uploads wait)
+    std::vector<uint8_t> slotUploadValid, slotFreeValid;
+    I64 pendingFreeSlot = -1;                // consumed by the latest cycle; its completion event is still to be recorded
+    hipStream_t lastComputeStream = nullptr;
+    U64 overflowCount = 0;
+    size_t elementBytes = 8;
 };
 
 }  // namespace jst::modules
