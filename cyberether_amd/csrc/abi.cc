@@ -367,6 +367,47 @@ jst_result jst_module_timing(jst_module m, uint64_t* cycles, double* ms) {
     if (ms) *ms = m->m->timing.computeTimeMs;
     return R(Result::SUCCESS);
 }
+// ---- live ring source: producer side ---------------------------------------------------------------
+namespace {
+modules::RingSource* ring_of(jst_module m) {
+    auto* r = m ? dynamic_cast<modules::RingSource*>(m->m.get()) : nullptr;
+    if (!r) JST_ERROR("[MODULE_RING_SOURCE] Not a ring_source module.");
+    return r;
+}
+}  // namespace
+jst_result jst_ring_push(jst_module source, const void* samples, uint64_t count) {
+    auto* r = ring_of(source);
+    return r ? R(r->ringPush(samples, count)) : R(Result::ERROR);
+}
+jst_result jst_ring_acquire(jst_module source, void** ptr, uint64_t* max_count) {
+    auto* r = ring_of(source);
+    return r ? R(r->ringAcquire(ptr, max_count)) : R(Result::ERROR);
+}
+jst_result jst_ring_commit(jst_module source, uint64_t count) {
+    auto* r = ring_of(source);
+    return r ? R(r->ringCommit(count)) : R(Result::ERROR);
+}
+jst_result jst_ring_wait(jst_module source, uint64_t size, uint32_t timeout_ms) {
+    auto* r = ring_of(source);
+    return r ? R(r->ringWait(size, timeout_ms)) : R(Result::ERROR);
+}
+jst_result jst_ring_clear(jst_module source) {
+    auto* r = ring_of(source);
+    return r ? R(r->ringClear()) : R(Result::ERROR);
+}
+uint64_t jst_ring_size(jst_module source) {
+    auto* r = ring_of(source);
+    return r ? r->ringSize() : 0;
+}
+uint64_t jst_ring_capacity(jst_module source) {
+    auto* r = ring_of(source);
+    return r ? r->ringCapacity() : 0;
+}
+uint64_t jst_ring_overflows(jst_module source) {
+    auto* r = ring_of(source);
+    return r ? r->ringOverflows() : 0;
+}
+
 jst_result jst_module_compute_initialize(jst_module m) {
     JST_ARG(m, "null module");
     const Result r = m->m->computeInitialize();

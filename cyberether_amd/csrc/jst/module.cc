@@ -260,6 +260,8 @@ Result Runtime::planUnits() {
     units_.clear();
     for (Module* m : ordered_)  // a decision of an earlier runtime does not outlive it
         if (auto* spec = dynamic_cast<modules::Spectrogram*>(m)) spec->combined = false;
+    for (Module* m : ordered_)
+        if (auto* cast = dynamic_cast<modules::Cast*>(m)) cast->fusedIntoSpectrum = false;
     // Static settlement: a STATIC_OUTPUT module with no inputs, or a STATELESS/STATIC module
     // whose inputs all come from settled producers, runs once
     // (src/scheduler_synchronous.cc:534-546,670-693).

@@ -18,6 +18,8 @@ inline bool use_pipe_kernel() {
 }
 inline bool window_contig(const LoadCF32&) { return true; }
 inline bool window_contig(const LoadCF32TimesWindow& p) { return p.wstride == 1; }
+template <class RAW, bool SIGNED>
+inline bool window_contig(const LoadCITimesWindow<RAW, SIGNED>& p) { return p.wstride == 1; }
 
 int compute_units() {
     static const int cus = [] {
@@ -136,12 +138,11 @@ hipError_t launch_fft_c2c(uint64_t n, bool forward, const FftLayout& L, const fl
                    : dispatch_n<false>(n, L, W, pro, epi, stream);
 }
 
-hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W,
-                                 const float2* in, const float2* window, int64_t window_stride,
-                                 float* out, float amp_coeff, bool with_range, float range_scale,
-                                 float range_offset, bool fast, float guard_h0, float guard_h1,
-                                 hipStream_t stream) {
-    const LoadCF32TimesWindow pro{in, window, window_stride};
+namespace {
+template <class Pro>
+hipError_t spectrum_fused_with(uint64_t n, const FftLayout& L, const float2* W, const Pro& pro, float* out,
+                               float amp_coeff, bool with_range, float range_scale, float range_offset, bool fast,
+                               float guard_h0, float guard_h1, hipStream_t stream) {
     if (with_range) {
         if (fast)
             return dispatch_fused_n(n, L, W, pro,
@@ -153,6 +154,38 @@ hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W
     }
     if (fast) return dispatch_fused_n(n, L, W, pro, StoreAmplitudeT<true>{out, amp_coeff}, stream);
     return dispatch_fused_n(n, L, W, pro, StoreAmplitudeT<false>{out, amp_coeff}, stream);
+}
+}  // namespace
+
+hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W,
+                                 const float2* in, const float2* window, int64_t window_stride,
+                                 float* out, float amp_coeff, bool with_range, float range_scale,
+                                 float range_offset, bool fast, float guard_h0, float guard_h1,
+                                 hipStream_t stream) {
+    return spectrum_fused_with(n, L, W, LoadCF32TimesWindow{in, window, window_stride}, out, amp_coeff, with_range,
+                               range_scale, range_offset, fast, guard_h0, guard_h1, stream);
+}
+
+// The same chain fed with raw SDR samples: Cast folded into the transform's first load (LoadCITimesWindow).
+// in_format: 1 = CI16, 2 = CI8, 3 = CU8; scaler = the Cast module's divisor (32768 / 128).
+hipError_t launch_spectrum_fused_cast(uint64_t n, const FftLayout& L, const float2* W, const void* in, int in_format,
+                                      float scaler, const float2* window, int64_t window_stride, float* out,
+                                      float amp_coeff, bool with_range, float range_scale, float range_offset, bool fast,
+                                      float guard_h0, float guard_h1, hipStream_t stream) {
+    const float inv = 1.0f / scaler;  // a power of two: x / scaler == x * inv, exactly
+    switch (in_format) {
+        case 1:
+            return spectrum_fused_with(n, L, W, LoadCI16TimesWindow{static_cast<const uint32_t*>(in), window, window_stride, inv},
+                                       out, amp_coeff, with_range, range_scale, range_offset, fast, guard_h0, guard_h1, stream);
+        case 2:
+            return spectrum_fused_with(n, L, W, LoadCI8TimesWindow{static_cast<const uint16_t*>(in), window, window_stride, inv},
+                                       out, amp_coeff, with_range, range_scale, range_offset, fast, guard_h0, guard_h1, stream);
+        case 3:
+            return spectrum_fused_with(n, L, W, LoadCU8TimesWindow{static_cast<const uint16_t*>(in), window, window_stride, inv},
+                                       out, amp_coeff, with_range, range_scale, range_offset, fast, guard_h0, guard_h1, stream);
+        default:
+            return hipErrorInvalidValue;
+    }
 }
 
 // ---- spectrum of cycle k + spectrogram of cycle k - 1 in ONE launch ------------------------------------------------

@@ -187,6 +187,9 @@ __device__ __forceinline__ void quad_transpose4(float (&a)[4], bool odd, bool hi
 // index with 32-bit offsets from a per-transform pointer so that addresses are base + constant.
 struct LoadCF32 {
     const float2* in;
+    using raw_t = float2;  // what the prefetch registers of the pipelined kernel hold
+    static constexpr uint32_t kRawBytes = 8;
+    static __device__ __forceinline__ raw_t load_raw_buf(rsrc_t r, uint32_t voff, uint32_t soff) { return buf_load_f2(r, voff, soff); }
     template <bool CONTIG>
     __device__ __forceinline__ float2 load(int64_t base, int64_t axis_stride, int pos) const {
         if constexpr (CONTIG) return (in + base)[(unsigned)pos];
@@ -213,6 +216,9 @@ struct LoadCF32TimesWindow {
     const float2* in;
     const float2* window;
     int64_t wstride;
+    using raw_t = float2;
+    static constexpr uint32_t kRawBytes = 8;
+    static __device__ __forceinline__ raw_t load_raw_buf(rsrc_t r, uint32_t voff, uint32_t soff) { return buf_load_f2(r, voff, soff); }
     template <bool CONTIG>
     __device__ __forceinline__ float2 load(int64_t base, int64_t axis_stride, int pos) const {
         if constexpr (CONTIG) {
@@ -237,6 +243,59 @@ struct LoadCF32TimesWindow {
     }
     __device__ __forceinline__ float2 apply(float2 v, float2 w) const { return cmul_full(v, w); }
 };
+
+// Raw SDR sample formats fused in: Cast (CI16 / CI8 / CU8 -> CF32, core/cast/module_impl_native_cpu.cc:150-229:
+// static_cast<F32>(x) / scaler with scaler = 32768 or 128 -- a power of two, so x * (1 / scaler) is the same float,
+// exactly) followed by the Multiply with the broadcast window.  The pipelined kernel prefetches the RAW words (4 or 2
+// bytes per complex sample instead of 8: half or a quarter of the input stream, and of the prefetch registers) and
+// converts when the transform starts.  RAW = uint32_t: CI16 (re in the low half); RAW = uint16_t: CI8 / CU8.
+template <class RAW, bool SIGNED>
+struct LoadCITimesWindow {
+    const RAW* in;
+    const float2* window;
+    int64_t wstride;
+    float inv_scaler;  // 1 / 32768 or 1 / 128
+    using raw_t = RAW;
+    static constexpr uint32_t kRawBytes = sizeof(RAW);
+    static __device__ __forceinline__ raw_t load_raw_buf(rsrc_t r, uint32_t voff, uint32_t soff) {
+        if constexpr (sizeof(RAW) == 4) return (RAW)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+        else return (RAW)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+    }
+    __device__ __forceinline__ float2 convert(RAW w) const {
+        float re, im;
+        if constexpr (sizeof(RAW) == 4) {  // CI16: always signed
+            re = (float)(int16_t)(w & 0xffffu);
+            im = (float)(int16_t)(w >> 16);
+        } else if constexpr (SIGNED) {
+            re = (float)(int8_t)(w & 0xffu);
+            im = (float)(int8_t)(w >> 8);
+        } else {
+            re = (float)(uint8_t)(w & 0xffu);
+            im = (float)(uint8_t)(w >> 8);
+        }
+        return mk(re * inv_scaler, im * inv_scaler);
+    }
+    template <bool CONTIG>
+    __device__ __forceinline__ float2 load(int64_t base, int64_t axis_stride, int pos) const {
+        if constexpr (CONTIG) return cmul_full(convert((in + base)[(unsigned)pos]), window[(unsigned)pos]);
+        else return cmul_full(convert(in[base + (int64_t)pos * axis_stride]), window[(int64_t)pos * wstride]);
+    }
+    __device__ __forceinline__ const void* row(int64_t base) const { return in + base; }
+    __device__ __forceinline__ const void* operand_row() const { return window; }
+    template <bool CONTIG>
+    __device__ __forceinline__ raw_t load_raw(int64_t base, int64_t axis_stride, int upos, int lpos) const {
+        return in[base + (int64_t)(upos + lpos) * axis_stride];
+    }
+    static constexpr bool kHasOperand = true;
+    template <bool CONTIG>
+    __device__ __forceinline__ float2 load_operand(int upos, int lpos) const {
+        return window[(int64_t)(upos + lpos) * wstride];
+    }
+    __device__ __forceinline__ float2 apply(raw_t v, float2 w) const { return cmul_full(convert(v), w); }
+};
+using LoadCI16TimesWindow = LoadCITimesWindow<uint32_t, true>;
+using LoadCI8TimesWindow = LoadCITimesWindow<uint16_t, true>;
+using LoadCU8TimesWindow = LoadCITimesWindow<uint16_t, false>;
 
 // ---- epilogues (what happens to CH of the last pass) ------------------------------------------
 struct StoreCF32 {
@@ -536,9 +595,9 @@ __device__ __forceinline__ void twiddle_inplace4(unsigned i, float2& y0, float2&
 // Which wide-access forms a pipe-kernel instantiation uses: 16-byte input loads when pass 0 is a radix-8 pass on a dense
 // row (one butterfly per thread: the two lanes of a pair split its eight 16-byte pieces and swap halves), 16-byte
 // stores when the epilogue produces one float per output on a dense row and the last pass is radix 4 or 8.
-template <int N, bool CONTIG>
+template <int N, bool CONTIG, class Pro = LoadCF32>
 constexpr bool pipe_load16() {
-    return JST_LOAD16 && CONTIG && make_plan(N).ip[0] == 8;
+    return JST_LOAD16 && CONTIG && make_plan(N).ip[0] == 8 && Pro::kRawBytes == 8;
 }
 template <int N, bool CONTIG, class Epi>
 constexpr bool pipe_store16() {
@@ -651,7 +710,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
 #endif
                 if constexpr (Pro::kHasOperand && !(JST_OPND_RESIDENT && CONTIG)) {
                     constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
-                    if constexpr (pipe_load16<N, CONTIG>()) {
+                    if constexpr (pipe_load16<N, CONTIG, Pro>()) {
                         const uint32_t vo = (uint32_t)(((tid & ~1) + 4 * IDO0 * (tid & 1)) * 8);
 #pragma unroll
                         for (int k2 = 0; k2 < 2; ++k2) {
@@ -695,7 +754,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                     if (CONTIG || more) {
                         constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
                         const int e = j * IP + c;  // constant after unrolling
-                        if constexpr (pipe_load16<N, CONTIG>()) {
+                        if constexpr (pipe_load16<N, CONTIG, Pro>()) {
                             if ((e & 1) == 1) {  // a 16-byte request once both halves have retired (folds after unrolling)
                                 const int k = e >> 1;
                                 const uint32_t vo = (uint32_t)(((tid & ~1) + 4 * IDO0 * (tid & 1)) * 8);
@@ -824,14 +883,16 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
     const bool young = bid >= (grid >> 1);
     int64_t in_base, out_base;
     fft_bases(L, t, in_base, out_base);
-    float2 raw[8], opnd[8];
+    typename Pro::raw_t raw[8];
+    float2 opnd[8];
+    constexpr uint32_t RB = Pro::kRawBytes;  // bytes per complex sample of the input stream (8: cf32, 4: ci16, 2: ci8 / cu8)
     const rsrc_t r_opnd = make_rsrc(pro.operand_row(), (uint32_t)N * 8u);
     // 16-byte loads (pipe_load16): the even lane of a pair requests {i, i+1} x b = 0..3, the odd lane {i-1, i} x b = 4..7
     // (i = tid: its own butterfly index); raw[2k] / raw[2k+1] hold the two elements of piece k until the halves are swapped.
-    constexpr bool L16 = pipe_load16<N, CONTIG>();
+    constexpr bool L16 = pipe_load16<N, CONTIG, Pro>();
     const uint32_t voff16 = (uint32_t)(((tid & ~1) + 4 * IDO0 * (tid & 1)) * 8);
     {
-        const rsrc_t r_in = make_rsrc(pro.row(in_base), (uint32_t)N * 8u);
+        const rsrc_t r_in = make_rsrc(pro.row(in_base), (uint32_t)N * RB);
         if constexpr (L16) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -851,8 +912,7 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
                 if constexpr (Pro::kHasOperand)
                     opnd[e] = buf_load_f2(r_opnd, (uint32_t)pos0[e / IP0] * 8u,
                                           (uint32_t)(IDO0 * (e % IP0)) * 8u);
-                raw[e] = buf_load_f2(r_in, (uint32_t)pos0[e / IP0] * 8u,
-                                     (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                raw[e] = Pro::load_raw_buf(r_in, (uint32_t)pos0[e / IP0] * RB, (uint32_t)(IDO0 * (e % IP0)) * RB);
             } else {
                 opnd[e] = pro.template load_operand<CONTIG>(IDO0 * (e % IP0), pos0[e / IP0]);
                 raw[e] = pro.template load_raw<CONTIG>(in_base, L.in_axis_stride,
@@ -902,7 +962,7 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
             // whole HBM round trip in front of the passes.  Past the last transform the descriptor has
             // zero records: the loads return 0 without touching memory.
             fft_bases(L, more ? tn : t, nin, nout);
-            const rsrc_t r_in = make_rsrc(pro.row(nin), more ? (uint32_t)N * 8u : 0u);
+            const rsrc_t r_in = make_rsrc(pro.row(nin), more ? (uint32_t)N * RB : 0u);
             if constexpr (L16) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -913,7 +973,7 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    raw[e] = buf_load_f2(r_in, (uint32_t)pos0[e / IP0] * 8u, (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                    raw[e] = Pro::load_raw_buf(r_in, (uint32_t)pos0[e / IP0] * RB, (uint32_t)(IDO0 * (e % IP0)) * RB);
             }
         } else if (more) {
             fft_bases(L, tn, nin, nout);

@@ -160,6 +160,12 @@ hipError_t launch_spectrum_fused(uint64_t n, const FftLayout& L, const float2* W
                                  float* out, float amp_coeff, bool with_range, float range_scale,
                                  float range_offset, bool fast, float guard_h0, float guard_h1,
                                  hipStream_t stream);
+// Cast (CI16 / CI8 / CU8 -> CF32) -> Multiply -> FFT -> Amplitude [-> Range]: raw SDR samples straight into the
+// transform's first load.  in_format: 1 = CI16, 2 = CI8, 3 = CU8; scaler: the Cast module's divisor.
+hipError_t launch_spectrum_fused_cast(uint64_t n, const FftLayout& L, const float2* W, const void* in, int in_format,
+                                      float scaler, const float2* window, int64_t window_stride, float* out,
+                                      float amp_coeff, bool with_range, float range_scale, float range_offset, bool fast,
+                                      float guard_h0, float guard_h1, hipStream_t stream);
 // guard_h0/h1 (fast + range only): heights of the Spectrogram modules that will quantise the output;
 // elements whose value * height lies within the fast path's error of a bin edge are computed with the
 // exact arithmetic instead, so the bins equal the exact provider's (dev::BinGuard, device_math.hh).

@@ -371,7 +371,7 @@ Result Cast::create() {
     return Result::SUCCESS;
 }
 Result Cast::computeSubmit(hipStream_t stream) {
-    if (bypass) return Result::SUCCESS;
+    if (bypass || fusedIntoSpectrum) return Result::SUCCESS;
     EwLayout L;
     if (!MakeEwLayout(output, &input, nullptr, L)) {
         JST_ERROR("[MODULE_CAST] Unsupported tensor rank.");
@@ -1423,6 +1423,24 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     }
     const float guard0 = guard[0], guard1 = guard[1];
 
+    // Raw SDR samples: a Cast (CI16 / CI8 / CU8 -> CF32, cast/module_impl.cc:49-70) whose output feeds ONLY this Multiply
+    // folds into the transform's first load -- the unit reads the cast's input (4 or 2 bytes per sample instead of 8)
+    // and the cast module launches nothing.  It need not be adjacent in the order (the window chain usually sits in
+    // between): its own unit stays, as a no-op.  LDS kernels only (n <= 16384), not with the combined spectrogram.
+    Cast* cast = nullptr;
+    if (!tiled) {
+        for (size_t i = 0; i < at; ++i) {
+            auto* c = dynamic_cast<Cast*>(ordered[i]);
+            if (!c || c->bypass || c->output.storageId() != sig.storageId()) continue;
+            const DataType it = c->input.dtype();
+            const bool raw_format = it == DataType::CI16 || it == DataType::CI8 || it == DataType::CU8;
+            if (raw_format && c->outputDtype == DataType::CF32 && c->input.contiguous() && c->output.contiguous() &&
+                sig.contiguous() && sig.offset() == c->output.offset() && sig.shape() == c->input.shape() &&
+                sole_consumer(c->output, mul))
+                cast = c;
+        }
+    }
+
     members = {mul, fft, amp};
     if (rng) members.push_back(rng);
     consumed = members.size();
@@ -1433,7 +1451,12 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     // launch (kernels::launch_spectrum_spectrogram_fused): the output becomes a ring of two slots, this unit takes the
     // module in, and `flush` runs the spectrogram that is still waiting when a compute call ends.
     static const bool no_combine = std::getenv("JST_NO_SPECTROGRAM_COMBINE") != nullptr;
-    if (allow_combine && flush && !tiled && !no_combine && at + consumed < ordered.size()) {
+    if (cast) {
+        cast->fusedIntoSpectrum = true;
+        name = "spectrum_fused(" + cast->name() + "+" + mul->name() + "+" + fft->name() + "+" + amp->name() +
+               (rng ? "+" + rng->name() : "") + ")";
+    }
+    if (allow_combine && flush && !tiled && !no_combine && !cast && at + consumed < ordered.size()) {
         auto* spec = dynamic_cast<Spectrogram*>(ordered[at + consumed]);
         Tensor& out = rng ? rng->output : amp->output;
         FftLayout L;
@@ -1514,7 +1537,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
         }
     }
 
-    submit = [mul, fft, amp, rng, axis, n, fast, tiled, guard0, guard1](hipStream_t stream) -> Result {
+    submit = [mul, fft, amp, rng, cast, axis, n, fast, tiled, guard0, guard1](hipStream_t stream) -> Result {
         const Tensor& sig = mul->a;
         const Tensor& win = mul->b;
         const Tensor& out = rng ? rng->output : amp->output;
@@ -1544,6 +1567,17 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                     rng != nullptr, rng ? rng->scalingCoeff : 0.0f, rng ? rng->offsetCoeff : 0.0f,
                     fast, guard0, guard1, static_cast<float2*>(fft->scratchA.data()), stream),
                 "fused spectrum (tiled) kernel");
+        if (cast) {  // raw samples: same dense shape as the cast's output, element strides therefore equal
+            const DataType it = cast->input.dtype();
+            L.in_offset = cast->input.offset();
+            return hip_result(
+                kernels::launch_spectrum_fused_cast(
+                    n, L, fft->twiddles, cast->input.data(), it == DataType::CI16 ? 1 : (it == DataType::CI8 ? 2 : 3),
+                    cast->scaler, static_cast<const float2*>(win.data()) + win.offset(), (int64_t)win.stride(axis),
+                    static_cast<float*>(out.data()), amp->scalingCoeff, rng != nullptr, rng ? rng->scalingCoeff : 0.0f,
+                    rng ? rng->offsetCoeff : 0.0f, fast, guard0, guard1, stream),
+                "fused spectrum kernel (raw sample input)");
+        }
         return hip_result(
             kernels::launch_spectrum_fused(
                 n, L, fft->twiddles, static_cast<const float2*>(sig.data()),

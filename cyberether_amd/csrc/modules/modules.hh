@@ -101,11 +101,15 @@ class Cast : public Module {
     Result define() override;
     Result create() override;
     Result computeSubmit(hipStream_t stream) override;
-    bool launchesKernels() const override { return !bypass; }
+    bool launchesKernels() const override { return !bypass && !fusedIntoSpectrum; }
     Tensor input, output;
     DataType outputDtype = DataType::None;
     F32 scaler = 1.0f;
     bool bypass = false;
+    // Set by the fusion planner (TryFuseSpectrum) when the spectrum unit reads this module's INPUT itself -- raw CI16 /
+    // CI8 / CU8 samples converted in the transform's first load -- and nobody else reads the output: the module then
+    // launches nothing.  A decision of one runtime; Runtime::planUnits clears it.
+    bool fusedIntoSpectrum = false;
 };
 
 // src/domains/core/multiply/{module_impl.cc:10-132, module_impl_native_cpu.cc:86-100}

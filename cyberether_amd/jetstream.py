@@ -128,6 +128,14 @@ _sig("jst_runtime_stream", C.c_void_p, _h)
 _sig("jst_runtime_period", C.c_uint64, _h)
 _sig("jst_runtime_graph_active", C.c_int, _h)
 _sig("jst_runtime_order", C.c_size_t, _h, C.c_char_p, C.c_size_t)
+_sig("jst_ring_push", R, _h, C.c_void_p, C.c_uint64)
+_sig("jst_ring_acquire", R, _h, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64))
+_sig("jst_ring_commit", R, _h, C.c_uint64)
+_sig("jst_ring_wait", R, _h, C.c_uint64, C.c_uint32)
+_sig("jst_ring_clear", R, _h)
+_sig("jst_ring_size", C.c_uint64, _h)
+_sig("jst_ring_capacity", C.c_uint64, _h)
+_sig("jst_ring_overflows", C.c_uint64, _h)
 _sig("jst_runtime_units", C.c_size_t, _h, C.c_char_p, C.c_size_t)
 _sig("jst_runtime_unit_mean_ms", C.c_double, _h, C.c_char_p)
 _sig("jst_runtime_event_overhead_ms", C.c_double, _h)
@@ -403,6 +411,54 @@ class Module:
     @property
     def taint(self) -> int:
         return int(_lib.jst_module_taint(self._h))
+
+    # -- producer side of a live ring_source (circular_buffer.hh:31-48 against the HBM ring) ---------
+    def ring_push(self, samples: np.ndarray) -> str:
+        """push(): any number of elements (complex samples of the source's dtype; integer formats as [..., 2]
+        arrays).  Returns "success" or "incomplete" (overflow policy reject: nothing was taken)."""
+        a = np.ascontiguousarray(samples)
+        count = a.size // 2 if a.dtype.kind in "iu" else a.size
+        r = _lib.jst_ring_push(self._h, a.ctypes.data_as(C.c_void_p), count)
+        if r == 9:
+            return "incomplete"
+        _check(r)
+        return "success"
+
+    def ring_acquire(self):
+        """(address, max_elements) of the pinned staging memory the next samples go to (zero-copy producer)."""
+        ptr, room = C.c_void_p(), C.c_uint64()
+        _check(_lib.jst_ring_acquire(self._h, C.byref(ptr), C.byref(room)))
+        return int(ptr.value), int(room.value)
+
+    def ring_commit(self, count: int) -> str:
+        r = _lib.jst_ring_commit(self._h, count)
+        if r == 9:
+            return "incomplete"
+        _check(r)
+        return "success"
+
+    def ring_wait(self, size: int, timeout_ms: int = 5000) -> bool:
+        """waitForSize(): True once `size` elements are buffered, False on timeout."""
+        r = _lib.jst_ring_wait(self._h, size, timeout_ms)
+        if r == 8:
+            return False
+        _check(r)
+        return True
+
+    def ring_clear(self):
+        _check(_lib.jst_ring_clear(self._h))
+
+    @property
+    def ring_size(self) -> int:
+        return int(_lib.jst_ring_size(self._h))
+
+    @property
+    def ring_capacity(self) -> int:
+        return int(_lib.jst_ring_capacity(self._h))
+
+    @property
+    def ring_overflows(self) -> int:
+        return int(_lib.jst_ring_overflows(self._h))
 
     @property
     def timing(self):

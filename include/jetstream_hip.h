@@ -175,6 +175,33 @@ jst_result jst_module_compute_initialize(jst_module m);
 jst_result jst_module_compute_submit(jst_module m, void* hip_stream);
 jst_result jst_module_compute_deinitialize(jst_module m);
 
+/* ---- live ring source: the producer side ------------------------------------------------------
+ * What the Soapy thread does with its host CircularBuffer in the reference -- push chunks of at most 8192 samples
+ * (src/domains/io/soapy/module_impl.cc:375-399) into tools/circular_buffer.hh:31-48, which the compute thread pops one
+ * batch at a time after waitForSize (soapy/module_impl_native_cpu.cc:39-60) -- against a `ring_source{live=true}`
+ * module whose ring lives in HBM.  `count` / `size` are in ELEMENTS of the source's sample format (config dtype:
+ * CF32 | CI16 | CI8 | CU8; one element = one complex sample).  Chunks of any size are assembled into batches in pinned
+ * staging memory; every completed batch is uploaded asynchronously (a stream of the source's own) into ring slot
+ * published % slots and becomes the input of one compute cycle (the source YIELDs when none is ready).  The LIBRARY
+ * keeps an upload from landing in a slot whose consuming cycle has not finished (per-slot events; the caller needs no
+ * synchronise of its own).  A full ring follows config overflow = "overwrite" (default, CircularBuffer's
+ * OverwriteOldest: the oldest unconsumed batch is dropped) or "reject" (JST_INCOMPLETE, nothing of the push taken);
+ * either way jst_ring_overflows counts it.  Thread-safe against the compute thread.
+ *   jst_ring_push     circular_buffer.hh push(): copies `count` elements out of caller memory (any memory)
+ *   jst_ring_acquire / jst_ring_commit   zero-copy form: the producer (a driver's readStream) writes up to *max_count
+ *                     elements straight into the pinned staging memory at *ptr, then commits how many it wrote
+ *   jst_ring_wait     waitForSize(): blocks until `size` elements are buffered (JST_SUCCESS) or JST_TIMEOUT
+ *   jst_ring_size / _capacity / _overflows / _clear   size() (published, unconsumed batches + the partial batch),
+ *                     capacity() (slots x batch), overflows(), clear() */
+jst_result jst_ring_push(jst_module source, const void* samples, uint64_t count);
+jst_result jst_ring_acquire(jst_module source, void** ptr, uint64_t* max_count);
+jst_result jst_ring_commit(jst_module source, uint64_t count);
+jst_result jst_ring_wait(jst_module source, uint64_t size, uint32_t timeout_ms);
+jst_result jst_ring_clear(jst_module source);
+uint64_t jst_ring_size(jst_module source);
+uint64_t jst_ring_capacity(jst_module source);
+uint64_t jst_ring_overflows(jst_module source);
+
 /* ---- block plans ----------------------------------------------------------------------------- */
 /* The Filter block's plan (src/domains/dsp/filter/block_impl.cc:40-168, CalculateCandidatePlan): convolution size,
  * whether the block resamples by spectral folding, the pad size after resampling and one fold offset per head.  A
