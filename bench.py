@@ -270,10 +270,8 @@ def main() -> None:
                                                "dtype": dtype}, {}, "source")
             buf = source.output("buffer")
             mods = [source]
-            if np_t is not None:
-                cast = js.Module("cast", {"outputType": "CF32"}, {"buffer": buf}, "cast")
-                mods.append(cast)
-                buf = cast.output("buffer")
+            # the spectrum_engine block starts with its own cast (spectrum_engine/block_impl.cc:120-217): raw integer
+            # samples go straight in, and the fusion planner folds that cast into the transform's first load
             engine = js.SpectrumEngine(buf, enable_scale=True, range_min=-100.0, range_max=0.0, provider=provider)
             spectrogram = js.Module("spectrogram", {"height": HEIGHT}, {"signal": engine.buffer}, "spectrogram")
             rt = js.Runtime(mods + engine.modules + [spectrogram], graph=False, fuse=not args.no_fuse, timing=False)

@@ -1374,6 +1374,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     auto sole_consumer = [&](const Tensor& t, const Module* consumer) {
         for (const Module* m : ordered) {
             if (m == consumer) continue;
+            if (const auto* c = dynamic_cast<const Cast*>(m); c && c->bypass) continue;  // a pure alias reads nothing
             for (const auto& kv : m->inputs())
                 if (kv.second.storageId() == t.storageId()) return false;
         }

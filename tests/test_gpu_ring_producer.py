@@ -112,7 +112,7 @@ def test_wait_for_size_and_zero_copy_commit(js):
 @pytest.mark.parametrize("dtype,np_t,scale", [("CI16", np.int16, 32768.0), ("CI8", np.int8, 128.0), ("CU8", np.uint8, 128.0)])
 def test_integer_sample_formats_through_the_ring(js, oracle, monkeypatch, dtype, np_t, scale, fuse, kernel):
     """Raw SDR formats: the ring holds CI16 / CI8 / CU8 samples (4 or 2 bytes over PCIe instead of 8) and a cast module
-    turns them into CF32 (cast/module_impl.cc:49-70: divide by 32768 / 128) in front of the spectrum chain.  Fused, the
+    (the spectrum_engine block's own first module) turns them into CF32 (cast/module_impl.cc:49-70: divide by 32768 / 128).  Fused, the
     conversion happens in the transform's first load: the unit reads the cast's INPUT, the cast launches nothing, and
     the result is bit-identical to the module-by-module path and to the oracle."""
     monkeypatch.setenv("JST_FFT_KERNEL", kernel)
@@ -121,11 +121,11 @@ def test_integer_sample_formats_through_the_ring(js, oracle, monkeypatch, dtype,
     info = np.iinfo(np_t)
     src, out = make(js, b, n, slots, dtype=dtype)
     assert out.dtype == dtype
-    cast = js.Module("cast", {"outputType": "CF32"}, {"buffer": out}, "cast")
-    eng = js.SpectrumEngine(cast.output("buffer"))
-    rt = js.Runtime([src, cast] + eng.modules, graph=True, fuse=fuse)
+    eng = js.SpectrumEngine(out)        # the block's own cast (spectrum_engine/block_impl.cc:120-217) takes the raw samples
+    cast = eng.cast
+    rt = js.Runtime([src] + eng.modules, graph=True, fuse=fuse)
     fused_names = [u for u in rt.units if u.startswith("spectrum_fused(")]
-    assert (fused_names and fused_names[0].startswith("spectrum_fused(cast+")) if fuse else not fused_names, rt.units
+    assert (fused_names and fused_names[0].startswith("spectrum_fused(spectrum.cast_input+")) if fuse else not fused_names, rt.units
     for k in range(5):
         raw = rng.integers(info.min, info.max + 1, (b, n, 2)).astype(np_t)
         if k == 0:
