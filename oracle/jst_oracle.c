@@ -1713,6 +1713,16 @@ float jst_oracle_approx_log10(float x) {
     return y * 0.3010299956639812f;
 }
 
+/* bulk form for the sweep against the reference's own inline function (oracle/ref_helpers.cc, tests/test_oracle_ref_helpers.py) */
+void jst_oracle_approx_log10_bits(uint32_t first, uint64_t count, float* out) {
+    for (uint64_t i = 0; i < count; ++i) {
+        const uint32_t b = first + (uint32_t)i;
+        float x;
+        memcpy(&x, &b, 4);
+        out[i] = jst_oracle_approx_log10(x);
+    }
+}
+
 float jst_oracle_amplitude_coeff(uint64_t normalization_size) {
     return 20.0f * log10f(1.0f / (float)normalization_size);
 }

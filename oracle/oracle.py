@@ -15,6 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libjst_oracle.so")
 _REF_PATH = os.path.join(_HERE, "_ref", "libref_pocketfft.so")
+_REF_HELPERS_PATH = os.path.join(_HERE, "_ref", "libref_helpers.so")
 
 _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)
@@ -27,7 +28,7 @@ def build(force: bool = False) -> None:
         os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "jst_oracle.c"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "libjst_oracle.so"], stdout=subprocess.DEVNULL)
-    if (force or not os.path.exists(_REF_PATH)) and os.path.exists(
+    if (force or not os.path.exists(_REF_PATH) or not os.path.exists(_REF_HELPERS_PATH)) and os.path.exists(
         "/root/reference/src/domains/dsp/fft/pocketfft.hh"
     ):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -69,6 +70,25 @@ def ref() -> C.CDLL:
         for name in ("ref_fft_c2c", "ref_fft_r2c", "ref_fft_r2r_fftpack"):
             getattr(_ref, name).restype = C.c_int
     return _ref
+
+
+_ref_helpers = None
+
+
+def have_ref_helpers() -> bool:
+    build()
+    return os.path.exists(_REF_HELPERS_PATH)
+
+
+def ref_helpers() -> C.CDLL:
+    """The reference's own inline ApproxLog10 and waterfall ring arithmetic (oracle/ref_helpers.cc, compiled in place)."""
+    global _ref_helpers
+    if _ref_helpers is None:
+        build()
+        _ref_helpers = C.CDLL(_REF_HELPERS_PATH)
+        _ref_helpers.ref_approx_log10.restype = C.c_float
+        _ref_helpers.ref_approx_log10.argtypes = [C.c_float]
+    return _ref_helpers
 
 
 def _p(a: np.ndarray, t=_f32p):

@@ -155,15 +155,18 @@ def test_no_upload_lands_in_a_slot_its_cycle_is_still_reading(js, oracle):
     water = js.Module("waterfall", {"height": total * b}, {"signal": amp.output("signal")}, "history")
     rt = js.Runtime([src, amp, water])
 
+    payload = [np.full((b, n), k + 1, np.complex64) for k in range(total)]
+
     def producer():
-        for k in range(total):
-            x = np.full((b, n), k + 1, np.complex64)
-            while src.ring_push(x) == "incomplete":
+        for x in payload:
+            while src.ring_push(x) == "incomplete":   # ring full: retry (nothing is dropped under "reject")
                 time.sleep(0.0001)
     th = threading.Thread(target=producer)
     th.start()
     cycles, deadline = 0, time.time() + 120
     while cycles < total and time.time() < deadline:
+        if cycles in (5, 20):
+            time.sleep(0.02)                            # a slow consumer for a moment: the producer fills the ring
         if src.ring_wait(b * n, timeout_ms=200):
             assert rt.compute(1, sync=False) == "success"   # never a host synchronise between cycles and uploads
             cycles += 1
