@@ -61,6 +61,8 @@ int main(int argc, char** argv) {
     const int mode = argc > 3 ? atoi(argv[3]) : 0;  // 0: bench data, 1: mid-range data (every tanh class), 2: zeros
 #ifdef FB_WG
     const int grid = 1024;
+#elif defined(FB_SPLIT)
+    const int grid = argc > 4 ? atoi(argv[4]) : 256;
 #else
     const int grid = argc > 4 ? atoi(argv[4]) : 512;
 #endif
@@ -110,6 +112,9 @@ int main(int argc, char** argv) {
 #ifdef FB_WG  // one transform per workgroup, 8 wavefronts per SIMD (fft_wg_kernel)
     auto k = fft_wg_kernel<N, true, true, LoadCF32TimesWindow, Epi>;
     const size_t lds = (size_t)lds_elems(N) * sizeof(float2);
+#elif defined(FB_SPLIT)  // role-split kernel: 16 wavefronts per workgroup, FFT role + epilogue role
+    auto k = fft_split_kernel<N, true, LoadCF32TimesWindow, Epi>;
+    const size_t lds = fft_split_lds_bytes(N);
 #else
     auto k = fft_pipe_kernel<N, true, true, LoadCF32TimesWindow, Epi>;
     const size_t lds = fft_pipe_lds_bytes(N);
@@ -125,7 +130,11 @@ int main(int argc, char** argv) {
 #else
         Epi epi{out, coeff, scale, offset, BinGuard{(FB_FAST && guard) ? 256.0f : 0.0f, 0.0f}};
 #endif
+#ifdef FB_SPLIT
+        k<<<grid, N / 4, lds, st>>>(L, W, pro, epi);
+#else
         k<<<grid, N / 8, lds, st>>>(L, W, pro, epi);
+#endif
     };
     for (int i = 0; i < 20; ++i) launch(i % SLOTS);
     CK(hipStreamSynchronize(st));
@@ -159,7 +168,11 @@ int main(int argc, char** argv) {
 #else
             Epi epi{outs[q], coeff, scale, offset, BinGuard{(FB_FAST && guard) ? 256.0f : 0.0f, 0.0f}};
 #endif
+#ifdef FB_SPLIT
+            k<<<grid, N / 4, lds, ss[q]>>>(L, W, pro, epi);
+#else
             k<<<grid, N / 8, lds, ss[q]>>>(L, W, pro, epi);
+#endif
         };
         for (int i = 0; i < 30; ++i) launch_on(i % SLOTS, i % ns);
         CK(hipDeviceSynchronize());
