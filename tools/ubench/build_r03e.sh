@@ -3,7 +3,7 @@
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 B=$ROOT/tools/ubench/bin
 mkdir -p $B
-HC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -D__HIP_PLATFORM_AMD__ -I $ROOT/cyberether_amd/csrc/kernels -I $ROOT/cyberether_amd/csrc -I $ROOT/include"
+HC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -D__HIP_PLATFORM_AMD__ -I $ROOT/cyberether_amd/csrc/kernels -I $ROOT/cyberether_amd/csrc -I $ROOT/include -I $ROOT/tools/ubench"
 $HC $ROOT/tools/ubench/fused_bench.hip -o $B/p_e &
 $HC -DFB_FAST=true $ROOT/tools/ubench/fused_bench.hip -o $B/p_f &
 $HC -DFB_TRIVIAL_EPI $ROOT/tools/ubench/fused_bench.hip -o $B/p_t &

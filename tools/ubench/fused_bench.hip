@@ -6,6 +6,9 @@
 //         -I cyberether_amd/csrc tools/ubench/fused_bench.hip -o fused_bench_<variant>
 // Diagnostic only; the product path is cyberether_amd/lib/libjetstream_hip.so.
 #include "fft_lds.hh"
+#ifdef FB_SPLIT
+#include "fft_split_experiment.hh"
+#endif
 
 #include <algorithm>
 #include <cmath>
