@@ -84,26 +84,57 @@ struct TiledPlan {
 // <= 512 threads and 32 KiB of LDS, i.e. three workgroups per CU whose load / pass / store phases
 // overlap; so take the widest of {32,16} lanes that stays within 4096 elements and still yields
 // kWantGroups workgroups, and fall back to 8 lanes (64-byte runs) up to the 8192-element cap.
-uint32_t pick_lanes(uint32_t len, uint64_t lanes_total) {
+constexpr uint32_t pick_lanes(uint32_t len, uint64_t lanes_total) {
     for (uint32_t c = 32; c >= 16; c /= 2)
         if ((uint64_t)len * c <= 4096 && (lanes_total + c - 1) / c >= kWantGroups) return c;
     return (uint64_t)len * 8 <= kTileElems ? 8u : 0u;
 }
-uint32_t ilog2(uint32_t v) {
+constexpr uint32_t ilog2(uint32_t v) {
     uint32_t s = 0;
     while ((1u << s) < v) ++s;
     return s;
 }
-uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
+constexpr uint32_t magic_of(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
 
-bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
+// pocketfft's cfftp::factorize (pocketfft.hh:1476-1497), usable in constant expressions (= kernels::fft_plan_factors)
+constexpr int plan_factors_ce(uint64_t n, uint32_t* fact) {
+    int nf = 0;
+    uint64_t len = n;
+    if (len == 0) return -1;
+    if (len == 1) return 0;
+    while ((len & 7) == 0) { fact[nf++] = 8; len >>= 3; }
+    while ((len & 3) == 0) { fact[nf++] = 4; len >>= 2; }
+    if ((len & 1) == 0) {
+        len >>= 1;
+        fact[nf++] = 2;
+        const uint32_t t = fact[0];
+        fact[0] = fact[nf - 1];
+        fact[nf - 1] = t;
+    }
+    for (uint64_t d = 3; d * d <= len; d += 2)
+        while (len % d == 0) {
+            if (nf >= 60) return -1;
+            fact[nf++] = (uint32_t)d;
+            len /= d;
+        }
+    if (len > 1) {
+        if (nf >= 60 || len > 0xffffffffull) return -1;
+        fact[nf++] = (uint32_t)len;
+    }
+    return nf;
+}
+
+// The plan as a constant expression: the generic launch path calls it at run time (with the A/B lane overrides), the
+// per-plan specialisations evaluate it at compile time (static_plan below) and the kernels then see every radix,
+// stride, shift and magic number as a literal.
+constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_ca, uint32_t force_cb, TiledPlan& p) {
     if (n < 2 || n > (1ull << 26)) return false;
-    uint32_t fact[64];
-    const int nf = fft_plan_factors(n, fact);
+    uint32_t fact[64] = {};
+    const int nf = plan_factors_ce(n, fact);
     if (nf <= 0 || nf > 20) return false;
     for (int i = 0; i < nf; ++i)
         if (fact[i] > 11) return false;
-    std::memset(&p, 0, sizeof(p));
+    p = TiledPlan{};
     p.n = (uint32_t)n;
     p.nf = (uint32_t)nf;
     for (int i = 0; i < nf; ++i) p.fact[i] = fact[i];
@@ -139,9 +170,6 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
         p.CA = pick_lanes(p.R1, transforms * p.S);
         p.CB = pick_lanes(p.S, transforms * p.R1);
         if (!p.CA || !p.CB) return false;
-        // A/B switches (read once): lanes per workgroup of the two kernels, powers of two
-        static const uint32_t force_cb = [] { const char* e = getenv("JST_TILED_CB"); return e ? (uint32_t)atoi(e) : 0u; }();
-        static const uint32_t force_ca = [] { const char* e = getenv("JST_TILED_CA"); return e ? (uint32_t)atoi(e) : 0u; }();
         if (force_cb) p.CB = force_cb;
         if (force_ca) p.CA = force_ca;
     }
@@ -168,6 +196,56 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
         off += (uint64_t)(p.fact[q] - 1) * ido;
         l1 *= p.fact[q];
     }
+    return true;
+}
+
+bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
+    // A/B switches (read once): lanes per workgroup of the two kernels, powers of two
+    static const uint32_t force_cb = [] { const char* e = getenv("JST_TILED_CB"); return e ? (uint32_t)atoi(e) : 0u; }();
+    static const uint32_t force_ca = [] { const char* e = getenv("JST_TILED_CA"); return e ? (uint32_t)atoi(e) : 0u; }();
+    return build_tiled_plan(n, transforms, force_ca, force_cb, p);
+}
+
+// The fold epilogue's lane grouping (see FoldProductEpi below): part of the plan.
+constexpr bool plan_fold_groups(TiledPlan& p, uint64_t fold) {
+    if (fold == 0 || p.n % fold != 0 || p.n / fold > 64) return false;
+    if (p.R1 == 1) return true;  // whole transforms per lane: every alias is in the lane's own column
+    const uint32_t d = (uint32_t)(fold % p.R1);
+    uint32_t a = p.R1, b = d;
+    while (b) { const uint32_t t = a % b; a = b; b = t; }  // a = gcd(R1, d), gcd(R1, 0) = R1
+    const uint32_t o = p.R1 / a;
+    if (o > p.CB || p.CB % o != 0) return false;
+    const uint32_t w = p.CB / o, stride = p.R1 / o;
+    if (stride % w != 0) return false;  // every tile full, no group runs into the next
+    p.grp_w = w;
+    p.grp_stride = stride;
+    p.grp_shift = ilog2(w);
+    return true;
+}
+
+// ---- per-plan specialisation (round 3) ---------------------------------------------------------------------------
+// The plans BASELINE.json's configurations run -- config 5: 16 x 65536 points; config 3: 100 x 160000 forward with the
+// fold epilogue and 100 x 16000 inverse -- are also compiled with the plan as a CONSTANT: SP > 0 selects static_plan(SP)
+// inside the kernels instead of the plan argument, every `rest / ido`, `x * pitch`, `1 << lane_shift`, radix switch and
+// pass loop folds, and what is left of a pass is its butterflies, twiddles and LDS traffic (the generic index
+// arithmetic was about a third of a pass's VALU work: quarter-rate v_mul_lo / v_mul_hi per butterfly).  The launcher
+// takes a specialisation only when the run-time plan equals the constant one field for field.
+struct StaticPlanKey { uint64_t n, transforms, fold; };  // fold != 0: with the fold epilogue's lane groups
+constexpr StaticPlanKey kStaticPlans[] = {{0, 0, 0}, {65536, 16, 0}, {160000, 100, 16000}, {16000, 100, 0}};
+constexpr int kStaticPlanCount = 4;
+constexpr TiledPlan static_plan(int sp) {
+    TiledPlan p{};
+    (void)build_tiled_plan(kStaticPlans[sp].n, kStaticPlans[sp].transforms, 0, 0, p);
+    if (kStaticPlans[sp].fold) (void)plan_fold_groups(p, kStaticPlans[sp].fold);
+    return p;
+}
+constexpr bool same_plan(const TiledPlan& a, const TiledPlan& b) {
+    if (a.n != b.n || a.nf != b.nf || a.g != b.g || a.R1 != b.R1 || a.S != b.S || a.CA != b.CA || a.CB != b.CB ||
+        a.ca_shift != b.ca_shift || a.cb_shift != b.cb_shift || a.grp_w != b.grp_w || a.grp_stride != b.grp_stride ||
+        a.grp_shift != b.grp_shift)
+        return false;
+    for (int i = 0; i < 20; ++i)
+        if (a.fact[i] != b.fact[i] || a.magic[i] != b.magic[i] || a.tw_off[i] != b.tw_off[i]) return false;
     return true;
 }
 
@@ -213,22 +291,6 @@ struct StoreScaledUnpad {
         else tail[base * (int64_t)tail_len + ((uint32_t)pos - body_len)] = r;
     }
 };
-
-bool plan_fold_groups(TiledPlan& p, uint64_t fold) {
-    if (fold == 0 || p.n % fold != 0 || p.n / fold > 64) return false;
-    if (p.R1 == 1) return true;  // whole transforms per lane: every alias is in the lane's own column
-    const uint32_t d = (uint32_t)(fold % p.R1);
-    uint32_t a = p.R1, b = d;
-    while (b) { const uint32_t t = a % b; a = b; b = t; }  // a = gcd(R1, d), gcd(R1, 0) = R1
-    const uint32_t o = p.R1 / a;
-    if (o > p.CB || p.CB % o != 0) return false;
-    const uint32_t w = p.CB / o, stride = p.R1 / o;
-    if (stride % w != 0) return false;  // every tile full, no group runs into the next
-    p.grp_w = w;
-    p.grp_stride = stride;
-    p.grp_shift = ilog2(w);
-    return true;
-}
 
 // Workgroup b runs on XCD b % 8 (observed placement, used for speed only) and every XCD has an L2 of its own.
 // Neighbouring tiles share cache lines (a column tile's 128-byte runs start 8 bytes off the line grid whenever the
@@ -331,12 +393,14 @@ __device__ __forceinline__ void tile_pass_any(uint32_t ip, float2* buf, const fl
 }
 
 // ---- kernel A: passes 0..g-1 on CA adjacent columns ---------------------------------------------
-template <bool FWD, class Pro>
+template <bool FWD, class Pro, int SP = 0>
 __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_columns_kernel(const FftLayout L,
-                                                                    const TiledPlan P,
+                                                                    const TiledPlan Prt,
                                                                     const float2* __restrict__ W,
                                                                     const Pro pro,
                                                                     float2* __restrict__ scratch) {
+    constexpr TiledPlan PS = static_plan(SP);  // SP > 0: the plan is a constant and the argument is ignored
+    const TiledPlan& P = SP > 0 ? PS : Prt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* buf0 = reinterpret_cast<float2*>(smem_raw);
     JST_TSTAMP(0);
@@ -369,6 +433,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_col
     __syncthreads();
     JST_TSTAMP(1);  // tile loaded
     uint32_t l1 = 1, m = P.R1;
+#pragma unroll
     for (uint32_t p = 0; p < P.g; ++p) {
         const uint32_t ip = P.fact[p];
         m /= ip;  // local ido'
@@ -388,12 +453,14 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_col
 }
 
 // ---- kernel B: passes g..nf-1 on CB adjacent blocks (or whole transforms when g == 0) -----------
-template <bool FWD, class Pro, class Epi>
+template <bool FWD, class Pro, class Epi, int SP = 0>
 __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blocks_kernel(const FftLayout L,
-                                                                   const TiledPlan P,
+                                                                   const TiledPlan Prt,
                                                                    const float2* __restrict__ W,
                                                                    const Pro pro, const Epi epi,
                                                                    const float2* __restrict__ scratch) {
+    constexpr TiledPlan PS = static_plan(SP);  // SP > 0: the plan is a constant and the argument is ignored
+    const TiledPlan& P = SP > 0 ? PS : Prt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ int64_t lane_in[32], lane_out[32];  // per lane of the tile: tensor row bases
     __shared__ uint32_t lane_off[32];              // fold epilogue: per lane, the fold offset of its transform (mod n)
@@ -458,6 +525,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
     JST_TSTAMP(1);  // tile loaded
     const float2* src = buf0;
     uint32_t l1 = P.R1, ido = P.S;
+#pragma unroll
     for (uint32_t p = P.g; p < P.nf; ++p) {
         const uint32_t ip = P.fact[p];
         ido /= ip;
@@ -577,15 +645,15 @@ inline unsigned threads_for(uint64_t tile_elems) {
     return (unsigned)t;
 }
 
-template <bool FWD, class Pro, class Epi>
-hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W, const Pro& pro,
-                        const Epi& epi, float2* scratch, hipStream_t s) {
+template <bool FWD, class Pro, class Epi, int SP = 0>
+hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2* W, const Pro& pro,
+                           const Epi& epi, float2* scratch, hipStream_t s) {
     if (L.transforms == 0) return hipSuccess;
     (void)hipGetLastError();
     if (P.g > 0) {
         if (!scratch) return hipErrorInvalidValue;
         const size_t lds_a = (size_t)P.R1 * P.CA * sizeof(float2);
-        auto ka = fft_tile_columns_kernel<FWD, Pro>;
+        auto ka = fft_tile_columns_kernel<FWD, Pro, SP>;
         {  // tiles never exceed kTileElems
             const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(ka), (int)(kTileElems * sizeof(float2)));
             if (e != hipSuccess) return e;
@@ -596,7 +664,7 @@ hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W,
                            pro, scratch);
     }
     const size_t lds_b = (size_t)P.S * (P.CB | 1u) * sizeof(float2);
-    auto kb = fft_tile_blocks_kernel<FWD, Pro, Epi>;
+    auto kb = fft_tile_blocks_kernel<FWD, Pro, Epi, SP>;
     {  // pitch CB|1 adds at most one lane of padding per row
         const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kb), (int)(2 * kTileElems * sizeof(float2)));
         if (e != hipSuccess) return e;
@@ -608,6 +676,24 @@ hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W,
     hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.S * P.CB)), lds_b, s, L, P, W, pro, epi,
                        (const float2*)scratch);
     return hipGetLastError();
+}
+
+// JST_TILED_STATIC=0: A/B switch, always the generic kernels
+inline bool static_plans_enabled() {
+    static const bool on = [] { const char* e = getenv("JST_TILED_STATIC"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+// WANT: the specialisation this call site is compiled for (0: none).  Taken when the run-time plan equals it.
+template <bool FWD, class Pro, class Epi, int WANT = 0>
+hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W, const Pro& pro,
+                        const Epi& epi, float2* scratch, hipStream_t s) {
+    if constexpr (WANT > 0) {
+        constexpr TiledPlan SPl = static_plan(WANT);
+        if (static_plans_enabled() && L.transforms == kStaticPlans[WANT].transforms && same_plan(P, SPl))
+            return launch_tiled_sp<FWD, Pro, Epi, WANT>(P, L, W, pro, epi, scratch, s);
+    }
+    return launch_tiled_sp<FWD, Pro, Epi, 0>(P, L, W, pro, epi, scratch, s);
 }
 
 template <class Pro, class Epi>
@@ -693,6 +779,8 @@ hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool for
         epi.dq = (uint32_t)f.fold;
         epi.nq = p.n;
     }
+    if (forward)
+        return launch_tiled<true, LoadCF32Padded, FoldProductEpi, 2>(p, L, W, LoadCF32Padded{in, (uint32_t)valid}, epi, scratch, s);
     return dispatch_dir(forward, p, L, W, LoadCF32Padded{in, (uint32_t)valid}, epi, scratch, s);
 }
 
@@ -709,8 +797,9 @@ hipError_t launch_fft_c2c_tiled_scaled_unpad(uint64_t n, bool forward, const Fft
     }
     T.out_offset = 0;
     T.out_axis_stride = 0;
-    return dispatch_dir(forward, p, T, W, LoadCF32{in},
-                        StoreScaledUnpad{body, tail, constant, (uint32_t)body_len, (uint32_t)(n - body_len)}, scratch, s);
+    const StoreScaledUnpad unpad{body, tail, constant, (uint32_t)body_len, (uint32_t)(n - body_len)};
+    if (!forward) return launch_tiled<false, LoadCF32, StoreScaledUnpad, 3>(p, T, W, LoadCF32{in}, unpad, scratch, s);
+    return dispatch_dir(forward, p, T, W, LoadCF32{in}, unpad, scratch, s);
 }
 
 hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const float2* W,
@@ -727,9 +816,8 @@ hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const flo
             return launch_tiled<true>(p, L, W, pro,
                                       StoreAmplitudeRangeT<true>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}},
                                       scratch, s);
-        return launch_tiled<true>(p, L, W, pro,
-                                  StoreAmplitudeRangeT<false>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}},
-                                  scratch, s);
+        return launch_tiled<true, LoadCF32TimesWindow, StoreAmplitudeRangeT<false>, 1>(
+            p, L, W, pro, StoreAmplitudeRangeT<false>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}}, scratch, s);
     }
     if (fast) return launch_tiled<true>(p, L, W, pro, StoreAmplitudeT<true>{out, amp_coeff}, scratch, s);
     return launch_tiled<true>(p, L, W, pro, StoreAmplitudeT<false>{out, amp_coeff}, scratch, s);
