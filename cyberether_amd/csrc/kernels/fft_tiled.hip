@@ -269,6 +269,12 @@ struct FoldProductEpi {
     // idx += fold in tile coordinates (filled by the launcher from the plan): row += dq, block += dk (carry into the
     // row at R1), lane group += grp_step (mod the number of groups); idx -= n is row -= nq
     uint32_t dq, dk, nq, grp_step;
+    // heads > 1 (the Filter block's multi-head form, filter/block_impl.cc:350-582): ONE spectrum per transform meets
+    // `heads` operand rows h + hd * h_head_stride, each with its own fold offset chan_offsets[hd]; out is dense
+    // [transforms, heads, fold].  The spectrum tile has to survive all heads but the last: those form their products
+    // inside the alias walk (operand loads from L2 in the loop), the last head multiplies in place like heads == 1.
+    uint32_t heads = 1;
+    int64_t h_head_stride = 0;
 };
 template <class E>
 constexpr bool is_tile_epilogue = requires { E::kTile; };
@@ -540,6 +546,14 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
         // aliases through LDS -- idx += fold is (block group + grp_step, q + dq [+ carry]) with no division.
         const uint32_t F = epi.fold, N = P.n;
         const uint32_t elems = P.S << P.cb_shift;
+        const double divisor = (double)epi.decim;
+        const uint32_t per_lane = P.R1 > 1 ? (F + P.R1 - 1) / P.R1 : F;
+        const uint32_t total = per_lane << P.cb_shift;
+        const uint32_t groups = P.CB >> P.grp_shift;
+        for (uint32_t hd = 0; hd < epi.heads; ++hd) {
+        const float2* hh = epi.h + (int64_t)hd * epi.h_head_stride;
+        const bool in_place = hd + 1u == epi.heads;  // the last head may overwrite the spectrum tile with its products
+        if (in_place) {
         for (uint32_t e0 = threadIdx.x; e0 < elems; e0 += 8 * blockDim.x) {
             float2 hv[8];
             uint32_t slot[8];
@@ -549,7 +563,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
                 const uint32_t ec = e < elems ? e : elems - 1u;
                 const uint32_t kb = ec & (P.CB - 1u), q = ec >> P.cb_shift;
                 const uint32_t idx = P.R1 > 1 ? block_of(kb) + P.R1 * q : q;
-                hv[k] = epi.h[(int64_t)idx * epi.h_stride];
+                hv[k] = hh[(int64_t)idx * epi.h_stride];
                 slot[k] = (e < elems && kb < live) ? q * pitch + kb : 0xffffffffu;
             }
 #pragma unroll
@@ -558,17 +572,14 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
                     buf0[slot[k]] = epi.spectrum_first ? cmul_full(buf0[slot[k]], hv[k]) : cmul_full(hv[k], buf0[slot[k]]);
         }
         __syncthreads();
-        const double divisor = (double)epi.decim;
-        const uint32_t per_lane = P.R1 > 1 ? (F + P.R1 - 1) / P.R1 : F;
-        const uint32_t total = per_lane << P.cb_shift;
-        const uint32_t groups = P.CB >> P.grp_shift;
+        }
         for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
             const uint32_t kb = e & (P.CB - 1u), q = e >> P.cb_shift;
             if (kb >= live) continue;
             const uint32_t r = P.R1 > 1 ? block_of(kb) + P.R1 * q : q;
             if (r >= F) continue;
             const uint64_t t = P.R1 > 1 ? t0 : t0 + kb;
-            const uint32_t off = lane_off[kb];
+            const uint32_t off = epi.heads > 1 ? (epi.chan_offsets ? (uint32_t)(epi.chan_offsets[hd] % P.n) : epi.off) : lane_off[kb];
             const uint32_t off_q = off / F, off_r = off - off_q * F;
             uint32_t m = r + off_r;  // output bin whose addends are the alias class of r
             uint32_t steps = epi.decim - off_q;  // r is alias number `decim - steps` of bin m ...
@@ -585,8 +596,10 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
                 grp = ((kb >> P.grp_shift) + steps * epi.grp_step) & (groups - 1u);  // groups is a power of two
             }
             double sr = 0.0, si = 0.0;
+            uint32_t cur = 0;  // idx of the alias `advance` just returned (for the operand of a product formed on the fly)
             auto advance = [&]() {  // (idx, qq, grp) of the next alias; returns the LDS slot of the current one
                 const uint32_t at = qq * pitch + (grp << P.grp_shift) + within;
+                cur = idx;
                 idx += F;
                 qq += epi.dq;
                 if (P.R1 > 1) {
@@ -599,6 +612,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
                 return at;
             };
             uint32_t g = 0;
+            if (in_place) {
             for (; g + 5u <= epi.decim; g += 5u) {  // five LDS reads in flight, added in order
                 float2 pr[5];
 #pragma unroll
@@ -614,7 +628,31 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
                 sr += (double)pr.x;
                 si += (double)pr.y;
             }
-            epi.out[t * F + m] = mk((float)(sr / divisor), (float)(si / divisor));  // 32-byte runs: plain store, merged in L2
+            } else {
+            for (; g + 5u <= epi.decim; g += 5u) {  // five spectrum reads (LDS) and five operand loads (L2) in flight
+                float2 sp[5], hv[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    sp[u] = src[advance()];
+                    hv[u] = hh[(int64_t)cur * epi.h_stride];
+                }
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const float2 pr = epi.spectrum_first ? cmul_full(sp[u], hv[u]) : cmul_full(hv[u], sp[u]);
+                    sr += (double)pr.x;
+                    si += (double)pr.y;
+                }
+            }
+            for (; g < epi.decim; ++g) {
+                const float2 sp = src[advance()];
+                const float2 hv = hh[(int64_t)cur * epi.h_stride];
+                const float2 pr = epi.spectrum_first ? cmul_full(sp, hv) : cmul_full(hv, sp);
+                sr += (double)pr.x;
+                si += (double)pr.y;
+            }
+            }
+            epi.out[(t * epi.heads + hd) * F + m] = mk((float)(sr / divisor), (float)(si / divisor));  // 32-byte runs: plain store, merged in L2
+        }
         }
     } else
     // store result q of block (t, k) at k + R1*q: block index fastest when R1 > 1 (adjacent k are
@@ -769,7 +807,8 @@ hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool for
     TiledPlan p;
     if (valid > n || !make_tiled_plan(n, L.transforms, p) || !plan_fold_groups(p, f.fold)) return hipErrorInvalidValue;
     FoldProductEpi epi{f.out, f.h, f.h_stride, (uint32_t)f.fold, (uint32_t)(n / f.fold), (uint32_t)(f.offset % n),
-                       f.chan_offsets, (uint32_t)f.chan_count, (uint32_t)f.chan_div, f.spectrum_first, 0, 0, 0, 0};
+                       f.chan_offsets, (uint32_t)f.chan_count, (uint32_t)f.chan_div, f.spectrum_first, 0, 0, 0, 0,
+                       (uint32_t)(f.heads ? f.heads : 1), f.h_head_stride};
     if (p.R1 > 1) {
         epi.dq = (uint32_t)(f.fold / p.R1);
         epi.dk = (uint32_t)(f.fold % p.R1);

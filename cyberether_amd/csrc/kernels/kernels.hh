@@ -107,6 +107,10 @@ struct FoldProductArgs {
     const uint64_t* chan_offsets;
     uint64_t chan_count, chan_div;
     bool spectrum_first;
+    // heads > 1: `heads` operand rows h + hd * h_head_stride (one per head, fold offset chan_offsets[hd]) meet ONE
+    // spectrum per transform; out is dense [transforms, heads, fold] (the Filter block's multi-head form)
+    uint64_t heads = 1;
+    int64_t h_head_stride = 0;
 };
 bool fft_tiled_fold_supported(uint64_t n, uint64_t transforms, uint64_t fold);
 hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,

@@ -1403,21 +1403,35 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
         if (at + 3 < ordered.size()) {
             auto* mul = dynamic_cast<Multiply*>(ordered[at + 2]);
             auto* fold = dynamic_cast<Fold*>(ordered[at + 3]);
+            // heads: the spectrum [.., 1, n] broadcast along the axis in front of the transform axis against an operand
+            // [1.., heads, n] (filter/block_impl.cc:350-582 with more than one head); 1 = the plain same-shape product
+            const Index rank = fft->output.rank();
+            const Index head_axis = rank >= 2 ? rank - 2 : 0;
+            U64 heads = 1;
             const auto whole_spectrum = [&](const Tensor& v) {
-                return v.storageId() == fft->output.storageId() && v.offset() == 0 && v.contiguous() &&
-                       v.shape() == fft->output.shape();
+                if (v.storageId() != fft->output.storageId() || v.offset() != 0 || v.rank() != rank) return false;
+                if (v.contiguous() && v.shape() == fft->output.shape()) return true;
+                if (rank < 2 || fft->output.shape(head_axis) != 1 || v.stride(head_axis) != 0) return false;
+                for (Index ax = 0; ax < rank; ++ax) {
+                    if (ax == head_axis) continue;
+                    if (v.shape(ax) != fft->output.shape(ax) || v.stride(ax) != fft->output.stride(ax)) return false;
+                }
+                heads = v.shape(head_axis);
+                return true;
             };
             const auto broadcast_row = [&](const Tensor& v) {
                 if (v.dtype() != DataType::CF32 || v.rank() != fft->output.rank()) return false;
-                for (Index ax = 0; ax + 1 < v.rank(); ++ax)
+                for (Index ax = 0; ax + 1 < v.rank(); ++ax) {
+                    if (heads > 1 && ax == head_axis) continue;  // one operand row per head
                     if (v.stride(ax) != 0 && v.shape(ax) != 1) return false;
+                }
                 return true;
             };
             bool ok = mul && fold && std::string(mul->type()) == "multiply" && fft->forward &&
                       fft->output.contiguous() && fft->output.offset() == 0 &&
                       sole_consumer(ordered, fft->output, mul) &&
                       fold->input.storageId() == mul->c.storageId() && sole_consumer(ordered, mul->c, fold) &&
-                      mul->c.dtype() == DataType::CF32 && mul->c.shape() == fft->output.shape() &&
+                      mul->c.dtype() == DataType::CF32 &&
                       fold->resolvedAxis + 1 == mul->c.rank() && fold->output.contiguous() &&
                       !no_fold_epilogue;
             bool spectrum_first = true;
@@ -1426,8 +1440,19 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
                 else if (whole_spectrum(mul->b) && broadcast_row(mul->a)) spectrum_first = false;
                 else ok = false;
             }
+            if (ok) {  // the product's shape: the spectrum's, with `heads` on the head axis
+                Shape want = fft->output.shape();
+                if (heads > 1) want[head_axis] = heads;
+                ok = mul->c.shape() == want;
+            }
             U64 chanCount = 1, chanDiv = 1;
-            if (ok && fold->channelAxis) {
+            if (ok && heads > 1) {
+                // one fold offset per head: the channel axis of the fold is the head axis
+                const Tensor& hop = spectrum_first ? mul->b : mul->a;
+                ok = fold->channelAxis && *fold->channelAxis == head_axis && hop.shape(head_axis) == heads &&
+                     hop.stride(head_axis) >= 0 && fold->output.shape(head_axis) == heads;
+                chanCount = heads;
+            } else if (ok && fold->channelAxis) {
                 U64 chanInner = 1;
                 chanCount = fold->output.shape(*fold->channelAxis);
                 for (Index i = *fold->channelAxis + 1; i < fold->output.rank(); ++i) chanInner *= fold->output.shape(i);
@@ -1440,7 +1465,7 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
                 members = {pad, fft, mul, fold};
                 consumed = 4;
                 name = "fft_padded_fold(" + pad->name() + "+" + fft->name() + "+" + mul->name() + "+" + fold->name() + ")";
-                submit = [pad, fft, mul, fold, axis, spectrum_first, chanCount, chanDiv, n](hipStream_t stream) -> Result {
+                submit = [pad, fft, mul, fold, axis, spectrum_first, chanCount, chanDiv, n, heads, head_axis](hipStream_t stream) -> Result {
                     dev::FftLayout L;
                     JST_CHECK(fft->layout(L));
                     int r = 0;
@@ -1461,6 +1486,8 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
                     f.chan_count = chanCount;
                     f.chan_div = chanDiv;
                     f.spectrum_first = spectrum_first;
+                    f.heads = heads;
+                    f.h_head_stride = heads > 1 ? (int64_t)h.stride(head_axis) : 0;
                     return hip_result(
                         kernels::launch_fft_c2c_tiled_padded_fold(n, pad->input.shape(axis), true, L, fft->twiddles,
                                                                   ptr<const float2>(pad->input),

@@ -21,7 +21,9 @@ def two_tone(rng, b, s, sr, f1, f2):
     dict(sr=20e6, bw=2e6, center=[0.0], taps=251, s=1750, b=3),            # resample /10, conv 2000
     dict(sr=20e6, bw=2e6, center=[0.0, 3.0e6, -5.0e6], taps=101, s=900, b=2),  # 3 heads, fold offsets
     dict(sr=2e6, bw=0.7e6, center=[0.1e6], taps=65, s=960, b=2),            # no resampling, conv 1024
-    dict(sr=20e6, bw=2e6, center=[0.0], taps=251, s=15750, b=2),            # conv 16000 (global FFT)
+    dict(sr=20e6, bw=2e6, center=[0.0], taps=251, s=15750, b=2),            # conv 16000: two tiled kernels
+    dict(sr=20e6, bw=2e6, center=[0.0, 3.0e6], taps=251, s=15750, b=2),     # the same with two heads (fold offsets)
+    dict(sr=20e6, bw=2e6, center=[-1.0e6, 0.0, 3.0e6, 7.0e6], taps=51, s=7950, b=3),  # four heads, conv 8000: one kernel
 ])
 @pytest.mark.parametrize("fuse", [False, True])
 def test_filter_block_matches_oracle_chain(js, oracle, case, fuse):
@@ -34,9 +36,9 @@ def test_filter_block_matches_oracle_chain(js, oracle, case, fuse):
     assert plan == js.filter_plan(sr, bw, center, taps, heads, s)
     rt = js.Runtime(blk.modules, graph=True, fuse=fuse)
     units = rt.units
-    if fuse:  # pad -> fft (-> multiply -> fold with one head) collapse into the tiled transform (mixed-radix sizes)
+    if fuse:  # pad -> fft (-> multiply -> fold, any number of heads) collapse into the tiled transform (mixed-radix sizes)
         conv_is_pow2 = plan["convolutionSize"] & (plan["convolutionSize"] - 1) == 0
-        one_unit = plan["resample"] and heads == 1 and not conv_is_pow2
+        one_unit = plan["resample"] and not conv_is_pow2
         assert any(u.startswith("fft_padded_fold(") for u in units) == one_unit, units
         assert any(u.startswith("fft_padded(") for u in units) == (not conv_is_pow2 and not one_unit), units
         assert any(u.startswith("fold_product(") for u in units) == (plan["resample"] and not one_unit), units
