@@ -554,6 +554,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
         const float2* hh = epi.h + (int64_t)hd * epi.h_head_stride;
         const bool in_place = hd + 1u == epi.heads;  // the last head may overwrite the spectrum tile with its products
         if (in_place) {
+        if (epi.heads > 1) __syncthreads();  // every walk of the earlier heads has read the spectrum tile
         for (uint32_t e0 = threadIdx.x; e0 < elems; e0 += 8 * blockDim.x) {
             float2 hv[8];
             uint32_t slot[8];
