@@ -350,6 +350,9 @@ __device__ __forceinline__ bool near_bin_edge(float r, float h) {
 // launch in double, FastRangePoly), the chain runs as four fused multiply-adds and the logistic form needs one v_exp_f32
 // and one v_rcp_f32: 17 VALU instructions from the power on, against ~50 for the round-2 fast form and ~105 for the
 // exact one.  Its deviation from the exact provider stays below 4e-7 (every float p, WHICH = 6 of the sweep: 2.4e-7 .. 3.6e-7).
+#ifndef JST_FAST_COLD_INLINE
+#define JST_FAST_COLD_INLINE 0
+#endif
 struct FastRangePoly {
     float k3 = 0.0f, k2 = 0.0f, k1 = 0.0f, k0 = 0.0f, ke = 0.0f;
 };
@@ -384,7 +387,11 @@ __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p
         cold |= near_bin_edge(r, g.h0);
         if (g.h1 > 0.0f) cold |= near_bin_edge(r, g.h1);
     }
+#if JST_FAST_COLD_INLINE  // A/B switch: the guarded elements through the inlined exact MAIN path (no call on a guard hit)
+    if (__builtin_expect(cold, 0)) r = amplitude_range_from_power(p, coeff, scale, offset);
+#else
     if (__builtin_expect(cold, 0)) r = amplitude_range_from_power_cold(p, coeff, scale, offset);
+#endif
     return r;
 }
 __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p, float coeff, float scale,
