@@ -27,7 +27,7 @@ __device__ __forceinline__ f2 cmul(f2 a, f2 b) {
     return mk(ac - bd, ad + bc);
 }
 
-__device__ __attribute__((noinline)) f2 cmul_recover(f2 p, f2 q) {
+__device__ __forceinline__ f2 cmul_recover_body(f2 p, f2 q) {
     float a = p.x, b = p.y, c = q.x, d = q.y;
     const float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
     float x = ac - bd, y = ad + bc;
@@ -63,11 +63,21 @@ __device__ __attribute__((noinline)) f2 cmul_recover(f2 p, f2 q) {
     return mk(x, y);
 }
 
+__device__ __attribute__((noinline)) f2 cmul_recover(f2 p, f2 q) { return cmul_recover_body(p, q); }
+
 // Full std::complex<float> product: the plain formula, and -- only when a part came out NaN,
 // which finite data never does -- the Annex G recovery path, kept out of line (cold).
+#ifndef JST_COLD_INLINE  // A/B switch: 1 = the cold paths of cmul_full / the exact epilogue are inlined (no calls in the kernel)
+#define JST_COLD_INLINE 0
+#endif
+__device__ __forceinline__ f2 cmul_recover_inl(f2 p, f2 q) { return cmul_recover_body(p, q); }
 __device__ __forceinline__ f2 cmul_full(f2 p, f2 q) {
     const f2 r = cmul(p, q);
+#if JST_COLD_INLINE
+    if (__builtin_expect(__builtin_isunordered(r.x, r.y), 0)) return cmul_recover_inl(p, q);
+#else
     if (__builtin_expect(__builtin_isunordered(r.x, r.y), 0)) return cmul_recover(p, q);
+#endif
     return r;
 }
 
@@ -289,7 +299,11 @@ __device__ __forceinline__ float amplitude_range_from_power(float p, float coeff
     const float t = libm_tanhf_main(4.0f * (normalized - 0.5f), rare);
     float r = 0.5f + 0.5f * t;
     rare |= (f2u(p) - kPowerLo) > (kPowerHi - kPowerLo);
+#if JST_COLD_INLINE
+    if (__builtin_expect(rare, 0)) r = range_f32_general(amplitude_from_power(p, coeff), scale, offset);
+#else
     if (__builtin_expect(rare, 0)) r = amplitude_range_from_power_cold(p, coeff, scale, offset);
+#endif
     return r;
 }
 __device__ __forceinline__ float amplitude_range_exact(f2 v, float coeff, float scale, float offset) {
