@@ -365,7 +365,7 @@ __device__ __forceinline__ bool near_bin_edge(float r, float h) {
 // and one v_rcp_f32: 17 VALU instructions from the power on, against ~50 for the round-2 fast form and ~105 for the
 // exact one.  Its deviation from the exact provider stays below 4e-7 (every float p, WHICH = 6 of the sweep: 2.4e-7 .. 3.6e-7).
 #ifndef JST_FAST_COLD_INLINE
-#define JST_FAST_COLD_INLINE 0
+#define JST_FAST_COLD_INLINE 1
 #endif
 struct FastRangePoly {
     float k3 = 0.0f, k2 = 0.0f, k1 = 0.0f, k0 = 0.0f, ke = 0.0f;
@@ -401,7 +401,12 @@ __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p
         cold |= near_bin_edge(r, g.h0);
         if (g.h1 > 0.0f) cold |= near_bin_edge(r, g.h1);
     }
-#if JST_FAST_COLD_INLINE  // A/B switch: the guarded elements through the inlined exact MAIN path (no call on a guard hit)
+    // A guard hit (~2.5 % of the wavefront-elements at height 256) goes through the INLINED exact main path, not through a
+    // call: with the out-of-line copy every epilogue carried a call site whose ABI (caller-saved v0-v31, live values
+    // parked in callee-saved registers around it) cost the whole kernel 1.5 us per launch although the call is rare --
+    // 17.6 -> 16.1 us, same box, same checksum (profiles/r03_experiments/g_fast_guard_inline.log).  The exact kernel's
+    // own bail-out (taken never on real spectra) showed no such effect (h_no_calls.log) and stays out of line.
+#if JST_FAST_COLD_INLINE  // A/B switch
     if (__builtin_expect(cold, 0)) r = amplitude_range_from_power(p, coeff, scale, offset);
 #else
     if (__builtin_expect(cold, 0)) r = amplitude_range_from_power_cold(p, coeff, scale, offset);
