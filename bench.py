@@ -130,10 +130,12 @@ def main() -> None:
                     help="run the spectrogram as its own graph on a second stream, one ring period behind "
                          "the spectrum graph (two hardware queues: +6 %% throughput, the spectrum kernel "
                          "itself stretches ~5 %% while it shares the CUs)")
-    ap.add_argument("--provider", default="generic", choices=["generic", "fast"],
-                    help="amplitude/range arithmetic: generic = bit-identical to the reference CPU "
-                         "path; fast = hardware transcendentals (floats within 3e-7 of it, spectrogram "
-                         "bins identical through the fused kernel's bin guard)")
+    ap.add_argument("--provider", default="fast", choices=["generic", "fast"],
+                    help="amplitude/range arithmetic.  fast (the default since round 3): what north_star specifies -- "
+                         "integer bin work bit-exact (the fused kernel's bin guard, proven on every input power), float "
+                         "spectra within 4e-7 absolute of the reference CPU path (north_star allows 1e-5) -- through the "
+                         "hardware transcendentals; generic: every float bit-identical to the reference CPU path (glibc "
+                         "2.35 libm restated).  The other provider is measured too and reported as alt_provider.")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the pinned-host -> async H2D -> chain measurement")
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the post-measurement parity leg (profiling runs: nothing but the timed workload in the trace)")
@@ -398,8 +400,8 @@ def main() -> None:
         if os.path.exists(pmc):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from kernel_hash import kernel_sources_sha256
-            rec = json.load(open(pmc))
-            if rec.get("kernel_sources_sha256") == kernel_sources_sha256() and args.provider == "generic":
+            rec = json.load(open(pmc)).get(args.provider, {})
+            if rec.get("kernel_sources_sha256") == kernel_sources_sha256():
                 traffic = rec.get("spectrum_fused_hbm_bytes_per_launch")
                 traffic_src = {"source": rec.get("source"), "kernel": rec.get("kernel"),
                                "kernel_sources_sha256": rec.get("kernel_sources_sha256"),
@@ -427,7 +429,11 @@ def main() -> None:
                                    "1024 batches cf32 per step, hipGraph capture",
                        "batches": BATCHES, "fft_size": N_FFT, "ring_slots": args.slots,
                        "graph": rt.graph_active, "fused": not args.no_fuse,
-                       "provider": args.provider, "pipelined": args.pipeline, "combined": args.combine,
+                       "provider": args.provider,
+                       "provider_contract": ("integer bin work bit-exact (proven per input power), float spectra within 4e-7 "
+                                             "absolute of the reference CPU path (north_star: 1e-5)" if args.provider == "fast"
+                                             else "every output bit-identical to the reference CPU path"),
+                       "pipelined": args.pipeline, "combined": args.combine,
                        "untimed_init_steps": 2 * max(rt.period, 1) + (-args.warmup) % max(rt.period, 1)
                                              + args.steps + (-args.steps) % max(rt.period, 1),
                        "repeats": repeats_main, "region_ms_min_max": [round(spread_main[0] * 1e3, 4),
@@ -459,18 +465,20 @@ def main() -> None:
                 line["parity"] = {"checked": False, "error": repr(exc)}
         else:
             line["parity"] = {"checked": False, "reason": "--no-parity / unfused / pipelined run"}
-        if world == 1 and args.provider == "generic" and not args.no_fuse and not args.no_alt:
-            # informational second measurement: same chain with provider "fast" (hardware
-            # transcendentals for amplitude/range: floats within 3e-7 of the CPU path -- BASELINE allows
-            # 1e-5 -- and spectrogram bins identical to it through the bin guard)
-            rt2, elapsed2 = measure("fast", seed_offset=0)
+        if world == 1 and not args.no_fuse and not args.no_alt:
+            # second measurement: the same chain with the OTHER amplitude/range provider ("generic" = every float
+            # bit-identical to the reference CPU path; "fast" = bins exact, floats within 4e-7), with its own roofline
+            # figure and parity stamp
+            other = "generic" if args.provider == "fast" else "fast"
+            rt2, elapsed2 = measure(other, seed_offset=0)
             raw2, pair2, ms2, ach2 = kernel_time(rt2)
-            line["alt_provider"] = {"provider": "fast", "value": samples / elapsed2 / 1e6, "unit": "MS/s",
+            line["alt_provider"] = {"provider": other, "value": samples / elapsed2 / 1e6, "unit": "MS/s",
                                     "ms_per_step": elapsed2 / args.steps * 1e3, "kernel_ms": ms2,
-                                    "roofline_frac": (ach2 / HBM_PEAK_GBS) if ach2 else None}
+                                    "roofline_frac": (ach2 / HBM_PEAK_GBS) if ach2 else None,
+                                    "step_frac": step_bytes / (elapsed2 / args.steps) / 1e9 / HBM_PEAK_GBS}
             if not args.no_parity:
                 try:
-                    line["alt_provider"]["parity"] = parity_check(rt2, "fast")
+                    line["alt_provider"]["parity"] = parity_check(rt2, other)
                 except Exception as exc:
                     line["alt_provider"]["parity"] = {"checked": False, "error": repr(exc)}
             rt2.destroy()
