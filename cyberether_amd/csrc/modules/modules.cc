@@ -1239,11 +1239,17 @@ Result RingSource::ensureProducer() {  // mu held
 
 Result RingSource::ringAcquire(void** ptr, U64* max_elements) {
     if (!ptr || !max_elements) return Result::ERROR;
-    std::lock_guard<std::mutex> lock(mu);
+    std::unique_lock<std::mutex> lock(mu);
     JST_CHECK(ensureProducer());
     if (stagingFill == 0 && stagingBusy[stagingIndex]) {  // the copy that last left this staging buffer must be done
-        JST_HIP_CHECK(hipEventSynchronize(stagingFree[stagingIndex]), "hipEventSynchronize");
-        stagingBusy[stagingIndex] = false;
+        // wait WITHOUT the lock: computeSubmit takes it, and a compute thread must not stall behind a producer that
+        // is waiting for PCIe (one producer thread is assumed, like the reference's Soapy thread)
+        const U64 index = stagingIndex;
+        hipEvent_t done = stagingFree[index];
+        lock.unlock();
+        JST_HIP_CHECK(hipEventSynchronize(done), "hipEventSynchronize");
+        lock.lock();
+        if (index == stagingIndex) stagingBusy[index] = false;
     }
     *ptr = static_cast<char*>(staging[stagingIndex]) + stagingFill * elementBytes;
     *max_elements = batches * samples - stagingFill;
