@@ -1009,7 +1009,10 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
 }
 
 template <int N, bool FWD, bool CONTIG, class Pro, class Epi>
-__global__ __launch_bounds__(N / 8, (N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 256) void fft_pipe_kernel(
+#ifndef JST_PIPE_WAVES
+#define JST_PIPE_WAVES ((N / 8) * 2 / 256 >= 4 ? 4 : (N / 8) * 2 / 256)
+#endif
+__global__ __launch_bounds__(N / 8, JST_PIPE_WAVES) void fft_pipe_kernel(
     const FftLayout L, const float2* __restrict__ W, const Pro pro, const Epi epi) {
     fft_pipe_body<N, FWD, CONTIG, Pro, Epi>(L, W, pro, epi, blockIdx.x, gridDim.x);
 }
