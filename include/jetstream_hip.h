@@ -229,14 +229,20 @@ jst_result jst_filter_plan(float sample_rate, float bandwidth, const float* cent
  *     fused unit "spectrum_fused(multiply+fft+amplitude[+range])": needs multiply.b STATIC and broadcast along every
  *     axis but the sample axis, fft forward on CF32, N a power of two in [256, 16384] or any length whose pocketfft
  *     plan uses radices <= 11 (tiled kernels); a Spectrogram consuming the range output passes its height to the
- *     "fast" provider's bin guard.
+ *     "fast" provider's bin guard.  A cast{CI16 | CI8 | CU8 -> CF32} whose output feeds only that multiply (the block's
+ *     own leading cast_input) joins the unit -- "spectrum_fused(cast+multiply+..)": the kernel reads the raw samples and
+ *     converts them in the transform's first load (N <= 16384); the cast module then launches nothing.
+ *   spectrogram{merge=counts} -> [all-reduce of the U32 counts over the ranks] -> spectrogram_merge{batches=total}: the
+ *     exact multi-GPU display (not in the reference, whose display is per process): bit-identical to one spectrogram
+ *     over the union of the batches.
  *   filter (filter/block_impl.cc:350-582), per the plan of CalculateCandidatePlan (:40-168):
  *       pad -> fft                      fused: the zeros are synthesised in the transform's first load
  *       multiply{fft output, taps spectrum} -> fold     fused: the broadcast product is never materialised
  *       pad -> fft -> multiply -> fold  ONE unit "fft_padded_fold(..)" when the transform runs on the LDS-tiled kernels
- *                                       (mixed-radix length), one head (the taps spectrum is broadcast over the
- *                                       transforms) and the fold's aliases fit one workgroup: neither the spectrum
- *                                       nor the product is written
+ *                                       (mixed-radix length), the taps spectrum is broadcast over the transforms
+ *                                       (any number of heads: one operand row and one fold offset per head) and
+ *                                       the fold's aliases fit one workgroup: neither the spectrum nor the
+ *                                       product is written
  *       fft{forward=false} -> multiply_constant -> unpad -> overlap_add     ONE unit "ifft_unpad_overlap(..)" (tiled
  *                                       transform, no phase_correction in between): scale and body / tail split on
  *                                       the transform's last store, one small kernel for the overlap region + state
