@@ -23,6 +23,7 @@
 #include "fft_radix.hh"
 #include "kernels.hh"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -677,7 +678,24 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
 
 // at least tile/8 threads (the in-place passes hold <= 8 points per thread); a multiple of 256 so
 // that every SIMD of the CU gets the same number of wavefronts and a second / third workgroup fits
-inline unsigned threads_for(uint64_t tile_elems) {
+// the fewest threads the passes [first, last) of a plan need on a tile of `tile_elems` elements: a thread owns at most
+// butterflies_per_thread(radix) butterflies of a pass (tile_pass)
+inline uint64_t min_threads_for_passes(const TiledPlan& P, uint32_t first, uint32_t last, uint64_t tile_elems) {
+    uint64_t need = 64;
+    for (uint32_t q = first; q < last; ++q) {
+        const uint32_t ip = P.fact[q];
+        const uint64_t per = ip <= 3 ? 4 : (ip <= 7 ? 2 : 1);
+        const uint64_t nb = tile_elems / ip;
+        need = std::max<uint64_t>(need, (nb + per - 1) / per);
+    }
+    return need;
+}
+inline unsigned threads_for(uint64_t tile_elems, const char* override_env = nullptr, uint64_t min_threads = 0) {
+    if (override_env) {  // A/B switches JST_TILED_TA / JST_TILED_TB: workgroup size of the columns / blocks kernel
+        const char* e = getenv(override_env);
+        const int v = e ? atoi(e) : 0;
+        if (v >= 64 && v <= kMaxThreads && v % 64 == 0 && (uint64_t)v >= min_threads) return (unsigned)v;
+    }
     uint64_t t = ((tile_elems / 8 + 255) / 256) * 256;
     if (t < 256) t = 256;
     if (t > (uint64_t)kMaxThreads) t = kMaxThreads;
@@ -699,7 +717,7 @@ hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2*
         }
         const uint64_t blocks = L.transforms * ((P.S + P.CA - 1) / P.CA);
         if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(ka, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.R1 * P.CA)), lds_a, s, L, P, W,
+        hipLaunchKernelGGL(ka, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.R1 * P.CA, "JST_TILED_TA", min_threads_for_passes(P, 0, P.g, (uint64_t)P.R1 * P.CA))), lds_a, s, L, P, W,
                            pro, scratch);
     }
     const size_t lds_b = (size_t)P.S * (P.CB | 1u) * sizeof(float2);
@@ -712,7 +730,7 @@ hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2*
     const uint64_t blocks = P.R1 > 1 ? L.transforms * ((P.R1 + P.CB - 1) / P.CB)
                                      : (L.transforms + P.CB - 1) / P.CB;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.S * P.CB)), lds_b, s, L, P, W, pro, epi,
+    hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.S * P.CB, "JST_TILED_TB", min_threads_for_passes(P, P.g, P.nf, (uint64_t)P.S * P.CB))), lds_b, s, L, P, W, pro, epi,
                        (const float2*)scratch);
     return hipGetLastError();
 }
