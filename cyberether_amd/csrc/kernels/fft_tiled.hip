@@ -231,12 +231,18 @@ constexpr bool plan_fold_groups(TiledPlan& p, uint64_t fold) {
 // pass loop folds, and what is left of a pass is its butterflies, twiddles and LDS traffic (the generic index
 // arithmetic was about a third of a pass's VALU work: quarter-rate v_mul_lo / v_mul_hi per butterfly).  The launcher
 // takes a specialisation only when the run-time plan equals the constant one field for field.
-struct StaticPlanKey { uint64_t n, transforms, fold; };  // fold != 0: with the fold epilogue's lane groups
-constexpr StaticPlanKey kStaticPlans[] = {{0, 0, 0}, {65536, 16, 0}, {160000, 100, 16000}, {16000, 100, 0}};
-constexpr int kStaticPlanCount = 4;
+struct StaticPlanKey { uint64_t n, transforms, fold; uint32_t force_ca, force_cb; };  // fold != 0: with the fold epilogue's lane groups
+// 1-3: the plans as build_tiled_plan picks them; 4-9: the same transforms with other lane counts (A/B through
+// JST_TILED_CA / JST_TILED_CB, which make the run-time plan match one of them)
+constexpr StaticPlanKey kStaticPlans[] = {{0, 0, 0, 0, 0},
+                                          {65536, 16, 0, 0, 0}, {160000, 100, 16000, 0, 0}, {16000, 100, 0, 0, 0},
+                                          {65536, 16, 0, 16, 0}, {65536, 16, 0, 32, 0}, {65536, 16, 0, 0, 16},
+                                          {160000, 100, 16000, 0, 4}, {160000, 100, 16000, 32, 0}, {160000, 100, 16000, 8, 0}};
+constexpr int kStaticPlanCount = 10;
 constexpr TiledPlan static_plan(int sp) {
     TiledPlan p{};
-    (void)build_tiled_plan(kStaticPlans[sp].n, kStaticPlans[sp].transforms, 0, 0, p);
+    (void)build_tiled_plan(kStaticPlans[sp].n, kStaticPlans[sp].transforms, kStaticPlans[sp].force_ca,
+                           kStaticPlans[sp].force_cb, p);
     if (kStaticPlans[sp].fold) (void)plan_fold_groups(p, kStaticPlans[sp].fold);
     return p;
 }
@@ -741,14 +747,26 @@ inline bool static_plans_enabled() {
     return on;
 }
 
-// WANT: the specialisation this call site is compiled for (0: none).  Taken when the run-time plan equals it.
-template <bool FWD, class Pro, class Epi, int WANT = 0>
+// WANT...: the specialisations this call site is compiled for.  The first whose constant plan equals the run-time
+// plan is taken; none: the generic kernels.
+template <bool FWD, class Pro, class Epi, int... WANT>
 hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W, const Pro& pro,
                         const Epi& epi, float2* scratch, hipStream_t s) {
-    if constexpr (WANT > 0) {
-        constexpr TiledPlan SPl = static_plan(WANT);
-        if (static_plans_enabled() && L.transforms == kStaticPlans[WANT].transforms && same_plan(P, SPl))
-            return launch_tiled_sp<FWD, Pro, Epi, WANT>(P, L, W, pro, epi, scratch, s);
+    if constexpr (sizeof...(WANT) > 0) {
+        if (static_plans_enabled()) {
+            hipError_t result = hipSuccess;
+            bool taken = false;
+            auto attempt = [&](auto id) {
+                constexpr int SPI = decltype(id)::value;
+                constexpr TiledPlan SPl = static_plan(SPI);
+                if (!taken && L.transforms == kStaticPlans[SPI].transforms && same_plan(P, SPl)) {
+                    taken = true;
+                    result = launch_tiled_sp<FWD, Pro, Epi, SPI>(P, L, W, pro, epi, scratch, s);
+                }
+            };
+            (attempt(std::integral_constant<int, WANT>{}), ...);
+            if (taken) return result;
+        }
     }
     return launch_tiled_sp<FWD, Pro, Epi, 0>(P, L, W, pro, epi, scratch, s);
 }
@@ -838,7 +856,7 @@ hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool for
         epi.nq = p.n;
     }
     if (forward)
-        return launch_tiled<true, LoadCF32Padded, FoldProductEpi, 2>(p, L, W, LoadCF32Padded{in, (uint32_t)valid}, epi, scratch, s);
+        return launch_tiled<true, LoadCF32Padded, FoldProductEpi, 2, 7, 8, 9>(p, L, W, LoadCF32Padded{in, (uint32_t)valid}, epi, scratch, s);
     return dispatch_dir(forward, p, L, W, LoadCF32Padded{in, (uint32_t)valid}, epi, scratch, s);
 }
 
@@ -874,7 +892,7 @@ hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const flo
             return launch_tiled<true>(p, L, W, pro,
                                       StoreAmplitudeRangeT<true>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}},
                                       scratch, s);
-        return launch_tiled<true, LoadCF32TimesWindow, StoreAmplitudeRangeT<false>, 1>(
+        return launch_tiled<true, LoadCF32TimesWindow, StoreAmplitudeRangeT<false>, 1, 4, 5, 6>(
             p, L, W, pro, StoreAmplitudeRangeT<false>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}}, scratch, s);
     }
     if (fast) return launch_tiled<true>(p, L, W, pro, StoreAmplitudeT<true>{out, amp_coeff}, scratch, s);
