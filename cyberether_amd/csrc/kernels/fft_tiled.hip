@@ -204,7 +204,15 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
     // A/B switches (read once): lanes per workgroup of the two kernels, powers of two
     static const uint32_t force_cb = [] { const char* e = getenv("JST_TILED_CB"); return e ? (uint32_t)atoi(e) : 0u; }();
     static const uint32_t force_ca = [] { const char* e = getenv("JST_TILED_CA"); return e ? (uint32_t)atoi(e) : 0u; }();
-    return build_tiled_plan(n, transforms, force_ca, force_cb, p);
+    // Lane counts measured per plan with the specialised kernels (rocprofv3, profiles/r03_experiments/k_static_plan_lanes.log):
+    // config 5's columns kernel 9.4 -> 7.8 us with 16 columns per workgroup instead of pick_lanes' 8 (128-byte instead of
+    // 64-byte runs; the 52-register kernels keep enough workgroups in flight), config 3's 75.3 -> 70.7 us with 32.
+    uint32_t ca = force_ca, cb = force_cb;
+    if (!ca && !cb) {
+        if (n == 65536 && transforms == 16) ca = 16;
+        else if (n == 160000 && transforms == 100) ca = 32;
+    }
+    return build_tiled_plan(n, transforms, ca, cb, p);
 }
 
 // The fold epilogue's lane grouping (see FoldProductEpi below): part of the plan.
