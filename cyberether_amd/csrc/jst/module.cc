@@ -259,7 +259,7 @@ Result Runtime::flushUnits() {
 Result Runtime::planUnits() {
     units_.clear();
     for (Module* m : ordered_)  // a decision of an earlier runtime does not outlive it
-        if (auto* spec = dynamic_cast<modules::Spectrogram*>(m)) spec->combined = false;
+        if (auto* spec = dynamic_cast<modules::Spectrogram*>(m)) spec->combined = spec->indexFed = false;
     for (Module* m : ordered_)
         if (auto* cast = dynamic_cast<modules::Cast*>(m)) cast->fusedIntoSpectrum = false;
     // Static settlement: a STATIC_OUTPUT module with no inputs, or a STATELESS/STATIC module
@@ -329,7 +329,8 @@ Result Runtime::planUnits() {
 // (the block wiring of src/domains/dsp/spectrum_engine/block_impl.cc:120-217).
 bool Runtime::tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed) {
     return modules::TryFuseSpectrum(ordered_, at, unit.name, unit.modules, unit.submit, consumed,
-                                    (flags_ & COMBINE) != 0 && (flags_ & PIPELINE) == 0, &unit.flush) ||
+                                    (flags_ & COMBINE) != 0 && (flags_ & PIPELINE) == 0, &unit.flush,
+                                    (flags_ & PIPELINE) == 0) ||
            modules::TryFuseFilter(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
 }
 

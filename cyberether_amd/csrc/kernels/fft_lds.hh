@@ -130,6 +130,9 @@ __device__ __forceinline__ void buf_store_f2(rsrc_t r, uint32_t voff_bytes, uint
 __device__ __forceinline__ void buf_store_f1(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(f2u(v), r, voff_bytes, soff_bytes, JST_STORE_AUX);
 }
+__device__ __forceinline__ void buf_store_u8(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, r, voff_bytes, soff_bytes, JST_STORE_AUX);
+}
 // 16-byte forms (A/B switches JST_STORE16 / JST_LOAD16, both OFF by default).  A wavefront's 4-byte store is one
 // 256-byte request per instruction and the epilogue issues eight of them per transform and thread; MI355X_MICROARCH.md
 // prices a scalar sc1 store at ~6x the dwordx4 time per byte and calls such store tails issue-bound.  Measured here
@@ -359,6 +362,30 @@ struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_na
         else store_agent(out + (base + (int64_t)pos * axis_stride), r);
     }
 };
+
+// Amplitude -> Range with a SIDE OUTPUT for one known Spectrogram consumer: beside every F32 value the row index the
+// Spectrogram derives from it (spectrogram/module_impl_native_cpu.cc:70-77: index = value * height, a hit when
+// 0 < index < height) goes out as one byte, U8[transforms][N] dense, 0 = no hit.  The index is formed from the very
+// float that is stored, so it is the consumer's own arithmetic moved in front of the store; the Spectrogram then reads
+// 1 byte per sample (one 16-byte request per row and tile) instead of re-reading the 4-byte values.  height <= 256.
+template <bool FAST>
+struct StoreAmplitudeRangeSideT : StoreAmplitudeRangeT<FAST> {
+    uint8_t* side;
+    float side_height;
+    static constexpr bool kHasSide = true;
+    __device__ __forceinline__ const void* side_row(uint64_t transform, uint32_t n) const { return side + transform * n; }
+    __device__ __forceinline__ void store_buf_side(rsrc_t r, rsrc_t rs, uint32_t voff, uint32_t soff, float2 v) const {
+        const float y = this->value(v);
+        buf_store_f1(r, voff, soff, y);
+        const float f = y * side_height;
+        buf_store_u8(rs, voff >> 2, soff >> 2, (f >= 1.0f && f < side_height) ? (uint32_t)f : 0u);
+    }
+};
+template <class Epi>
+constexpr bool epi_has_side() {
+    if constexpr (requires { Epi::kHasSide; }) return Epi::kHasSide;
+    else return false;
+}
 
 using StoreAmplitude = StoreAmplitudeT<false>;
 using StoreAmplitudeRange = StoreAmplitudeRangeT<false>;
@@ -613,7 +640,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                                             const float2* twl, int tid, int64_t out_base,
                                             int64_t out_as, const Epi& epi, const Pro& pro,
                                             float2 (&opnd)[8], bool more, rsrc_t r_out,
-                                            rsrc_t r_opnd, bool young JST_TL_ARG) {
+                                            rsrc_t r_opnd, rsrc_t r_side, bool young JST_TL_ARG) {
     constexpr Plan plan = make_plan(N);
     constexpr TwPlan tp = make_twplan(N);
     constexpr int IP = plan.ip[P], IDO = plan.ido[P];
@@ -734,7 +761,10 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
         } else if constexpr (LAST) {
 #pragma unroll
             for (int c = 0; c < IP; ++c) {
-                if constexpr (CONTIG)
+                if constexpr (CONTIG && epi_has_side<Epi>())
+                    epi.store_buf_side(r_out, r_side, (uint32_t)u * Epi::kElemBytes,
+                                       (uint32_t)(c * BUT) * Epi::kElemBytes, y[c]);
+                else if constexpr (CONTIG)
                     epi.store_buf(r_out, (uint32_t)u * Epi::kElemBytes,
                                   (uint32_t)(c * BUT) * Epi::kElemBytes, y[c]);
                 else
@@ -808,7 +838,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
         }
         pipe_passes<N, T, FWD, CONTIG, P + 1, Pro, Epi>(x, buf1, buf0, twr, twl, tid, out_base,
                                                         out_as, epi, pro, opnd, more, r_out,
-                                                        r_opnd, young JST_TL_PASS);
+                                                        r_opnd, r_side, young JST_TL_PASS);
     }
 }
 
@@ -983,19 +1013,21 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
         }
         const rsrc_t r_out = make_rsrc(epi.row(out_base), (uint32_t)N * Epi::kElemBytes);
         const rsrc_t r_opnd_next = make_rsrc(pro.operand_row(), more ? (uint32_t)N * 8u : 0u);
+        rsrc_t r_side = r_out;  // unused unless the epilogue has a side output
+        if constexpr (CONTIG && epi_has_side<Epi>()) r_side = make_rsrc(epi.side_row(t, (uint32_t)N), (uint32_t)N);
 #ifdef JST_FB_SKIP_PASSES  // decomposition experiment (tools/ubench/fused_bench.hip): last pass + epilogue only
         pipe_passes<N, T, FWD, CONTIG, plan.nf - 1, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
                                                               L.out_axis_stride, epi, pro, opnd,
-                                                              more, r_out, r_opnd_next, young JST_TL_PASS);
+                                                              more, r_out, r_opnd_next, r_side, young JST_TL_PASS);
 #else
         if (flip)
             pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufB, bufA, twr, twl, tid, out_base,
                                                         L.out_axis_stride, epi, pro, opnd,
-                                                        more, r_out, r_opnd_next, young JST_TL_PASS);
+                                                        more, r_out, r_opnd_next, r_side, young JST_TL_PASS);
         else
             pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
                                                         L.out_axis_stride, epi, pro, opnd,
-                                                        more, r_out, r_opnd_next, young JST_TL_PASS);
+                                                        more, r_out, r_opnd_next, r_side, young JST_TL_PASS);
 #endif
 #ifdef JST_FFT_TIMELINE
         ++tl_it;

@@ -1,0 +1,102 @@
+// fft_side.hip -- the fused spectrum kernel (fft_lds.hh: fft_pipe_kernel) with the Spectrogram's row index as a side
+// output (StoreAmplitudeRangeSideT): Multiply(window) -> FFT -> Amplitude -> Range writes its F32 rows as before and,
+// beside every value, the one-byte index `(u32)(value * height)` (0 = no hit) the Spectrogram consumer would derive
+// from it (spectrogram/module_impl_native_cpu.cc:70-77).  The consumer (spectrogram.hip: spectrogram_index_kernel)
+// then reads 1 byte per sample instead of 4.  Its own translation unit: the instantiations compile beside
+// fft_kernels.hip, not behind it.
+#include "fft_lds.hh"
+#include "kernels.hh"
+
+#include <cstdlib>
+
+namespace jst::kernels {
+
+using namespace jst::dev;
+
+namespace {
+
+int side_compute_units() {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    return cus;
+}
+
+template <int N, class Pro, class Epi>
+hipError_t launch_side(const FftLayout& L, const float2* W, const Pro& pro, const Epi& epi, hipStream_t stream) {
+    constexpr size_t lds = fft_pipe_lds_bytes(N);
+    auto kernel = fft_pipe_kernel<N, true, true, Pro, Epi>;
+    if (lds > 64 * 1024) {
+        const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kernel), (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    if (L.transforms == 0) return hipSuccess;
+    uint64_t per_cu = (160 * 1024) / lds > 0 ? (160 * 1024) / lds : 1;  // as launch_pipe (fft_kernels.hip)
+    if (per_cu > 2048 / (N / 8)) per_cu = 2048 / (N / 8);
+    const uint64_t resident = per_cu * (uint64_t)side_compute_units();
+    const uint64_t blocks = L.transforms < resident ? L.transforms : resident;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(N / 8), lds, stream, L, W, pro, epi);
+    return hipGetLastError();
+}
+
+template <class Pro>
+hipError_t side_with(uint64_t n, const FftLayout& L, const float2* W, const Pro& pro, float* out, float amp_coeff,
+                     float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1, uint8_t* side,
+                     float side_height, hipStream_t stream) {
+    const StoreAmplitudeRangeSideT<true> ef{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}}, side, side_height};
+    const StoreAmplitudeRangeSideT<false> ee{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}}, side, side_height};
+    switch (n) {
+#define JST_SIDE_CASE(NN)                                                  \
+    case NN:                                                               \
+        return fast ? launch_side<NN, Pro>(L, W, pro, ef, stream) : launch_side<NN, Pro>(L, W, pro, ee, stream);
+        JST_SIDE_CASE(1024)
+        JST_SIDE_CASE(2048)
+        JST_SIDE_CASE(4096)
+        JST_SIDE_CASE(8192)
+#undef JST_SIDE_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stride, uint64_t height) {
+    const char* k = getenv("JST_FFT_KERNEL");
+    if (k && k[0] == 's') return false;  // the non-pipelined kernel has no side store
+    if (n != 1024 && n != 2048 && n != 4096 && n != 8192) return false;
+    // dense rows on both sides, transform t's output row at element t * n (the side tensor follows the same numbering)
+    if (L.in_axis_stride != 1 || L.out_axis_stride != 1 || window_stride != 1 || L.outer_rank != 1) return false;
+    if (L.out_outer_stride[0] != (int64_t)n) return false;
+    return height >= 2 && height <= 256 && L.transforms * n < (1ull << 32);
+}
+
+hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const float2* W, const void* in, int in_format,
+                                      float scaler, const float2* window, float* out, float amp_coeff,
+                                      float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1,
+                                      uint8_t* side, uint64_t height, hipStream_t stream) {
+    if (!spectrum_side_supported(n, L, 1, height) || !side) return hipErrorInvalidValue;
+    const float h = (float)height;
+    const float inv = in_format ? 1.0f / scaler : 1.0f;  // a power of two: x / scaler == x * inv, exactly
+    switch (in_format) {
+        case 0:
+            return side_with(n, L, W, LoadCF32TimesWindow{static_cast<const float2*>(in), window, 1}, out, amp_coeff,
+                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, stream);
+        case 1:
+            return side_with(n, L, W, LoadCI16TimesWindow{static_cast<const uint32_t*>(in), window, 1, inv}, out, amp_coeff,
+                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, stream);
+        case 2:
+            return side_with(n, L, W, LoadCI8TimesWindow{static_cast<const uint16_t*>(in), window, 1, inv}, out, amp_coeff,
+                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, stream);
+        case 3:
+            return side_with(n, L, W, LoadCU8TimesWindow{static_cast<const uint16_t*>(in), window, 1, inv}, out, amp_coeff,
+                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, stream);
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace jst::kernels

@@ -170,6 +170,14 @@ hipError_t launch_spectrum_fused_cast(uint64_t n, const FftLayout& L, const floa
                                       float scaler, const float2* window, int64_t window_stride, float* out,
                                       float amp_coeff, bool with_range, float range_scale, float range_offset, bool fast,
                                       float guard_h0, float guard_h1, hipStream_t stream);
+// The same chain with the Spectrogram consumer's row index as a one-byte SIDE OUTPUT (fft_side.hip): `side` is
+// U8[transforms][n] dense, side[t][x] = (u32)(out[t][x] * height) when that hits (1 <= value * height < height), else 0.
+// in_format: 0 = CF32, 1 = CI16, 2 = CI8, 3 = CU8 (scaler as above).  Range is always on; window dense.
+bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stride, uint64_t height);
+hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const float2* W, const void* in, int in_format,
+                                      float scaler, const float2* window, float* out, float amp_coeff,
+                                      float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1,
+                                      uint8_t* side, uint64_t height, hipStream_t stream);
 // guard_h0/h1 (fast + range only): heights of the Spectrogram modules that will quantise the output;
 // elements whose value * height lies within the fast path's error of a bin edge are computed with the
 // exact arithmetic instead, so the bins equal the exact provider's (dev::BinGuard, device_math.hh).
@@ -251,6 +259,11 @@ size_t spectrogram_lds_bytes(uint64_t height);
 hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, uint64_t batches,
                               uint64_t width, uint64_t height, int64_t batch_stride,
                               int64_t elem_stride, float decay, hipStream_t stream);
+// The Spectrogram fed with the fused spectrum kernel's one-byte row indices (U8[batches][width] dense, 0 = no hit)
+// instead of the values: same state update, a quarter of the bytes, a quarter of the wavefronts.
+bool spectrogram_index_supported(uint64_t batches, uint64_t width, uint64_t height);
+hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t batches, uint64_t width, uint64_t height,
+                                    float decay, hipStream_t stream);
 // The exact multi-GPU merge of spectrograms: this cycle's hit COUNTS as a U32[height][width] tensor
 // (no state touched) -- all-reduce(sum) them over the ranks -- then one shared decay and the count-times update.
 hipError_t launch_spectrogram_counts(uint32_t* counts, const float* in, uint64_t in_offset, uint64_t batches,

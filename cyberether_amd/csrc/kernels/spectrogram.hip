@@ -54,12 +54,121 @@ __global__ __launch_bounds__(256) void spectrogram_apply_counts_kernel(float* __
                                                                        const uint32_t* __restrict__ counts,
                                                                        uint64_t cells, float decay) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (uint64_t)gridDim.x * 256) {
-        float w = bins[i] * decay;
-        uint32_t k = counts[i];
-        k = k < 64u ? k : 64u;  // 0.02 * 51 > 1: pinned at 1.0f long before 64 hits
-        for (uint32_t n = 0; n < k && w < 1.0f; ++n) w = fminf(w + 0.02f, 1.0f);
-        store_state(bins + i, w);
+        const uint32_t k = counts[i];
+        store_state(bins + i, apply_hits(bins[i] * decay, k < 64u ? k : 64u));  // 0.02 * 51 > 1: pinned at 1.0f long before 64 hits
     }
+}
+
+
+// The Spectrogram fed with ROW INDICES instead of values: `idx` is the U8[batches][width] side output of the fused
+// spectrum kernel (fft_lds.hh: StoreAmplitudeRangeSideT) -- per sample the index `(u32)(value * height)` the loop of
+// spectrogram/module_impl_native_cpu.cc:70-77 would form, 0 where it does not hit.  One workgroup per tile of 16
+// columns as above, but a thread takes whole ROWS of the tile: one 16-byte request per row instead of sixteen 4-byte
+// ones (4 MiB instead of 16 MiB per 1024 x 4096 cycle), so a workgroup needs far fewer wavefronts to keep its reads in
+// flight -- and the dispatch of the value kernel's 4096 wavefronts was ~40 % of its 7 us.  Lane l starts at column
+// l % 16 and walks the tile cyclically: the 16 lanes of one LDS-atomic group always hold 16 different columns (no bank
+// shared inside a group whatever the rows), and each of the four groups of a wavefront has a histogram copy of its own.
+// width % 16 == 0, height <= 256, batches * width < 2^32.
+#ifdef JST_SPEC_TIMELINE  // tools/ubench/spec_index_timeline.hip: wall-clock stamps of workgroup phases (100 MHz)
+unsigned long long* jst_spec_tl_host = nullptr;  // device buffer [workgroups][8], passed as a kernel argument
+#define JST_SPEC_TL_PARAM , unsigned long long* __restrict__ jst_spec_tl
+#define JST_SPEC_TL_ARG , jst_spec_tl_host
+#define JST_SPEC_STAMP(slot) do { if (threadIdx.x == 0) jst_spec_tl[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define JST_SPEC_TL_PARAM
+#define JST_SPEC_TL_ARG
+#define JST_SPEC_STAMP(slot) do {} while (0)
+#endif
+template <int COPIES, int kThreads>
+__global__ __launch_bounds__(kThreads) void spectrogram_index_kernel(float* __restrict__ bins, const uint8_t* __restrict__ idx,
+                                                                     uint32_t batches, uint32_t width, uint32_t height,
+                                                                     float decay JST_SPEC_TL_PARAM) {
+    constexpr uint32_t TW = 16;
+    extern __shared__ __attribute__((aligned(64))) unsigned char smem_raw[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);  // [COPIES][height][TW] (+8 words between copies)
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cells = height * TW;
+    const uint32_t copy_stride = cells + 16u;  // 64-byte aligned copies (the column offset is OR-ed into the base), banks staggered
+    JST_SPEC_STAMP(0);
+    uint32_t tile = blockIdx.x;  // tiles sharing a 128-byte line of a row on one XCD (see spectrogram_body)
+    if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+
+    constexpr uint32_t kCells = 4096 / kThreads;  // height <= 256: the whole state tile in registers
+    float state[kCells];
+#pragma unroll
+    for (uint32_t j = 0; j < kCells; ++j) {
+        const uint32_t e = tid + j * kThreads;
+        state[j] = e < cells ? bins[(uint64_t)(e / TW) * width + tile * TW + (e % TW)] : 0.0f;
+    }
+
+    // rows tid, tid + kThreads, ...: kRows requests in flight per thread and round (a round covers 1024 rows)
+    constexpr uint32_t kRows = 1024 / kThreads;
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t r_idx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(idx), 0, batches * width, 0x00020000);
+    v4u q[kRows];
+    auto request = [&](uint32_t first_row) {
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r) {
+            const uint32_t row = first_row + tid + r * kThreads;  // a row that does not exist reads as 0: no hits
+            q[r] = __builtin_amdgcn_raw_buffer_load_b128(r_idx, row < batches ? row * width + tile * TW : 0xfffffff0u, 0, 0);
+        }
+    };
+    request(0);
+    JST_SPEC_STAMP(1);
+    for (uint32_t e = tid * 4u; e < copy_stride * COPIES; e += kThreads * 4u)  // copy_stride % 4 == 0
+        *reinterpret_cast<uint4*>(hist + e) = make_uint4(0u, 0u, 0u, 0u);
+    lds_only_barrier();
+    JST_SPEC_STAMP(2);
+
+    const uint32_t rot = tid & 15u;  // this lane's first column
+    // LDS byte address of (row i, column c) in this lane group's copy: base + 64 i + 4 c.  Index 0 (no hit) is NOT
+    // predicated away: it counts into row 0, which no sample can hit (0 < index) and which the update below skips.
+    const uint32_t my_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)hist +
+                             ((tid >> 4) % COPIES) * copy_stride * 4u;
+    typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+    for (uint32_t first = 0; first < batches; first += 1024u) {
+        if (first != 0u) request(first);
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r) {
+            // rotate the row's 16 bytes left by `rot`: whole dwords (two select stages), then bytes (v_alignbyte)
+            const bool r1 = (rot & 4u) != 0u, r2 = (rot & 8u) != 0u;
+            const uint32_t a0 = r1 ? q[r].y : q[r].x, a1 = r1 ? q[r].z : q[r].y, a2 = r1 ? q[r].w : q[r].z, a3 = r1 ? q[r].x : q[r].w;
+            const uint32_t b0 = r2 ? a2 : a0, b1 = r2 ? a3 : a1, b2 = r2 ? a0 : a2, b3 = r2 ? a1 : a3;
+            const uint32_t sh = rot & 3u;
+            const uint32_t g[4] = {__builtin_amdgcn_alignbyte(b1, b0, sh), __builtin_amdgcn_alignbyte(b2, b1, sh),
+                                   __builtin_amdgcn_alignbyte(b3, b2, sh), __builtin_amdgcn_alignbyte(b0, b3, sh)};
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j) {
+                const uint32_t i = (g[j >> 2] >> (8u * (j & 3u))) & 0xffu;  // the index at column (rot + j) % 16
+                const uint32_t addr = (i << 6) + ((((rot + j) & 15u) << 2) | my_base);
+                __hip_atomic_fetch_add((lds_u32)(uintptr_t)addr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    JST_SPEC_STAMP(3);
+    lds_only_barrier();
+    JST_SPEC_STAMP(4);
+
+    auto hits = [&](uint32_t e) {
+        uint32_t k = 0;
+#pragma unroll
+        for (int cp = 0; cp < COPIES; ++cp) k += hist[cp * copy_stride + e];
+        if (e < TW) k = 0u;        // row 0 collected the samples that do not hit
+        return k < 64u ? k : 64u;  // 0.02 * 51 > 1: the value is pinned at 1.0f long before 64 hits
+    };
+    uint32_t k[kCells];
+#pragma unroll
+    for (uint32_t j = 0; j < kCells; ++j) k[j] = hits(tid + j * kThreads < cells ? tid + j * kThreads : 0u);
+    JST_SPEC_STAMP(5);
+#pragma unroll
+    for (uint32_t j = 0; j < kCells; ++j) {
+        const uint32_t e = tid + j * kThreads;
+        if (e >= cells) continue;
+        const float w = apply_hits(state[j] * decay, k[j]);
+        store_state(bins + (uint64_t)(e / TW) * width + tile * TW + (e % TW), w);
+    }
+    JST_SPEC_STAMP(6);
 }
 
 }  // namespace
@@ -116,6 +225,35 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
     else JST_SPEC_LAUNCH(8, 1, 1024, 16, tiles8);
 #undef JST_SPEC_LAUNCH
 #undef JST_SPEC_LAUNCH_B
+    return hipGetLastError();
+}
+
+bool spectrogram_index_supported(uint64_t batches, uint64_t width, uint64_t height) {
+    return width > 0 && width % 16 == 0 && height >= 2 && height <= 256 && batches > 0 && batches * width < (1ull << 32);
+}
+
+hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t batches, uint64_t width, uint64_t height,
+                                    float decay, hipStream_t stream) {
+    if (!spectrogram_index_supported(batches, width, height)) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)height * 16 + 16) * 4 * sizeof(uint32_t);  // four copies, 64-byte aligned
+    static const int threads = [] {  // A/B switch: JST_SPEC_INDEX_THREADS = 256 | 512 | 1024
+        const char* e = getenv("JST_SPEC_INDEX_THREADS");
+        return e ? atoi(e) : 1024;
+    }();
+    (void)hipGetLastError();
+#define JST_SPEC_INDEX(THREADS)                                                                                      \
+    do {                                                                                                             \
+        const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(spectrogram_index_kernel<4, THREADS>),  \
+                                               80 * 1024);                                                           \
+        if (e != hipSuccess) return e;                                                                               \
+        hipLaunchKernelGGL((spectrogram_index_kernel<4, THREADS>), dim3((unsigned)(width / 16)), dim3(THREADS), lds, \
+                           stream, bins, idx, (uint32_t)batches, (uint32_t)width, (uint32_t)height,                  \
+                           decay JST_SPEC_TL_ARG);                                                                   \
+    } while (0)
+    if (threads == 1024) JST_SPEC_INDEX(1024);
+    else if (threads == 512) JST_SPEC_INDEX(512);
+    else JST_SPEC_INDEX(256);
+#undef JST_SPEC_INDEX
     return hipGetLastError();
 }
 

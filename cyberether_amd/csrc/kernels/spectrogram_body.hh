@@ -21,6 +21,26 @@ __device__ __forceinline__ void store_state(float* p, float v) { *p = v; }
 
 constexpr int kThreadsDefault = 1024;
 
+// std::min(val + 0.02f, 1.0f) applied k times to w (spectrogram/module_impl_native_cpu.cc:70-77, once per hit), w in
+// [0, 1], k <= 64.  Without the clamp the additions form a non-decreasing sequence s_n = fl(s_(n-1) + 0.02f); the
+// clamped sequence equals it until it first reaches 1 and is 1.0f from there on (a fixed point: fl(1 + 0.02) > 1).  So
+// the result is min(s_k, 1): k dependent additions and ONE clamp, no clamp or exit test inside the loop (the loop with
+// both cost three dependent operations per hit, and the wavefronts that own the noise-floor rows -- ~30 hits per cell
+// and cycle -- were a quarter of the kernel's life).  A cell whose hits carry it past 1 by a margin far above the
+// rounding of 64 additions (each within 2^-24 of ~1) ends at exactly 1.0f and skips the loop.
+__device__ __forceinline__ float apply_hits(float w, uint32_t k) {
+    if (w + 0.02f * (float)k >= 1.001f) return 1.0f;
+    uint32_t n = 0;
+    for (; n + 4u <= k; n += 4u) {
+        w += 0.02f;
+        w += 0.02f;
+        w += 0.02f;
+        w += 0.02f;
+    }
+    for (; n < k; ++n) w += 0.02f;
+    return fminf(w, 1.0f);
+}
+
 // Workgroup barrier that orders LDS traffic only: __syncthreads() is a full fence and puts s_waitcnt vmcnt(0)
 // in front of s_barrier, which would drain the input loads in flight across the histogram clear.
 __device__ __forceinline__ void lds_only_barrier() {
@@ -154,22 +174,7 @@ __device__ __forceinline__ void spectrogram_body(
         }
         return;
     }
-    auto apply = [&](float w, uint32_t k) {
-        w *= decay;
-        // std::min(val + 0.02f, 1.0f), k times.  1.0f is a fixed point of the update, so the early exit only has to be
-        // looked at every fourth hit; inside the loop w < 1 (never NaN), where fminf IS std::min.  With 1024 batches
-        // the decay is 0.999^1024 = 0.36: a noise-floor cell climbs back through ~33 updates every cycle, and the
-        // wavefronts that own the hot rows are the kernel's critical path (dependent VALU at one wavefront's rate).
-        uint32_t n = 0;
-        for (; n + 4u <= k && w < 1.0f; n += 4u) {
-            w = fminf(w + 0.02f, 1.0f);
-            w = fminf(w + 0.02f, 1.0f);
-            w = fminf(w + 0.02f, 1.0f);
-            w = fminf(w + 0.02f, 1.0f);
-        }
-        for (; n < k && w < 1.0f; ++n) w = fminf(w + 0.02f, 1.0f);
-        return w;
-    };
+    auto apply = [&](float w, uint32_t k) { return apply_hits(w * decay, k); };
     uint32_t k[kCells];  // every count is read before the first (divergent, serial) update loop starts
 #pragma unroll
     for (uint32_t j = 0; j < kCells; ++j) k[j] = hits(tid + j * kThreads < cells ? tid + j * kThreads : 0u);

@@ -1029,6 +1029,10 @@ Result Spectrogram::computeSubmit(hipStream_t stream) {
                                                numberOfBatches, numberOfElements, height, (int64_t)inputBatchStride,
                                                (int64_t)inputElementStride, stream),
             "spectrogram counts kernel");
+    if (indexFed)
+        return hip_result(kernels::launch_spectrogram_index(ptr<float>(frequencyBins), static_cast<const uint8_t*>(rowIndices.data()),
+                                                            numberOfBatches, numberOfElements, height, decayFactor, stream),
+                          "spectrogram kernel (row indices)");
     return hip_result(
         kernels::launch_spectrogram(ptr<float>(frequencyBins), ptr<const float>(input),
                                     input.offset(), numberOfBatches, numberOfElements, height,
@@ -1362,7 +1366,7 @@ Result RingSource::ringClear() {
 // ---- fusion ------------------------------------------------------------------------------------
 bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string& name,
                      std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
-                     size_t& consumed, bool allow_combine, std::function<Result(hipStream_t)>* flush) {
+                     size_t& consumed, bool allow_combine, std::function<Result(hipStream_t)>* flush, bool allow_side) {
     if (at + 2 >= ordered.size()) return false;
     auto* mul = dynamic_cast<Multiply*>(ordered[at]);
     auto* fft = dynamic_cast<Fft*>(ordered[at + 1]);
@@ -1544,7 +1548,48 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
         }
     }
 
-    submit = [mul, fft, amp, rng, cast, axis, n, fast, tiled, guard0, guard1](hipStream_t stream) -> Result {
+    // Row indices for the Spectrogram: when exactly ONE Spectrogram quantises the whole range output (dense {batches, n}
+    // rows, height <= 256, its own display -- not the counts of a multi-rank merge), the kernel writes the index that
+    // module would derive from every value as one byte beside it (fft_side.hip) and the module reads those instead of
+    // the values: 1 byte instead of 4 per sample on its side, a quarter of the wavefronts.  Not for the surfaces of a
+    // pipelined runtime (they read one cycle behind).  JST_NO_SPECTROGRAM_SIDE=1 is the A/B switch.
+    Spectrogram* fed = nullptr;
+    static const bool no_side = std::getenv("JST_NO_SPECTROGRAM_SIDE") != nullptr;
+    if (allow_side && !no_side && rng && !tiled && sig.rank() == 2 && axis == 1 && rng->output.ringSlots() == 1) {
+        int readers = 0;
+        Spectrogram* only = nullptr;
+        for (Module* m : ordered) {
+            auto* spec = dynamic_cast<Spectrogram*>(m);
+            if (!spec) continue;
+            for (const auto& kv : m->inputs())
+                if (kv.second.storageId() == rng->output.storageId()) {
+                    ++readers;
+                    only = spec;
+                }
+        }
+        FftLayout L;
+        std::memset(&L, 0, sizeof(L));
+        L.transforms = sig.shape(0);
+        L.outer_rank = 1;
+        L.outer_shape[0] = sig.shape(0);
+        L.in_outer_stride[0] = (int64_t)sig.stride(0);
+        L.out_outer_stride[0] = (int64_t)rng->output.stride(0);
+        L.in_axis_stride = (int64_t)sig.stride(1);
+        L.out_axis_stride = (int64_t)rng->output.stride(1);
+        if (readers == 1 && !only->countsOnly && !only->combined && only->input.offset() == rng->output.offset() &&
+            only->numberOfElements == n && only->numberOfBatches == sig.shape(0) && only->inputElementStride == 1 &&
+            only->inputBatchStride == n &&
+            kernels::spectrum_side_supported(n, L, (int64_t)win.stride(axis), only->height) &&
+            kernels::spectrogram_index_supported(only->numberOfBatches, n, only->height) &&
+            (!cast || sig.stride(1) == 1) &&
+            only->rowIndices.create(DeviceType::HIP, DataType::U8, {sig.shape(0), n}) == Result::SUCCESS) {
+            fed = only;
+            fed->indexFed = true;
+            name += "+indices";
+        }
+    }
+
+    submit = [mul, fft, amp, rng, cast, fed, axis, n, fast, tiled, guard0, guard1](hipStream_t stream) -> Result {
         const Tensor& sig = mul->a;
         const Tensor& win = mul->b;
         const Tensor& out = rng ? rng->output : amp->output;
@@ -1574,6 +1619,18 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                     rng != nullptr, rng ? rng->scalingCoeff : 0.0f, rng ? rng->offsetCoeff : 0.0f,
                     fast, guard0, guard1, static_cast<float2*>(fft->scratchA.data()), stream),
                 "fused spectrum (tiled) kernel");
+        if (fed) {  // + the Spectrogram's row indices as a side output
+            const DataType it = cast ? cast->input.dtype() : DataType::CF32;
+            if (cast) L.in_offset = cast->input.offset();
+            return hip_result(
+                kernels::launch_spectrum_fused_side(
+                    n, L, fft->twiddles, cast ? cast->input.data() : sig.data(),
+                    !cast ? 0 : (it == DataType::CI16 ? 1 : (it == DataType::CI8 ? 2 : 3)), cast ? cast->scaler : 1.0f,
+                    static_cast<const float2*>(win.data()) + win.offset(), static_cast<float*>(out.data()),
+                    amp->scalingCoeff, rng->scalingCoeff, rng->offsetCoeff, fast, guard0, guard1,
+                    static_cast<uint8_t*>(fed->rowIndices.data()), fed->height, stream),
+                "fused spectrum kernel (+ row indices)");
+        }
         if (cast) {  // raw samples: same dense shape as the cast's output, element strides therefore equal
             const DataType it = cast->input.dtype();
             L.in_offset = cast->input.offset();

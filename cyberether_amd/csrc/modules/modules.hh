@@ -30,10 +30,12 @@ bool MakeEwLayout(const Tensor& out, const Tensor* a, const Tensor* b, dev::EwLa
 // Scheduler hook: recognise multiply -> fft -> amplitude [-> range] starting at ordered[at].
 // allow_combine: a Spectrogram that is the only consumer of the fused output may ride on the next cycle's launch
 // (then `flush` is set: the runtime calls it at the end of every compute call to run the waiting spectrogram).
+// allow_side: the one Spectrogram that quantises the fused output (height <= 256) may be fed with one-byte row indices
+// written by the fused kernel beside its values (Spectrogram::indexFed) instead of re-reading the values.
 bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string& name,
                      std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
                      size_t& consumed, bool allow_combine = false,
-                     std::function<Result(hipStream_t)>* flush = nullptr);
+                     std::function<Result(hipStream_t)>* flush = nullptr, bool allow_side = true);
 
 // Filter-chain fusions (filter_modules.cc): pad -> fft (zeros synthesised in the FFT's first load)
 // and multiply -> fold (the broadcast product is never materialised).  Same contract.
@@ -225,6 +227,12 @@ class Spectrogram : public Module {
     // the spectrum output is then a ring of two slots, cycle k writes slot k & 1, and this module keeps the count of
     // cycles submitted or replayed that way (host side of the ring) and whether one is still waiting for its
     // spectrogram (the flush at the end of a compute call runs it).
+    // Fed with ROW INDICES by the fused spectrum unit that produces its input (TryFuseSpectrum, allow_side): the unit
+    // writes, beside every F32 value, the one-byte index this module would derive from it into `rowIndices`
+    // (U8 {batches, width}, 0 = no hit), and computeSubmit reads those instead of the values
+    // (kernels::launch_spectrogram_index).  Same state, bit for bit; a decision of the runtime's planner, reset by it.
+    bool indexFed = false;
+    Tensor rowIndices;
     bool combined = false, combinedPending = false;
     U64 combinedCycle = 0;
     Tensor combineCtrl;  // two zeroed device words {pending, ticket}
