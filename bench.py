@@ -439,6 +439,9 @@ def main() -> None:
                        "repeats": repeats_main, "region_ms_min_max": [round(spread_main[0] * 1e3, 4),
                                                                       round(spread_main[1] * 1e3, 4)],
                        "ring_period": rt.period, "backend": backend if world > 1 else None,
+                       # what the Spectrogram reads: the fused kernel's one-byte row indices (its side output) or the values
+                       "spectrogram_input": "row indices (U8 side output of the fused kernel)"
+                                            if any(u.endswith("+indices") for u in rt.units) else "values (F32)",
                        "units_ms": {u.split("(")[0]: rt.unit_mean_ms(u) for u in rt.units
                                     if rt.unit_mean_ms(u) > 0},
                        "sharding": "independent batches per GPU, no data-path collective"},
@@ -453,6 +456,9 @@ def main() -> None:
                          "kernel_ms_event_pair_raw": kernel_ms_raw,
                          "event_pair_overhead_ms": pair_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
+                         # what the launch moves beyond that: +1 B/sample written when the kernel also emits the
+                         # Spectrogram's row indices (the consumer then reads 1 B/sample instead of 4)
+                         "side_output_bytes_per_launch": float(BATCHES * N_FFT) if any(u.endswith("+indices") for u in rt.units) else 0.0,
                          # the whole step on SURVEY 8(d)'s 14 B/sample (spectrum 12 + spectrogram state 2), per rank
                          "step_bytes": step_bytes,
                          "step_achieved": step_bytes / (step_ms * 1e-3) / 1e9,

@@ -118,9 +118,21 @@ __device__ __forceinline__ void store_agent(float2* p, float2 v) { *p = v; }
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
+#ifndef JST_LOAD_AUX  // A/B switch: cache policy of the 8-byte stream loads (2 = nt)
+#define JST_LOAD_AUX 0
+#endif
+#ifndef JST_SIDE_STORE_AUX  // A/B switch: cache policy of the one-byte side-output stores
+#define JST_SIDE_STORE_AUX JST_STORE_AUX
+#endif
 __device__ __forceinline__ float2 buf_load_f2(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes) {
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff_bytes, soff_bytes, 0));
+    return mk(v.x, v.y);
+}
+// the input stream: every element is read once, by one CU (the window operand and tables keep the default policy)
+__device__ __forceinline__ float2 buf_load_f2_stream(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff_bytes, soff_bytes, JST_LOAD_AUX));
     return mk(v.x, v.y);
 }
 __device__ __forceinline__ void buf_store_f2(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, float2 v) {
@@ -131,7 +143,7 @@ __device__ __forceinline__ void buf_store_f1(rsrc_t r, uint32_t voff_bytes, uint
     __builtin_amdgcn_raw_buffer_store_b32(f2u(v), r, voff_bytes, soff_bytes, JST_STORE_AUX);
 }
 __device__ __forceinline__ void buf_store_u8(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, uint32_t v) {
-    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, r, voff_bytes, soff_bytes, JST_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, r, voff_bytes, soff_bytes, JST_SIDE_STORE_AUX);
 }
 // 16-byte forms (A/B switches JST_STORE16 / JST_LOAD16, both OFF by default).  A wavefront's 4-byte store is one
 // 256-byte request per instruction and the epilogue issues eight of them per transform and thread; MI355X_MICROARCH.md
@@ -192,7 +204,7 @@ struct LoadCF32 {
     const float2* in;
     using raw_t = float2;  // what the prefetch registers of the pipelined kernel hold
     static constexpr uint32_t kRawBytes = 8;
-    static __device__ __forceinline__ raw_t load_raw_buf(rsrc_t r, uint32_t voff, uint32_t soff) { return buf_load_f2(r, voff, soff); }
+    static __device__ __forceinline__ raw_t load_raw_buf(rsrc_t r, uint32_t voff, uint32_t soff) { return buf_load_f2_stream(r, voff, soff); }
     template <bool CONTIG>
     __device__ __forceinline__ float2 load(int64_t base, int64_t axis_stride, int pos) const {
         if constexpr (CONTIG) return (in + base)[(unsigned)pos];
@@ -221,7 +233,7 @@ struct LoadCF32TimesWindow {
     int64_t wstride;
     using raw_t = float2;
     static constexpr uint32_t kRawBytes = 8;
-    static __device__ __forceinline__ raw_t load_raw_buf(rsrc_t r, uint32_t voff, uint32_t soff) { return buf_load_f2(r, voff, soff); }
+    static __device__ __forceinline__ raw_t load_raw_buf(rsrc_t r, uint32_t voff, uint32_t soff) { return buf_load_f2_stream(r, voff, soff); }
     template <bool CONTIG>
     __device__ __forceinline__ float2 load(int64_t base, int64_t axis_stride, int pos) const {
         if constexpr (CONTIG) {

@@ -5,8 +5,8 @@ import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("fft_lds.hh", "fft_kernels.hip", "fft_radix.hh", "device_math.hh", "libm_float.hh", "kernels.hh",
-                  "spectrogram_body.hh")
+KERNEL_SOURCES = ("fft_lds.hh", "fft_kernels.hip", "fft_side.hip", "fft_radix.hh", "device_math.hh", "libm_float.hh",
+                  "kernels.hh", "spectrogram_body.hh")
 
 
 def kernel_sources_sha256() -> str:

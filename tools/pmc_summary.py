@@ -40,8 +40,9 @@ if traffic_json:
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from kernel_hash import kernel_sources_sha256
     provider = sys.argv[5] if len(sys.argv) > 5 and sys.argv[4] == "--provider" else "generic"
-    tag = "StoreAmplitudeRangeT<true>" if provider == "fast" else "StoreAmplitudeRangeT<false>"
-    pick = [k for k in acc if "fft_pipe_kernel<4096" in k and "LoadCF32TimesWindow" in k and tag in k]
+    # StoreAmplitudeRangeT<..> or, with the Spectrogram's row indices as a side output, StoreAmplitudeRangeSideT<..>
+    tag = "T<true>" if provider == "fast" else "T<false>"
+    pick = [k for k in acc if "fft_pipe_kernel<4096" in k and "LoadCF32TimesWindow" in k and "StoreAmplitudeRange" in k and tag in k]
     if not pick or "FETCH_SIZE" not in acc[pick[0]] or "WRITE_SIZE" not in acc[pick[0]]:
         sys.exit("no FETCH_SIZE / WRITE_SIZE pass for the fused spectrum kernel (" + provider + ") under " + root)
     k = pick[0]
