@@ -232,6 +232,11 @@ jst_result jst_filter_plan(float sample_rate, float bandwidth, const float* cent
  *     "fast" provider's bin guard.  A cast{CI16 | CI8 | CU8 -> CF32} whose output feeds only that multiply (the block's
  *     own leading cast_input) joins the unit -- "spectrum_fused(cast+multiply+..)": the kernel reads the raw samples and
  *     converts them in the transform's first load (N <= 16384); the cast module then launches nothing.
+ *     When exactly ONE spectrogram{height <= 256} quantises the whole range output (dense {batches, n} rows,
+ *     n = 1024 .. 8192), the unit -- then named "spectrum_fused(..)+indices" -- also writes, beside every F32 value, the
+ *     one-byte row index that module derives from it ((u32)(value * height), 0 = no hit), and the spectrogram reads
+ *     those instead of re-reading the values: same state bit for bit, every other reader of the output unaffected
+ *     (spectrogram/module_impl_native_cpu.cc:61-87; JST_NO_SPECTROGRAM_SIDE=1 keeps the value path).
  *   spectrogram{merge=counts} -> [all-reduce of the U32 counts over the ranks] -> spectrogram_merge{batches=total}: the
  *     exact multi-GPU display (not in the reference, whose display is per process): bit-identical to one spectrogram
  *     over the union of the batches.
