@@ -187,6 +187,17 @@ __device__ __forceinline__ void quad_transpose4(float (&a)[4], bool odd, bool hi
 #ifndef JST_LOAD16
 #define JST_LOAD16 0
 #endif
+// JST_OPND_REAL: an operand whose imaginary parts are all +-0 (a window: window -> invert -> reshape, the spectrum_engine
+// block's own wiring) is kept RESIDENT as 8 real parts + one word of signs per thread and never re-requested: each
+// wavefront looks at the 8 elements it loaded for its first transform (they are the same for every transform it takes),
+// and when all 64 lanes agree the re-requests go through a zero-record descriptor (they return 0 without touching
+// memory) and the products use mk(re, +-0) -- the same four multiplications on the same operand bits, so the result is
+// bit-identical; any other operand keeps the re-request path.  Measured (profiles/r03_experiments/s_real_operand_resident.log,
+// same box, 103 chain tests bit-exact either way): 17.16-17.39 vs 16.80 us (fast), 20.97-21.15 vs 20.89 us (exact) -- the
+// kernel grows from 105 / 102 to 123 / 120 VGPRs and loses more in its passes than the re-requests cost.  OFF.
+#ifndef JST_OPND_REAL
+#define JST_OPND_REAL 0
+#endif
 // The Multiply operand of the prologue (the window taps of this thread's eight pass-0 positions) stays in VGPRs across
 // the transforms of a workgroup instead of being re-requested from L2 behind every retired output: a thread visits
 // the same positions in every transform.  Round 2 could not afford the 16 registers (127 VGPRs); the in-place twiddles
@@ -968,6 +979,23 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
         if (tid + q * T < tp.lds_entries) twl[tid + q * T] = twv[q];
     if constexpr (tp.lds_entries > 0 && tp.lds_off[0] >= 0) lds_barrier();  // pass 0 reads the table
 
+    // JST_OPND_REAL (see the switch): is this wavefront's slice of the operand real?
+    constexpr bool REALOP = JST_OPND_REAL && CONTIG && Pro::kHasOperand && !L16 && !JST_OPND_RESIDENT;
+    [[maybe_unused]] float kept[8];
+    [[maybe_unused]] uint32_t kept_signs = 0;
+    [[maybe_unused]] bool wave_real = false;
+    if constexpr (REALOP) {
+        uint32_t imag_or = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            kept[e] = opnd[e].x;
+            const uint32_t b = f2u(opnd[e].y);
+            imag_or |= b;
+            kept_signs |= (b >> 31) << e;
+        }
+        wave_real = __all((imag_or & 0x7fffffffu) == 0u) != 0;
+    }
+
     bool flip = false;
 #ifdef JST_FFT_TIMELINE
     int tl_it = 0;
@@ -988,6 +1016,12 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
                 const float2 nhi = mk(dpp_quad<kQuadXor1>(hi.x), dpp_quad<kQuadXor1>(hi.y));
                 x[k] = odd ? nhi : lo;
                 x[4 + k] = odd ? hi : nlo;
+            }
+        } else if constexpr (REALOP) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float2 w = wave_real ? mk(kept[e], u2f(((kept_signs >> e) & 1u) << 31)) : opnd[e];
+                x[e] = pro.apply(raw[e], w);
             }
         } else {
 #pragma unroll
@@ -1024,7 +1058,7 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
                 raw[e] = pro.template load_raw<CONTIG>(nin, L.in_axis_stride, IDO0 * (e % IP0), pos0[e / IP0]);
         }
         const rsrc_t r_out = make_rsrc(epi.row(out_base), (uint32_t)N * Epi::kElemBytes);
-        const rsrc_t r_opnd_next = make_rsrc(pro.operand_row(), more ? (uint32_t)N * 8u : 0u);
+        const rsrc_t r_opnd_next = make_rsrc(pro.operand_row(), (more && !(REALOP && wave_real)) ? (uint32_t)N * 8u : 0u);
         rsrc_t r_side = r_out;  // unused unless the epilogue has a side output
         if constexpr (CONTIG && epi_has_side<Epi>()) r_side = make_rsrc(epi.side_row(t, (uint32_t)N), (uint32_t)N);
 #ifdef JST_FB_SKIP_PASSES  // decomposition experiment (tools/ubench/fused_bench.hip): last pass + epilogue only
