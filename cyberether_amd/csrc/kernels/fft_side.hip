@@ -71,7 +71,7 @@ bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stri
     // dense rows on both sides, transform t's output row at element t * n (the side tensor follows the same numbering)
     if (L.in_axis_stride != 1 || L.out_axis_stride != 1 || window_stride != 1 || L.outer_rank != 1) return false;
     if (L.out_outer_stride[0] != (int64_t)n) return false;
-    return height >= 2 && height <= 256 && L.transforms * n < (1ull << 32);
+    return height >= 2 && height <= 256 && L.transforms * n < (1ull << 31);
 }
 
 hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const float2* W, const void* in, int in_format,

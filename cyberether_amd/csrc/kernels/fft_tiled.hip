@@ -468,7 +468,11 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_col
         const uint32_t r = idx >> P.ca_shift, col = idx & (P.CA - 1u);
         // plain store: the scratch image is re-read at once by the second kernel and L2 / MALL absorb most of it; written
         // through at agent scope (see JST_STORE_AUX in fft_lds.hh) config 3 lost 3 % (128 MB per cycle)
+#ifdef JST_TILED_SC1  // A/B switch
+        if (col < live) store_agent(o + (c0 + col + P.S * r), buf0[idx]);
+#else
         if (col < live) o[c0 + col + P.S * r] = buf0[idx];
+#endif
     }
     JST_TSTAMP_FLUSH();  // stores issued
 }

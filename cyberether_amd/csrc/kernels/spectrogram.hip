@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void spectrogram_apply_counts_kernel(float* __
 // flight -- and the dispatch of the value kernel's 4096 wavefronts was ~40 % of its 7 us.  Lane l starts at column
 // l % 16 and walks the tile cyclically: the 16 lanes of one LDS-atomic group always hold 16 different columns (no bank
 // shared inside a group whatever the rows), and each of the four groups of a wavefront has a histogram copy of its own.
-// width % 16 == 0, height <= 256, batches * width < 2^32.
+// width % 16 == 0, height <= 256, batches * width < 2^31.
 #ifdef JST_SPEC_TIMELINE  // tools/ubench/spec_index_timeline.hip: wall-clock stamps of workgroup phases (100 MHz)
 unsigned long long* jst_spec_tl_host = nullptr;  // device buffer [workgroups][8], passed as a kernel argument
 #define JST_SPEC_TL_PARAM , unsigned long long* __restrict__ jst_spec_tl
@@ -229,7 +229,9 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
 }
 
 bool spectrogram_index_supported(uint64_t batches, uint64_t width, uint64_t height) {
-    return width > 0 && width % 16 == 0 && height >= 2 && height <= 256 && batches > 0 && batches * width < (1ull << 32);
+    // < 2^31 bytes of indices: a row that does not exist is requested at byte offset 0xfffffff0, which must lie beyond the
+    // descriptor's range for every accepted shape
+    return width > 0 && width % 16 == 0 && height >= 2 && height <= 256 && batches > 0 && batches * width < (1ull << 31);
 }
 
 hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t batches, uint64_t width, uint64_t height,
