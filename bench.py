@@ -126,6 +126,11 @@ def main() -> None:
     ap.add_argument("--combine", action="store_true",
                     help="JST_RUNTIME_COMBINE: the spectrogram of cycle k - 1 rides on the fused spectrum launch of cycle k "
                          "(one kernel per cycle); default off: reported as alt_combined beside the headline")
+    ap.add_argument("--no-batch", action="store_true",
+                    help="one launch per unit and CYCLE (the round-2 form) instead of cycle batching (JST_RUNTIME_BATCH: the "
+                         "cycles of a captured ring period run as one launch per unit -- the persistent fused kernel over all "
+                         "16 resident slots, the Spectrogram over their 16 index tensors); the per-cycle form is measured and "
+                         "reported beside the headline either way (alt_per_cycle_launch)")
     ap.add_argument("--pipeline", action="store_true",
                     help="run the spectrogram as its own graph on a second stream, one ring period behind "
                          "the spectrum graph (two hardware queues: +6 %% throughput, the spectrum kernel "
@@ -185,7 +190,8 @@ def main() -> None:
         if world > 1:
             dist.barrier()
 
-    def measure(provider: str, seed_offset: int = 0, pipeline: bool = args.pipeline, combine: bool = args.combine):
+    def measure(provider: str, seed_offset: int = 0, pipeline: bool = args.pipeline, combine: bool = args.combine,
+                batch: bool = not args.no_batch):
         """Builds ring_source -> spectrum_engine -> spectrogram with the given amplitude/range
         provider, runs W untimed + K timed steps; returns (runtime, elapsed seconds over ranks)."""
         source = js.Module("ring_source", {"batches": BATCHES, "samples": N_FFT, "slots": args.slots},
@@ -201,7 +207,8 @@ def main() -> None:
                                 "spectrogram")
         rt = js.Runtime([source] + engine.modules + [spectrogram], graph=not args.no_graph,
                         fuse=not args.no_fuse, timing=not args.no_timing,
-                        pipeline=pipeline, combine=combine and not pipeline)
+                        pipeline=pipeline, combine=combine and not pipeline,
+                        batch=batch and not pipeline and not combine and not args.no_graph and not args.no_fuse)
         rt._keep = (source, engine, spectrogram)  # module handles must outlive the runtime
         rt._seed = 1234 + rank + seed_offset
         # Initialisation, not measurement: the first replays of a freshly instantiated hipGraph carry its
@@ -344,7 +351,9 @@ def main() -> None:
         raw = rt.unit_mean_ms(dominant)
         pair = max(rt.event_overhead_ms(), 0.0)
         ms = raw - 0.5 * pair if raw > 0 else -1.0
-        return raw, pair, ms, (algo_bytes / (ms * 1e-3) / 1e9 if ms > 0 else None)
+        # a cycle-batched runtime's timed launches carry a whole ring period each: algorithmic bytes per LAUNCH scale with it
+        kernel_time.cycles = max(rt.unit_mean_cycles(dominant), 1.0) if raw > 0 else 1.0
+        return raw, pair, ms, (algo_bytes * kernel_time.cycles / (ms * 1e-3) / 1e9 if ms > 0 else None)
 
     def parity_check(rt, provider: str) -> dict:
         """The checker leg (never inside a timed region): the runtime that was just timed -- same graphs, same ring
@@ -376,11 +385,25 @@ def main() -> None:
         rt.compute(tail_cycles, sync=True)  # a whole-period graph replay and a span graph
         for c in range(tail_cycles):
             oracle.spectrogram(state, refs[c % slots], HEIGHT)
+        ring_rows = 0
+        if rt.batched:
+            # cycle batching: the replay just ran the period (and the 3-cycle span) as ONE launch per unit, every cycle's
+            # output in its ring slot -- the same row sample of EVERY slot must still equal the oracle's output
+            for s in range(slots):
+                got = engine.buffer.ring_select(s).numpy()[rows]
+                same = np.array_equal(got.view(np.uint32), refs[s][rows].view(np.uint32))
+                out_equal &= bool(same)
+                ring_rows += int(rows.size)
+                if not same:
+                    bad_words += int(np.count_nonzero(got.view(np.uint32) != refs[s][rows].view(np.uint32)))
+                    max_err = max(max_err, float(np.max(np.abs(got.astype(np.float64) - refs[s][rows]))))
+            engine.buffer.ring_select((tail_cycles - 1) % slots)
         dev = spectrogram.state("frequencyBins").numpy().reshape(-1)
         state_equal = bool(np.array_equal(dev.view(np.uint32), state.view(np.uint32)))
         exact_provider = provider == "generic"
         return {"checked": True, "against": "oracle/jst_oracle.c chain pass (FFT restatement pinned to the reference's pocketfft)",
-                "slots": slots, "rows_per_slot": int(rows.size), "output_rows": int(rows.size) * slots,
+                "slots": slots, "rows_per_slot": int(rows.size), "output_rows": int(rows.size) * slots + ring_rows,
+                "cycle_batched": bool(rt.batched), "batched_launch_output_rows": ring_rows,
                 "cycles": slots + tail_cycles, "graph_replayed": bool(rt.graph_active),
                 "output_bit_exact": bool(out_equal), "output_max_abs_err": max_err, "output_words_differing": bad_words,
                 "spectrogram_state_bit_exact": state_equal, "spectrogram_state_words": int(state.size),
@@ -392,6 +415,7 @@ def main() -> None:
     repeats_main, spread_main = measure.repeats, measure.spread
     samples = float(args.steps) * BATCHES * N_FFT * world
     kernel_ms_raw, pair_ms, kernel_ms, achieved = kernel_time(rt)
+    cycles_per_launch = kernel_time.cycles
 
     line = None
     if rank == 0:
@@ -401,15 +425,17 @@ def main() -> None:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from kernel_hash import kernel_sources_sha256
             rec = json.load(open(pmc)).get(args.provider, {})
-            if rec.get("kernel_sources_sha256") == kernel_sources_sha256():
+            if rec.get("kernel_sources_sha256") == kernel_sources_sha256() and \
+                    int(rec.get("cycles_per_launch", 1)) == int(round(cycles_per_launch)):
                 traffic = rec.get("spectrum_fused_hbm_bytes_per_launch")
                 traffic_src = {"source": rec.get("source"), "kernel": rec.get("kernel"),
                                "kernel_sources_sha256": rec.get("kernel_sources_sha256"),
+                               "cycles_per_launch": rec.get("cycles_per_launch", 1),
                                "fetch_size_kib_mean": rec.get("fetch_size_kib_mean"),
                                "write_size_kib_mean": rec.get("write_size_kib_mean"), "correction": rec.get("correction")}
             else:
                 traffic_src = {"source": None, "stale": "profiles/pmc_traffic.json was measured on other kernel sources "
-                                                         "(or another provider): not quoted"}
+                                                         "(another provider, or another launch form): not quoted"}
         step_ms = elapsed / args.steps * 1e3
         step_bytes = STEP_BYTES_PER_SAMPLE * BATCHES * N_FFT
         line = {
@@ -434,6 +460,10 @@ def main() -> None:
                                              "absolute of the reference CPU path (north_star: 1e-5)" if args.provider == "fast"
                                              else "every output bit-identical to the reference CPU path"),
                        "pipelined": args.pipeline, "combined": args.combine,
+                       # cycle batching (JST_RUNTIME_BATCH): the 16 resident ring slots of a period run as ONE launch per
+                       # unit; every step is still one pass over one CF32[1024, 4096] batch (its output in its ring slot,
+                       # its own decay + hit update of the Spectrogram state); alt_per_cycle_launch is the other form
+                       "cycle_batching": bool(rt.batched), "cycles_per_launch": cycles_per_launch,
                        "untimed_init_steps": 2 * max(rt.period, 1) + (-args.warmup) % max(rt.period, 1)
                                              + args.steps + (-args.steps) % max(rt.period, 1),
                        "repeats": repeats_main, "region_ms_min_max": [round(spread_main[0] * 1e3, 4),
@@ -455,10 +485,12 @@ def main() -> None:
                                              "(profiles/) is the cross-check, not this number's source",
                          "kernel_ms_event_pair_raw": kernel_ms_raw,
                          "event_pair_overhead_ms": pair_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_bytes_per_launch": algo_bytes * cycles_per_launch,
+                         "cycles_per_launch": cycles_per_launch,
+                         "transforms_per_launch": BATCHES * cycles_per_launch,
                          # what the launch moves beyond that: +1 B/sample written when the kernel also emits the
                          # Spectrogram's row indices (the consumer then reads 1 B/sample instead of 4)
-                         "side_output_bytes_per_launch": float(BATCHES * N_FFT) if any(u.endswith("+indices") for u in rt.units) else 0.0,
+                         "side_output_bytes_per_launch": float(BATCHES * N_FFT) * cycles_per_launch if any(u.endswith("+indices") for u in rt.units) else 0.0,
                          # the whole step on SURVEY 8(d)'s 14 B/sample (spectrum 12 + spectrogram state 2), per rank
                          "step_bytes": step_bytes,
                          "step_achieved": step_bytes / (step_ms * 1e-3) / 1e9,
@@ -488,10 +520,28 @@ def main() -> None:
                 except Exception as exc:
                     line["alt_provider"]["parity"] = {"checked": False, "error": repr(exc)}
             rt2.destroy()
+        if world == 1 and rt.batched and not args.no_alt:
+            # the same chain with ONE LAUNCH PER UNIT AND CYCLE (rounds 1-2's form; --no-batch makes it the headline):
+            # its own kernel time, roofline fraction and parity stamp
+            rt5, elapsed5 = measure(args.provider, seed_offset=0, batch=False)
+            raw5, pair5, ms5, ach5 = kernel_time(rt5)
+            line["alt_per_cycle_launch"] = {"value": samples / elapsed5 / 1e6, "unit": "MS/s",
+                                            "ms_per_step": elapsed5 / args.steps * 1e3, "kernel_ms": ms5,
+                                            "cycles_per_launch": kernel_time.cycles,
+                                            "roofline_frac": (ach5 / HBM_PEAK_GBS) if ach5 else None,
+                                            "step_frac": step_bytes / (elapsed5 / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                            "units_ms": {u.split("(")[0]: rt5.unit_mean_ms(u) for u in rt5.units
+                                                         if rt5.unit_mean_ms(u) > 0}}
+            if not args.no_parity:
+                try:
+                    line["alt_per_cycle_launch"]["parity"] = parity_check(rt5, args.provider)
+                except Exception as exc:
+                    line["alt_per_cycle_launch"]["parity"] = {"checked": False, "error": repr(exc)}
+            rt5.destroy()
         if world == 1 and not args.pipeline and not args.combine and not args.no_graph and not args.no_fuse and not args.no_alt:
             # informational third measurement: one kernel per cycle (spectrum of cycle k + spectrogram of cycle k - 1);
             # kernel_ms is then the combined kernel's and is not comparable with the 12 B/sample roofline above
-            rt4, elapsed4 = measure(args.provider, seed_offset=0, pipeline=False, combine=True)
+            rt4, elapsed4 = measure(args.provider, seed_offset=0, pipeline=False, combine=True, batch=False)
             line["alt_combined"] = {"value": samples / elapsed4 / 1e6, "unit": "MS/s",
                                     "ms_per_step": elapsed4 / args.steps * 1e3,
                                     "units": [u.split("(")[0] for u in rt4.units if not u.startswith("spectrum.")]}

@@ -494,6 +494,13 @@ double jst_runtime_unit_mean_ms(jst_runtime r, const char* prefix) {
     return -1.0;
 }
 double jst_runtime_event_overhead_ms(jst_runtime r) { return r ? r->rt.eventPairOverheadMs() : -1.0; }
+double jst_runtime_unit_mean_cycles(jst_runtime r, const char* prefix) {
+    if (!r || !prefix) return -1.0;
+    for (const auto& name : r->rt.units())
+        if (name.compare(0, std::strlen(prefix), prefix) == 0) return r->rt.unitMeanCycles(name);
+    return -1.0;
+}
+int jst_runtime_batched(jst_runtime r) { return r && r->rt.batched() ? 1 : 0; }
 jst_result jst_runtime_reset_timing(jst_runtime r) {
     JST_ARG(r, "null runtime");
     r->rt.resetTiming();

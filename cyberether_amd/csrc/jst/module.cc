@@ -315,6 +315,7 @@ Result Runtime::planUnits() {
             u.span.begin.assign(period_, nullptr);
             u.span.end.assign(period_, nullptr);
             u.span.recorded.assign(period_, false);
+            u.span.sampleCycles.assign(period_, 1);
             for (U64 s = 0; s < period_; ++s) {
                 JST_HIP_CHECK(hipEventCreate(&u.span.begin[s]), "hipEventCreate");
                 JST_HIP_CHECK(hipEventCreate(&u.span.end[s]), "hipEventCreate");
@@ -330,7 +331,8 @@ Result Runtime::planUnits() {
 bool Runtime::tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed) {
     return modules::TryFuseSpectrum(ordered_, at, unit.name, unit.modules, unit.submit, consumed,
                                     (flags_ & COMBINE) != 0 && (flags_ & PIPELINE) == 0, &unit.flush,
-                                    (flags_ & PIPELINE) == 0) ||
+                                    (flags_ & PIPELINE) == 0,
+                                    (flags_ & BATCH) && (flags_ & GRAPH) && !(flags_ & (PIPELINE | COMBINE)) ? &unit.batch : nullptr) ||
            modules::TryFuseFilter(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
 }
 
@@ -376,10 +378,103 @@ Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
     {
         Result r = planUnits();
         if (r == Result::SUCCESS && (flags_ & PIPELINE) && (flags_ & GRAPH)) r = planPipeline();
+        if (r == Result::SUCCESS) r = planBatch();
         if (r != Result::SUCCESS) return fail(r);
     }
     cycles_ = 0;
     created_ = true;
+    return Result::SUCCESS;
+}
+
+// BATCH planning.  With the inputs of a whole ring period resident in HBM (a ring source that is not live), the cycles
+// of a captured period need not be one launch per unit and cycle: the persistent fused spectrum kernel pays its ramp,
+// cold start and tail once per LAUNCH (~4 of the ~17 us of a 1024-transform launch), so the unit runs the
+// transforms of all `n` slots of a span as one launch into output rings of as many slots, and the index-fed Spectrogram
+// walks the n index tensors in one launch with its state tile in registers.  What is visible after compute() is what
+// the per-cycle submissions leave: every cycle's output sits in its ring slot (the handles show the latest), the
+// Spectrogram's state went through the same n decays and hit updates.  Batched only when EVERY dynamic unit can do it:
+// the one fused spectrum unit with span support, modules that are spanCapable(), and kernel-less modules (their host
+// state moves through advanceHostState); anything else (a waterfall, a live source, two spectrum units) leaves the
+// runtime per cycle.  JST_RUNTIME_NO_BATCH=1 is the A/B switch.
+Result Runtime::planBatch() {
+    batched_ = false;
+    if (!(flags_ & BATCH) || !(flags_ & GRAPH) || !(flags_ & FUSE) || (flags_ & (PIPELINE | COMBINE)) || period_ < 2 ||
+        getenv("JST_RUNTIME_NO_BATCH") != nullptr)
+        return Result::SUCCESS;
+    size_t fused = units_.size();
+    for (size_t i = 0; i < units_.size(); ++i) {
+        Unit& u = units_[i];
+        if (u.is_static) continue;
+        if (u.batch) {
+            if (fused != units_.size()) return Result::SUCCESS;  // two spectrum units: per cycle
+            fused = i;
+            continue;
+        }
+        for (Module* m : u.modules) {
+            if (!m->capturable()) return Result::SUCCESS;
+            if (m->launchesKernels() ? !m->spanCapable() : (m->cyclePeriod() != 1 && m->cyclePeriod() != period_))
+                return Result::SUCCESS;
+        }
+    }
+    if (fused == units_.size()) return Result::SUCCESS;
+    SpanSupport& b = units_[fused].batch;
+    if (!b.phase.valid() || b.phase.ringSlots() != period_) return Result::SUCCESS;
+    JST_CHECK(b.prepare(period_));
+    batch_unit_ = fused;
+    batched_ = true;
+    return Result::SUCCESS;
+}
+
+// `n` consecutive cycles from the current phase, one submission per unit.  Kernel-less dynamic modules (the source)
+// expose the span's FIRST cycle before the units that read them run (advanceHostState(1)) and move on to its last
+// cycle afterwards, so the host side ends where n per-cycle submissions would have left it.
+Result Runtime::submitBatched(U64 n, bool record_events) {
+    U64 first = ~0ull;
+    Result r = Result::SUCCESS;
+    for (auto& u : units_) {
+        if (u.is_static && u.settled) continue;
+        const bool rec = record_events && !u.span.begin.empty();
+        if (rec) JST_HIP_CHECK(hipEventRecord(u.span.begin[0], stream_), "hipEventRecord");
+        if (u.batch) {
+            first = u.batch.phase.ringSlot();
+            r = u.batch.submit_span(stream_, first, n);
+        } else {
+            for (Module* m : u.modules) {
+                if (!m->launchesKernels()) {
+                    m->advanceHostState(1);
+                } else if (first == ~0ull) {
+                    JST_ERROR("[RUNTIME] Batched span: '%s' runs before the spectrum unit that feeds it.", u.name.c_str());
+                    r = Result::ERROR;
+                } else {
+                    r = m->computeSubmitSpan(stream_, first, n);
+                }
+                if (r != Result::SUCCESS) break;
+            }
+        }
+        if (r != Result::SUCCESS) {
+            JST_ERROR("[RUNTIME] Batched submission failed in '%s' (%s): %s", u.name.c_str(), ResultName(r), last_error());
+            return r;
+        }
+        if (rec) {
+            JST_HIP_CHECK(hipEventRecord(u.span.end[0], stream_), "hipEventRecord");
+            u.span.recorded[0] = true;
+            u.span.sampleCycles[0] = n;
+        }
+    }
+    for (auto& u : units_) {
+        if ((u.is_static && u.settled) || u.batch) continue;
+        for (Module* m : u.modules)
+            if (!m->launchesKernels() && n > 1) m->advanceHostState(n - 1);
+    }
+    return Result::SUCCESS;
+}
+
+// BATCH: a reader of the promoted output rings sees the most recent cycle's slot (graph replays do not run the host
+// side that selects it).
+Result Runtime::showLatestSlot() {
+    if (!batched_) return Result::SUCCESS;
+    SpanSupport& b = units_[batch_unit_].batch;
+    for (Tensor& t : b.rings) JST_CHECK(t.ringSelect(b.phase.ringSlot() % t.ringSlots()));
     return Result::SUCCESS;
 }
 
@@ -542,6 +637,7 @@ Result Runtime::submitAll(bool record_events, U64 slot, bool count_cycles) {
         if (rec) {
             JST_HIP_CHECK(hipEventRecord(u.span.end[slot], stream_), "hipEventRecord");
             u.span.recorded[slot] = true;
+            u.span.sampleCycles[slot] = 1;
         }
         if (count_cycles)
             for (Module* m : u.modules) m->timing.cycles++;
@@ -560,6 +656,7 @@ Result Runtime::harvestTiming() {
             if (hipEventElapsedTime(&ms, u.span.begin[s], u.span.end[s]) == hipSuccess) {
                 u.span.totalMs += ms;
                 u.span.count += 1;
+                u.span.cycles += s < u.span.sampleCycles.size() ? u.span.sampleCycles[s] : 1;
                 for (Module* m : u.modules) m->timing.computeTimeMs += ms / (F64)u.modules.size();
             }
         }
@@ -662,7 +759,8 @@ Result Runtime::launchSpan(U64 n, bool timing) {
         Result r = Result::SUCCESS;
         // No event-record nodes in span graphs: the unit timers live in the period graph (every timingStride()-th
         // cycle) and in eager cycles; a span is a head or a tail of at most period - 1 cycles.
-        for (U64 c = 0; c < n && r == Result::SUCCESS; ++c)
+        if (batched_) r = submitBatched(n, false);
+        for (U64 c = 0; !batched_ && c < n && r == Result::SUCCESS; ++c)
             r = submitAll(false, (phase + c) % period_, false);  // advances the host cursors
         if (r != Result::SUCCESS) return abortCapture(r);
         SpanGraph sg;
@@ -740,7 +838,8 @@ Result Runtime::compute(U64 cycles, bool sync) {
                 JST_HIP_CHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal),
                               "hipStreamBeginCapture");
                 Result r = Result::SUCCESS;
-                for (U64 c = 0; c < period_ && r == Result::SUCCESS; ++c)
+                if (batched_) r = submitBatched(period_, false);  // one launch per unit for the whole period
+                for (U64 c = 0; !batched_ && c < period_ && r == Result::SUCCESS; ++c)
                     r = submitAll(false, c, false);  // event records under capture record nothing on replay (see above)
                 if (r != Result::SUCCESS) return abortCapture(r);
                 hipGraph_t g = nullptr;
@@ -801,7 +900,31 @@ Result Runtime::compute(U64 cycles, bool sync) {
             bool capturable = true;
             for (auto& u : units_)
                 for (Module* m : u.modules) capturable &= (u.is_static || m->capturable());
-            if (capturable) {
+            if (capturable && batched_) {
+                // A cycle-batched runtime times what it replays: a whole period submitted EAGERLY, one launch per unit,
+                // between real event records (the sample then covers period_ cycles: unitMeanCycles).  A call too short
+                // to hold a period leaves the timers alone and replays as a span.
+                if (cycles >= period_) {
+                    bool busy = false;
+                    for (auto& u : units_) busy |= (!u.span.recorded.empty() && u.span.recorded[0]);
+                    if (busy) {
+                        JST_HIP_CHECK(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+                        timing_pending_ = true;
+                        JST_CHECK(harvestTiming());
+                    }
+                    last_timed_cycle_ = cycles_;
+                    JST_CHECK(submitBatched(period_, true));
+                    timed_once_ = true;
+                    timing_pending_ = true;
+                    for (auto& u : units_) {
+                        if (u.is_static && u.settled) continue;
+                        for (Module* m : u.modules) m->timing.cycles += period_;
+                    }
+                    cycles_ += period_;
+                    cycles -= period_;
+                    continue;
+                }
+            } else if (capturable) {
                 last_timed_cycle_ = cycles_;
                 const Result r = eagerCycle(needs_sync, true);  // the timed cycle: real event records
                 if (r != Result::SUCCESS) return r;
@@ -847,6 +970,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
         --cycles;
     }
     JST_CHECK(flushUnits());  // work a unit deferred past its cycle (a spectrogram riding on the next launch)
+    JST_CHECK(showLatestSlot());
     if (needs_sync) {
         JST_CHECK(joinLanes());
         JST_CHECK(harvestTiming());
@@ -874,7 +998,14 @@ void Runtime::resetTiming() {
     for (auto& u : units_) {
         u.span.totalMs = 0.0;
         u.span.count = 0;
+        u.span.cycles = 0;
     }
+}
+
+F64 Runtime::unitMeanCycles(const std::string& name) {
+    for (auto& u : units_)
+        if (u.name == name && u.span.count) return (F64)u.span.cycles / (F64)u.span.count;
+    return -1.0;
 }
 
 }  // namespace jst

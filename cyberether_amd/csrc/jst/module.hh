@@ -75,6 +75,12 @@ class Module {
     // Moves that host-side state forward by 'cycles' cycles without submitting anything: a cached hipGraph of
     // those cycles is about to be replayed (a capture advances the state itself, a replay does not).
     virtual void advanceHostState(U64 /*cycles*/) {}
+    // Cycle batching (MI355X-first; no counterpart in the reference): a module that can take `n` CONSECUTIVE compute
+    // cycles as one piece of work -- the cycles whose inputs sit in ring slots first_slot, first_slot + 1, ... (mod the
+    // ring) of the tensors the runtime's planner promoted for it -- with the result every one of the `n` per-cycle
+    // submissions would have left (Runtime::planBatch).  spanCapable() is asked at planning time.
+    virtual bool spanCapable() const { return false; }
+    virtual Result computeSubmitSpan(hipStream_t /*stream*/, U64 /*first_slot*/, U64 /*n*/) { return Result::ERROR; }
     // False for view/bookkeeping modules whose computeSubmit enqueues nothing on the stream.
     virtual bool launchesKernels() const { return true; }
     // Named internal state tensors (spectrogram/waterfall "frequencyBins"), for read-back.
@@ -148,13 +154,29 @@ struct KernelSpan {  // hipEvent pairs around one execution unit, for live per-k
     std::string name;
     std::vector<hipEvent_t> begin, end;  // one pair per cycle of the capture period
     std::vector<bool> recorded;
+    std::vector<U64> sampleCycles;       // compute cycles the pair of that slot brackets (1, or a whole batched period)
     F64 totalMs = 0.0;
     U64 count = 0;
+    U64 cycles = 0;                      // compute cycles covered by the `count` samples
+};
+
+// What a fused spectrum unit offers to a cycle-batched runtime (modules::TryFuseSpectrum fills it when the unit reads a
+// resident ring and feeds one index-fed Spectrogram): `prepare` turns the unit's outputs into rings of as many slots as
+// the source has, `submit_span` runs the transforms of n consecutive ring slots as ONE launch.
+struct SpanSupport {
+    std::function<Result(U64 slots)> prepare;
+    std::function<Result(hipStream_t, U64 first_slot, U64 n)> submit_span;
+    Tensor phase;                        // the ring whose selected slot is the current cycle's slot (the source's output)
+    std::vector<Tensor> rings;           // the promoted outputs (the runtime shows a reader the latest cycle's slot)
+    explicit operator bool() const { return static_cast<bool>(submit_span); }
 };
 
 class Runtime {
  public:
-    enum Flags : U32 { NONE = 0, GRAPH = 1 << 0, FUSE = 1 << 1, TIMING = 1 << 2, PIPELINE = 1 << 3, COMBINE = 1 << 4 };
+    // BATCH: cycle batching -- the cycles of a captured ring period (or of a span of it) run as ONE launch per unit
+    // (needs GRAPH and FUSE and a chain the planner can batch: resident ring source -> fused spectrum unit -> index-fed
+    // Spectrogram; anything else silently stays per cycle).
+    enum Flags : U32 { NONE = 0, GRAPH = 1 << 0, FUSE = 1 << 1, TIMING = 1 << 2, PIPELINE = 1 << 3, COMBINE = 1 << 4, BATCH = 1 << 5 };
 
     Runtime();
     ~Runtime();
@@ -182,6 +204,10 @@ class Runtime {
     // Mean duration of an EMPTY event pair recorded in the same graph/stream (one kernel-less
     // unit keeps its pair for this purpose): the cost of the measurement itself.
     F64 eventPairOverheadMs();
+    // Mean number of compute cycles one timing sample of the named unit covers: 1, or the ring period for a
+    // cycle-batched runtime (whose timed launches carry a whole period each); <0 if unknown.
+    F64 unitMeanCycles(const std::string& name);
+    bool batched() const { return batched_; }
     void resetTiming();
 
  private:
@@ -195,6 +221,7 @@ class Runtime {
         bool timed = true;                 // carries an event pair
         int lane = 0;                      // PIPELINE: 1 = surface lane (runs beside the next cycle)
         bool settled = false;
+        SpanSupport batch;                 // BATCH: the fused spectrum unit's multi-cycle launch
         KernelSpan span;
     };
     Result planOrder(const std::vector<Module*>& modules);
@@ -213,6 +240,13 @@ class Runtime {
     // the periods in between instead of running eagerly.
     Result launchSpan(U64 n, bool timing);
     Result abortCapture(Result r);
+    // BATCH: `n` consecutive cycles from the current phase, one submission per unit (under capture, or eagerly between
+    // real event records when record_events).
+    Result planBatch();
+    Result submitBatched(U64 n, bool record_events);
+    Result showLatestSlot();
+    bool batched_ = false;
+    size_t batch_unit_ = 0;
 
     hipStream_t stream_ = nullptr;
     U32 flags_ = 0;

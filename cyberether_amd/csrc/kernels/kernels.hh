@@ -264,6 +264,11 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
 bool spectrogram_index_supported(uint64_t batches, uint64_t width, uint64_t height);
 hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t batches, uint64_t width, uint64_t height,
                                     float decay, hipStream_t stream);
+// The same over `cycles` consecutive compute cycles in ONE launch: `cycles` index tensors one behind the other (the
+// side output of a fused spectrum launch that carried that many ring slots), the state tile in registers in between.
+bool spectrogram_index_span_supported(uint64_t batches, uint64_t width, uint64_t height, uint64_t cycles);
+hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64_t batches, uint64_t width, uint64_t height,
+                                         float decay, uint64_t cycles, hipStream_t stream);
 // The exact multi-GPU merge of spectrograms: this cycle's hit COUNTS as a U32[height][width] tensor
 // (no state touched) -- all-reduce(sum) them over the ranks -- then one shared decay and the count-times update.
 hipError_t launch_spectrogram_counts(uint32_t* counts, const float* in, uint64_t in_offset, uint64_t batches,

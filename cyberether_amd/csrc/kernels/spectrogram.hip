@@ -171,6 +171,110 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_kernel(float* __re
     JST_SPEC_STAMP(6);
 }
 
+
+// The index-fed Spectrogram over SEVERAL consecutive compute cycles in one launch (a cycle-batched runtime: the fused
+// spectrum kernel of `cycles` ring slots ran as one launch and left `cycles` index tensors U8[batches][width] one behind
+// the other).  What spectrogram/module_impl_native_cpu.cc:61-87 does per cycle -- decay every bin by 0.999^batches, then
+// min(v + 0.02f, 1.0f) once per hit -- happens here cycle after cycle on a state tile that STAYS IN REGISTERS: the state
+// is read once and written once per launch instead of once per cycle, a launch (4096 wavefronts to dispatch, ~3 us) is
+// paid once per span, and the next cycle's rows are in flight while this cycle's are counted.  Per cycle: the atomics,
+// a barrier, every thread reads AND zeroes the counts of its own cells (no clear pass, no barrier between the two), a
+// barrier.  Bit-identical to `cycles` launches of spectrogram_index_kernel by construction (same counts, same update).
+template <int COPIES, int kThreads>
+__global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float* __restrict__ bins, const uint8_t* __restrict__ idx,
+                                                                          uint32_t batches, uint32_t width, uint32_t height,
+                                                                          float decay, uint32_t cycles) {
+    constexpr uint32_t TW = 16;
+    extern __shared__ __attribute__((aligned(64))) unsigned char smem_raw[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cells = height * TW;
+    const uint32_t copy_stride = cells + 16u;
+    uint32_t tile = blockIdx.x;
+    if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+
+    constexpr uint32_t kCells = 4096 / kThreads;
+    float state[kCells];
+#pragma unroll
+    for (uint32_t j = 0; j < kCells; ++j) {
+        const uint32_t e = tid + j * kThreads;
+        state[j] = e < cells ? bins[(uint64_t)(e / TW) * width + tile * TW + (e % TW)] : 0.0f;
+    }
+
+    constexpr uint32_t kRows = 1024 / kThreads;
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const uint32_t cycle_bytes = batches * width;
+    const __amdgpu_buffer_rsrc_t r_idx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(idx), 0, cycles * cycle_bytes, 0x00020000);
+    v4u q[kRows];
+    auto request = [&](uint32_t cycle, uint32_t first_row) {
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r) {
+            const uint32_t row = first_row + tid + r * kThreads;  // a row that does not exist reads as 0: no hits
+            q[r] = __builtin_amdgcn_raw_buffer_load_b128(
+                r_idx, (row < batches && cycle < cycles) ? cycle * cycle_bytes + row * width + tile * TW : 0xfffffff0u, 0, 0);
+        }
+    };
+    request(0, 0);
+    for (uint32_t e = tid * 4u; e < copy_stride * COPIES; e += kThreads * 4u)
+        *reinterpret_cast<uint4*>(hist + e) = make_uint4(0u, 0u, 0u, 0u);
+    lds_only_barrier();
+
+    const uint32_t rot = tid & 15u;
+    const uint32_t my_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)hist +
+                             ((tid >> 4) % COPIES) * copy_stride * 4u;
+    typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+    for (uint32_t c = 0; c < cycles; ++c) {
+        for (uint32_t first = 0; first < batches; first += 1024u) {
+            v4u cur[kRows];
+#pragma unroll
+            for (uint32_t r = 0; r < kRows; ++r) cur[r] = q[r];
+            // the next round's rows (this cycle's, or the next cycle's first) are requested before these are counted
+            if (first + 1024u < batches) request(c, first + 1024u);
+            else request(c + 1u, 0u);
+#pragma unroll
+            for (uint32_t r = 0; r < kRows; ++r) {
+                const bool r1 = (rot & 4u) != 0u, r2 = (rot & 8u) != 0u;
+                const uint32_t a0 = r1 ? cur[r].y : cur[r].x, a1 = r1 ? cur[r].z : cur[r].y, a2 = r1 ? cur[r].w : cur[r].z,
+                               a3 = r1 ? cur[r].x : cur[r].w;
+                const uint32_t b0 = r2 ? a2 : a0, b1 = r2 ? a3 : a1, b2 = r2 ? a0 : a2, b3 = r2 ? a1 : a3;
+                const uint32_t sh = rot & 3u;
+                const uint32_t g[4] = {__builtin_amdgcn_alignbyte(b1, b0, sh), __builtin_amdgcn_alignbyte(b2, b1, sh),
+                                       __builtin_amdgcn_alignbyte(b3, b2, sh), __builtin_amdgcn_alignbyte(b0, b3, sh)};
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) {
+                    const uint32_t i = (g[j >> 2] >> (8u * (j & 3u))) & 0xffu;
+                    const uint32_t addr = (i << 6) + ((((rot + j) & 15u) << 2) | my_base);
+                    __hip_atomic_fetch_add((lds_u32)(uintptr_t)addr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        lds_only_barrier();
+        uint32_t k[kCells];
+#pragma unroll
+        for (uint32_t j = 0; j < kCells; ++j) {
+            const uint32_t e = tid + j * kThreads < cells ? tid + j * kThreads : 0u;
+            uint32_t n = 0;
+#pragma unroll
+            for (int cp = 0; cp < COPIES; ++cp) {
+                n += hist[cp * copy_stride + e];
+                if (tid + j * kThreads < cells) hist[cp * copy_stride + e] = 0u;  // this thread's own cells: cleared for the next cycle
+            }
+            if (e < TW) n = 0u;
+            k[j] = n < 64u ? n : 64u;
+        }
+        lds_only_barrier();
+#pragma unroll
+        for (uint32_t j = 0; j < kCells; ++j) state[j] = apply_hits(state[j] * decay, k[j]);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kCells; ++j) {
+        const uint32_t e = tid + j * kThreads;
+        if (e >= cells) continue;
+        store_state(bins + (uint64_t)(e / TW) * width + tile * TW + (e % TW), state[j]);
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -256,6 +360,23 @@ hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t ba
     else if (threads == 512) JST_SPEC_INDEX(512);
     else JST_SPEC_INDEX(256);
 #undef JST_SPEC_INDEX
+    return hipGetLastError();
+}
+
+// `cycles` consecutive index tensors U8[batches][width] behind `idx` (a cycle-batched span), one launch.
+bool spectrogram_index_span_supported(uint64_t batches, uint64_t width, uint64_t height, uint64_t cycles) {
+    return cycles >= 1 && spectrogram_index_supported(batches, width, height) && cycles * batches * width < (1ull << 31);
+}
+
+hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64_t batches, uint64_t width, uint64_t height,
+                                         float decay, uint64_t cycles, hipStream_t stream) {
+    if (!spectrogram_index_span_supported(batches, width, height, cycles)) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)height * 16 + 16) * 4 * sizeof(uint32_t);
+    (void)hipGetLastError();
+    const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(spectrogram_index_span_kernel<4, 1024>), 80 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((spectrogram_index_span_kernel<4, 1024>), dim3((unsigned)(width / 16)), dim3(1024), lds, stream, bins,
+                       idx, (uint32_t)batches, (uint32_t)width, (uint32_t)height, decay, (uint32_t)cycles);
     return hipGetLastError();
 }
 

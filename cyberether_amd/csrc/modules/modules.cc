@@ -1041,6 +1041,27 @@ Result Spectrogram::computeSubmit(hipStream_t stream) {
         "spectrogram kernel");
 }
 
+Result Spectrogram::computeSubmitSpan(hipStream_t stream, U64 first_slot, U64 n) {
+    const U64 ring = rowIndices.ringSlots();
+    if (!spanCapable() || ring < 2 || first_slot >= ring) {
+        JST_ERROR("[MODULE_SPECTROGRAM] A cycle-batched span needs the row-index ring of a batched spectrum unit.");
+        return Result::ERROR;
+    }
+    U64 slot = first_slot;
+    while (n > 0) {  // runs of consecutive slots: a span that wraps the ring is two launches
+        U64 run = std::min<U64>(n, ring - slot);
+        while (!kernels::spectrogram_index_span_supported(numberOfBatches, numberOfElements, height, run) && run > 1) run /= 2;
+        JST_CHECK(hip_result(kernels::launch_spectrogram_index_span(ptr<float>(frequencyBins),
+                                                                    static_cast<const uint8_t*>(rowIndices.ringSlotData(slot)),
+                                                                    numberOfBatches, numberOfElements, height, decayFactor,
+                                                                    run, stream),
+                             "spectrogram kernel (row indices, cycle-batched span)"));
+        slot = (slot + run) % ring;
+        n -= run;
+    }
+    return rowIndices.ringSelect((slot + ring - 1) % ring);
+}
+
 Result SpectrogramMerge::validate() {
     bool ok = true;
     totalBatches = ConfigU64(config_, "batches", 0, &ok);
@@ -1366,7 +1387,8 @@ Result RingSource::ringClear() {
 // ---- fusion ------------------------------------------------------------------------------------
 bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string& name,
                      std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
-                     size_t& consumed, bool allow_combine, std::function<Result(hipStream_t)>* flush, bool allow_side) {
+                     size_t& consumed, bool allow_combine, std::function<Result(hipStream_t)>* flush, bool allow_side,
+                     SpanSupport* batch) {
     if (at + 2 >= ordered.size()) return false;
     auto* mul = dynamic_cast<Multiply*>(ordered[at]);
     auto* fft = dynamic_cast<Fft*>(ordered[at + 1]);
@@ -1589,9 +1611,84 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
         }
     }
 
-    submit = [mul, fft, amp, rng, cast, fed, axis, n, fast, tiled, guard0, guard1](hipStream_t stream) -> Result {
+    // Cycle batching: the signal is a dense, offset-free view of a RESIDENT ring (slots one behind the other in one
+    // allocation, tensor.cc: createRing), so the transforms of n consecutive slots are one dense {n * batches, samples}
+    // problem for the persistent kernel -- its ramp, cold start and tail are paid once per launch instead of once per
+    // cycle.  `prepare` (called by Runtime::planBatch once every dynamic unit of the runtime can be batched) turns the
+    // range output and the Spectrogram's row indices into rings of as many slots; from then on the per-cycle submit
+    // below writes the slot the source exposes, and submit_span covers runs of consecutive slots.
+    auto batched = std::make_shared<bool>(false);
+    if (batch && fed) {
+        const Tensor in_t = cast ? cast->input : sig;
+        const U64 slot_elems = sig.shape(0) * n;
+        const bool dense_ring = in_t.ringSlots() > 1 && in_t.contiguous() && in_t.offset() == 0 && in_t.size() == slot_elems &&
+                                rng->output.offset() == 0 && rng->output.size() == slot_elems;
+        // per launch: < 2^31 bytes of input (buffer-descriptor offsets), i.e. at most max_run slots
+        const U64 in_bytes = slot_elems * DataTypeSize(in_t.dtype());
+        const U64 max_run = in_bytes ? ((1ull << 31) - 1) / in_bytes : 0;
+        if (dense_ring && max_run >= 2) {
+            batch->phase = in_t;
+            batch->prepare = [rng, fed, batched](U64 slots) -> Result {
+                if (rng->output.ringSlots() != slots) JST_CHECK(rng->output.promoteToRing(slots));
+                if (fed->rowIndices.ringSlots() != slots) JST_CHECK(fed->rowIndices.promoteToRing(slots));
+                if (fed->input.ringSlots() != slots) {
+                    JST_ERROR("[RUNTIME] The Spectrogram's input did not follow the spectrum output's ring.");
+                    return Result::ERROR;
+                }
+                *batched = true;
+                return Result::SUCCESS;
+            };
+            batch->rings = {rng->output, fed->rowIndices};
+            batch->submit_span = [mul, fft, amp, rng, cast, fed, n, fast, guard0, guard1, max_run](hipStream_t stream, U64 first,
+                                                                                                  U64 cycles) -> Result {
+                const Tensor& sig = mul->a;
+                const Tensor& win = mul->b;
+                const Tensor in_t = cast ? cast->input : sig;
+                Tensor& out = rng->output;
+                const U64 ring = in_t.ringSlots();
+                if (first >= ring || out.ringSlots() != ring || fed->rowIndices.ringSlots() != ring) {
+                    JST_ERROR("[RUNTIME] Batched spectrum span: the output rings do not match the source ring.");
+                    return Result::ERROR;
+                }
+                const DataType it = in_t.dtype();
+                U64 slot = first;
+                while (cycles > 0) {  // runs of consecutive slots: a span that wraps the ring is two launches
+                    const U64 run = std::min<U64>(std::min<U64>(cycles, ring - slot), max_run);
+                    FftLayout L;
+                    std::memset(&L, 0, sizeof(L));
+                    L.transforms = sig.shape(0) * run;
+                    L.outer_rank = 1;
+                    L.outer_shape[0] = L.transforms;
+                    L.in_outer_stride[0] = (int64_t)n;
+                    L.out_outer_stride[0] = (int64_t)n;
+                    L.in_axis_stride = 1;
+                    L.out_axis_stride = 1;
+                    JST_CHECK(hip_result(
+                        kernels::launch_spectrum_fused_side(
+                            n, L, fft->twiddles, in_t.ringSlotData(slot),
+                            !cast ? 0 : (it == DataType::CI16 ? 1 : (it == DataType::CI8 ? 2 : 3)), cast ? cast->scaler : 1.0f,
+                            static_cast<const float2*>(win.data()) + win.offset(), static_cast<float*>(out.ringSlotData(slot)),
+                            amp->scalingCoeff, rng->scalingCoeff, rng->offsetCoeff, fast, guard0, guard1,
+                            static_cast<uint8_t*>(fed->rowIndices.ringSlotData(slot)), fed->height, stream),
+                        "fused spectrum kernel (+ row indices, cycle-batched span)"));
+                    slot = (slot + run) % ring;
+                    cycles -= run;
+                }
+                const U64 last = (slot + ring - 1) % ring;
+                JST_CHECK(out.ringSelect(last));
+                return fed->rowIndices.ringSelect(last);
+            };
+        }
+    }
+
+    submit = [mul, fft, amp, rng, cast, fed, axis, n, fast, tiled, guard0, guard1, batched](hipStream_t stream) -> Result {
         const Tensor& sig = mul->a;
         const Tensor& win = mul->b;
+        if (*batched) {  // cycle-batched runtime: this cycle writes the ring slot the source exposes
+            const U64 slot = (cast ? cast->input : sig).ringSlot();
+            JST_CHECK(rng->output.ringSelect(slot));
+            JST_CHECK(fed->rowIndices.ringSelect(slot));
+        }
         const Tensor& out = rng ? rng->output : amp->output;
         FftLayout L;
         std::memset(&L, 0, sizeof(L));

@@ -32,10 +32,13 @@ bool MakeEwLayout(const Tensor& out, const Tensor* a, const Tensor* b, dev::EwLa
 // (then `flush` is set: the runtime calls it at the end of every compute call to run the waiting spectrogram).
 // allow_side: the one Spectrogram that quantises the fused output (height <= 256) may be fed with one-byte row indices
 // written by the fused kernel beside its values (Spectrogram::indexFed) instead of re-reading the values.
+// batch: filled when the unit can run the transforms of several consecutive ring slots as one launch (a cycle-batched
+// runtime, Runtime::planBatch): the signal is a dense view of a resident ring and the unit feeds one index-fed Spectrogram.
 bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string& name,
                      std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
                      size_t& consumed, bool allow_combine = false,
-                     std::function<Result(hipStream_t)>* flush = nullptr, bool allow_side = true);
+                     std::function<Result(hipStream_t)>* flush = nullptr, bool allow_side = true,
+                     SpanSupport* batch = nullptr);
 
 // Filter-chain fusions (filter_modules.cc): pad -> fft (zeros synthesised in the FFT's first load)
 // and multiply -> fold (the broadcast product is never materialised).  Same contract.
@@ -233,6 +236,11 @@ class Spectrogram : public Module {
     // (kernels::launch_spectrogram_index).  Same state, bit for bit; a decision of the runtime's planner, reset by it.
     bool indexFed = false;
     Tensor rowIndices;
+    // Cycle batching (Runtime::planBatch): rowIndices is then a ring of as many slots as the source has, and a span of n
+    // cycles is ONE launch over n consecutive index tensors with the state tile in registers in between
+    // (kernels::launch_spectrogram_index_span; a span that wraps the ring is two launches).
+    bool spanCapable() const override { return indexFed && !countsOnly && !combined; }
+    Result computeSubmitSpan(hipStream_t stream, U64 first_slot, U64 n) override;
     bool combined = false, combinedPending = false;
     U64 combinedCycle = 0;
     Tensor combineCtrl;  // two zeroed device words {pending, ticket}

@@ -47,7 +47,7 @@ DTYPE_OF_NP = {np.dtype(v): k for k, v in NP_DTYPE.items()}
 RESULT_NAMES = ["SUCCESS", "ERROR", "WARNING", "FATAL", "SKIP", "YIELD", "RELOAD", "RECREATE",
                 "TIMEOUT", "INCOMPLETE"]
 
-RUNTIME_GRAPH, RUNTIME_FUSE, RUNTIME_TIMING, RUNTIME_PIPELINE, RUNTIME_COMBINE = 1, 2, 4, 8, 16
+RUNTIME_GRAPH, RUNTIME_FUSE, RUNTIME_TIMING, RUNTIME_PIPELINE, RUNTIME_COMBINE, RUNTIME_BATCH = 1, 2, 4, 8, 16, 32
 
 TAINT = {"IN_PLACE": 1, "DISCONTIGUOUS": 2, "SURFACE": 4, "CROSS_DEVICE": 16,
          "STATIC_OUTPUT": 64, "STATELESS": 128}
@@ -138,6 +138,8 @@ _sig("jst_ring_capacity", C.c_uint64, _h)
 _sig("jst_ring_overflows", C.c_uint64, _h)
 _sig("jst_runtime_units", C.c_size_t, _h, C.c_char_p, C.c_size_t)
 _sig("jst_runtime_unit_mean_ms", C.c_double, _h, C.c_char_p)
+_sig("jst_runtime_unit_mean_cycles", C.c_double, _h, C.c_char_p)
+_sig("jst_runtime_batched", C.c_int, _h)
 _sig("jst_runtime_event_overhead_ms", C.c_double, _h)
 _sig("jst_runtime_reset_timing", R, _h)
 _sig("jst_fft_twiddles", R, C.c_uint64, C.POINTER(C.c_float))
@@ -481,11 +483,11 @@ class Runtime:
     """One device segment: ordered modules on one HIP stream, optionally as a hipGraph."""
 
     def __init__(self, modules: Iterable[Module], graph: bool = False, fuse: bool = False,
-                 timing: bool = False, pipeline: bool = False, combine: bool = False):
+                 timing: bool = False, pipeline: bool = False, combine: bool = False, batch: bool = False):
         self.modules = list(modules)
         flags = (RUNTIME_GRAPH if graph else 0) | (RUNTIME_FUSE if fuse else 0) | \
                 (RUNTIME_TIMING if timing else 0) | (RUNTIME_PIPELINE if pipeline else 0) | \
-                (RUNTIME_COMBINE if combine else 0)
+                (RUNTIME_COMBINE if combine else 0) | (RUNTIME_BATCH if batch else 0)
         arr = (C.c_void_p * max(len(self.modules), 1))(*[m._h for m in self.modules])
         out = C.c_void_p()
         self._h = None
@@ -542,6 +544,15 @@ class Runtime:
 
     def unit_mean_ms(self, prefix: str) -> float:
         return float(_lib.jst_runtime_unit_mean_ms(self._h, prefix.encode()))
+
+    def unit_mean_cycles(self, prefix: str) -> float:
+        """Compute cycles one timing sample of the unit covers (1, or the ring period when cycle-batched)."""
+        return float(_lib.jst_runtime_unit_mean_cycles(self._h, prefix.encode()))
+
+    @property
+    def batched(self) -> bool:
+        """True when `batch=True` took effect: the cycles of a ring period run as one launch per unit."""
+        return bool(_lib.jst_runtime_batched(self._h))
 
     def event_overhead_ms(self) -> float:
         return float(_lib.jst_runtime_event_overhead_ms(self._h))

@@ -67,10 +67,20 @@ enum {
     JST_RUNTIME_PIPELINE = 1 << 3, /* with GRAPH: SURFACE units (spectrogram, waterfall, lineplot) run on
                                      a second captured stream beside the NEXT cycle's producers; the
                                      tensors they read are double-buffered */
-    JST_RUNTIME_COMBINE = 1 << 4  /* with FUSE: a Spectrogram that is the only reader of the fused spectrum unit's
+    JST_RUNTIME_COMBINE = 1 << 4, /* with FUSE: a Spectrogram that is the only reader of the fused spectrum unit's
                                      output rides on the NEXT cycle's spectrum launch (one kernel per cycle, output a
                                      ring of two slots); the one still waiting when a compute call ends is run then,
                                      so results and their visibility after jst_runtime_compute are unchanged */
+    JST_RUNTIME_BATCH = 1 << 5    /* with GRAPH and FUSE: CYCLE BATCHING.  When the chain is a resident ring_source
+                                     (R slots) -> fused spectrum unit -> ONE index-fed Spectrogram, the cycles of a
+                                     captured ring period (and of every span of it) run as ONE launch per unit: the
+                                     persistent spectrum kernel takes the transforms of all the span's slots (its ramp,
+                                     cold start and tail are paid once per launch, not once per cycle), the range
+                                     output and the row indices become rings of R slots (cycle c writes slot c mod R;
+                                     the tensor handles show the latest cycle), and the Spectrogram walks the span's
+                                     index tensors in one launch with its state tile in registers.  What is visible
+                                     after jst_runtime_compute is bit-identical to the per-cycle submissions.  Any other
+                                     chain silently stays per cycle (jst_runtime_batched tells). */
 };
 
 typedef struct jst_tensor_s* jst_tensor;
@@ -271,6 +281,11 @@ double jst_runtime_unit_mean_ms(jst_runtime r, const char* unit_prefix);
 /* mean duration of an EMPTY hipEvent pair recorded in the same graph (cost of the measurement
  * itself; < 0 when the runtime has no kernel-less dynamic unit to carry it) */
 double jst_runtime_event_overhead_ms(jst_runtime r);
+/* mean number of compute cycles ONE timing sample of that unit covers: 1, or the ring period for a cycle-batched
+ * runtime (its timed launches carry a whole period each); < 0 without samples */
+double jst_runtime_unit_mean_cycles(jst_runtime r, const char* unit_prefix);
+/* 1 when JST_RUNTIME_BATCH took effect (the planner could batch every dynamic unit), else 0 */
+int jst_runtime_batched(jst_runtime r);
 jst_result jst_runtime_reset_timing(jst_runtime r);
 
 /* ---- test/bench probes -------------------------------------------------------------------- */
