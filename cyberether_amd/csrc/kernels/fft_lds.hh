@@ -391,17 +391,48 @@ struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_na
 // 0 < index < height) goes out as one byte, U8[transforms][N] dense, 0 = no hit.  The index is formed from the very
 // float that is stored, so it is the consumer's own arithmetic moved in front of the store; the Spectrogram then reads
 // 1 byte per sample (one 16-byte request per row and tile) instead of re-reading the 4-byte values.  height <= 256.
+// Layout of the side tensor: U8[cycle][n / 128][side_pitch][128] (rows [0, side_batches) used) -- TILE-MAJOR: the 128 columns [128 q, 128 q + 128)
+// of all rows of one compute cycle lie one behind the other (side_batches = the rows of one cycle; a cycle-batched launch
+// carries several cycles).  The consumer works on tiles of 16 columns x ALL rows: with row-major indices each of its
+// 16-byte requests opened another 4096-byte row (64 MiB per 16-cycle span at ~1.3 TB/s when they come from HBM: 50 us
+// where the Infinity Cache would have served them in 30); tile-major it walks 128 KiB contiguously.  On this side
+// nothing changes: a wavefront's 64 one-byte stores are still one 64-byte run, and the two wavefronts of a 128-column
+// group still complete a 128-byte line together; the group index (tid >> 7, wave-uniform) goes into the descriptor base.
 template <bool FAST>
 struct StoreAmplitudeRangeSideT : StoreAmplitudeRangeT<FAST> {
     uint8_t* side;
     float side_height;
+    uint32_t side_batches;
+    uint32_t side_pitch;  // rows a column group occupies in memory (>= side_batches: see kernels.hh, the pad skews the groups over the HBM channels)
     static constexpr bool kHasSide = true;
-    __device__ __forceinline__ const void* side_row(uint64_t transform, uint32_t n) const { return side + transform * n; }
+    // IN_BASE: every thread stores ONE butterfly of the last pass (u = tid), so the column group u >> 7 is wave-uniform and
+    // rides in the descriptor base; otherwise (several butterflies per thread) it is formed per lane.
+    template <bool IN_BASE>
+    __device__ __forceinline__ rsrc_t side_rsrc(uint64_t transform, uint32_t n, int tid) const {
+        const uint32_t t = (uint32_t)transform;
+        const uint32_t cycle = t / side_batches, row = t - cycle * side_batches;
+#ifdef JST_SIDE_ROW_MAJOR  // A/B switch: U8[cycle][side_pitch][n], the round-3 layout (spectrogram.hip must be built alike)
+        (void)tid;
+        const uint32_t in_cycle = row * n;
+#else
+        const uint32_t group = IN_BASE ? (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 7) : 0u;
+        const uint32_t in_cycle = (group * side_pitch + row) * 128u;
+#endif
+        return make_rsrc(side + (size_t)cycle * side_pitch * n + in_cycle, side_pitch * n - in_cycle);
+    }
+    // voff / soff: the F32 store's byte offsets (4 * u, 4 * c * BUT with BUT a multiple of 128)
+    template <bool IN_BASE>
     __device__ __forceinline__ void store_buf_side(rsrc_t r, rsrc_t rs, uint32_t voff, uint32_t soff, float2 v) const {
         const float y = this->value(v);
         buf_store_f1(r, voff, soff, y);
         const float f = y * side_height;
-        buf_store_u8(rs, voff >> 2, soff >> 2, (f >= 1.0f && f < side_height) ? (uint32_t)f : 0u);
+        const uint32_t u = voff >> 2;
+#ifdef JST_SIDE_ROW_MAJOR
+        buf_store_u8(rs, u, soff >> 2, (f >= 1.0f && f < side_height) ? (uint32_t)f : 0u);
+#else
+        const uint32_t lane_off = IN_BASE ? (u & 127u) : (u >> 7) * (side_pitch * 128u) + (u & 127u);
+        buf_store_u8(rs, lane_off, (soff >> 2) * side_pitch, (f >= 1.0f && f < side_height) ? (uint32_t)f : 0u);
+#endif
     }
 };
 template <class Epi>
@@ -430,6 +461,11 @@ constexpr int pcphys(int q) { return q + (q >> 3); }
 __device__ __forceinline__ int pphys(int p) { return p + ((p >> 4) << 1); }
 constexpr int pcphys(int q) { return q + ((q >> 4) << 1); }
 #endif
+
+// One butterfly per thread in the last pass (u = tid): the side output's column group is wave-uniform (see
+// StoreAmplitudeRangeSideT); the last pass's butterfly count is a multiple of 128 for every n the side output supports.
+template <int N, int T>
+constexpr bool kSideGroupInBase = (N / make_plan(N).ip[make_plan(N).nf - 1]) == T;
 
 // ---- one Stockham pass -----------------------------------------------------------------------
 // Butterfly u in [0, N/IP): i = u % IDO, k = u / IDO.
@@ -785,7 +821,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
 #pragma unroll
             for (int c = 0; c < IP; ++c) {
                 if constexpr (CONTIG && epi_has_side<Epi>())
-                    epi.store_buf_side(r_out, r_side, (uint32_t)u * Epi::kElemBytes,
+                    epi.template store_buf_side<kSideGroupInBase<N, T>>(r_out, r_side, (uint32_t)u * Epi::kElemBytes,
                                        (uint32_t)(c * BUT) * Epi::kElemBytes, y[c]);
                 else if constexpr (CONTIG)
                     epi.store_buf(r_out, (uint32_t)u * Epi::kElemBytes,
@@ -1060,7 +1096,7 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
         const rsrc_t r_out = make_rsrc(epi.row(out_base), (uint32_t)N * Epi::kElemBytes);
         const rsrc_t r_opnd_next = make_rsrc(pro.operand_row(), (more && !(REALOP && wave_real)) ? (uint32_t)N * 8u : 0u);
         rsrc_t r_side = r_out;  // unused unless the epilogue has a side output
-        if constexpr (CONTIG && epi_has_side<Epi>()) r_side = make_rsrc(epi.side_row(t, (uint32_t)N), (uint32_t)N);
+        if constexpr (CONTIG && epi_has_side<Epi>()) r_side = epi.template side_rsrc<kSideGroupInBase<N, T>>(t, (uint32_t)N, tid);
 #ifdef JST_FB_SKIP_PASSES  // decomposition experiment (tools/ubench/fused_bench.hip): last pass + epilogue only
         pipe_passes<N, T, FWD, CONTIG, plan.nf - 1, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
                                                               L.out_axis_stride, epi, pro, opnd,

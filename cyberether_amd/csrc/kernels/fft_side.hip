@@ -1,9 +1,17 @@
 // fft_side.hip -- the fused spectrum kernel (fft_lds.hh: fft_pipe_kernel) with the Spectrogram's row index as a side
 // output (StoreAmplitudeRangeSideT): Multiply(window) -> FFT -> Amplitude -> Range writes its F32 rows as before and,
-// beside every value, the one-byte index `(u32)(value * height)` (0 = no hit) the Spectrogram consumer would derive
-// from it (spectrogram/module_impl_native_cpu.cc:70-77).  The consumer (spectrogram.hip: spectrogram_index_kernel)
+// beside every value, the one-byte index `(u32)(value * height)` (0 = no hit; tile-major, see the functor) the
+// Spectrogram consumer would derive from it (spectrogram/module_impl_native_cpu.cc:70-77).  The consumer (spectrogram.hip: spectrogram_index_kernel)
 // then reads 1 byte per sample instead of 4.  Its own translation unit: the instantiations compile beside
 // fft_kernels.hip, not behind it.
+// The input stream is read ONCE: `nt` on its 8-byte loads keeps it from displacing what the consumer comes back for -- under
+// cycle batching the Spectrogram walks 64 MiB of indices behind a launch that streamed 512 MiB in and 256 MiB out, and with
+// plain loads little of them was left in the Infinity Cache (same box, tools/ubench/run_r03u.sh: spectrogram span 40.8 ->
+// 36.1 us, fused span 188-193 -> 187 us, step 14.46-14.73 -> 14.07 us; per-cycle launches within the noise: 19.3 vs 19.4-20.1
+// us).  `nt` on the F32 stores as well was no better (35.5 / 190.0 us); fft_kernels.hip keeps plain loads.
+#ifndef JST_LOAD_AUX
+#define JST_LOAD_AUX 2
+#endif
 #include "fft_lds.hh"
 #include "kernels.hh"
 
@@ -45,9 +53,9 @@ hipError_t launch_side(const FftLayout& L, const float2* W, const Pro& pro, cons
 template <class Pro>
 hipError_t side_with(uint64_t n, const FftLayout& L, const float2* W, const Pro& pro, float* out, float amp_coeff,
                      float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1, uint8_t* side,
-                     float side_height, hipStream_t stream) {
-    const StoreAmplitudeRangeSideT<true> ef{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}}, side, side_height};
-    const StoreAmplitudeRangeSideT<false> ee{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}}, side, side_height};
+                     float side_height, uint32_t side_batches, uint32_t side_pitch, hipStream_t stream) {
+    const StoreAmplitudeRangeSideT<true> ef{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}}, side, side_height, side_batches, side_pitch};
+    const StoreAmplitudeRangeSideT<false> ee{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}}, side, side_height, side_batches, side_pitch};
     switch (n) {
 #define JST_SIDE_CASE(NN)                                                  \
     case NN:                                                               \
@@ -64,6 +72,16 @@ hipError_t side_with(uint64_t n, const FftLayout& L, const float2* W, const Pro&
 
 }  // namespace
 
+// Rows a 128-column group of the tile-major side tensor occupies: the batches plus a pad that takes the group stride off
+// the powers of two (JST_SIDE_PAD_ROWS, default 2 rows = 256 bytes of skew per group).
+uint64_t spectrum_side_pitch(uint64_t batches) {
+    static const uint64_t pad = [] {
+        const char* e = getenv("JST_SIDE_PAD_ROWS");
+        return e ? (uint64_t)atoll(e) : 2ull;
+    }();
+    return batches + pad;
+}
+
 bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stride, uint64_t height) {
     const char* k = getenv("JST_FFT_KERNEL");
     if (k && k[0] == 's') return false;  // the non-pipelined kernel has no side store
@@ -77,23 +95,26 @@ bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stri
 hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const float2* W, const void* in, int in_format,
                                       float scaler, const float2* window, float* out, float amp_coeff,
                                       float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1,
-                                      uint8_t* side, uint64_t height, hipStream_t stream) {
-    if (!spectrum_side_supported(n, L, 1, height) || !side) return hipErrorInvalidValue;
+                                      uint8_t* side, uint64_t height, uint64_t side_batches, uint64_t side_pitch, hipStream_t stream) {
+    // side_batches: the rows of ONE index tensor (a compute cycle's batches); L.transforms is a whole number of them
+    if (!spectrum_side_supported(n, L, 1, height) || !side || side_batches == 0 || L.transforms % side_batches != 0 ||
+        side_pitch < side_batches || (L.transforms / side_batches) * side_pitch * n >= (1ull << 31))
+        return hipErrorInvalidValue;
     const float h = (float)height;
     const float inv = in_format ? 1.0f / scaler : 1.0f;  // a power of two: x / scaler == x * inv, exactly
     switch (in_format) {
         case 0:
             return side_with(n, L, W, LoadCF32TimesWindow{static_cast<const float2*>(in), window, 1}, out, amp_coeff,
-                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, stream);
+                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, stream);
         case 1:
             return side_with(n, L, W, LoadCI16TimesWindow{static_cast<const uint32_t*>(in), window, 1, inv}, out, amp_coeff,
-                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, stream);
+                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, stream);
         case 2:
             return side_with(n, L, W, LoadCI8TimesWindow{static_cast<const uint16_t*>(in), window, 1, inv}, out, amp_coeff,
-                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, stream);
+                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, stream);
         case 3:
             return side_with(n, L, W, LoadCU8TimesWindow{static_cast<const uint16_t*>(in), window, 1, inv}, out, amp_coeff,
-                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, stream);
+                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, stream);
         default:
             return hipErrorInvalidValue;
     }

@@ -170,14 +170,19 @@ hipError_t launch_spectrum_fused_cast(uint64_t n, const FftLayout& L, const floa
                                       float scaler, const float2* window, int64_t window_stride, float* out,
                                       float amp_coeff, bool with_range, float range_scale, float range_offset, bool fast,
                                       float guard_h0, float guard_h1, hipStream_t stream);
-// The same chain with the Spectrogram consumer's row index as a one-byte SIDE OUTPUT (fft_side.hip): `side` is
-// U8[transforms][n] dense, side[t][x] = (u32)(out[t][x] * height) when that hits (1 <= value * height < height), else 0.
+// The same chain with the Spectrogram consumer's row index as a one-byte SIDE OUTPUT (fft_side.hip): the index of
+// out[t][x] is (u32)(out[t][x] * height) when that hits (1 <= value * height < height), else 0.  `side` holds
+// transforms / side_batches index tensors one behind the other, each TILE-MAJOR U8[n / 128][side_pitch][128] (the 128
+// columns of a group for all rows of one compute cycle contiguous: what the column-tiled consumer walks; rows
+// [side_batches, side_pitch) are padding -- with side_pitch = side_batches = 1024 the groups lie 128 KiB apart and
+// every store of a row lands on the same few HBM channels: spectrum_side_pitch() picks the pad).
+uint64_t spectrum_side_pitch(uint64_t batches);
 // in_format: 0 = CF32, 1 = CI16, 2 = CI8, 3 = CU8 (scaler as above).  Range is always on; window dense.
 bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stride, uint64_t height);
 hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const float2* W, const void* in, int in_format,
                                       float scaler, const float2* window, float* out, float amp_coeff,
                                       float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1,
-                                      uint8_t* side, uint64_t height, hipStream_t stream);
+                                      uint8_t* side, uint64_t height, uint64_t side_batches, uint64_t side_pitch, hipStream_t stream);
 // guard_h0/h1 (fast + range only): heights of the Spectrogram modules that will quantise the output;
 // elements whose value * height lies within the fast path's error of a bin edge are computed with the
 // exact arithmetic instead, so the bins equal the exact provider's (dev::BinGuard, device_math.hh).
@@ -259,16 +264,16 @@ size_t spectrogram_lds_bytes(uint64_t height);
 hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, uint64_t batches,
                               uint64_t width, uint64_t height, int64_t batch_stride,
                               int64_t elem_stride, float decay, hipStream_t stream);
-// The Spectrogram fed with the fused spectrum kernel's one-byte row indices (U8[batches][width] dense, 0 = no hit)
-// instead of the values: same state update, a quarter of the bytes, a quarter of the wavefronts.
+// The Spectrogram fed with the fused spectrum kernel's one-byte row indices (tile-major U8[width / 128][batches][128],
+// 0 = no hit) instead of the values: same state update, a quarter of the bytes, a quarter of the wavefronts.
 bool spectrogram_index_supported(uint64_t batches, uint64_t width, uint64_t height);
-hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t batches, uint64_t width, uint64_t height,
-                                    float decay, hipStream_t stream);
+hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t batches, uint64_t pitch, uint64_t width,
+                                    uint64_t height, float decay, hipStream_t stream);
 // The same over `cycles` consecutive compute cycles in ONE launch: `cycles` index tensors one behind the other (the
 // side output of a fused spectrum launch that carried that many ring slots), the state tile in registers in between.
 bool spectrogram_index_span_supported(uint64_t batches, uint64_t width, uint64_t height, uint64_t cycles);
-hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64_t batches, uint64_t width, uint64_t height,
-                                         float decay, uint64_t cycles, hipStream_t stream);
+hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64_t batches, uint64_t pitch, uint64_t width,
+                                         uint64_t height, float decay, uint64_t cycles, hipStream_t stream);
 // The exact multi-GPU merge of spectrograms: this cycle's hit COUNTS as a U32[height][width] tensor
 // (no state touched) -- all-reduce(sum) them over the ranks -- then one shared decay and the count-times update.
 hipError_t launch_spectrogram_counts(uint32_t* counts, const float* in, uint64_t in_offset, uint64_t batches,

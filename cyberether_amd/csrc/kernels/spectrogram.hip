@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void spectrogram_apply_counts_kernel(float* __
 }
 
 
-// The Spectrogram fed with ROW INDICES instead of values: `idx` is the U8[batches][width] side output of the fused
+// The Spectrogram fed with ROW INDICES instead of values: `idx` is the tile-major U8[width / 128][batches][128] side output of the fused
 // spectrum kernel (fft_lds.hh: StoreAmplitudeRangeSideT) -- per sample the index `(u32)(value * height)` the loop of
 // spectrogram/module_impl_native_cpu.cc:70-77 would form, 0 where it does not hit.  One workgroup per tile of 16
 // columns as above, but a thread takes whole ROWS of the tile: one 16-byte request per row instead of sixteen 4-byte
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void spectrogram_apply_counts_kernel(float* __
 // flight -- and the dispatch of the value kernel's 4096 wavefronts was ~40 % of its 7 us.  Lane l starts at column
 // l % 16 and walks the tile cyclically: the 16 lanes of one LDS-atomic group always hold 16 different columns (no bank
 // shared inside a group whatever the rows), and each of the four groups of a wavefront has a histogram copy of its own.
-// width % 16 == 0, height <= 256, batches * width < 2^31.
+// width % 128 == 0 (the indices are tile-major in groups of 128 columns), height <= 256, batches * width < 2^31.
 #ifdef JST_SPEC_TIMELINE  // tools/ubench/spec_index_timeline.hip: wall-clock stamps of workgroup phases (100 MHz)
 unsigned long long* jst_spec_tl_host = nullptr;  // device buffer [workgroups][8], passed as a kernel argument
 #define JST_SPEC_TL_PARAM , unsigned long long* __restrict__ jst_spec_tl
@@ -81,8 +81,8 @@ unsigned long long* jst_spec_tl_host = nullptr;  // device buffer [workgroups][8
 #endif
 template <int COPIES, int kThreads>
 __global__ __launch_bounds__(kThreads) void spectrogram_index_kernel(float* __restrict__ bins, const uint8_t* __restrict__ idx,
-                                                                     uint32_t batches, uint32_t width, uint32_t height,
-                                                                     float decay JST_SPEC_TL_PARAM) {
+                                                                     uint32_t batches, uint32_t pitch, uint32_t width,
+                                                                     uint32_t height, float decay JST_SPEC_TL_PARAM) {
     constexpr uint32_t TW = 16;
     extern __shared__ __attribute__((aligned(64))) unsigned char smem_raw[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);  // [COPIES][height][TW] (+8 words between copies)
@@ -105,13 +105,19 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_kernel(float* __re
     constexpr uint32_t kRows = 1024 / kThreads;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t r_idx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(idx), 0, batches * width, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(idx), 0, pitch * width, 0x00020000);
+    // tile-major indices (fft_lds.hh: StoreAmplitudeRangeSideT): U8[width / 128][batches][128], this tile's 16 bytes of row r at
+#ifdef JST_SIDE_ROW_MAJOR  // A/B switch (fft_lds.hh)
+    const uint32_t tile_base = tile * TW, row_bytes = width;
+#else
+    const uint32_t tile_base = (tile >> 3) * pitch * 128u + (tile & 7u) * TW, row_bytes = 128u;
+#endif
     v4u q[kRows];
     auto request = [&](uint32_t first_row) {
 #pragma unroll
         for (uint32_t r = 0; r < kRows; ++r) {
             const uint32_t row = first_row + tid + r * kThreads;  // a row that does not exist reads as 0: no hits
-            q[r] = __builtin_amdgcn_raw_buffer_load_b128(r_idx, row < batches ? row * width + tile * TW : 0xfffffff0u, 0, 0);
+            q[r] = __builtin_amdgcn_raw_buffer_load_b128(r_idx, row < batches ? tile_base + row * row_bytes : 0xfffffff0u, 0, 0);
         }
     };
     request(0);
@@ -173,17 +179,31 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_kernel(float* __re
 
 
 // The index-fed Spectrogram over SEVERAL consecutive compute cycles in one launch (a cycle-batched runtime: the fused
-// spectrum kernel of `cycles` ring slots ran as one launch and left `cycles` index tensors U8[batches][width] one behind
+// spectrum kernel of `cycles` ring slots ran as one launch and left `cycles` index tensors (tile-major, as above) one behind
 // the other).  What spectrogram/module_impl_native_cpu.cc:61-87 does per cycle -- decay every bin by 0.999^batches, then
 // min(v + 0.02f, 1.0f) once per hit -- happens here cycle after cycle on a state tile that STAYS IN REGISTERS: the state
 // is read once and written once per launch instead of once per cycle, a launch (4096 wavefronts to dispatch, ~3 us) is
 // paid once per span, and the next cycle's rows are in flight while this cycle's are counted.  Per cycle: the atomics,
 // a barrier, every thread reads AND zeroes the counts of its own cells (no clear pass, no barrier between the two), a
 // barrier.  Bit-identical to `cycles` launches of spectrogram_index_kernel by construction (same counts, same update).
+#ifdef JST_SPAN_TIMELINE  // tools/ubench/spec_span_timeline.hip: shader-clock cycles per phase, summed per wavefront
+unsigned long long* jst_span_tl_host = nullptr;  // device buffer [workgroups][16 waves][8 phases]
+#define JST_SPAN_TL_PARAM , unsigned long long* __restrict__ jst_span_tl
+#define JST_SPAN_TL_ARG , jst_span_tl_host
+#define JST_SPAN_T0() unsigned long long jst_tl_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long jst_tl_t = __builtin_readcyclecounter()
+#define JST_SPAN_MARK(ph) do { const unsigned long long n_ = __builtin_readcyclecounter(); jst_tl_acc[ph] += n_ - jst_tl_t; jst_tl_t = n_; } while (0)
+#define JST_SPAN_DUMP() do { if ((threadIdx.x & 63u) == 0u) for (int p_ = 0; p_ < 8; ++p_) jst_span_tl[(blockIdx.x * 16u + (threadIdx.x >> 6)) * 8u + p_] = jst_tl_acc[p_]; } while (0)
+#else
+#define JST_SPAN_TL_PARAM
+#define JST_SPAN_TL_ARG
+#define JST_SPAN_T0() do {} while (0)
+#define JST_SPAN_MARK(ph) do {} while (0)
+#define JST_SPAN_DUMP() do {} while (0)
+#endif
 template <int COPIES, int kThreads>
 __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float* __restrict__ bins, const uint8_t* __restrict__ idx,
-                                                                          uint32_t batches, uint32_t width, uint32_t height,
-                                                                          float decay, uint32_t cycles) {
+                                                                          uint32_t batches, uint32_t pitch, uint32_t width,
+                                                                          uint32_t height, float decay, uint32_t cycles JST_SPAN_TL_PARAM) {
     constexpr uint32_t TW = 16;
     extern __shared__ __attribute__((aligned(64))) unsigned char smem_raw[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
@@ -203,19 +223,41 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
 
     constexpr uint32_t kRows = 1024 / kThreads;
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    const uint32_t cycle_bytes = batches * width;
+    const uint32_t cycle_bytes = pitch * width;
     const __amdgpu_buffer_rsrc_t r_idx =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(idx), 0, cycles * cycle_bytes, 0x00020000);
-    v4u q[kRows];
-    auto request = [&](uint32_t cycle, uint32_t first_row) {
+    // A ROUND is 1024 rows of one cycle; rounds are numbered through the whole span.  Several register sets take the rounds
+    // in turn (the loop below is unrolled over them): with ONE set refilled inside the loop hipcc keeps the rows being
+    // counted in a copy made at the END of the previous iteration, i.e. behind `s_waitcnt vmcnt(0)` on the request
+    // just issued -- the round trip to the index tensor was exposed in every cycle (4.2 us per cycle and workgroup).
+#ifdef JST_SIDE_ROW_MAJOR
+    const uint32_t tile_base = tile * TW, row_bytes = width;
+#else
+    const uint32_t tile_base = (tile >> 3) * pitch * 128u + (tile & 7u) * TW, row_bytes = 128u;  // tile-major indices, see spectrogram_index_kernel
+#endif
+    const uint32_t rounds_per_cycle = (batches + 1023u) >> 10;
+    const uint32_t total_rounds = cycles * rounds_per_cycle;
+    uint32_t req_cycle = 0, req_first = 0;  // the next round to request
+    auto request = [&](v4u (&dst)[kRows]) {
 #pragma unroll
         for (uint32_t r = 0; r < kRows; ++r) {
-            const uint32_t row = first_row + tid + r * kThreads;  // a row that does not exist reads as 0: no hits
-            q[r] = __builtin_amdgcn_raw_buffer_load_b128(
-                r_idx, (row < batches && cycle < cycles) ? cycle * cycle_bytes + row * width + tile * TW : 0xfffffff0u, 0, 0);
+            const uint32_t row = req_first + tid + r * kThreads;  // a row (or a round) that does not exist reads as 0: no hits
+            dst[r] = __builtin_amdgcn_raw_buffer_load_b128(
+                r_idx, (row < batches && req_cycle < cycles) ? req_cycle * cycle_bytes + tile_base + row * row_bytes : 0xfffffff0u, 0, 0);
+        }
+        req_first += 1024u;
+        if (req_first >= batches) {
+            req_first = 0u;
+            ++req_cycle;
         }
     };
-    request(0, 0);
+    // Four register sets, requests three rounds ahead: behind the fused kernel of a batched span the index tensors come
+    // from HBM (64 MiB written beside 256 MiB of values: little of it is left in the Infinity Cache), and one round of
+    // counting (< 2 us) does not cover that round trip.
+    v4u q0[kRows], q1[kRows], q2[kRows], q3[kRows];
+    request(q0);
+    request(q1);
+    request(q2);
     for (uint32_t e = tid * 4u; e < copy_stride * COPIES; e += kThreads * 4u)
         *reinterpret_cast<uint4*>(hist + e) = make_uint4(0u, 0u, 0u, 0u);
     lds_only_barrier();
@@ -224,32 +266,35 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
     const uint32_t my_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)hist +
                              ((tid >> 4) % COPIES) * copy_stride * 4u;
     typedef __attribute__((address_space(3))) uint32_t* lds_u32;
-    for (uint32_t c = 0; c < cycles; ++c) {
-        for (uint32_t first = 0; first < batches; first += 1024u) {
-            v4u cur[kRows];
+    auto count_rows = [&](const v4u (&cur)[kRows]) {
 #pragma unroll
-            for (uint32_t r = 0; r < kRows; ++r) cur[r] = q[r];
-            // the next round's rows (this cycle's, or the next cycle's first) are requested before these are counted
-            if (first + 1024u < batches) request(c, first + 1024u);
-            else request(c + 1u, 0u);
+        for (uint32_t r = 0; r < kRows; ++r) {
+            const bool r1 = (rot & 4u) != 0u, r2 = (rot & 8u) != 0u;
+            const uint32_t a0 = r1 ? cur[r].y : cur[r].x, a1 = r1 ? cur[r].z : cur[r].y, a2 = r1 ? cur[r].w : cur[r].z,
+                           a3 = r1 ? cur[r].x : cur[r].w;
+            const uint32_t b0 = r2 ? a2 : a0, b1 = r2 ? a3 : a1, b2 = r2 ? a0 : a2, b3 = r2 ? a1 : a3;
+            const uint32_t sh = rot & 3u;
+            const uint32_t g[4] = {__builtin_amdgcn_alignbyte(b1, b0, sh), __builtin_amdgcn_alignbyte(b2, b1, sh),
+                                   __builtin_amdgcn_alignbyte(b3, b2, sh), __builtin_amdgcn_alignbyte(b0, b3, sh)};
 #pragma unroll
-            for (uint32_t r = 0; r < kRows; ++r) {
-                const bool r1 = (rot & 4u) != 0u, r2 = (rot & 8u) != 0u;
-                const uint32_t a0 = r1 ? cur[r].y : cur[r].x, a1 = r1 ? cur[r].z : cur[r].y, a2 = r1 ? cur[r].w : cur[r].z,
-                               a3 = r1 ? cur[r].x : cur[r].w;
-                const uint32_t b0 = r2 ? a2 : a0, b1 = r2 ? a3 : a1, b2 = r2 ? a0 : a2, b3 = r2 ? a1 : a3;
-                const uint32_t sh = rot & 3u;
-                const uint32_t g[4] = {__builtin_amdgcn_alignbyte(b1, b0, sh), __builtin_amdgcn_alignbyte(b2, b1, sh),
-                                       __builtin_amdgcn_alignbyte(b3, b2, sh), __builtin_amdgcn_alignbyte(b0, b3, sh)};
-#pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) {
-                    const uint32_t i = (g[j >> 2] >> (8u * (j & 3u))) & 0xffu;
-                    const uint32_t addr = (i << 6) + ((((rot + j) & 15u) << 2) | my_base);
-                    __hip_atomic_fetch_add((lds_u32)(uintptr_t)addr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+            for (uint32_t j = 0; j < 16; ++j) {
+                const uint32_t i = (g[j >> 2] >> (8u * (j & 3u))) & 0xffu;
+                const uint32_t addr = (i << 6) + ((((rot + j) & 15u) << 2) | my_base);
+#if defined(JST_SPAN_DIAG_NOATOMICS)  // timing diagnostics only
+                if (addr == 0xffffffffu) hist[j] = i;
+#else
+                __hip_atomic_fetch_add((lds_u32)(uintptr_t)addr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
             }
         }
+    };
+    // End of a cycle: every thread reads AND zeroes the counts of its own cells (cells past the tile alias cell 0, whose
+    // count -- row 0, the samples that do not hit -- nobody uses), then the cycle's decay and hit update on the registers.
+    JST_SPAN_T0();
+    auto end_cycle = [&]() {
+        JST_SPAN_MARK(1);  // rows counted (incl. the wait for them)
         lds_only_barrier();
+        JST_SPAN_MARK(2);  // barrier: every wavefront's atomics are in
         uint32_t k[kCells];
 #pragma unroll
         for (uint32_t j = 0; j < kCells; ++j) {
@@ -258,14 +303,51 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
 #pragma unroll
             for (int cp = 0; cp < COPIES; ++cp) {
                 n += hist[cp * copy_stride + e];
-                if (tid + j * kThreads < cells) hist[cp * copy_stride + e] = 0u;  // this thread's own cells: cleared for the next cycle
+                hist[cp * copy_stride + e] = 0u;
             }
             if (e < TW) n = 0u;
             k[j] = n < 64u ? n : 64u;
         }
+        JST_SPAN_MARK(3);  // counts read and zeroed
         lds_only_barrier();
+        JST_SPAN_MARK(4);  // barrier
+#if defined(JST_SPAN_DIAG_NOHITS)  // timing diagnostics only (tools/ubench/spec_span_timeline.hip)
+#pragma unroll
+        for (uint32_t j = 0; j < kCells; ++j) state[j] = state[j] * decay + (float)k[j];
+#else
 #pragma unroll
         for (uint32_t j = 0; j < kCells; ++j) state[j] = apply_hits(state[j] * decay, k[j]);
+#endif
+        JST_SPAN_MARK(5);  // decay + hits
+    };
+    uint32_t in_cycle = 0;
+    auto round_done = [&]() {
+        if (++in_cycle == rounds_per_cycle) {
+            in_cycle = 0;
+            end_cycle();
+        }
+    };
+    for (uint32_t round = 0; round < total_rounds; round += 4u) {
+        // every request is issued whether or not its round exists (beyond the span it reads as zeros and is never
+        // counted): conditional requests make hipcc's vmcnt bookkeeping conservative, i.e. the prefetch shallower
+        request(q3);
+        count_rows(q0);
+        round_done();
+        request(q0);
+        if (round + 1u < total_rounds) {
+            count_rows(q1);
+            round_done();
+        }
+        request(q1);
+        if (round + 2u < total_rounds) {
+            count_rows(q2);
+            round_done();
+        }
+        request(q2);
+        if (round + 3u < total_rounds) {
+            count_rows(q3);
+            round_done();
+        }
     }
 #pragma unroll
     for (uint32_t j = 0; j < kCells; ++j) {
@@ -273,6 +355,8 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
         if (e >= cells) continue;
         store_state(bins + (uint64_t)(e / TW) * width + tile * TW + (e % TW), state[j]);
     }
+    JST_SPAN_MARK(6);
+    JST_SPAN_DUMP();
 }
 
 }  // namespace
@@ -335,12 +419,13 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
 bool spectrogram_index_supported(uint64_t batches, uint64_t width, uint64_t height) {
     // < 2^31 bytes of indices: a row that does not exist is requested at byte offset 0xfffffff0, which must lie beyond the
     // descriptor's range for every accepted shape
-    return width > 0 && width % 16 == 0 && height >= 2 && height <= 256 && batches > 0 && batches * width < (1ull << 31);
+    return width > 0 && width % 128 == 0 && height >= 2 && height <= 256 && batches > 0 && batches * width < (1ull << 31);
 }
 
-hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t batches, uint64_t width, uint64_t height,
-                                    float decay, hipStream_t stream) {
-    if (!spectrogram_index_supported(batches, width, height)) return hipErrorInvalidValue;
+hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t batches, uint64_t pitch, uint64_t width,
+                                    uint64_t height, float decay, hipStream_t stream) {
+    if (!spectrogram_index_supported(batches, width, height) || pitch < batches || pitch * width >= (1ull << 31))
+        return hipErrorInvalidValue;
     const size_t lds = ((size_t)height * 16 + 16) * 4 * sizeof(uint32_t);  // four copies, 64-byte aligned
     static const int threads = [] {  // A/B switch: JST_SPEC_INDEX_THREADS = 256 | 512 | 1024
         const char* e = getenv("JST_SPEC_INDEX_THREADS");
@@ -353,7 +438,7 @@ hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t ba
                                                80 * 1024);                                                           \
         if (e != hipSuccess) return e;                                                                               \
         hipLaunchKernelGGL((spectrogram_index_kernel<4, THREADS>), dim3((unsigned)(width / 16)), dim3(THREADS), lds, \
-                           stream, bins, idx, (uint32_t)batches, (uint32_t)width, (uint32_t)height,                  \
+                           stream, bins, idx, (uint32_t)batches, (uint32_t)pitch, (uint32_t)width, (uint32_t)height, \
                            decay JST_SPEC_TL_ARG);                                                                   \
     } while (0)
     if (threads == 1024) JST_SPEC_INDEX(1024);
@@ -363,20 +448,36 @@ hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t ba
     return hipGetLastError();
 }
 
-// `cycles` consecutive index tensors U8[batches][width] behind `idx` (a cycle-batched span), one launch.
+// `cycles` consecutive index tensors behind `idx` (a cycle-batched span), one launch.
 bool spectrogram_index_span_supported(uint64_t batches, uint64_t width, uint64_t height, uint64_t cycles) {
     return cycles >= 1 && spectrogram_index_supported(batches, width, height) && cycles * batches * width < (1ull << 31);
 }
 
-hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64_t batches, uint64_t width, uint64_t height,
-                                         float decay, uint64_t cycles, hipStream_t stream) {
-    if (!spectrogram_index_span_supported(batches, width, height, cycles)) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)height * 16 + 16) * 4 * sizeof(uint32_t);
+hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64_t batches, uint64_t pitch, uint64_t width,
+                                         uint64_t height, float decay, uint64_t cycles, hipStream_t stream) {
+    if (!spectrogram_index_span_supported(batches, width, height, cycles) || pitch < batches ||
+        cycles * pitch * width >= (1ull << 31))
+        return hipErrorInvalidValue;
+    static const int copies = [] {  // A/B switch: JST_SPEC_SPAN_COPIES = 1 | 2 | 4 private histogram copies per workgroup
+        const char* e = getenv("JST_SPEC_SPAN_COPIES");
+        const int c = e ? atoi(e) : 4;
+        return c == 1 || c == 2 ? c : 4;
+    }();
+    const size_t lds = ((size_t)height * 16 + 16) * (size_t)copies * sizeof(uint32_t);
     (void)hipGetLastError();
-    const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(spectrogram_index_span_kernel<4, 1024>), 80 * 1024);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((spectrogram_index_span_kernel<4, 1024>), dim3((unsigned)(width / 16)), dim3(1024), lds, stream, bins,
-                       idx, (uint32_t)batches, (uint32_t)width, (uint32_t)height, decay, (uint32_t)cycles);
+#define JST_SPEC_SPAN(COPIES)                                                                                             \
+    do {                                                                                                                  \
+        const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(spectrogram_index_span_kernel<COPIES, 1024>), \
+                                               80 * 1024);                                                                \
+        if (e != hipSuccess) return e;                                                                                    \
+        hipLaunchKernelGGL((spectrogram_index_span_kernel<COPIES, 1024>), dim3((unsigned)(width / 16)), dim3(1024), lds,  \
+                           stream, bins, idx, (uint32_t)batches, (uint32_t)pitch, (uint32_t)width, (uint32_t)height,      \
+                           decay, (uint32_t)cycles JST_SPAN_TL_ARG);                                                      \
+    } while (0)
+    if (copies == 1) JST_SPEC_SPAN(1);
+    else if (copies == 2) JST_SPEC_SPAN(2);
+    else JST_SPEC_SPAN(4);
+#undef JST_SPEC_SPAN
     return hipGetLastError();
 }
 

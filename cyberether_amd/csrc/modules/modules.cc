@@ -1031,7 +1031,8 @@ Result Spectrogram::computeSubmit(hipStream_t stream) {
             "spectrogram counts kernel");
     if (indexFed)
         return hip_result(kernels::launch_spectrogram_index(ptr<float>(frequencyBins), static_cast<const uint8_t*>(rowIndices.data()),
-                                                            numberOfBatches, numberOfElements, height, decayFactor, stream),
+                                                            numberOfBatches, rowIndices.shape(0), numberOfElements, height,
+                                                            decayFactor, stream),
                           "spectrogram kernel (row indices)");
     return hip_result(
         kernels::launch_spectrogram(ptr<float>(frequencyBins), ptr<const float>(input),
@@ -1053,8 +1054,8 @@ Result Spectrogram::computeSubmitSpan(hipStream_t stream, U64 first_slot, U64 n)
         while (!kernels::spectrogram_index_span_supported(numberOfBatches, numberOfElements, height, run) && run > 1) run /= 2;
         JST_CHECK(hip_result(kernels::launch_spectrogram_index_span(ptr<float>(frequencyBins),
                                                                     static_cast<const uint8_t*>(rowIndices.ringSlotData(slot)),
-                                                                    numberOfBatches, numberOfElements, height, decayFactor,
-                                                                    run, stream),
+                                                                    numberOfBatches, rowIndices.shape(0), numberOfElements, height,
+                                                                    decayFactor, run, stream),
                              "spectrogram kernel (row indices, cycle-batched span)"));
         slot = (slot + run) % ring;
         n -= run;
@@ -1604,7 +1605,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
             kernels::spectrum_side_supported(n, L, (int64_t)win.stride(axis), only->height) &&
             kernels::spectrogram_index_supported(only->numberOfBatches, n, only->height) &&
             (!cast || sig.stride(1) == 1) &&
-            only->rowIndices.create(DeviceType::HIP, DataType::U8, {sig.shape(0), n}) == Result::SUCCESS) {
+            only->rowIndices.create(DeviceType::HIP, DataType::U8, {kernels::spectrum_side_pitch(sig.shape(0)), n}) == Result::SUCCESS) {
             fed = only;
             fed->indexFed = true;
             name += "+indices";
@@ -1669,7 +1670,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                             !cast ? 0 : (it == DataType::CI16 ? 1 : (it == DataType::CI8 ? 2 : 3)), cast ? cast->scaler : 1.0f,
                             static_cast<const float2*>(win.data()) + win.offset(), static_cast<float*>(out.ringSlotData(slot)),
                             amp->scalingCoeff, rng->scalingCoeff, rng->offsetCoeff, fast, guard0, guard1,
-                            static_cast<uint8_t*>(fed->rowIndices.ringSlotData(slot)), fed->height, stream),
+                            static_cast<uint8_t*>(fed->rowIndices.ringSlotData(slot)), fed->height, sig.shape(0), fed->rowIndices.shape(0), stream),
                         "fused spectrum kernel (+ row indices, cycle-batched span)"));
                     slot = (slot + run) % ring;
                     cycles -= run;
@@ -1725,7 +1726,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                     !cast ? 0 : (it == DataType::CI16 ? 1 : (it == DataType::CI8 ? 2 : 3)), cast ? cast->scaler : 1.0f,
                     static_cast<const float2*>(win.data()) + win.offset(), static_cast<float*>(out.data()),
                     amp->scalingCoeff, rng->scalingCoeff, rng->offsetCoeff, fast, guard0, guard1,
-                    static_cast<uint8_t*>(fed->rowIndices.data()), fed->height, stream),
+                    static_cast<uint8_t*>(fed->rowIndices.data()), fed->height, sig.shape(0), fed->rowIndices.shape(0), stream),
                 "fused spectrum kernel (+ row indices)");
         }
         if (cast) {  // raw samples: same dense shape as the cast's output, element strides therefore equal

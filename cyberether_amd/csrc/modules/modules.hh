@@ -232,7 +232,7 @@ class Spectrogram : public Module {
     // spectrogram (the flush at the end of a compute call runs it).
     // Fed with ROW INDICES by the fused spectrum unit that produces its input (TryFuseSpectrum, allow_side): the unit
     // writes, beside every F32 value, the one-byte index this module would derive from it into `rowIndices`
-    // (U8 {batches, width}, 0 = no hit), and computeSubmit reads those instead of the values
+    // (U8, batches * width bytes, TILE-MAJOR [width / 128][batches][128], 0 = no hit), and computeSubmit reads those instead of the values
     // (kernels::launch_spectrogram_index).  Same state, bit for bit; a decision of the runtime's planner, reset by it.
     bool indexFed = false;
     Tensor rowIndices;

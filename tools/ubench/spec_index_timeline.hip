@@ -37,9 +37,9 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 50; ++i) jst::kernels::launch_spectrogram_index(d_bins, d_idx, B, N, H, 0.36f, nullptr);
+    for (int i = 0; i < 50; ++i) jst::kernels::launch_spectrogram_index(d_bins, d_idx, B, B, N, H, 0.36f, nullptr);
     hipEventRecord(e0);
-    for (int i = 0; i < 200; ++i) jst::kernels::launch_spectrogram_index(d_bins, d_idx, B, N, H, 0.36f, nullptr);
+    for (int i = 0; i < 200; ++i) jst::kernels::launch_spectrogram_index(d_bins, d_idx, B, B, N, H, 0.36f, nullptr);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms = 0;
