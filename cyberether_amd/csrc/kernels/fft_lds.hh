@@ -428,6 +428,7 @@ struct StoreAmplitudeRangeSideT : StoreAmplitudeRangeT<FAST> {
         const float f = y * side_height;
         const uint32_t u = voff >> 2;
 #ifdef JST_SIDE_ROW_MAJOR
+        (void)IN_BASE;
         buf_store_u8(rs, u, soff >> 2, (f >= 1.0f && f < side_height) ? (uint32_t)f : 0u);
 #else
         const uint32_t lane_off = IN_BASE ? (u & 127u) : (u >> 7) * (side_pitch * 128u) + (u & 127u);
@@ -685,9 +686,12 @@ template <int N, bool CONTIG, class Pro = LoadCF32>
 constexpr bool pipe_load16() {
     return JST_LOAD16 && CONTIG && make_plan(N).ip[0] == 8 && Pro::kRawBytes == 8;
 }
+// (not for an epilogue with a side output: with the four indices of a lane packed into one dword store beside the 16-byte
+// store the side kernel measured 196.5 vs 188.6 us per 16384-transform launch, tools/ubench/run_r03v.sh)
 template <int N, bool CONTIG, class Epi>
 constexpr bool pipe_store16() {
-    if constexpr (JST_STORE16 && CONTIG && Epi::kElemBytes == 4 && (make_plan(N).ip[make_plan(N).nf - 1] % 4) == 0)
+    if constexpr (epi_has_side<Epi>()) return false;
+    else if constexpr (JST_STORE16 && CONTIG && Epi::kElemBytes == 4 && (make_plan(N).ip[make_plan(N).nf - 1] % 4) == 0)
         return requires(const Epi& e, float2 v) { e.value(v); };
     else
         return false;
@@ -1096,7 +1100,8 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
         const rsrc_t r_out = make_rsrc(epi.row(out_base), (uint32_t)N * Epi::kElemBytes);
         const rsrc_t r_opnd_next = make_rsrc(pro.operand_row(), (more && !(REALOP && wave_real)) ? (uint32_t)N * 8u : 0u);
         rsrc_t r_side = r_out;  // unused unless the epilogue has a side output
-        if constexpr (CONTIG && epi_has_side<Epi>()) r_side = epi.template side_rsrc<kSideGroupInBase<N, T>>(t, (uint32_t)N, tid);
+        if constexpr (CONTIG && epi_has_side<Epi>())
+            r_side = epi.template side_rsrc<kSideGroupInBase<N, T>>(t, (uint32_t)N, tid);
 #ifdef JST_FB_SKIP_PASSES  // decomposition experiment (tools/ubench/fused_bench.hip): last pass + epilogue only
         pipe_passes<N, T, FWD, CONTIG, plan.nf - 1, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
                                                               L.out_axis_stride, epi, pro, opnd,

@@ -12,6 +12,14 @@
 #ifndef JST_LOAD_AUX
 #define JST_LOAD_AUX 2
 #endif
+// The window operand stays RESIDENT in 16 VGPRs instead of being re-requested from L2 behind every retired output
+// (fft_lds.hh: JST_OPND_RESIDENT).  Per 1024-transform launch that was a wash (the launch is bound by its ramp and tail,
+// DESIGN.md section 4); in the steady state of a cycle-batched launch it is not: 188.6 -> 178.0 us per 16384 transforms
+// (fast; exact 253.3 -> 250.6), same box, bit-identical (tools/ubench/run_r03v.sh).  Re-checked there and left as they
+// were: 16-byte loads (195.9), no wave priorities (201.1), two other priority sets (193.5), the real-operand form (193.0).
+#ifndef JST_OPND_RESIDENT
+#define JST_OPND_RESIDENT 1
+#endif
 #include "fft_lds.hh"
 #include "kernels.hh"
 

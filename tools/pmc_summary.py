@@ -40,18 +40,23 @@ if traffic_json:
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from kernel_hash import kernel_sources_sha256
     provider = sys.argv[5] if len(sys.argv) > 5 and sys.argv[4] == "--provider" else "generic"
+    # --cycles N: the profiled run was cycle-batched, its full launches carry N compute cycles each (bench.py quotes the
+    # figure only for a run with the same launch form)
+    cycles = int(sys.argv[7]) if len(sys.argv) > 7 and sys.argv[6] == "--cycles" else 1
     # StoreAmplitudeRangeT<..> or, with the Spectrogram's row indices as a side output, StoreAmplitudeRangeSideT<..>
     tag = "T<true>" if provider == "fast" else "T<false>"
     pick = [k for k in acc if "fft_pipe_kernel<4096" in k and "LoadCF32TimesWindow" in k and "StoreAmplitudeRange" in k and tag in k]
     if not pick or "FETCH_SIZE" not in acc[pick[0]] or "WRITE_SIZE" not in acc[pick[0]]:
         sys.exit("no FETCH_SIZE / WRITE_SIZE pass for the fused spectrum kernel (" + provider + ") under " + root)
     k = pick[0]
-    mean = lambda c: (lambda v: sum(v[len(v) // 4:]) / len(v[len(v) // 4:]))(acc[k][c])
+    # full launches only: a cycle-batched run also holds a few shorter launches (the settle cycle, span heads and tails)
+    full = lambda c: [x for x in acc[k][c] if x >= 0.9 * max(acc[k][c])]
+    mean = lambda c: sum(full(c)) / len(full(c))
     fetch_kib, write_kib = mean("FETCH_SIZE"), mean("WRITE_SIZE")
     rec = {"spectrum_fused_hbm_bytes_per_launch": int(round((2.0 * fetch_kib + write_kib) * 1024.0)),
            "source": "pmc-file", "written_by": "tools/pmc_summary.py --traffic-json", "passes_dir": root,
            "kernel": k[:200], "fetch_size_kib_mean": fetch_kib, "write_size_kib_mean": write_kib,
-           "launches": len(acc[k]["FETCH_SIZE"]),
+           "launches": len(full("FETCH_SIZE")), "cycles_per_launch": cycles,
            "correction": "FETCH_SIZE x 2 (gfx950 tallies 128-B requests of a streaming read at 64 B, "
                          "MI355X_MICROARCH.md section HBM; the doubled value reproduces the known 32 MiB input + tables to "
                          "0.1 %), WRITE_SIZE as reported",
