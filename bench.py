@@ -7,13 +7,22 @@ one compute cycle over one batch tensor CF32[1024, 4096] that is ALREADY RESIDEN
 of `--slots` distinct batches (default 16 x 32 MiB = 512 MiB, larger than the 256 MiB Infinity
 Cache, so every step's input really comes from HBM).
 
+Cycle batching (default; `--no-batch` and `alt_per_cycle_launch` are the other form): the runtime captures a ring period of 16
+cycles into its graph anyway, and with all 16 slots resident it submits them as ONE launch per unit -- the persistent fused
+kernel over 16 x 1024 transforms, the Spectrogram over the 16 index tensors with its state in registers -- instead of 16
+launches each (JST_RUNTIME_BATCH).  Every step is still one pass over one CF32[1024, 4096] batch: its
+range output lands in its slot of the output ring, the Spectrogram state takes that cycle's decay and hit update, and the
+parity leg checks both per cycle; what changes is that the kernel's ramp, cold start and tail are paid once per 16 steps.
+`roofline` prices the launch that is timed: cycles_per_launch x 50.33 MB over its event-pair duration.
+
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (the fused spectrum kernel): algorithmic bytes per launch
-                  (12 B per complex sample: 8 B cf32 read + 4 B f32 write) over its
-                  mean launch duration measured with hipEvent pairs recorded on the runtime's own
-                  stream inside the timed region (in-graph event nodes).
+                  (12 B per complex sample: 8 B cf32 read + 4 B f32 write; a cycle-batched
+                  launch carries cycles_per_launch x 1024 transforms) over its mean launch duration measured
+                  with hipEvent pairs recorded on the runtime's own stream inside the timed region (every
+                  sixteenth ring period is submitted eagerly between real event records).
   cpu_baseline -- the reference's CPU path timed on this host: dense C loops per stage (oracle/jst_oracle.c),
                   the FFT through the reference's OWN pocketfft (oracle/_ref, kind "reference"; the C
                   restatement, kind "port", only when that library is absent), nanobench-style like
@@ -480,9 +489,10 @@ def main() -> None:
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": traffic, "traffic_provenance": traffic_src, "kernel_ms": kernel_ms,
                          "kernel_ms_method": "hipEvent pair on the runtime's stream around the kernel's eager launches "
-                                             "inside the timed region (one cycle of every 16th ring period), minus half "
-                                             "of an empty pair measured the same way; rocprofv3's per-dispatch mean "
-                                             "(profiles/) is the cross-check, not this number's source",
+                                             "inside the timed region (every 16th ring period: one cycle of it, or -- cycle "
+                                             "batching -- the whole period as one launch per unit), minus half of an empty "
+                                             "pair measured the same way; rocprofv3's per-dispatch mean (profiles/) is the "
+                                             "cross-check, not this number's source",
                          "kernel_ms_event_pair_raw": kernel_ms_raw,
                          "event_pair_overhead_ms": pair_ms,
                          "algorithmic_bytes_per_launch": algo_bytes * cycles_per_launch,
