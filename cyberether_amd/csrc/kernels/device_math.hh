@@ -348,10 +348,13 @@ __device__ __forceinline__ float range_f32_fast(float v, float scale, float offs
 struct BinGuard {
     float h0 = 0.0f, h1 = 0.0f;  // consumer heights (0 = none)
 };
-__device__ __forceinline__ bool near_bin_edge(float r, float h) {
-    const float f = r * h, fr = f - __builtin_floorf(f);  // v_fract_f32
+// f = r * h, already formed.  v_fract_f32 (for finite f >= 0 it IS f - floor(f): that difference is exact and below 1, so the
+// instruction's clamp never acts; written as `f - floorf(f)` hipcc emits v_floor + v_sub because it cannot know the sign).
+__device__ __forceinline__ bool near_bin_edge_of(float f, float h) {
+    const float fr = __builtin_amdgcn_fractf(f);
     return f >= 0.5f && __builtin_fabsf(fr - 0.5f) > 0.5f - h * 7.5e-7f;
 }
+__device__ __forceinline__ bool near_bin_edge(float r, float h) { return near_bin_edge_of(r * h, h); }
 // One out-of-line copy of the exact arithmetic serves the rare guarded elements (amplitude_range_from_power_cold,
 // above).  Everything from the power p = re^2 + im^2 on is a function of ONE float, identical in both providers up to
 // p, so the guarantee "guarded fast value and exact value fall into the same Spectrogram bin" is checked on
@@ -391,14 +394,20 @@ __device__ __forceinline__ float amplitude_range_lean(float p, const FastRangePo
     const float z = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(q.k3, f, q.k2), f, q.k1), f, tail);
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));  // 2^z = inf -> 0, 2^z = 0 -> 1
 }
+// f0 receives value * g.h0 (the product the first consumer's quantiser forms: the side-output epilogue of fft_lds.hh takes
+// its row index from it instead of multiplying again); undefined when g.h0 == 0.
 __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p, float coeff, float scale,
                                                                          float offset, const BinGuard& g,
-                                                                         const FastRangePoly& q) {
-    if (scale == 0.0f) return 0.5f;  // wave-uniform
+                                                                         const FastRangePoly& q, float& f0) {
+    if (scale == 0.0f) {  // wave-uniform
+        f0 = 0.5f * g.h0;
+        return 0.5f;
+    }
     float r = amplitude_range_lean(p, q);
     bool cold = (f2u(p) - kPowerLo) > (kPowerHi - kPowerLo);  // zero, subnormal, huge, inf, NaN: the exact ladder
+    f0 = r * g.h0;
     if (g.h0 > 0.0f) {  // wave-uniform
-        cold |= near_bin_edge(r, g.h0);
+        cold |= near_bin_edge_of(f0, g.h0);
         if (g.h1 > 0.0f) cold |= near_bin_edge(r, g.h1);
     }
     // A guard hit (~2.5 % of the wavefront-elements at height 256) goes through the INLINED exact main path, not through a
@@ -407,11 +416,23 @@ __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p
     // 17.6 -> 16.1 us, same box, same checksum (profiles/r03_experiments/g_fast_guard_inline.log).  The exact kernel's
     // own bail-out (taken never on real spectra) showed no such effect (h_no_calls.log) and stays out of line.
 #if JST_FAST_COLD_INLINE  // A/B switch
-    if (__builtin_expect(cold, 0)) r = amplitude_range_from_power(p, coeff, scale, offset);
+    if (__builtin_expect(cold, 0)) {
+        r = amplitude_range_from_power(p, coeff, scale, offset);
+        f0 = r * g.h0;
+    }
 #else
-    if (__builtin_expect(cold, 0)) r = amplitude_range_from_power_cold(p, coeff, scale, offset);
+    if (__builtin_expect(cold, 0)) {
+        r = amplitude_range_from_power_cold(p, coeff, scale, offset);
+        f0 = r * g.h0;
+    }
 #endif
     return r;
+}
+__device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p, float coeff, float scale,
+                                                                         float offset, const BinGuard& g,
+                                                                         const FastRangePoly& q) {
+    float f0;
+    return amplitude_range_fast_guarded_from_power(p, coeff, scale, offset, g, q, f0);
 }
 __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p, float coeff, float scale,
                                                                          float offset, const BinGuard& g) {

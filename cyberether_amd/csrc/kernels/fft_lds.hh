@@ -268,6 +268,8 @@ struct LoadCF32TimesWindow {
         return window[(int64_t)(upos + lpos) * wstride];
     }
     __device__ __forceinline__ float2 apply(float2 v, float2 w) const { return cmul_full(v, w); }
+    // the same product for a REAL operand (imaginary part +-0), without the terms that are +-0: see RealOperand below
+    __device__ __forceinline__ float2 apply_real(float2 v, float wx) const { return mk(v.x * wx, v.y * wx); }
 };
 
 // Raw SDR sample formats fused in: Cast (CI16 / CI8 / CU8 -> CF32, core/cast/module_impl_native_cpu.cc:150-229:
@@ -318,10 +320,31 @@ struct LoadCITimesWindow {
         return window[(int64_t)(upos + lpos) * wstride];
     }
     __device__ __forceinline__ float2 apply(raw_t v, float2 w) const { return cmul_full(convert(v), w); }
+    __device__ __forceinline__ float2 apply_real(raw_t v, float wx) const {
+        const float2 c = convert(v);
+        return mk(c.x * wx, c.y * wx);
+    }
 };
 using LoadCI16TimesWindow = LoadCITimesWindow<uint32_t, true>;
 using LoadCI8TimesWindow = LoadCITimesWindow<uint16_t, true>;
 using LoadCU8TimesWindow = LoadCITimesWindow<uint16_t, false>;
+
+// A prologue whose Multiply operand is known (on the host) to be REAL -- a window: every imaginary part +-0.  Provider
+// "fast" only (bins exact, floats within tolerance): (a + bi)(c +- 0i) = (ac - b(+-0)) + (a(+-0) + bc)i, and for finite a, b
+// the terms b(+-0), a(+-0) are zeros that change nothing but the sign of a zero result -- ac and bc ARE the products, bit for
+// bit, wherever they are not zero.  A zero's sign can only turn into another zero's sign in the butterflies (sums,
+// differences and products of zeros), and the power re^2 + im^2 the epilogue starts from does not see it: for finite input
+// the output is bit-identical, with two VALU instructions per sample instead of seven (four products, two sums, the
+// unordered test of __mulsc3's recovery branch) -- 40 of ~610 per wavefront and transform in a kernel that is VALU-issue
+// bound in its steady state -- and the imaginary halves of the resident operand are dead: 8 VGPRs.
+// Non-finite input (where inf * 0 = NaN and the recovery branch differ from a real multiply) is outside what provider
+// "fast" promises bit for bit; provider "generic" never uses this.  A SEPARATE instantiation, chosen on the host: with
+// both products in one kernel (decided per wavefront on the device) both operand forms stayed live across the loop --
+// 128 VGPRs + 96 B of scratch, 203 instead of 187 us per 16384-transform launch.
+template <class Pro>
+struct RealOperand : Pro {
+    __device__ __forceinline__ float2 apply(typename Pro::raw_t v, float2 w) const { return Pro::apply_real(v, w.x); }
+};
 
 // ---- epilogues (what happens to CH of the last pass) ------------------------------------------
 struct StoreCF32 {
@@ -420,19 +443,29 @@ struct StoreAmplitudeRangeSideT : StoreAmplitudeRangeT<FAST> {
 #endif
         return make_rsrc(side + (size_t)cycle * side_pitch * n + in_cycle, side_pitch * n - in_cycle);
     }
-    // voff / soff: the F32 store's byte offsets (4 * u, 4 * c * BUT with BUT a multiple of 128)
+    // voff / soff: the F32 store's byte offsets (4 * u, 4 * c * BUT with BUT a multiple of 128).
+    // FAST: guard.h0 == side_height (fft_side.hip puts the fed Spectrogram's height first), so the product value * height
+    // the bin guard formed IS the quantiser's: the index comes from it, no second multiply.  The index rule
+    // `1 <= f < height ? (u32)f : 0` is `f < height ? (u32)f : 0` for f >= 0: the conversion truncates everything below 1 to 0.
     template <bool IN_BASE>
     __device__ __forceinline__ void store_buf_side(rsrc_t r, rsrc_t rs, uint32_t voff, uint32_t soff, float2 v) const {
-        const float y = this->value(v);
+        float y, f;
+        if constexpr (FAST) {
+            y = amplitude_range_fast_guarded_from_power((v.x * v.x) + (v.y * v.y), this->coeff, this->scale, this->offset,
+                                                        this->guard, this->poly, f);
+        } else {
+            y = this->value(v);
+            f = y * side_height;
+        }
         buf_store_f1(r, voff, soff, y);
-        const float f = y * side_height;
+        const uint32_t index = (f < side_height) ? (uint32_t)f : 0u;
         const uint32_t u = voff >> 2;
 #ifdef JST_SIDE_ROW_MAJOR
         (void)IN_BASE;
-        buf_store_u8(rs, u, soff >> 2, (f >= 1.0f && f < side_height) ? (uint32_t)f : 0u);
+        buf_store_u8(rs, u, soff >> 2, index);
 #else
         const uint32_t lane_off = IN_BASE ? (u & 127u) : (u >> 7) * (side_pitch * 128u) + (u & 127u);
-        buf_store_u8(rs, lane_off, (soff >> 2) * side_pitch, (f >= 1.0f && f < side_height) ? (uint32_t)f : 0u);
+        buf_store_u8(rs, lane_off, (soff >> 2) * side_pitch, index);
 #endif
     }
 };

@@ -62,7 +62,10 @@ template <class Pro>
 hipError_t side_with(uint64_t n, const FftLayout& L, const float2* W, const Pro& pro, float* out, float amp_coeff,
                      float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1, uint8_t* side,
                      float side_height, uint32_t side_batches, uint32_t side_pitch, hipStream_t stream) {
-    const StoreAmplitudeRangeSideT<true> ef{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}}, side, side_height, side_batches, side_pitch};
+    // the fed Spectrogram's height first in the guard (the epilogue takes the row index from the guard's own product
+    // value * h0), the other consumer height -- if any -- second
+    const float other = guard_h0 != side_height ? guard_h0 : (guard_h1 != side_height ? guard_h1 : 0.0f);
+    const StoreAmplitudeRangeSideT<true> ef{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{side_height, other}}, side, side_height, side_batches, side_pitch};
     const StoreAmplitudeRangeSideT<false> ee{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}}, side, side_height, side_batches, side_pitch};
     switch (n) {
 #define JST_SIDE_CASE(NN)                                                  \
@@ -103,29 +106,35 @@ bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stri
 hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const float2* W, const void* in, int in_format,
                                       float scaler, const float2* window, float* out, float amp_coeff,
                                       float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1,
-                                      uint8_t* side, uint64_t height, uint64_t side_batches, uint64_t side_pitch, hipStream_t stream) {
+                                      uint8_t* side, uint64_t height, uint64_t side_batches, uint64_t side_pitch, bool real_window,
+                                      hipStream_t stream) {
     // side_batches: the rows of ONE index tensor (a compute cycle's batches); L.transforms is a whole number of them
     if (!spectrum_side_supported(n, L, 1, height) || !side || side_batches == 0 || L.transforms % side_batches != 0 ||
         side_pitch < side_batches || (L.transforms / side_batches) * side_pitch * n >= (1ull << 31))
         return hipErrorInvalidValue;
     const float h = (float)height;
     const float inv = in_format ? 1.0f / scaler : 1.0f;  // a power of two: x / scaler == x * inv, exactly
+    // real_window (host knowledge: every imaginary part of the window is +-0) with provider "fast": the RealOperand
+    // instantiations (fft_lds.hh) -- two products per sample instead of std::complex's full product
+    const bool real = real_window && fast;
+#define JST_SIDE_WITH(PRO)                                                                                             \
+    (real ? side_with(n, L, W, RealOperand<decltype(PRO)>{PRO}, out, amp_coeff, range_scale, range_offset, fast, guard_h0, \
+                      guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, stream)                          \
+          : side_with(n, L, W, PRO, out, amp_coeff, range_scale, range_offset, fast, guard_h0, guard_h1, side, h,       \
+                      (uint32_t)side_batches, (uint32_t)side_pitch, stream))
     switch (in_format) {
         case 0:
-            return side_with(n, L, W, LoadCF32TimesWindow{static_cast<const float2*>(in), window, 1}, out, amp_coeff,
-                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, stream);
+            return JST_SIDE_WITH((LoadCF32TimesWindow{static_cast<const float2*>(in), window, 1}));
         case 1:
-            return side_with(n, L, W, LoadCI16TimesWindow{static_cast<const uint32_t*>(in), window, 1, inv}, out, amp_coeff,
-                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, stream);
+            return JST_SIDE_WITH((LoadCI16TimesWindow{static_cast<const uint32_t*>(in), window, 1, inv}));
         case 2:
-            return side_with(n, L, W, LoadCI8TimesWindow{static_cast<const uint16_t*>(in), window, 1, inv}, out, amp_coeff,
-                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, stream);
+            return JST_SIDE_WITH((LoadCI8TimesWindow{static_cast<const uint16_t*>(in), window, 1, inv}));
         case 3:
-            return side_with(n, L, W, LoadCU8TimesWindow{static_cast<const uint16_t*>(in), window, 1, inv}, out, amp_coeff,
-                             range_scale, range_offset, fast, guard_h0, guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, stream);
+            return JST_SIDE_WITH((LoadCU8TimesWindow{static_cast<const uint16_t*>(in), window, 1, inv}));
         default:
             return hipErrorInvalidValue;
     }
+#undef JST_SIDE_WITH
 }
 
 }  // namespace jst::kernels

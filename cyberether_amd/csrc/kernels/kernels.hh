@@ -178,11 +178,14 @@ hipError_t launch_spectrum_fused_cast(uint64_t n, const FftLayout& L, const floa
 // every store of a row lands on the same few HBM channels: spectrum_side_pitch() picks the pad).
 uint64_t spectrum_side_pitch(uint64_t batches);
 // in_format: 0 = CF32, 1 = CI16, 2 = CI8, 3 = CU8 (scaler as above).  Range is always on; window dense.
+// real_window: the caller KNOWS every imaginary part of the window to be +-0; with provider "fast" the Multiply then runs
+// as two products per sample (fft_lds.hh: RealOperand), bit-identical for finite input.
 bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stride, uint64_t height);
 hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const float2* W, const void* in, int in_format,
                                       float scaler, const float2* window, float* out, float amp_coeff,
                                       float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1,
-                                      uint8_t* side, uint64_t height, uint64_t side_batches, uint64_t side_pitch, hipStream_t stream);
+                                      uint8_t* side, uint64_t height, uint64_t side_batches, uint64_t side_pitch, bool real_window,
+                                      hipStream_t stream);
 // guard_h0/h1 (fast + range only): heights of the Spectrogram modules that will quantise the output;
 // elements whose value * height lies within the fast path's error of a bin edge are computed with the
 // exact arithmetic instead, so the bins equal the exact provider's (dev::BinGuard, device_math.hh).

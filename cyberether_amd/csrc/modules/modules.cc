@@ -1618,6 +1618,35 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     // cycle.  `prepare` (called by Runtime::planBatch once every dynamic unit of the runtime can be batched) turns the
     // range output and the Spectrogram's row indices into rings of as many slots; from then on the per-cycle submit
     // below writes the slot the source exposes, and submit_span covers runs of consecutive slots.
+    // Is the window REAL (every imaginary part +-0)?  Provider "fast" then multiplies it as two products per sample
+    // (kernels.hh: launch_spectrum_fused_side, real_window).  The table is a STATIC tensor that the window chain fills in
+    // the first, eager cycle, on this very stream in front of this unit: the first submission outside a capture waits for
+    // it, reads it back once (n complex values) and remembers the answer; until then the full product is used.
+    auto window_real = std::make_shared<int>(-1);
+    auto know_window = [mul, n, axis, window_real](hipStream_t stream) -> bool {
+        if (*window_real >= 0) return *window_real == 1;
+        const Tensor& win = mul->b;
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+        if (win.stride(axis) != 1 || hipStreamIsCapturing(stream, &status) != hipSuccess ||
+            status != hipStreamCaptureStatusNone)
+            return false;
+        std::vector<float2> host(n);
+        if (hipStreamSynchronize(stream) != hipSuccess ||
+            hipMemcpy(host.data(), static_cast<const float2*>(win.data()) + win.offset(), n * sizeof(float2),
+                      hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        bool real = true;
+        for (const float2& w : host) {
+            uint32_t bits;
+            std::memcpy(&bits, &w.y, sizeof(bits));
+            real &= (bits & 0x7fffffffu) == 0u;
+        }
+        *window_real = real ? 1 : 0;
+        return real;
+    };
+
     auto batched = std::make_shared<bool>(false);
     if (batch && fed) {
         const Tensor in_t = cast ? cast->input : sig;
@@ -1640,7 +1669,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                 return Result::SUCCESS;
             };
             batch->rings = {rng->output, fed->rowIndices};
-            batch->submit_span = [mul, fft, amp, rng, cast, fed, n, fast, guard0, guard1, max_run](hipStream_t stream, U64 first,
+            batch->submit_span = [mul, fft, amp, rng, cast, fed, n, fast, guard0, guard1, max_run, know_window](hipStream_t stream, U64 first,
                                                                                                   U64 cycles) -> Result {
                 const Tensor& sig = mul->a;
                 const Tensor& win = mul->b;
@@ -1670,7 +1699,8 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                             !cast ? 0 : (it == DataType::CI16 ? 1 : (it == DataType::CI8 ? 2 : 3)), cast ? cast->scaler : 1.0f,
                             static_cast<const float2*>(win.data()) + win.offset(), static_cast<float*>(out.ringSlotData(slot)),
                             amp->scalingCoeff, rng->scalingCoeff, rng->offsetCoeff, fast, guard0, guard1,
-                            static_cast<uint8_t*>(fed->rowIndices.ringSlotData(slot)), fed->height, sig.shape(0), fed->rowIndices.shape(0), stream),
+                            static_cast<uint8_t*>(fed->rowIndices.ringSlotData(slot)), fed->height, sig.shape(0), fed->rowIndices.shape(0),
+                            fast && know_window(stream), stream),
                         "fused spectrum kernel (+ row indices, cycle-batched span)"));
                     slot = (slot + run) % ring;
                     cycles -= run;
@@ -1682,7 +1712,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
         }
     }
 
-    submit = [mul, fft, amp, rng, cast, fed, axis, n, fast, tiled, guard0, guard1, batched](hipStream_t stream) -> Result {
+    submit = [mul, fft, amp, rng, cast, fed, axis, n, fast, tiled, guard0, guard1, batched, know_window](hipStream_t stream) -> Result {
         const Tensor& sig = mul->a;
         const Tensor& win = mul->b;
         if (*batched) {  // cycle-batched runtime: this cycle writes the ring slot the source exposes
@@ -1726,7 +1756,8 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                     !cast ? 0 : (it == DataType::CI16 ? 1 : (it == DataType::CI8 ? 2 : 3)), cast ? cast->scaler : 1.0f,
                     static_cast<const float2*>(win.data()) + win.offset(), static_cast<float*>(out.data()),
                     amp->scalingCoeff, rng->scalingCoeff, rng->offsetCoeff, fast, guard0, guard1,
-                    static_cast<uint8_t*>(fed->rowIndices.data()), fed->height, sig.shape(0), fed->rowIndices.shape(0), stream),
+                    static_cast<uint8_t*>(fed->rowIndices.data()), fed->height, sig.shape(0), fed->rowIndices.shape(0),
+                    fast && know_window(stream), stream),
                 "fused spectrum kernel (+ row indices)");
         }
         if (cast) {  // raw samples: same dense shape as the cast's output, element strides therefore equal

@@ -137,3 +137,34 @@ def test_batched_timing_samples_cover_a_period(js, oracle):
     for k in range(slots * 41):
         oracle.spectrogram(bins, refs[k % slots], h)
     assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins, "timed (eager batched) and replayed periods")
+
+
+@pytest.mark.parametrize("provider", ["fast", "generic"])
+def test_side_kernel_with_a_complex_operand(js, oracle, provider):
+    """Provider "fast" multiplies a REAL window as two products per sample (fft_lds.hh: REALFAST, decided per wavefront
+    on the device); an operand with imaginary parts must take std::complex's full product.  A complex broadcast operand
+    through multiply -> fft -> amplitude -> range -> index-fed Spectrogram: values and state against the oracle."""
+    n, b, h = 4096, 40, 256
+    rng = np.random.default_rng(17)
+    x = tone_batch(oracle, b, n, 3) * np.float32(0.4)
+    w = (rng.standard_normal((1, n, 2), dtype=np.float32) * np.float32(0.5)).view(np.complex64)[..., 0]
+    sig = js.Tensor.from_numpy(x, sample=1, batch=0)
+    win = js.Tensor.from_numpy(w, sample=1)
+    mul = js.Module("multiply", {}, {"a": sig, "b": win}, "multiply")
+    fft = js.Module("fft", {"forward": True}, {"signal": mul.output("product")}, "fft")
+    amp = js.Module("amplitude", {}, {"signal": fft.output("signal")}, "amplitude", provider=provider)
+    rge = js.Module("range", {"min": -100.0, "max": 0.0}, {"signal": amp.output("signal")}, "range", provider=provider)
+    spec = js.Module("spectrogram", {"height": h}, {"signal": rge.output("signal")}, "spectrogram")
+    rt = js.Runtime([mul, fft, amp, rge, spec], fuse=True, graph=True)
+    assert any(u.startswith("spectrum_fused(") and u.endswith("+indices") for u in rt.units), rt.units
+    rt.compute(3)
+    ref = oracle.range_(oracle.amplitude(oracle.fft_c2c(oracle.multiply(x, w)), n), -100.0, 0.0)
+    got = rge.output("signal").numpy()
+    if provider == "generic":
+        assert_bit_equal(got, ref, "complex operand, exact provider")
+    else:
+        assert np.max(np.abs(got - ref)) <= 4e-7
+    bins = np.zeros(n * h, np.float32)
+    for _ in range(3):
+        oracle.spectrogram(bins, ref, h)
+    assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins, "state with a complex operand")

@@ -7,7 +7,7 @@ mkdir -p $O
 cp $ROOT/cyberether_amd/lib/libjetstream_hip.so $O/base.so
 run() {
   name=$1
-  for prov in fast generic; do
+  for prov in ${PROVS:-fast generic}; do
   timeout 300 python $ROOT/bench.py --provider $prov --no-cpu-baseline --no-alt > $O/${name}_$prov.json 2> $O/${name}_$prov.err
   echo "== $name $prov: $(python -c "
 import json; d=json.loads(open('$O/${name}_$prov.json').read().strip().splitlines()[-1])
