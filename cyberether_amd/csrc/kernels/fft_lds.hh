@@ -26,11 +26,18 @@
 
 namespace jst::dev {
 
+// Row of the tensors that transform t of the launch works on: t itself, or -- a span of a ring (FftLayout::ring_*) --
+// (ring_first + t) mod ring_transforms.  Both below 2^31 (the launchers check), so the remainder is a 32-bit one.
+__device__ __forceinline__ uint64_t fft_ring_row(const FftLayout& L, uint64_t t) {
+    if (L.ring_transforms == 0) return t;
+    return (uint64_t)(((uint32_t)L.ring_first + (uint32_t)t) % (uint32_t)L.ring_transforms);
+}
 __device__ __forceinline__ void fft_bases(const FftLayout& L, uint64_t t, int64_t& in_base,
                                           int64_t& out_base) {
     in_base = (int64_t)L.in_offset;
     out_base = (int64_t)L.out_offset;
     if (L.outer_rank == 1) {  // one batch axis (every dense [B, N] tensor): no 64-bit divisions
+        t = fft_ring_row(L, t);
         in_base += (int64_t)t * L.in_outer_stride[0];
         out_base += (int64_t)t * L.out_outer_stride[0];
         return;
@@ -1134,7 +1141,7 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
         const rsrc_t r_opnd_next = make_rsrc(pro.operand_row(), (more && !(REALOP && wave_real)) ? (uint32_t)N * 8u : 0u);
         rsrc_t r_side = r_out;  // unused unless the epilogue has a side output
         if constexpr (CONTIG && epi_has_side<Epi>())
-            r_side = epi.template side_rsrc<kSideGroupInBase<N, T>>(t, (uint32_t)N, tid);
+            r_side = epi.template side_rsrc<kSideGroupInBase<N, T>>(fft_ring_row(L, t), (uint32_t)N, tid);
 #ifdef JST_FB_SKIP_PASSES  // decomposition experiment (tools/ubench/fused_bench.hip): last pass + epilogue only
         pipe_passes<N, T, FWD, CONTIG, plan.nf - 1, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
                                                               L.out_axis_stride, epi, pro, opnd,

@@ -100,7 +100,10 @@ bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stri
     // dense rows on both sides, transform t's output row at element t * n (the side tensor follows the same numbering)
     if (L.in_axis_stride != 1 || L.out_axis_stride != 1 || window_stride != 1 || L.outer_rank != 1) return false;
     if (L.out_outer_stride[0] != (int64_t)n) return false;
-    return height >= 2 && height <= 256 && L.transforms * n < (1ull << 31);
+    if (L.ring_transforms != 0 && (L.ring_first >= L.ring_transforms || L.ring_transforms * n >= (1ull << 28) ||
+                                   L.transforms >= (1ull << 31)))
+        return false;  // a ring's rows are addressed with 32-bit byte offsets: < 2^31 bytes of cf32
+    return height >= 2 && height <= 256 && (L.ring_transforms != 0 || L.transforms * n < (1ull << 31));
 }
 
 hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const float2* W, const void* in, int in_format,
@@ -110,7 +113,9 @@ hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const floa
                                       hipStream_t stream) {
     // side_batches: the rows of ONE index tensor (a compute cycle's batches); L.transforms is a whole number of them
     if (!spectrum_side_supported(n, L, 1, height) || !side || side_batches == 0 || L.transforms % side_batches != 0 ||
-        side_pitch < side_batches || (L.transforms / side_batches) * side_pitch * n >= (1ull << 31))
+        side_pitch < side_batches ||
+        ((L.ring_transforms ? L.ring_transforms : L.transforms) / side_batches) * side_pitch * n >= (1ull << 31) ||
+        (L.ring_transforms % side_batches) != 0 || (L.ring_first % side_batches) != 0)
         return hipErrorInvalidValue;
     const float h = (float)height;
     const float inv = in_format ? 1.0f / scaler : 1.0f;  // a power of two: x / scaler == x * inv, exactly

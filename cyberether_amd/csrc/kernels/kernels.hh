@@ -23,6 +23,11 @@ struct FftLayout {
     int64_t out_axis_stride;
     uint64_t in_offset;
     uint64_t out_offset;
+    // A span of a RING (cycle batching, one batch axis only): transform t of the launch is row (ring_first + t) mod
+    // ring_transforms of tensors that hold ring_transforms rows (all the slots of the ring one behind the other), so a span
+    // that wraps the ring -- or laps it -- is still ONE launch.  ring_transforms = 0: no ring, transform t is row t.
+    uint64_t ring_first;
+    uint64_t ring_transforms;
 };
 
 // N-ary strided elementwise traversal (the device counterpart of
@@ -275,8 +280,11 @@ hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t ba
 // The same over `cycles` consecutive compute cycles in ONE launch: `cycles` index tensors one behind the other (the
 // side output of a fused spectrum launch that carried that many ring slots), the state tile in registers in between.
 bool spectrogram_index_span_supported(uint64_t batches, uint64_t width, uint64_t height, uint64_t cycles);
+// idx: the FIRST slot of a ring of ring_slots index tensors; the span's cycle c reads slot (first_slot + c) mod ring_slots
+// (ring_slots = 0: `cycles` tensors one behind the other from idx on, no wrap).
 hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64_t batches, uint64_t pitch, uint64_t width,
-                                         uint64_t height, float decay, uint64_t cycles, hipStream_t stream);
+                                         uint64_t height, float decay, uint64_t cycles, uint64_t first_slot,
+                                         uint64_t ring_slots, hipStream_t stream);
 // The exact multi-GPU merge of spectrograms: this cycle's hit COUNTS as a U32[height][width] tensor
 // (no state touched) -- all-reduce(sum) them over the ranks -- then one shared decay and the count-times update.
 hipError_t launch_spectrogram_counts(uint32_t* counts, const float* in, uint64_t in_offset, uint64_t batches,

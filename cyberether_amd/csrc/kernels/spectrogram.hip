@@ -203,7 +203,8 @@ unsigned long long* jst_span_tl_host = nullptr;  // device buffer [workgroups][1
 template <int COPIES, int kThreads>
 __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float* __restrict__ bins, const uint8_t* __restrict__ idx,
                                                                           uint32_t batches, uint32_t pitch, uint32_t width,
-                                                                          uint32_t height, float decay, uint32_t cycles JST_SPAN_TL_PARAM) {
+                                                                          uint32_t height, float decay, uint32_t cycles,
+                                                                          uint32_t first_slot, uint32_t ring_slots JST_SPAN_TL_PARAM) {
     constexpr uint32_t TW = 16;
     extern __shared__ __attribute__((aligned(64))) unsigned char smem_raw[];
     uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
@@ -225,7 +226,9 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     const uint32_t cycle_bytes = pitch * width;
     const __amdgpu_buffer_rsrc_t r_idx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(idx), 0, cycles * cycle_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(idx), 0, (ring_slots ? ring_slots : cycles) * cycle_bytes, 0x00020000);
+    // cycle c of the span reads ring slot (first_slot + c) mod ring_slots (ring_slots = 0: tensor c behind idx)
+    uint32_t req_slot = ring_slots ? first_slot : 0u;
     // A ROUND is 1024 rows of one cycle; rounds are numbered through the whole span.  Several register sets take the rounds
     // in turn (the loop below is unrolled over them): with ONE set refilled inside the loop hipcc keeps the rows being
     // counted in a copy made at the END of the previous iteration, i.e. behind `s_waitcnt vmcnt(0)` on the request
@@ -243,12 +246,14 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
         for (uint32_t r = 0; r < kRows; ++r) {
             const uint32_t row = req_first + tid + r * kThreads;  // a row (or a round) that does not exist reads as 0: no hits
             dst[r] = __builtin_amdgcn_raw_buffer_load_b128(
-                r_idx, (row < batches && req_cycle < cycles) ? req_cycle * cycle_bytes + tile_base + row * row_bytes : 0xfffffff0u, 0, 0);
+                r_idx, (row < batches && req_cycle < cycles) ? req_slot * cycle_bytes + tile_base + row * row_bytes : 0xfffffff0u, 0, 0);
         }
         req_first += 1024u;
         if (req_first >= batches) {
             req_first = 0u;
             ++req_cycle;
+            ++req_slot;
+            if (ring_slots && req_slot == ring_slots) req_slot = 0u;
         }
     };
     // Four register sets, requests three rounds ahead: behind the fused kernel of a batched span the index tensors come
@@ -454,9 +459,10 @@ bool spectrogram_index_span_supported(uint64_t batches, uint64_t width, uint64_t
 }
 
 hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64_t batches, uint64_t pitch, uint64_t width,
-                                         uint64_t height, float decay, uint64_t cycles, hipStream_t stream) {
-    if (!spectrogram_index_span_supported(batches, width, height, cycles) || pitch < batches ||
-        cycles * pitch * width >= (1ull << 31))
+                                         uint64_t height, float decay, uint64_t cycles, uint64_t first_slot,
+                                         uint64_t ring_slots, hipStream_t stream) {
+    if (cycles < 1 || cycles >= (1ull << 31) || !spectrogram_index_supported(batches, width, height) || pitch < batches ||
+        (ring_slots ? ring_slots : cycles) * pitch * width >= (1ull << 31) || (ring_slots && first_slot >= ring_slots))
         return hipErrorInvalidValue;
     // Private histogram copies per workgroup (JST_SPEC_SPAN_COPIES = 1 | 2 | 4 is the A/B switch).  The single-cycle kernel
     // is launch bound and does not care (5.08 / 5.10 / 5.18 us); here the counting is what is left, and every copy is
@@ -476,7 +482,7 @@ hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64
         if (e != hipSuccess) return e;                                                                                    \
         hipLaunchKernelGGL((spectrogram_index_span_kernel<COPIES, 1024>), dim3((unsigned)(width / 16)), dim3(1024), lds,  \
                            stream, bins, idx, (uint32_t)batches, (uint32_t)pitch, (uint32_t)width, (uint32_t)height,      \
-                           decay, (uint32_t)cycles JST_SPAN_TL_ARG);                                                      \
+                           decay, (uint32_t)cycles, (uint32_t)first_slot, (uint32_t)ring_slots JST_SPAN_TL_ARG);         \
     } while (0)
     if (copies == 1) JST_SPEC_SPAN(1);
     else if (copies == 2) JST_SPEC_SPAN(2);

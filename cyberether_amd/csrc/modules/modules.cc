@@ -1048,19 +1048,13 @@ Result Spectrogram::computeSubmitSpan(hipStream_t stream, U64 first_slot, U64 n)
         JST_ERROR("[MODULE_SPECTROGRAM] A cycle-batched span needs the row-index ring of a batched spectrum unit.");
         return Result::ERROR;
     }
-    U64 slot = first_slot;
-    while (n > 0) {  // runs of consecutive slots: a span that wraps the ring is two launches
-        U64 run = std::min<U64>(n, ring - slot);
-        while (!kernels::spectrogram_index_span_supported(numberOfBatches, numberOfElements, height, run) && run > 1) run /= 2;
-        JST_CHECK(hip_result(kernels::launch_spectrogram_index_span(ptr<float>(frequencyBins),
-                                                                    static_cast<const uint8_t*>(rowIndices.ringSlotData(slot)),
-                                                                    numberOfBatches, rowIndices.shape(0), numberOfElements, height,
-                                                                    decayFactor, run, stream),
-                             "spectrogram kernel (row indices, cycle-batched span)"));
-        slot = (slot + run) % ring;
-        n -= run;
-    }
-    return rowIndices.ringSelect((slot + ring - 1) % ring);
+    // ONE launch whatever the span: cycle c reads ring slot (first_slot + c) mod ring (a span that wraps the ring, or laps it)
+    JST_CHECK(hip_result(kernels::launch_spectrogram_index_span(ptr<float>(frequencyBins),
+                                                                static_cast<const uint8_t*>(rowIndices.ringSlotData(0)),
+                                                                numberOfBatches, rowIndices.shape(0), numberOfElements, height,
+                                                                decayFactor, n, first_slot, ring, stream),
+                         "spectrogram kernel (row indices, cycle-batched span)"));
+    return rowIndices.ringSelect((first_slot + n - 1) % ring);
 }
 
 Result SpectrogramMerge::validate() {
@@ -1656,7 +1650,8 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
         // per launch: < 2^31 bytes of input (buffer-descriptor offsets), i.e. at most max_run slots
         const U64 in_bytes = slot_elems * DataTypeSize(in_t.dtype());
         const U64 max_run = in_bytes ? ((1ull << 31) - 1) / in_bytes : 0;
-        if (dense_ring && max_run >= 2) {
+        // (the span launch addresses the whole ring: kernels::spectrum_side_supported bounds it at 2^28 elements)
+        if (dense_ring && max_run >= 2 && in_t.ringSlots() * slot_elems < (1ull << 28)) {
             batch->phase = in_t;
             batch->prepare = [rng, fed, batched](U64 slots) -> Result {
                 if (rng->output.ringSlots() != slots) JST_CHECK(rng->output.promoteToRing(slots));
@@ -1681,30 +1676,30 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                     return Result::ERROR;
                 }
                 const DataType it = in_t.dtype();
-                U64 slot = first;
-                while (cycles > 0) {  // runs of consecutive slots: a span that wraps the ring is two launches
-                    const U64 run = std::min<U64>(std::min<U64>(cycles, ring - slot), max_run);
-                    FftLayout L;
-                    std::memset(&L, 0, sizeof(L));
-                    L.transforms = sig.shape(0) * run;
-                    L.outer_rank = 1;
-                    L.outer_shape[0] = L.transforms;
-                    L.in_outer_stride[0] = (int64_t)n;
-                    L.out_outer_stride[0] = (int64_t)n;
-                    L.in_axis_stride = 1;
-                    L.out_axis_stride = 1;
-                    JST_CHECK(hip_result(
-                        kernels::launch_spectrum_fused_side(
-                            n, L, fft->twiddles, in_t.ringSlotData(slot),
-                            !cast ? 0 : (it == DataType::CI16 ? 1 : (it == DataType::CI8 ? 2 : 3)), cast ? cast->scaler : 1.0f,
-                            static_cast<const float2*>(win.data()) + win.offset(), static_cast<float*>(out.ringSlotData(slot)),
-                            amp->scalingCoeff, rng->scalingCoeff, rng->offsetCoeff, fast, guard0, guard1,
-                            static_cast<uint8_t*>(fed->rowIndices.ringSlotData(slot)), fed->height, sig.shape(0), fed->rowIndices.shape(0),
-                            fast && know_window(stream), stream),
-                        "fused spectrum kernel (+ row indices, cycle-batched span)"));
-                    slot = (slot + run) % ring;
-                    cycles -= run;
-                }
+                // ONE launch whatever the span: transform t is row (first * batches + t) mod (ring * batches) of the ring
+                // tensors (FftLayout::ring_*) -- a span that wraps the ring, or laps it, included
+                (void)max_run;
+                FftLayout L;
+                std::memset(&L, 0, sizeof(L));
+                L.transforms = sig.shape(0) * cycles;
+                L.outer_rank = 1;
+                L.outer_shape[0] = L.transforms;
+                L.in_outer_stride[0] = (int64_t)n;
+                L.out_outer_stride[0] = (int64_t)n;
+                L.in_axis_stride = 1;
+                L.out_axis_stride = 1;
+                L.ring_first = first * sig.shape(0);
+                L.ring_transforms = ring * sig.shape(0);
+                JST_CHECK(hip_result(
+                    kernels::launch_spectrum_fused_side(
+                        n, L, fft->twiddles, in_t.ringSlotData(0),
+                        !cast ? 0 : (it == DataType::CI16 ? 1 : (it == DataType::CI8 ? 2 : 3)), cast ? cast->scaler : 1.0f,
+                        static_cast<const float2*>(win.data()) + win.offset(), static_cast<float*>(out.ringSlotData(0)),
+                        amp->scalingCoeff, rng->scalingCoeff, rng->offsetCoeff, fast, guard0, guard1,
+                        static_cast<uint8_t*>(fed->rowIndices.ringSlotData(0)), fed->height, sig.shape(0),
+                        fed->rowIndices.shape(0), fast && know_window(stream), stream),
+                    "fused spectrum kernel (+ row indices, cycle-batched span)"));
+                const U64 slot = (first + cycles) % ring;
                 const U64 last = (slot + ring - 1) % ring;
                 JST_CHECK(out.ringSelect(last));
                 return fed->rowIndices.ringSelect(last);

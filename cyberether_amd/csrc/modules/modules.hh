@@ -238,7 +238,7 @@ class Spectrogram : public Module {
     Tensor rowIndices;
     // Cycle batching (Runtime::planBatch): rowIndices is then a ring of as many slots as the source has, and a span of n
     // cycles is ONE launch over n consecutive index tensors with the state tile in registers in between
-    // (kernels::launch_spectrogram_index_span; a span that wraps the ring is two launches).
+    // (kernels::launch_spectrogram_index_span; cycle c of the span reads slot (first + c) mod R: one launch whatever the span).
     bool spanCapable() const override { return indexFed && !countsOnly && !combined; }
     Result computeSubmitSpan(hipStream_t stream, U64 first_slot, U64 n) override;
     bool combined = false, combinedPending = false;

@@ -73,7 +73,7 @@ enum {
                                      so results and their visibility after jst_runtime_compute are unchanged */
     JST_RUNTIME_BATCH = 1 << 5    /* with GRAPH and FUSE: CYCLE BATCHING.  When the chain is a resident ring_source
                                      (R slots) -> fused spectrum unit -> ONE index-fed Spectrogram, the cycles of a
-                                     captured ring period (and of every span of it) run as ONE launch per unit: the
+                                     captured ring period (and of every span of it, wrapping or lapping the ring included) run as ONE launch per unit: the
                                      persistent spectrum kernel takes the transforms of all the span's slots (its ramp,
                                      cold start and tail are paid once per launch, not once per cycle), the range
                                      output and the row indices become rings of R slots (cycle c writes slot c mod R;

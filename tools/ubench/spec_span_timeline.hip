@@ -50,9 +50,9 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 10; ++i) jst::kernels::launch_spectrogram_index_span(d_bins, d_idx, B, B, N, H, 0.36f, C, nullptr);
+    for (int i = 0; i < 10; ++i) jst::kernels::launch_spectrogram_index_span(d_bins, d_idx, B, B, N, H, 0.36f, C, 0, 0, nullptr);
     hipEventRecord(e0);
-    for (int i = 0; i < 50; ++i) jst::kernels::launch_spectrogram_index_span(d_bins, d_idx, B, B, N, H, 0.36f, C, nullptr);
+    for (int i = 0; i < 50; ++i) jst::kernels::launch_spectrogram_index_span(d_bins, d_idx, B, B, N, H, 0.36f, C, 0, 0, nullptr);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms = 0;
@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 20; ++i) {
             hipMemsetAsync(big, i, 768u << 20, nullptr);
             hipEventRecord(e0);
-            jst::kernels::launch_spectrogram_index_span(d_bins, d_idx, B, B, N, H, 0.36f, C, nullptr);
+            jst::kernels::launch_spectrogram_index_span(d_bins, d_idx, B, B, N, H, 0.36f, C, 0, 0, nullptr);
             hipEventRecord(e1);
             hipDeviceSynchronize();
             hipEventElapsedTime(&ms, e0, e1);
