@@ -50,7 +50,11 @@ if traffic_json:
         sys.exit("no FETCH_SIZE / WRITE_SIZE pass for the fused spectrum kernel (" + provider + ") under " + root)
     k = pick[0]
     # full launches only: a cycle-batched run also holds a few shorter launches (the settle cycle, span heads and tails)
-    full = lambda c: [x for x in acc[k][c] if x >= 0.9 * max(acc[k][c])]
+    # (within 5 % of the median of the launches that are at least half the largest: one cold outlier must not become "the" launch)
+    def full(c):
+        big = sorted(x for x in acc[k][c] if x >= 0.5 * max(acc[k][c]))
+        med = big[len(big) // 2]
+        return [x for x in big if abs(x - med) <= 0.05 * med]
     mean = lambda c: sum(full(c)) / len(full(c))
     fetch_kib, write_kib = mean("FETCH_SIZE"), mean("WRITE_SIZE")
     rec = {"spectrum_fused_hbm_bytes_per_launch": int(round((2.0 * fetch_kib + write_kib) * 1024.0)),
