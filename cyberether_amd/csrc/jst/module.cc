@@ -394,8 +394,9 @@ Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
 // the per-cycle submissions leave: every cycle's output sits in its ring slot (the handles show the latest), the
 // Spectrogram's state went through the same n decays and hit updates.  Batched only when EVERY dynamic unit can do it:
 // the one fused spectrum unit with span support, modules that are spanCapable(), and kernel-less modules (their host
-// state moves through advanceHostState); anything else (a waterfall, a live source, two spectrum units) leaves the
-// runtime per cycle.  JST_RUNTIME_NO_BATCH=1 is the A/B switch.
+// state moves through advanceHostState), and sinks of the batched unit (see below); anything else (a live source, two
+// spectrum units, a dynamic module in front of the unit) leaves the runtime per cycle.  JST_RUNTIME_NO_BATCH=1 is the
+// A/B switch.
 Result Runtime::planBatch() {
     batched_ = false;
     if (!(flags_ & BATCH) || !(flags_ & GRAPH) || !(flags_ & FUSE) || (flags_ & (PIPELINE | COMBINE)) || period_ < 2 ||
@@ -412,13 +413,33 @@ Result Runtime::planBatch() {
         }
         for (Module* m : u.modules) {
             if (!m->capturable()) return Result::SUCCESS;
-            if (m->launchesKernels() ? !m->spanCapable() : (m->cyclePeriod() != 1 && m->cyclePeriod() != period_))
-                return Result::SUCCESS;
+            if (!m->launchesKernels() && m->cyclePeriod() != 1 && m->cyclePeriod() != period_) return Result::SUCCESS;
         }
     }
     if (fused == units_.size()) return Result::SUCCESS;
     SpanSupport& b = units_[fused].batch;
     if (!b.phase.valid() || b.phase.ringSlots() != period_) return Result::SUCCESS;
+    // Kernel modules without a span form may still sit in a batched runtime when they are SINKS of the batched unit: a
+    // surface (waterfall, lineplot, a second Spectrogram ...) with no outputs whose inputs are all views of the batched
+    // unit's output or of the source ring.  Every cycle's data is in its ring slot when the span's big launches are
+    // through, so such a module simply runs its n per-cycle submissions behind them, slot after slot (submitBatched).
+    for (size_t i = 0; i < units_.size(); ++i) {
+        Unit& u = units_[i];
+        u.per_cycle_in_span = false;
+        if (u.is_static || i == fused) continue;
+        for (Module* m : u.modules) {
+            if (!m->launchesKernels() || m->spanCapable()) continue;
+            bool sink = (m->taint() & SURFACE) != 0 && m->outputs().empty() && m->cyclePeriod() == 1 && u.modules.size() == 1;
+            for (const auto& kv : m->inputs()) {
+                bool from_ring = kv.second.storageId() == b.phase.storageId();
+                for (Module* prod : units_[fused].modules)
+                    for (const auto& out : prod->outputs()) from_ring |= out.second.storageId() == kv.second.storageId();
+                sink &= from_ring;
+            }
+            if (!sink) return Result::SUCCESS;
+            u.per_cycle_in_span = true;
+        }
+    }
     JST_CHECK(b.prepare(period_));
     batch_unit_ = fused;
     batched_ = true;
@@ -438,6 +459,21 @@ Result Runtime::submitBatched(U64 n, bool record_events) {
         if (u.batch) {
             first = u.batch.phase.ringSlot();
             r = u.batch.submit_span(stream_, first, n);
+        } else if (u.per_cycle_in_span) {
+            // a sink of the batched unit: its n per-cycle submissions, each looking at its cycle's slot of the rings
+            SpanSupport& b = units_[batch_unit_].batch;
+            if (first == ~0ull) {
+                JST_ERROR("[RUNTIME] Batched span: '%s' runs before the spectrum unit that feeds it.", u.name.c_str());
+                r = Result::ERROR;
+            }
+            const U64 ring = b.phase.ringSlots();
+            for (U64 c = 0; c < n && r == Result::SUCCESS; ++c) {
+                const U64 slot = (first + c) % ring;
+                JST_CHECK(b.phase.ringSelect(slot));
+                for (Tensor& t : b.rings) JST_CHECK(t.ringSelect(slot % t.ringSlots()));
+                r = u.submit(stream_);
+                if (r == Result::RELOAD) r = Result::SUCCESS;
+            }
         } else {
             for (Module* m : u.modules) {
                 if (!m->launchesKernels()) {

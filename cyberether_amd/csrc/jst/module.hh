@@ -222,6 +222,7 @@ class Runtime {
         int lane = 0;                      // PIPELINE: 1 = surface lane (runs beside the next cycle)
         bool settled = false;
         SpanSupport batch;                 // BATCH: the fused spectrum unit's multi-cycle launch
+        bool per_cycle_in_span = false;    // BATCH: a sink that reads the batched unit's rings: n per-cycle submissions inside a span
         KernelSpan span;
     };
     Result planOrder(const std::vector<Module*>& modules);

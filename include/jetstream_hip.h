@@ -79,8 +79,10 @@ enum {
                                      output and the row indices become rings of R slots (cycle c writes slot c mod R;
                                      the tensor handles show the latest cycle), and the Spectrogram walks the span's
                                      index tensors in one launch with its state tile in registers.  What is visible
-                                     after jst_runtime_compute is bit-identical to the per-cycle submissions.  Any other
-                                     chain silently stays per cycle (jst_runtime_batched tells). */
+                                     after jst_runtime_compute is bit-identical to the per-cycle submissions.  Other
+                                     surfaces on the same output (waterfall, lineplot) run their per-cycle submissions
+                                     behind the span's launches; any other chain silently stays per cycle
+                                     (jst_runtime_batched tells). */
 };
 
 typedef struct jst_tensor_s* jst_tensor;

@@ -13,7 +13,7 @@ from util import assert_bit_equal
 pytestmark = pytest.mark.gpu
 
 
-def _ring_chain(js, xs, h, provider="generic", dtype=None, waterfall=False, **runtime):
+def _ring_chain(js, xs, h, provider="generic", dtype=None, **runtime):
     b, n = xs[0].shape[:2]
     cfg = {"batches": b, "samples": n, "slots": len(xs)}
     if dtype:
@@ -26,8 +26,6 @@ def _ring_chain(js, xs, h, provider="generic", dtype=None, waterfall=False, **ru
     eng = js.SpectrumEngine(buf, enable_scale=True, range_min=-100.0, range_max=0.0, provider=provider)
     spec = js.Module("spectrogram", {"height": h}, {"signal": eng.buffer}, "spectrogram")
     mods = [ring] + eng.modules + [spec]
-    if waterfall:
-        mods.append(js.Module("waterfall", {"height": 32}, {"signal": eng.buffer}, "waterfall"))
     rt = js.Runtime(mods, fuse=True, graph=True, **runtime)
     rt._keep = mods
     return eng, spec, rt
@@ -100,23 +98,56 @@ def test_batched_raw_sample_ring(js, oracle):
 def test_planner_stays_per_cycle_when_a_unit_cannot_batch(js, oracle):
     n, b, h, slots = 4096, 16, 256, 3
     xs = [tone_batch(oracle, b, n, 21 + s) for s in range(slots)]
-    # a waterfall also reads the output: it has no span form, the runtime runs per cycle
-    eng, spec, rt = _ring_chain(js, xs, h, waterfall=True, batch=True)
+    # height > 256: the Spectrogram reads values, not indices -> no span support in the spectrum unit -> per cycle
+    eng, spec, rt = _ring_chain(js, xs, 512, batch=True)
     assert not rt.batched
     rt.compute(7)
     refs = [oracle.spectrum_chain(x, -100.0, 0.0)["range"] for x in xs]
-    bins = np.zeros(n * h, np.float32)
+    bins = np.zeros(n * 512, np.float32)
     for k in range(7):
-        oracle.spectrogram(bins, refs[k % slots], h)
+        oracle.spectrogram(bins, refs[k % slots], 512)
     assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins)
     assert_bit_equal(eng.buffer.numpy(), refs[6 % slots])
     rt.destroy()
-    # height > 256: the Spectrogram reads values, not indices -> per cycle
-    eng, spec, rt = _ring_chain(js, xs, 512, batch=True)
-    assert not rt.batched
     # no flag: per cycle
     eng, spec, rt = _ring_chain(js, xs, h)
     assert not rt.batched
+
+
+def test_sink_surfaces_ride_inside_batched_spans(js, oracle):
+    """A waterfall and a lineplot on the same range output have no span form: in a batched runtime they run their n
+    per-cycle submissions behind the span's big launches, each on its cycle's slot of the output ring.  Every state must
+    equal the per-cycle runtime's, bit for bit, after every call."""
+    n, b, h, slots = 4096, 24, 256, 4
+    xs = [tone_batch(oracle, b, n, 40 + s) * np.float32(0.2 + 0.25 * s) for s in range(slots)]
+    traces = []
+    for batch in (False, True):
+        ring = js.Module("ring_source", {"batches": b, "samples": n, "slots": slots}, {}, "ring")
+        buf = ring.output("buffer")
+        for s, x in enumerate(xs):
+            buf.ring_select(s).copy_from(x)
+        buf.ring_select(0)
+        eng = js.SpectrumEngine(buf, enable_scale=True, range_min=-100.0, range_max=0.0)
+        spec = js.Module("spectrogram", {"height": h}, {"signal": eng.buffer}, "spectrogram")
+        wf = js.Module("waterfall", {"height": 100}, {"signal": eng.buffer}, "waterfall")
+        lp = js.Module("lineplot", {"averaging": 4}, {"signal": eng.buffer}, "lineplot")
+        rt = js.Runtime([ring] + eng.modules + [spec, wf, lp], fuse=True, graph=True, batch=batch)
+        assert rt.batched == batch, rt.units
+        trace = []
+        for call in (1, 4, 3, 6, 2, 9, 8):
+            rt.compute(call)
+            trace.append([spec.state("frequencyBins").numpy().copy(), wf.state("frequencyBins").numpy().copy(),
+                          wf.state("ringState").numpy().copy(), lp.state("signalPoints").numpy().copy(),
+                          lp.state("averagingBuffer").numpy().copy(), eng.buffer.numpy().copy()])
+        traces.append(trace)
+        rt.destroy()
+    names = ("spectrogram", "waterfall bins", "waterfall cursor", "lineplot points", "lineplot average", "range output")
+    for i, (per_cycle, batched) in enumerate(zip(*traces)):
+        for name, a, bb in zip(names, per_cycle, batched):
+            if a.dtype == np.float32:
+                assert_bit_equal(bb, a, f"{name} after call {i}")
+            else:
+                assert np.array_equal(bb, a), f"{name} after call {i}"
 
 
 def test_batched_timing_samples_cover_a_period(js, oracle):
