@@ -1572,7 +1572,11 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     // pipelined runtime (they read one cycle behind).  JST_NO_SPECTROGRAM_SIDE=1 is the A/B switch.
     Spectrogram* fed = nullptr;
     static const bool no_side = std::getenv("JST_NO_SPECTROGRAM_SIDE") != nullptr;
-    if (allow_side && !no_side && rng && !tiled && sig.rank() == 2 && axis == 1 && rng->output.ringSlots() == 1) {
+    // (an output that is already a ring of the source's size was promoted by an earlier cycle-batched runtime over these
+    // very modules: a runtime re-created on them plans the same way again)
+    const U64 source_slots = (cast ? cast->input : sig).ringSlots();
+    const bool out_plain_or_batched = rng && (rng->output.ringSlots() == 1 || (batch && source_slots > 1 && rng->output.ringSlots() == source_slots));
+    if (allow_side && !no_side && rng && !tiled && sig.rank() == 2 && axis == 1 && out_plain_or_batched) {
         int readers = 0;
         Spectrogram* only = nullptr;
         for (Module* m : ordered) {
@@ -1599,7 +1603,9 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
             kernels::spectrum_side_supported(n, L, (int64_t)win.stride(axis), only->height) &&
             kernels::spectrogram_index_supported(only->numberOfBatches, n, only->height) &&
             (!cast || sig.stride(1) == 1) &&
-            only->rowIndices.create(DeviceType::HIP, DataType::U8, {kernels::spectrum_side_pitch(sig.shape(0)), n}) == Result::SUCCESS) {
+            ((only->rowIndices.valid() && only->rowIndices.shape() == Shape{kernels::spectrum_side_pitch(sig.shape(0)), n} &&
+              only->rowIndices.ringSlots() == rng->output.ringSlots()) ||
+             only->rowIndices.create(DeviceType::HIP, DataType::U8, {kernels::spectrum_side_pitch(sig.shape(0)), n}) == Result::SUCCESS)) {
             fed = only;
             fed->indexFed = true;
             name += "+indices";

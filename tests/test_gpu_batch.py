@@ -199,3 +199,24 @@ def test_side_kernel_with_a_complex_operand(js, oracle, provider):
     for _ in range(3):
         oracle.spectrogram(bins, ref, h)
     assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins, "state with a complex operand")
+
+
+def test_runtime_recreated_on_the_same_modules_batches_again(js, oracle):
+    """The planner turned the range output and the row indices into rings; a second runtime over the same modules must
+    find them usable (not fall back to the value-fed, per-cycle path) and carry the Spectrogram state on."""
+    n, b, h, slots = 4096, 16, 256, 3
+    xs = [tone_batch(oracle, b, n, 60 + s) for s in range(slots)]
+    eng, spec, rt = _ring_chain(js, xs, h, batch=True)
+    mods = rt._keep
+    assert rt.batched
+    rt.compute(5)
+    rt.destroy()
+    rt2 = js.Runtime(mods, fuse=True, graph=True, batch=True)
+    assert rt2.batched and any(u.endswith("+indices") for u in rt2.units), rt2.units
+    rt2.compute(7)
+    refs = [oracle.spectrum_chain(x, -100.0, 0.0)["range"] for x in xs]
+    bins = np.zeros(n * h, np.float32)
+    for k in range(12):  # the ring source's cursor went on from where the first runtime left it
+        oracle.spectrogram(bins, refs[k % slots], h)
+    assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins, "state across two runtimes")
+    assert_bit_equal(eng.buffer.numpy(), refs[11 % slots])
