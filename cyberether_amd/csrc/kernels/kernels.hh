@@ -305,6 +305,12 @@ hipError_t launch_lineplot(float* points, float* average, const float* in, uint6
                            uint64_t batches, uint64_t elements, int64_t batch_stride,
                            int64_t elem_stride, uint64_t decimation, float normalization,
                            float averaging, hipStream_t stream);
+// `cycles` consecutive compute cycles of a cycle-batched span in one launch: cycle c reads slot (first_slot + c) mod
+// ring_slots of the input ring (in_ring = slot 0, slots slot_stride elements apart); the average stays in a register.
+hipError_t launch_lineplot_span(float* points, float* average, const float* in_ring, uint64_t in_offset, uint64_t slot_stride,
+                                uint64_t first_slot, uint64_t ring_slots, uint64_t cycles, uint64_t batches, uint64_t elements,
+                                int64_t batch_stride, int64_t elem_stride, uint64_t decimation, float normalization,
+                                float averaging, hipStream_t stream);
 
 // ---- Filter / FM side chains (filter_kernels.hip) ----------------------------------------------
 hipError_t launch_pad(void* out, const void* in, bool complex, uint64_t outer, uint64_t in_axis,

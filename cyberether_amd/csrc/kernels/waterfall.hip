@@ -110,7 +110,55 @@ __global__ __launch_bounds__(256) void lineplot_kernel(float* __restrict__ point
     average[i] = avg;
     points[(i * 2) + 1] = avg;
 }
+// The same over `cycles` consecutive compute cycles of a cycle-batched span in ONE launch: cycle c reads slot
+// (first_slot + c) mod ring_slots of the input ring (slots slot_stride elements apart), the moving average stays in a
+// register from the first cycle to the last -- the recursion is per bin, so the cycles of a bin are one thread's loop.
+__global__ __launch_bounds__(256) void lineplot_span_kernel(float* __restrict__ points, float* __restrict__ average,
+                                                            const float* __restrict__ in, uint64_t in_offset,
+                                                            uint64_t slot_stride, uint32_t first_slot, uint32_t ring_slots,
+                                                            uint32_t cycles, uint64_t batches, uint64_t elements,
+                                                            int64_t batch_stride, int64_t elem_stride, uint64_t decimation,
+                                                            float normalization, float averaging) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elements) return;
+    float avg = average[i];
+    uint32_t slot = first_slot;
+    for (uint32_t c = 0; c < cycles; ++c) {
+        const float* col = in + (uint64_t)slot * slot_stride + in_offset + (int64_t)(i * decimation) * elem_stride;
+        float sum = 0.0f;
+        for (uint64_t b0 = 0; b0 < batches; b0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint64_t b = b0 + (uint64_t)k;
+                const float x = col[(int64_t)(b < batches ? b : batches - 1) * batch_stride];
+                v[k] = b < batches ? x : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += v[k];
+        }
+        const float amplitude = fminf(fmaxf((sum * normalization) - 1.0f, -1.0f), 1.0f);
+        avg -= avg / averaging;
+        avg += amplitude / averaging;
+        if (++slot == ring_slots) slot = 0;
+    }
+    average[i] = avg;
+    points[(i * 2) + 1] = avg;
+}
 }  // namespace
+
+hipError_t launch_lineplot_span(float* points, float* average, const float* in_ring, uint64_t in_offset, uint64_t slot_stride,
+                                uint64_t first_slot, uint64_t ring_slots, uint64_t cycles, uint64_t batches, uint64_t elements,
+                                int64_t batch_stride, int64_t elem_stride, uint64_t decimation, float normalization,
+                                float averaging, hipStream_t stream) {
+    if (elements == 0 || cycles == 0) return hipSuccess;
+    if (ring_slots == 0 || first_slot >= ring_slots || cycles > 0xffffffffull) return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(lineplot_span_kernel, dim3((unsigned)((elements + 255) / 256)), dim3(256), 0, stream, points, average,
+                       in_ring, in_offset, slot_stride, (uint32_t)first_slot, (uint32_t)ring_slots, (uint32_t)cycles, batches,
+                       elements, batch_stride, elem_stride, decimation, normalization, averaging);
+    return hipGetLastError();
+}
 
 hipError_t launch_lineplot(float* points, float* average, const float* in, uint64_t in_offset,
                            uint64_t batches, uint64_t elements, int64_t batch_stride,

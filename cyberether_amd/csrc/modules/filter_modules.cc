@@ -1140,6 +1140,25 @@ class Lineplot : public Module {
                                      decimation, normalizationFactor, static_cast<F32>(averaging), s),
             "lineplot kernel");
     }
+    // Cycle batching (Runtime::planBatch): the n cycles of a span as ONE launch when the input is a ring the batched
+    // spectrum unit fills (the moving average is a per-bin recursion: one thread's loop over the cycles); any other input
+    // -- the same tensor every cycle -- is n per-cycle launches.
+    bool spanCapable() const override { return true; }
+    Result computeSubmitSpan(hipStream_t s, U64 first_slot, U64 n) override {
+        const U64 ring = input.ringSlots();
+        if (ring < 2 || first_slot >= ring) {
+            for (U64 c = 0; c < n; ++c) JST_CHECK(computeSubmit(s));
+            return Result::SUCCESS;
+        }
+        const U64 slot_elems = (U64)((const char*)input.ringSlotData(1) - (const char*)input.ringSlotData(0)) / sizeof(float);
+        return hip_result(
+            kernels::launch_lineplot_span(ptr<float>(signalPoints), ptr<float>(averagingBuffer),
+                                          static_cast<const float*>(input.ringSlotData(0)), input.offset(), slot_elems,
+                                          first_slot, ring, n, numberOfBatches, numberOfElements, (int64_t)batchStride,
+                                          (int64_t)elementStride, decimation, normalizationFactor,
+                                          static_cast<F32>(averaging), s),
+            "lineplot kernel (cycle-batched span)");
+    }
     const Tensor* state(const std::string& key) const override {
         if (key == "signalPoints") return &signalPoints;
         if (key == "averagingBuffer") return &averagingBuffer;

@@ -1713,13 +1713,73 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
         }
     }
 
+    // Cycle batching for the TILED unit (beyond 16384 points / mixed radix: config 5's 65536-point transforms, whose three
+    // launches per cycle of 1 Mi samples are launch bound): the transforms of a run of consecutive ring slots are one dense
+    // problem for the columns / blocks kernel pair too.  No ring arithmetic in those kernels: a span that wraps is two runs;
+    // the scratch image grows to a whole ring's transforms.  Surfaces behind it (lineplot, waterfall) ride as sinks.
+    if (batch && !fed && tiled && !cast && sig.rank() == 2 && axis == 1) {
+        const Tensor in_t = sig;
+        Tensor& out_t = rng ? rng->output : amp->output;
+        const U64 slot_elems = sig.shape(0) * n;
+        const bool dense_ring = in_t.ringSlots() > 1 && in_t.contiguous() && in_t.offset() == 0 && in_t.size() == slot_elems &&
+                                out_t.offset() == 0 && out_t.size() == slot_elems && win.stride(axis) <= 1 &&
+                                (out_t.ringSlots() == 1 || out_t.ringSlots() == in_t.ringSlots()) &&
+                                in_t.ringSlots() * slot_elems < (1ull << 28);
+        if (dense_ring) {
+            batch->phase = in_t;
+            batch->prepare = [fft, amp, rng, batched, n, slot_elems](U64 slots) -> Result {
+                Tensor& out = rng ? rng->output : amp->output;
+                if (out.ringSlots() != slots) JST_CHECK(out.promoteToRing(slots));
+                if (fft->scratchA.valid() && fft->scratchA.size() < slots * slot_elems)
+                    JST_CHECK(fft->scratchA.create(DeviceType::HIP, DataType::CF32, {slots * slot_elems}));
+                *batched = true;
+                return Result::SUCCESS;
+            };
+            batch->rings = {out_t};
+            batch->submit_span = [mul, fft, amp, rng, n, fast, guard0, guard1, axis](hipStream_t stream, U64 first, U64 cycles) -> Result {
+                const Tensor& sig = mul->a;
+                const Tensor& win = mul->b;
+                Tensor& out = rng ? rng->output : amp->output;
+                const U64 ring = sig.ringSlots();
+                if (first >= ring || out.ringSlots() != ring) {
+                    JST_ERROR("[RUNTIME] Batched spectrum span (tiled): the output ring does not match the source ring.");
+                    return Result::ERROR;
+                }
+                U64 slot = first;
+                while (cycles > 0) {
+                    const U64 run = std::min<U64>(cycles, ring - slot);
+                    FftLayout L;
+                    std::memset(&L, 0, sizeof(L));
+                    L.transforms = sig.shape(0) * run;
+                    L.outer_rank = 1;
+                    L.outer_shape[0] = L.transforms;
+                    L.in_outer_stride[0] = (int64_t)n;
+                    L.out_outer_stride[0] = (int64_t)n;
+                    L.in_axis_stride = 1;
+                    L.out_axis_stride = 1;
+                    JST_CHECK(hip_result(
+                        kernels::launch_spectrum_fused_tiled(
+                            n, L, fft->twiddles, static_cast<const float2*>(sig.ringSlotData(slot)),
+                            static_cast<const float2*>(win.data()) + win.offset(), (int64_t)win.stride(axis),
+                            static_cast<float*>(out.ringSlotData(slot)), amp->scalingCoeff, rng != nullptr,
+                            rng ? rng->scalingCoeff : 0.0f, rng ? rng->offsetCoeff : 0.0f, fast, guard0, guard1,
+                            static_cast<float2*>(fft->scratchA.data()), stream),
+                        "fused spectrum (tiled) kernel, cycle-batched span"));
+                    slot = (slot + run) % ring;
+                    cycles -= run;
+                }
+                return out.ringSelect((slot + ring - 1) % ring);
+            };
+        }
+    }
+
     submit = [mul, fft, amp, rng, cast, fed, axis, n, fast, tiled, guard0, guard1, batched, know_window](hipStream_t stream) -> Result {
         const Tensor& sig = mul->a;
         const Tensor& win = mul->b;
         if (*batched) {  // cycle-batched runtime: this cycle writes the ring slot the source exposes
             const U64 slot = (cast ? cast->input : sig).ringSlot();
-            JST_CHECK(rng->output.ringSelect(slot));
-            JST_CHECK(fed->rowIndices.ringSelect(slot));
+            JST_CHECK((rng ? rng->output : amp->output).ringSelect(slot));
+            if (fed) JST_CHECK(fed->rowIndices.ringSelect(slot));
         }
         const Tensor& out = rng ? rng->output : amp->output;
         FftLayout L;

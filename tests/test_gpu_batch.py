@@ -220,3 +220,39 @@ def test_runtime_recreated_on_the_same_modules_batches_again(js, oracle):
         oracle.spectrogram(bins, refs[k % slots], h)
     assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins, "state across two runtimes")
     assert_bit_equal(eng.buffer.numpy(), refs[11 % slots])
+
+
+@pytest.mark.parametrize("n,b", [(65536, 4), (12000, 6)])
+def test_tiled_spectrum_unit_batches_too(js, oracle, n, b):
+    """The LDS-tiled spectrum unit (65536 points: config 5; a mixed-radix length) has a span form as well: runs of
+    consecutive ring slots as one columns / blocks launch pair, a lineplot riding behind it as a sink.  Batched and
+    per-cycle runtimes must agree bit for bit after every call; the first cycle is checked against the oracle."""
+    slots = 3
+    rng = np.random.default_rng(n)
+    xs = [((rng.standard_normal((b, n)) + 1j * rng.standard_normal((b, n))) * (0.1 + 0.2 * s)).astype(np.complex64)
+          for s in range(slots)]
+    traces = []
+    for batch in (False, True):
+        ring = js.Module("ring_source", {"batches": b, "samples": n, "slots": slots}, {}, "ring")
+        buf = ring.output("buffer")
+        for s, x in enumerate(xs):
+            buf.ring_select(s).copy_from(x)
+        buf.ring_select(0)
+        eng = js.SpectrumEngine(buf, enable_scale=True, range_min=-100.0, range_max=0.0)
+        lp = js.Module("lineplot", {"averaging": 8}, {"signal": eng.buffer}, "psd")
+        rt = js.Runtime([ring] + eng.modules + [lp], fuse=True, graph=True, batch=batch)
+        assert rt.batched == batch, rt.units
+        trace = []
+        for call in (1, 3, 2, 5, 7):
+            rt.compute(call)
+            trace.append([eng.buffer.numpy().copy(), lp.state("averagingBuffer").numpy().copy(),
+                          lp.state("signalPoints").numpy().copy()])
+        traces.append(trace)
+        if batch:
+            for s in range(slots):
+                assert_bit_equal(eng.buffer.ring_select(s).numpy(), oracle.spectrum_chain(xs[s], -100.0, 0.0)["range"],
+                                 f"output ring slot {s} against the oracle")
+        rt.destroy()
+    for i, (per_cycle, batched) in enumerate(zip(*traces)):
+        for name, a, bb in zip(("range output", "lineplot average", "lineplot points"), per_cycle, batched):
+            assert_bit_equal(bb, a, f"{name} after call {i}")

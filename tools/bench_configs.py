@@ -196,6 +196,23 @@ def run_c5(js, out, rng):
                 "roofline": roofline(28.0, b * n, dt, "two HBM passes: 8 r + 8 w + 8 r + 4 w per sample (SURVEY 8d); 1 Mi samples "
                                                      "per cycle: launch/occupancy bound")})
     rt.destroy()
+    # the same chain on a resident ring of 16 slots (16 x 8 MiB), per cycle and CYCLE-BATCHED (runs of consecutive slots as
+    # one columns / blocks launch pair, the lineplot riding behind as a sink): what three launches per 1 Mi samples cost
+    for batch in (False, True):
+        slots = 16
+        ring = js.Module("ring_source", {"batches": b, "samples": n, "slots": slots}, {}, "iq")
+        buf = ring.output("buffer")
+        for s in range(slots):
+            buf.ring_select(s).copy_from(np.roll(x, s, axis=0))
+        buf.ring_select(0)
+        eng = js.SpectrumEngine(buf, enable_scale=True)
+        lp = js.Module("lineplot", {"averaging": 8}, {"signal": eng.buffer}, "psd")
+        rt = js.Runtime([ring] + eng.modules + [lp], graph=True, fuse=True, batch=batch)
+        dt = timed(rt, 320, 48)
+        out.append({"config": "C5 on a resident ring of 16 slots" + (", cycle-batched" if batch else ", one launch per unit and cycle"),
+                    "us_per_cycle": dt * 1e6, "MS_per_s": b * n / dt / 1e6, "batched": bool(rt.batched),
+                    "roofline": roofline(28.0, b * n, dt, "as C5")})
+        rt.destroy()
 
 
 
