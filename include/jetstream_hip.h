@@ -73,16 +73,17 @@ enum {
                                      so results and their visibility after jst_runtime_compute are unchanged */
     JST_RUNTIME_BATCH = 1 << 5    /* with GRAPH and FUSE: CYCLE BATCHING.  When the chain is a resident ring_source
                                      (R slots) -> fused spectrum unit -> ONE index-fed Spectrogram, the cycles of a
-                                     captured ring period (and of every span of it, wrapping or lapping the ring included) run as ONE launch per unit: the
-                                     persistent spectrum kernel takes the transforms of all the span's slots (its ramp,
-                                     cold start and tail are paid once per launch, not once per cycle), the range
-                                     output and the row indices become rings of R slots (cycle c writes slot c mod R;
-                                     the tensor handles show the latest cycle), and the Spectrogram walks the span's
-                                     index tensors in one launch with its state tile in registers.  What is visible
-                                     after jst_runtime_compute is bit-identical to the per-cycle submissions.  Other
-                                     surfaces on the same output (waterfall, lineplot) run their per-cycle submissions
-                                     behind the span's launches; any other chain silently stays per cycle
-                                     (jst_runtime_batched tells). */
+                                     captured ring period -- and of every span of it, wrapping or lapping the ring
+                                     included -- run as ONE launch per unit: the persistent spectrum kernel takes the
+                                     transforms of all the span's slots (its ramp, cold start and tail are paid once
+                                     per launch, not once per cycle), the range output and the row indices become
+                                     rings of R slots (cycle c writes slot c mod R; the tensor handles show the latest
+                                     cycle), and the Spectrogram walks the span's index tensors in one launch with its
+                                     state tile in registers.  The LDS-tiled spectrum unit (beyond 16384 points) and the
+                                     Lineplot have span forms too; a waterfall on the same output runs its per-cycle
+                                     submissions behind the span's launches.  What is visible after
+                                     jst_runtime_compute is bit-identical to the per-cycle submissions; any other
+                                     chain silently stays per cycle (jst_runtime_batched tells). */
 };
 
 typedef struct jst_tensor_s* jst_tensor;
