@@ -209,8 +209,14 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
     // 64-byte runs; the 52-register kernels keep enough workgroups in flight), config 3's 75.3 -> 70.7 us with 32.
     uint32_t ca = force_ca, cb = force_cb;
     if (!ca && !cb) {
-        if (n == 65536 && transforms == 16) ca = 16;
-        else if (n == 160000 && transforms == 100) ca = 32;
+        // (a cycle-batched span of config 5 is 16 * k transforms: it keeps the 16-transform plan -- in the two-kernel
+        // form only the lane counts depend on the transform count -- and with it the kernels compiled for that plan)
+        if (n == 65536 && transforms % 16 == 0) {
+            ca = 16;
+            transforms = 16;
+        } else if (n == 160000 && transforms == 100) {
+            ca = 32;
+        }
     }
     return build_tiled_plan(n, transforms, ca, cb, p);
 }
@@ -771,7 +777,11 @@ hipError_t launch_tiled(const TiledPlan& P, const FftLayout& L, const float2* W,
             auto attempt = [&](auto id) {
                 constexpr int SPI = decltype(id)::value;
                 constexpr TiledPlan SPl = static_plan(SPI);
-                if (!taken && L.transforms == kStaticPlans[SPI].transforms && same_plan(P, SPl)) {
+                // the constant plan is the run-time plan field for field; the transform count itself only sizes the grid
+                // of the two-kernel form (R1 > 1), so a whole multiple of the plan's count runs the same kernels
+                const bool count_ok = L.transforms == kStaticPlans[SPI].transforms ||
+                                      (P.R1 > 1 && kStaticPlans[SPI].fold == 0 && L.transforms % kStaticPlans[SPI].transforms == 0);
+                if (!taken && count_ok && same_plan(P, SPl)) {
                     taken = true;
                     result = launch_tiled_sp<FWD, Pro, Epi, SPI>(P, L, W, pro, epi, scratch, s);
                 }
