@@ -467,7 +467,7 @@ hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64
     // Private histogram copies per workgroup (JST_SPEC_SPAN_COPIES = 1 | 2 | 4 is the A/B switch).  The single-cycle kernel
     // is launch bound and does not care (5.08 / 5.10 / 5.18 us); here the counting is what is left, and every copy is
     // 16 KiB more to read back and zero per cycle: 36.4 us per 16-cycle span with four, 32.2 with two, 32.8 with one (more
-    // same-address collisions among the four rows of an atomic instruction) -- profiles/r03_experiments/w_...log.
+    // same-address collisions among the four rows of an atomic instruction) -- profiles/r03_experiments/w_span_kernel_diagnosis.log.
     static const int copies = [] {
         const char* e = getenv("JST_SPEC_SPAN_COPIES");
         const int c = e ? atoi(e) : 2;
