@@ -117,3 +117,24 @@ def test_no_gpu_means_loud_failure(js):
     x = np.zeros((1, 64), np.complex64)
     with pytest.raises(js.JetstreamError):  # create() must allocate its output on the device
         js.Module("fft", {}, {"signal": _host_view(js, x, sample=1, batch=0)})
+
+
+def test_runtime_flags_agree_between_header_and_mirror(js):
+    """The Python mirror's RUNTIME_* constants are the header's JST_RUNTIME_* enumerators (cycle batching included)."""
+    header = open(os.path.join(ROOT, "include", "jetstream_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    flags = {m.group(1): 1 << int(m.group(2)) for m in re.finditer(r"JST_RUNTIME_([A-Z]+)\s*=\s*1\s*<<\s*(\d+)", header)}
+    assert set(flags) == {"GRAPH", "FUSE", "TIMING", "PIPELINE", "COMBINE", "BATCH"}, flags
+    for name, value in flags.items():
+        assert getattr(js, "RUNTIME_" + name) == value, name
+
+
+def test_batching_needs_a_gpu_but_the_flag_is_understood(js):
+    """No GPU here: asking for a batched runtime must fail loudly like every other compute request (no CPU fallback),
+    and the two symbols the bench reads the launch form from must be there."""
+    lib = C.CDLL(js.LIB_PATH)
+    assert hasattr(lib, "jst_runtime_batched") and hasattr(lib, "jst_runtime_unit_mean_cycles")
+    lib.jst_runtime_batched.restype = C.c_int
+    lib.jst_runtime_unit_mean_cycles.restype = C.c_double
+    assert lib.jst_runtime_batched(None) == 0
+    assert lib.jst_runtime_unit_mean_cycles(None, b"spectrum_fused") < 0
