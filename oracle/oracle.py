@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libjst_oracle.so")
 _REF_PATH = os.path.join(_HERE, "_ref", "libref_pocketfft.so")
 _REF_HELPERS_PATH = os.path.join(_HERE, "_ref", "libref_helpers.so")
+_REF_JETSTREAM_PATH = os.path.join(_HERE, "_ref", "libref_jetstream.so")
 
 _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)
@@ -28,7 +29,8 @@ def build(force: bool = False) -> None:
         os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "jst_oracle.c"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "libjst_oracle.so"], stdout=subprocess.DEVNULL)
-    if (force or not os.path.exists(_REF_PATH) or not os.path.exists(_REF_HELPERS_PATH)) and os.path.exists(
+    if (force or not os.path.exists(_REF_PATH) or not os.path.exists(_REF_HELPERS_PATH)
+            or not os.path.exists(_REF_JETSTREAM_PATH)) and os.path.exists(
         "/root/reference/src/domains/dsp/fft/pocketfft.hh"
     ):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)

@@ -1,0 +1,362 @@
+// ref_jetstream.cc -- extern "C" harness around the REFERENCE's own libjetstream core, compiled IN PLACE from
+// /root/reference by oracle/ref_jetstream_build.sh into oracle/_ref/libref_jetstream.so.  TEST INFRASTRUCTURE ONLY:
+// tests/ and tools/make_reference_vectors.py drive it (ctypes) to pin oracle/jst_oracle.c and to generate golden
+// vectors; the product never loads it.  Everything numeric that runs behind these entry points is the reference's
+// code (Registry::BuildModule / Module::create / Runtime::compute for single modules -- what TestContext does,
+// src/testing.cc:123-186 -- and Flowgraph::blockCreate / Flowgraph::compute for blocks, as tests/support/
+// flowgraph_fixture.hh does).  What is mine: this glue, a non-static source module + block ("oracle_source": the
+// counterpart of the reference's test-only flowgraph_test_source, with a dtype and a shape), and three symbols the
+// core references from subsystems that are not built (python runtime, YAML parser).
+#include <any>
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "jetstream/block.hh"
+#include "jetstream/detail/block_impl.hh"
+#include "jetstream/detail/module_impl.hh"
+#include "jetstream/flowgraph.hh"
+#include "jetstream/flowgraph_view.hh"
+#include "jetstream/logger.hh"
+#include "jetstream/module.hh"
+#include "jetstream/module_context.hh"
+#include "jetstream/parser.hh"
+#include "jetstream/registry.hh"
+#include "jetstream/runtime.hh"
+#include "jetstream/runtime_context_native_cpu.hh"
+#include "jetstream/scheduler_context.hh"
+
+namespace Jetstream {
+
+// ---- symbols of subsystems that are not part of this build ----------------------------------------------------
+std::shared_ptr<Runtime::Impl> PythonRuntimeFactory() { return nullptr; }
+Result Parser::YamlDecode(const std::string&, Map&) { return Result::ERROR; }
+Result Parser::YamlEncode(const Map&, std::string&) { return Result::ERROR; }
+
+// ---- oracle_source: a source whose tensor the test fills between computes ---------------------------------------
+namespace Modules {
+struct OracleSource : public Module::Config {
+    std::vector<U64> shape = {1};
+    std::string dataType = "CF32";
+    JST_MODULE_TYPE(oracle_source);
+    JST_MODULE_PARAMS(shape, dataType);
+};
+struct OracleSourceImpl : public Module::Impl,
+                          public DynamicConfig<OracleSource>,
+                          public NativeCpuRuntimeContext,
+                          public Scheduler::Context {
+    Result validate() override {
+        const auto& c = *candidate();
+        if (c.shape.empty() || NameToDataType(c.dataType) == DataType::None) return Result::ERROR;
+        for (const U64 d : c.shape) if (d == 0) return Result::ERROR;
+        return Result::SUCCESS;
+    }
+    Result define() override { return defineInterfaceOutput("signal"); }
+    Result create() override {
+        JST_CHECK(signal.create(device(), NameToDataType(dataType), shape));
+        outputs()["signal"].produced(name(), "signal", signal);
+        return Result::SUCCESS;
+    }
+    Result computeSubmit() override { return Result::SUCCESS; }
+    Tensor signal;
+};
+JST_REGISTER_MODULE(OracleSourceImpl, DeviceType::CPU, RuntimeType::NATIVE, "generic");
+}  // namespace Modules
+
+namespace Blocks {
+struct OracleSource : public Block::Config {
+    std::vector<U64> shape = {1};
+    std::string dataType = "CF32";
+    JST_BLOCK_TYPE(oracle_source);
+    JST_BLOCK_DOMAIN("Test");
+    JST_BLOCK_PARAMS(shape, dataType);
+    JST_BLOCK_DESCRIPTION("Oracle Source", "Test-owned tensor.", "Source block of the oracle harness.");
+};
+struct OracleSourceBlockImpl : public Block::Impl, public DynamicConfig<Blocks::OracleSource> {
+    Result configure() override {
+        moduleConfig->shape = shape;
+        moduleConfig->dataType = dataType;
+        return Result::SUCCESS;
+    }
+    Result define() override { return defineInterfaceOutput("signal", "Output", "Test-owned tensor."); }
+    Result create() override {
+        JST_CHECK(moduleCreate("source", moduleConfig, {}));
+        return moduleExposeOutput("signal", {"source", "signal"});
+    }
+    std::shared_ptr<Modules::OracleSource> moduleConfig = std::make_shared<Modules::OracleSource>();
+};
+JST_REGISTER_BLOCK(OracleSourceBlockImpl, {"oracle_source"});
+}  // namespace Blocks
+
+}  // namespace Jetstream
+
+using namespace Jetstream;
+
+namespace {
+
+// "key=value" lines -> Parser::Map of strings (the decoder turns them into the typed config fields,
+// include/jetstream/parser.hh Decode: a std::string entry goes through StringToTyped)
+Parser::Map parse_config(const char* lines) {
+    Parser::Map m;
+    if (!lines) return m;
+    std::istringstream in(lines);
+    std::string line;
+    while (std::getline(in, line)) {
+        const auto eq = line.find('=');
+        if (eq == std::string::npos) continue;
+        m[line.substr(0, eq)] = std::string(line.substr(eq + 1));
+    }
+    return m;
+}
+
+struct Desc {  // what the Python side reads back: element strides / offset like Tensor::stride() / offset()
+    void* data;
+    uint64_t offset;
+    uint32_t dtype;
+    uint32_t rank;
+    uint64_t shape[8];
+    uint64_t stride[8];
+    int64_t sample_axis, batch_axis, channel_axis;
+};
+
+int64_t axis_attr(const Tensor& t, const char* key) {
+    if (!t.hasAttribute(key)) return -1;
+    const std::any a = t.attribute(key);
+    if (const auto* v = std::any_cast<Index>(&a)) return (int64_t)*v;
+    return -1;
+}
+
+int fill_desc(const Tensor& t, Desc* d) {
+    if (t.rank() > 8) return 1;
+    d->data = const_cast<void*>(t.data());
+    d->offset = t.offset();
+    d->dtype = (uint32_t)t.dtype();
+    d->rank = (uint32_t)t.rank();
+    for (Index a = 0; a < t.rank(); ++a) {
+        d->shape[a] = t.shape(a);
+        d->stride[a] = t.stride(a);
+    }
+    d->sample_axis = axis_attr(t, "sampleAxis");
+    d->batch_axis = axis_attr(t, "batchAxis");
+    d->channel_axis = axis_attr(t, "channelAxis");
+    return 0;
+}
+
+// attribute kinds the path's modules read: 0 Index, 1 F32, 2 vector<F32>, 3 vector<U64>, 4 vector<F64>, 5 F64
+int set_attr(Tensor& t, const char* key, int kind, const double* v, uint64_t n) {
+    Result r = Result::ERROR;
+    switch (kind) {
+        case 0: r = t.setAttribute(key, Index{(Index)v[0]}); break;
+        case 1: r = t.setAttribute(key, F32{(F32)v[0]}); break;
+        case 2: { std::vector<F32> x(n); for (uint64_t i = 0; i < n; ++i) x[i] = (F32)v[i]; r = t.setAttribute(key, x); break; }
+        case 3: { std::vector<U64> x(n); for (uint64_t i = 0; i < n; ++i) x[i] = (U64)v[i]; r = t.setAttribute(key, x); break; }
+        case 4: { std::vector<F64> x(v, v + n); r = t.setAttribute(key, x); break; }
+        case 5: r = t.setAttribute(key, F64{v[0]}); break;
+        default: break;
+    }
+    return r == Result::SUCCESS ? 0 : 1;
+}
+
+// ---- one module + one runtime, alive across computes (TestContext::start / compute / stop) --------------------
+struct ModSession {
+    std::string type;
+    Parser::Map config;
+    std::unordered_map<std::string, Tensor> inputs;
+    std::shared_ptr<Module> module;
+    std::unique_ptr<Runtime> runtime;
+    ~ModSession() {
+        if (runtime) { (void)runtime->destroy(); runtime.reset(); }
+        if (module) { (void)module->destroy(); module.reset(); }
+    }
+};
+
+struct FgSession {
+    std::unique_ptr<Flowgraph> fg;
+    ~FgSession() {
+        if (!fg) return;
+        std::vector<std::string> names;
+        if (fg->view().keys(names) == Result::SUCCESS)
+            for (const auto& n : names) (void)fg->blockDestroy(n, false);
+        (void)fg->destroy();
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int ref_jst_probe() { return 1; }
+uint64_t ref_jst_desc_size() { return sizeof(Desc); }
+
+// quiet by default: the reference logs every created module at INFO
+void ref_jst_log_level(int level) { JST_LOG_SET_DEBUG_LEVEL(level); }
+
+// ---- modules ---------------------------------------------------------------------------------------------------
+void* ref_mod_new(const char* type, const char* config_lines) {
+    auto* s = new ModSession();
+    s->type = type;
+    s->config = parse_config(config_lines);
+    return s;
+}
+// allocates the input tensor (CPU, zero-filled) and returns its description; the caller writes the data in place
+int ref_mod_input(void* h, const char* port, const char* dtype, uint32_t rank, const uint64_t* shape, Desc* out) {
+    auto* s = static_cast<ModSession*>(h);
+    Shape sh(shape, shape + rank);
+    Tensor t;
+    if (t.create(DeviceType::CPU, NameToDataType(dtype), sh) != Result::SUCCESS) return 1;
+    s->inputs[port] = t;
+    return fill_desc(t, out);
+}
+int ref_mod_input_attr(void* h, const char* port, const char* key, int kind, const double* v, uint64_t n) {
+    auto* s = static_cast<ModSession*>(h);
+    const auto it = s->inputs.find(port);
+    if (it == s->inputs.end()) return 1;
+    return set_attr(it->second, key, kind, v, n);
+}
+// layout edits of an input before start(): op 0 permute(axes), 1 reshape(shape), 2 expandDims(axis), 3 broadcastTo(shape)
+int ref_mod_input_view(void* h, const char* port, int op, const uint64_t* v, uint64_t n, Desc* out) {
+    auto* s = static_cast<ModSession*>(h);
+    const auto it = s->inputs.find(port);
+    if (it == s->inputs.end()) return 1;
+    Result r = Result::ERROR;
+    const Shape sh(v, v + n);
+    if (op == 0) r = it->second.permute(sh);
+    else if (op == 1) r = it->second.reshape(sh);
+    else if (op == 2) r = it->second.expandDims((Index)v[0]);
+    else if (op == 3) r = it->second.broadcastTo(sh);
+    if (r != Result::SUCCESS) return 1;
+    return fill_desc(it->second, out);
+}
+// Registry::BuildModule + Module::create + Runtime::create; returns the reference's Result value
+int ref_mod_start(void* h) {
+    auto* s = static_cast<ModSession*>(h);
+    if (s->module || s->runtime) return (int)Result::ERROR;
+    Result r = Registry::BuildModule(s->type, DeviceType::CPU, RuntimeType::NATIVE, "generic", s->module);
+    if (r != Result::SUCCESS) return (int)r;
+    TensorMap in;
+    for (auto& [name, t] : s->inputs) {
+        in[name].requested("test", name);
+        in[name].tensor = t;
+    }
+    r = s->module->create("test", s->config, in);
+    if (r != Result::SUCCESS) { s->module.reset(); return (int)r; }
+    s->runtime = std::make_unique<Runtime>("test", DeviceType::CPU, RuntimeType::NATIVE);
+    r = s->runtime->create({{"test", s->module}});
+    if (r != Result::SUCCESS) { (void)s->module->destroy(); s->module.reset(); s->runtime.reset(); }
+    return (int)r;
+}
+int ref_mod_compute(void* h) {
+    auto* s = static_cast<ModSession*>(h);
+    if (!s->module || !s->runtime) return (int)Result::ERROR;
+    std::unordered_set<std::string> skipped, failed;
+    return (int)s->runtime->compute({}, skipped, failed);
+}
+int ref_mod_output(void* h, const char* port, Desc* out) {
+    auto* s = static_cast<ModSession*>(h);
+    if (!s->module) return 1;
+    const auto& outs = s->module->outputs();
+    const auto it = outs.find(port);
+    if (it == outs.end()) return 1;
+    return fill_desc(it->second.tensor, out);
+}
+// reads an output attribute back: kind as in set_attr; returns the element count written (0 = absent / other type)
+uint64_t ref_mod_output_attr(void* h, const char* port, const char* key, int kind, double* v, uint64_t cap) {
+    auto* s = static_cast<ModSession*>(h);
+    if (!s->module) return 0;
+    const auto& outs = s->module->outputs();
+    const auto it = outs.find(port);
+    if (it == outs.end() || !it->second.tensor.hasAttribute(key)) return 0;
+    const std::any a = it->second.tensor.attribute(key);
+    if (kind == 0) { if (const auto* p = std::any_cast<Index>(&a)) { v[0] = (double)*p; return 1; } }
+    if (kind == 1) { if (const auto* p = std::any_cast<F32>(&a)) { v[0] = (double)*p; return 1; } }
+    if (kind == 2) { if (const auto* p = std::any_cast<std::vector<F32>>(&a)) { uint64_t n = p->size() < cap ? p->size() : cap; for (uint64_t i = 0; i < n; ++i) v[i] = (*p)[i]; return n; } }
+    if (kind == 3) { if (const auto* p = std::any_cast<std::vector<U64>>(&a)) { uint64_t n = p->size() < cap ? p->size() : cap; for (uint64_t i = 0; i < n; ++i) v[i] = (double)(*p)[i]; return n; } }
+    return 0;
+}
+void ref_mod_free(void* h) { delete static_cast<ModSession*>(h); }
+
+// ---- flowgraphs of blocks --------------------------------------------------------------------------------------
+void* ref_fg_new() {
+    auto* s = new FgSession();
+    s->fg = std::make_unique<Flowgraph>();
+    if (s->fg->create({}, nullptr, nullptr, nullptr) != Result::SUCCESS) { s->fg.reset(); delete s; return nullptr; }
+    return s;
+}
+// inputs_lines: "port=block:port" per line
+int ref_fg_block(void* h, const char* name, const char* type, const char* config_lines, const char* inputs_lines) {
+    auto* s = static_cast<FgSession*>(h);
+    TensorMap in;
+    if (inputs_lines) {
+        std::istringstream is(inputs_lines);
+        std::string line;
+        while (std::getline(is, line)) {
+            const auto eq = line.find('=');
+            const auto colon = line.find(':', eq == std::string::npos ? 0 : eq);
+            if (eq == std::string::npos || colon == std::string::npos) continue;
+            in[line.substr(0, eq)].requested(line.substr(eq + 1, colon - eq - 1), line.substr(colon + 1));
+        }
+    }
+    return (int)s->fg->blockCreate(name, std::string(type), parse_config(config_lines), in);
+}
+// state of a block: Block::State value, or -1 when the block does not exist
+int ref_fg_block_state(void* h, const char* name) {
+    auto* s = static_cast<FgSession*>(h);
+    Flowgraph::View::BlockInfo info;
+    if (s->fg->view().info(name, info) != Result::SUCCESS) return -1;
+    return (int)info.state;
+}
+int ref_fg_tensor(void* h, const char* block, const char* port, Desc* out) {
+    auto* s = static_cast<FgSession*>(h);
+    TensorMap outs;
+    if (s->fg->view().outputs(block, outs) != Result::SUCCESS) return 1;
+    const auto it = outs.find(port);
+    if (it == outs.end()) return 1;
+    return fill_desc(it->second.tensor, out);
+}
+int ref_fg_tensor_attr(void* h, const char* block, const char* port, const char* key, int kind, const double* v, uint64_t n) {
+    auto* s = static_cast<FgSession*>(h);
+    TensorMap outs;
+    if (s->fg->view().outputs(block, outs) != Result::SUCCESS) return 1;
+    const auto it = outs.find(port);
+    if (it == outs.end()) return 1;
+    Tensor t = it->second.tensor;  // copies share the attribute store (the reference's own tests set them this way)
+    return set_attr(t, key, kind, v, n);
+}
+// op as in ref_mod_input_view, applied to a block's output tensor (e.g. reshape a source to [heads, taps])
+int ref_fg_tensor_view(void* h, const char* block, const char* port, int op, const uint64_t* v, uint64_t n) {
+    auto* s = static_cast<FgSession*>(h);
+    TensorMap outs;
+    if (s->fg->view().outputs(block, outs) != Result::SUCCESS) return 1;
+    const auto it = outs.find(port);
+    if (it == outs.end()) return 1;
+    Tensor t = it->second.tensor;
+    const Shape sh(v, v + n);
+    Result r = Result::ERROR;
+    if (op == 0) r = t.permute(sh);
+    else if (op == 1) r = t.reshape(sh);
+    else if (op == 2) r = t.expandDims((Index)v[0]);
+    return r == Result::SUCCESS ? 0 : 1;
+}
+uint64_t ref_fg_tensor_attr_get(void* h, const char* block, const char* port, const char* key, int kind, double* v, uint64_t cap) {
+    auto* s = static_cast<FgSession*>(h);
+    TensorMap outs;
+    if (s->fg->view().outputs(block, outs) != Result::SUCCESS) return 0;
+    const auto it = outs.find(port);
+    if (it == outs.end() || !it->second.tensor.hasAttribute(key)) return 0;
+    const std::any a = it->second.tensor.attribute(key);
+    if (kind == 0) { if (const auto* p = std::any_cast<Index>(&a)) { v[0] = (double)*p; return 1; } }
+    if (kind == 1) { if (const auto* p = std::any_cast<F32>(&a)) { v[0] = (double)*p; return 1; } }
+    if (kind == 2) { if (const auto* p = std::any_cast<std::vector<F32>>(&a)) { uint64_t n = p->size() < cap ? p->size() : cap; for (uint64_t i = 0; i < n; ++i) v[i] = (*p)[i]; return n; } }
+    if (kind == 3) { if (const auto* p = std::any_cast<std::vector<U64>>(&a)) { uint64_t n = p->size() < cap ? p->size() : cap; for (uint64_t i = 0; i < n; ++i) v[i] = (double)(*p)[i]; return n; } }
+    return 0;
+}
+int ref_fg_compute(void* h) { return (int)static_cast<FgSession*>(h)->fg->compute(); }
+void ref_fg_free(void* h) { delete static_cast<FgSession*>(h); }
+
+}  // extern "C"

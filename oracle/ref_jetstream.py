@@ -1,0 +1,264 @@
+"""ctypes front-end for oracle/_ref/libref_jetstream.so: the REFERENCE's own libjetstream core and native-CPU
+modules / blocks, compiled IN PLACE from /root/reference by oracle/ref_jetstream_build.sh (harness: ref_jetstream.cc).
+
+TEST INFRASTRUCTURE ONLY.  Used by tests/ to pin oracle/jst_oracle.c stage by stage against the reference itself and
+by tools/make_reference_vectors.py to freeze golden vectors (tests/golden/reference_modules.npz) for boxes without the
+reference tree.  The product package never imports this.
+
+    with RefModule("fm", {"mode": "wide", "sampleRate": 200e3}) as m:
+        m.input("signal", x, sample=0)        # numpy array; a CPU tensor of the reference holds a copy
+        m.start(); m.compute()
+        y = m.output("signal")                # numpy copy, layout as the reference's tensor
+        m.write("signal", x2); m.compute()    # next submission: state carries over
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_ref", "libref_jetstream.so")
+
+RESULT_SUCCESS = 0
+
+_DTYPES = {1: np.float32, 2: np.float64, 3: np.int8, 4: np.int16, 5: np.int32, 6: np.int64, 7: np.uint8, 8: np.uint16,
+           9: np.uint32, 10: np.uint64, 11: np.complex64, 12: np.complex128}
+_NAMES = {np.dtype(np.float32): "F32", np.dtype(np.float64): "F64", np.dtype(np.complex64): "CF32",
+          np.dtype(np.complex128): "CF64", np.dtype(np.int8): "I8", np.dtype(np.int16): "I16", np.dtype(np.int32): "I32",
+          np.dtype(np.uint8): "U8", np.dtype(np.uint16): "U16", np.dtype(np.uint32): "U32", np.dtype(np.uint64): "U64"}
+# complex integer formats travel as [..., 2] integer arrays
+_CI = {"CI8": (np.int8, 13), "CI16": (np.int16, 14), "CU8": (np.uint8, 17), "CU16": (np.uint16, 18)}
+
+
+class _Desc(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("offset", C.c_uint64), ("dtype", C.c_uint32), ("rank", C.c_uint32),
+                ("shape", C.c_uint64 * 8), ("stride", C.c_uint64 * 8),
+                ("sample_axis", C.c_int64), ("batch_axis", C.c_int64), ("channel_axis", C.c_int64)]
+
+
+_lib = None
+
+
+def build(force: bool = False) -> None:
+    if os.path.exists("/root/reference/src/module.cc") and (force or not os.path.exists(_PATH)):
+        subprocess.check_call([os.path.join(_HERE, "ref_jetstream_build.sh"), "-j", "16"], stdout=subprocess.DEVNULL)
+
+
+def available() -> bool:
+    build()
+    return os.path.exists(_PATH)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_PATH)
+        assert _lib.ref_jst_desc_size() == C.sizeof(_Desc)
+        for n in ("ref_mod_new", "ref_fg_new"):
+            getattr(_lib, n).restype = C.c_void_p
+        for n in ("ref_mod_output_attr", "ref_fg_tensor_attr_get"):
+            getattr(_lib, n).restype = C.c_uint64
+        _lib.ref_jst_log_level(int(os.environ.get("JST_REF_LOG", "1")))
+    return _lib
+
+
+def _cfg(config: Optional[Dict]) -> bytes:
+    def enc(v):
+        if isinstance(v, bool):
+            return "true" if v else "false"
+        if isinstance(v, (list, tuple, np.ndarray)):
+            return "[" + ", ".join(enc(e) for e in v) + "]"
+        if isinstance(v, (float, np.floating)):
+            return repr(float(v))
+        return str(v)
+    return "\n".join(f"{k}={enc(v)}" for k, v in (config or {}).items()).encode()
+
+
+def _view(d: _Desc) -> np.ndarray:
+    """numpy view (no copy) of a reference tensor: element strides and offset as Tensor::stride() / offset()."""
+    code = int(d.dtype)
+    rank = int(d.rank)
+    shape = [int(d.shape[a]) for a in range(rank)]
+    stride = [int(d.stride[a]) for a in range(rank)]
+    if code in _DTYPES:
+        dt = np.dtype(_DTYPES[code])
+    else:
+        raise TypeError(f"dtype code {code}")
+    extent = 1 + sum((s - 1) * st for s, st in zip(shape, stride)) if all(shape) else 0
+    if extent == 0:
+        return np.empty(shape, dt)
+    base = np.ctypeslib.as_array(C.cast(C.c_void_p(d.data + 0), C.POINTER(C.c_uint8)), ((int(d.offset) + extent) * dt.itemsize,))
+    flat = base.view(dt)[int(d.offset):]
+    return np.lib.stride_tricks.as_strided(flat, shape=shape, strides=[st * dt.itemsize for st in stride])
+
+
+def _attr_args(value):
+    if isinstance(value, (list, tuple, np.ndarray)):
+        arr = np.asarray(value, dtype=np.float64).reshape(-1)
+        return arr, len(arr)
+    return np.asarray([value], dtype=np.float64), 1
+
+
+ATTR_INDEX, ATTR_F32, ATTR_VEC_F32, ATTR_VEC_U64, ATTR_VEC_F64, ATTR_F64 = range(6)
+
+
+class RefModule:
+    """One module of the reference behind Registry::BuildModule / Module::create / Runtime::compute."""
+
+    def __init__(self, mtype: str, config: Optional[Dict] = None):
+        self._l = lib()
+        self._h = C.c_void_p(self._l.ref_mod_new(mtype.encode(), _cfg(config)))
+        self._in: Dict[str, np.ndarray] = {}
+        self._in_desc: Dict[str, _Desc] = {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        if self._h:
+            self._l.ref_mod_free(self._h)
+            self._h = None
+
+    def input(self, port: str, x: np.ndarray, sample=None, batch=None, channel=None, attrs: Optional[Dict] = None):
+        x = np.asarray(x)
+        shape = (C.c_uint64 * max(x.ndim, 1))(*x.shape)
+        d = _Desc()
+        assert self._l.ref_mod_input(self._h, port.encode(), _NAMES[x.dtype].encode(), x.ndim, shape, C.byref(d)) == 0
+        v = _view(d)
+        v[...] = x
+        self._in[port] = v
+        self._in_desc[port] = d
+        for key, val in (("sampleAxis", sample), ("batchAxis", batch), ("channelAxis", channel)):
+            if val is not None:
+                self.input_attr(port, key, ATTR_INDEX, val)
+        for key, (kind, val) in (attrs or {}).items():
+            self.input_attr(port, key, kind, val)
+        return v
+
+    def input_attr(self, port: str, key: str, kind: int, value):
+        arr, n = _attr_args(value)
+        assert self._l.ref_mod_input_attr(self._h, port.encode(), key.encode(), kind,
+                                          arr.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(n)) == 0
+
+    def input_view(self, port: str, op: str, values: Sequence[int]):
+        """permute / reshape / expand_dims / broadcast of an input before start() (Tensor::permute etc.)."""
+        code = {"permute": 0, "reshape": 1, "expand_dims": 2, "broadcast": 3}[op]
+        v = (C.c_uint64 * max(len(values), 1))(*values)
+        d = _Desc()
+        assert self._l.ref_mod_input_view(self._h, port.encode(), code, v, C.c_uint64(len(values)), C.byref(d)) == 0
+        self._in[port] = _view(d)
+        return self._in[port]
+
+    def write(self, port: str, x: np.ndarray):
+        self._in[port][...] = x
+
+    def start(self) -> int:
+        return int(self._l.ref_mod_start(self._h))
+
+    def compute(self) -> int:
+        return int(self._l.ref_mod_compute(self._h))
+
+    def output_view(self, port: str) -> np.ndarray:
+        d = _Desc()
+        assert self._l.ref_mod_output(self._h, port.encode(), C.byref(d)) == 0, f"no output {port}"
+        return _view(d)
+
+    def output(self, port: str) -> np.ndarray:
+        return np.array(self.output_view(port))
+
+    def output_axes(self, port: str):
+        d = _Desc()
+        assert self._l.ref_mod_output(self._h, port.encode(), C.byref(d)) == 0
+        f = lambda a: None if a < 0 else int(a)
+        return {"sample": f(d.sample_axis), "batch": f(d.batch_axis), "channel": f(d.channel_axis)}
+
+    def output_attr(self, port: str, key: str, kind: int):
+        buf = np.zeros(64, np.float64)
+        n = int(self._l.ref_mod_output_attr(self._h, port.encode(), key.encode(), kind,
+                                            buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(64)))
+        if n == 0:
+            return None
+        return buf[:n].tolist() if kind in (ATTR_VEC_F32, ATTR_VEC_U64) else buf[0]
+
+    def run(self) -> int:
+        r = self.start()
+        return r if r != RESULT_SUCCESS else self.compute()
+
+
+class RefFlowgraph:
+    """A Flowgraph of the reference's BLOCKS (Flowgraph::blockCreate / compute, as tests/support/flowgraph_fixture.hh)."""
+
+    def __init__(self):
+        self._l = lib()
+        h = self._l.ref_fg_new()
+        assert h, "Flowgraph::create failed"
+        self._h = C.c_void_p(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        if self._h:
+            self._l.ref_fg_free(self._h)
+            self._h = None
+
+    def source(self, name: str, x: np.ndarray, sample=None, batch=None, channel=None) -> np.ndarray:
+        """oracle_source block holding a copy of x; returns the live view (write into it between computes)."""
+        x = np.asarray(x)
+        assert self.block(name, "oracle_source", {"shape": list(x.shape), "dataType": _NAMES[x.dtype]}) == 0
+        v = self.tensor(name, "signal")
+        v[...] = x
+        for key, val in (("sampleAxis", sample), ("batchAxis", batch), ("channelAxis", channel)):
+            if val is not None:
+                self.set_attr(name, "signal", key, ATTR_INDEX, val)
+        return v
+
+    def block(self, name: str, btype: str, config: Optional[Dict] = None, inputs: Optional[Dict[str, str]] = None) -> int:
+        ins = "\n".join(f"{port}={src}" for port, src in (inputs or {}).items()).encode()
+        return int(self._l.ref_fg_block(self._h, name.encode(), btype.encode(), _cfg(config), ins))
+
+    def state(self, name: str) -> int:
+        return int(self._l.ref_fg_block_state(self._h, name.encode()))
+
+    def tensor(self, block: str, port: str) -> np.ndarray:
+        d = _Desc()
+        assert self._l.ref_fg_tensor(self._h, block.encode(), port.encode(), C.byref(d)) == 0, f"no {block}:{port}"
+        return _view(d)
+
+    def axes(self, block: str, port: str):
+        d = _Desc()
+        assert self._l.ref_fg_tensor(self._h, block.encode(), port.encode(), C.byref(d)) == 0
+        f = lambda a: None if a < 0 else int(a)
+        return {"sample": f(d.sample_axis), "batch": f(d.batch_axis), "channel": f(d.channel_axis)}
+
+    def set_attr(self, block: str, port: str, key: str, kind: int, value):
+        arr, n = _attr_args(value)
+        assert self._l.ref_fg_tensor_attr(self._h, block.encode(), port.encode(), key.encode(), kind,
+                                          arr.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(n)) == 0
+
+    def get_attr(self, block: str, port: str, key: str, kind: int):
+        buf = np.zeros(64, np.float64)
+        n = int(self._l.ref_fg_tensor_attr_get(self._h, block.encode(), port.encode(), key.encode(), kind,
+                                               buf.ctypes.data_as(C.POINTER(C.c_double)), C.c_uint64(64)))
+        if n == 0:
+            return None
+        return buf[:n].tolist() if kind in (ATTR_VEC_F32, ATTR_VEC_U64) else buf[0]
+
+    def view(self, block: str, port: str, op: str, values: Sequence[int]):
+        code = {"permute": 0, "reshape": 1, "expand_dims": 2}[op]
+        v = (C.c_uint64 * max(len(values), 1))(*values)
+        assert self._l.ref_fg_tensor_view(self._h, block.encode(), port.encode(), code, v, C.c_uint64(len(values))) == 0
+
+    def compute(self) -> int:
+        return int(self._l.ref_fg_compute(self._h))

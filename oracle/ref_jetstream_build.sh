@@ -1,0 +1,63 @@
+#!/bin/bash
+# oracle/ref_jetstream_build.sh -- TEST INFRASTRUCTURE: compiles the REFERENCE's own core (Tensor / Module / Block /
+# Flowgraph / Registry / native-CPU runtime / synchronous scheduler) and the native-CPU module and block
+# implementations of the hot path IN PLACE from /root/reference into oracle/_ref/libref_jetstream.so (git-ignored;
+# travels to the GPU box like the other built libraries).  Nothing is copied: every translation unit is compiled
+# where it lies, with oracle/ref_shim first on the include path (a stub config.hh; jst::fmt forwarded to the fmt
+# headers torch ships, header-only).  The reference's own build (meson + network wraps) is NOT run.  What is left out:
+# render / compositor / viewport / remote instance / YAML parser (rapidyaml is a network wrap) / python runtime /
+# non-CPU devices -- none of them is on the path; oracle/ref_jetstream.cc provides the three symbols the core still
+# asks for (PythonRuntimeFactory and two Platform helpers) and the extern "C" harness the tests drive.
+#   usage: oracle/ref_jetstream_build.sh [-j N]   (REF=/root/reference by default)
+set -u
+HERE=$(cd "$(dirname "$0")" && pwd)
+REF=${REF:-/root/reference}
+JOBS=8
+[ "${1:-}" = "-j" ] && JOBS=$2
+if [ ! -f "$REF/src/module.cc" ]; then echo "reference tree absent: keeping prebuilt _ref/ (if any)"; exit 0; fi
+TORCH_INC=$(python3 -c "import torch,os;print(os.path.join(os.path.dirname(torch.__file__),'include'))" 2>/dev/null)
+if [ -z "$TORCH_INC" ] || [ ! -f "$TORCH_INC/fmt/format.h" ]; then echo "fmt headers not found: libref_jetstream.so not built"; exit 0; fi
+OUT=$HERE/_ref
+OBJ=$OUT/obj_jetstream
+mkdir -p "$OBJ"
+# -O3, no -march (meson_options.txt:1, meson.build:8); -ffp-contract=off is a no-op on baseline x86-64 (no FMA) and
+# keeps it that way if someone adds -march flags.
+CXXFLAGS="-O3 -std=c++20 -fPIC -ffp-contract=off -w -DFMT_HEADER_ONLY=1 -I$HERE/ref_shim -I$REF/include -I$REF/src -I$TORCH_INC"
+
+CORE="logger module module_impl module_context module_interface module_surface block block_impl block_context
+      block_interface registry parser_map parser_decode parser_encode tensor_link testing scheduler scheduler_context
+      scheduler_synchronous flowgraph flowgraph_metadata flowgraph_environment flowgraph_view runtime/runtime runtime/native/cpu/context
+      runtime/native/cpu/impl memory/tensor memory/buffer memory/buffer_cpu memory/axis memory/types memory/token
+      platform/terminal platform/process platform/paths"
+MODULES="core/add core/arithmetic core/cast core/duplicate core/expand_dims core/flatten core/multiply
+         core/multiply_constant core/ones_tensor core/pad core/permutation core/range core/reshape core/signal_axes
+         core/slice core/squeeze_dims core/unpad
+         dsp/agc dsp/am dsp/amplitude dsp/fft dsp/filter_taps dsp/fm dsp/fold dsp/invert dsp/overlap_add
+         dsp/phase_correction dsp/signal_generator dsp/squelch dsp/window
+"
+BLOCKS="$MODULES dsp/filter dsp/filter_engine dsp/spectrum_engine dsp/decimator"
+
+LIST=$OBJ/units.txt
+: > "$LIST"
+for c in $CORE; do echo "src/$c.cc" >> "$LIST"; done
+for m in $MODULES; do
+  for f in module_impl.cc module_impl_native_cpu.cc; do
+    [ -f "$REF/src/domains/$m/$f" ] && echo "src/domains/$m/$f" >> "$LIST"
+  done
+done
+for b in $BLOCKS; do [ -f "$REF/src/domains/$b/block_impl.cc" ] && echo "src/domains/$b/block_impl.cc" >> "$LIST"; done
+[ -n "${EXTRA_UNITS:-}" ] && for u in $EXTRA_UNITS; do echo "$u" >> "$LIST"; done
+
+compile_one() {
+  u=$1
+  o=$OBJ/$(echo "$u" | tr '/' '_' | sed 's/\.cc$//').o
+  if [ ! -f "$o" ] || [ "$REF/$u" -nt "$o" ]; then
+    g++ $CXXFLAGS -I"$(dirname "$REF/$u")" -c "$REF/$u" -o "$o" 2> "$o.err" || { echo "FAILED $u"; head -5 "$o.err"; rm -f "$o"; return 1; }
+  fi
+  rm -f "$o.err"
+}
+export -f compile_one; export OBJ REF CXXFLAGS
+xargs -a "$LIST" -P "$JOBS" -I{} bash -c 'compile_one {}' || { echo "libref_jetstream.so: some units failed"; exit 1; }
+g++ $CXXFLAGS -c "$HERE/ref_jetstream.cc" -o "$OBJ/harness.o" || exit 1
+OBJS=$(sed 's|/|_|g; s|\.cc$|.o|' "$LIST" | sed "s|^|$OBJ/|")
+g++ -shared -fPIC -o "$OUT/libref_jetstream.so" $OBJS "$OBJ/harness.o" -Wl,--no-undefined -lpthread && echo "built _ref/libref_jetstream.so from $REF"
