@@ -143,7 +143,7 @@ class Flowgraph:
             pending.append(e)
         # instantiate in dependency order (the file order is the editor's, not topological)
         done = set()
-        composite = {"soapy", "spectrum_engine", "filter", "decimator", "slice", "filter_taps", "squelch", "flatten",
+        composite = {"soapy", "spectrum_engine", "filter", "filter_engine", "decimator", "slice", "filter_taps", "squelch", "flatten",
                      "permutation"}
         while pending:
             progressed = False
@@ -222,6 +222,9 @@ class Flowgraph:
                             heads, name=name,
                             provider=provider if provider in ("generic", "fast") else "generic")
             node.impl, node.modules, node.outputs = flt, flt.modules, {"buffer": flt.buffer}
+        elif block == "filter_engine":  # dsp/filter_engine/block_impl.cc: external coefficient tensor
+            eng = js.FilterEngine(inputs["signal"], inputs["filter"], name=name)
+            node.impl, node.modules, node.outputs = eng, eng.modules, {"buffer": eng.buffer}
         elif block == "squelch":  # dsp/squelch/block_impl.cc: one module, ports signal -> signal
             sq = js.Module("squelch", {"threshold": float(cfg.get("threshold", 0.1))},
                            {"signal": inputs["signal"]}, name + ".squelch")
@@ -271,7 +274,7 @@ class Flowgraph:
             node.outputs = {bp: m.output(mp) for bp, mp in ports.items()}
         else:
             raise FlowgraphError(f"node '{name}': block type '{block}' is not implemented on the HIP "
-                                 f"device (implemented: {sorted(set(_SIMPLE) | {'soapy', 'spectrum_engine', 'filter', 'decimator', 'slice', 'filter_taps', 'flatten', 'permutation', 'squelch'})})")
+                                 f"device (implemented: {sorted(set(_SIMPLE) | {'soapy', 'spectrum_engine', 'filter', 'filter_engine', 'decimator', 'slice', 'filter_taps', 'flatten', 'permutation', 'squelch'})})")
         self.nodes[name] = node
         self.order.append(name)
 

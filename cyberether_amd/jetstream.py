@@ -756,6 +756,130 @@ class Filter:
         return [m for m in ms if m is not None]
 
 
+class FilterEngine:
+    """The filter_engine BLOCK (src/domains/dsp/filter_engine/block_impl.cc:213-673): FFT overlap-add convolution of
+    `signal` with an EXTERNAL coefficient tensor `filt` -- [T] with sampleAxis 0 (one head: no head axis is added, the
+    fold offset and the phase increment are plain config values) or [C, T] with channelAxis 0 / sampleAxis 1 (C heads,
+    per-head fold offsets / phase increments as tensor attributes).  Resampling is planned from the filter tensor's
+    `sampleRate` / `bandwidth` / `center` attributes (what filter_taps publishes) and bypassed when one is missing
+    (CalculateResampleHeuristics, :43-176; the integers come from the library's jst_filter_plan)."""
+
+    def __init__(self, signal: Tensor, filt: Tensor, name: str = "filter_engine"):
+        import math
+        axes, rank = signal.axes, len(signal.shape)
+        s_axis = axes["sample"] if axes["sample"] is not None else (0 if rank == 1 else None)
+        faxes, frank = filt.axes, len(filt.shape)
+        f_sample = faxes["sample"] if faxes["sample"] is not None else (0 if frank == 1 else None)
+        if s_axis is None:
+            raise JetstreamError(1, "[BLOCK_FILTER_ENGINE] Signal axis metadata is invalid.")
+        if frank not in (1, 2):
+            raise JetstreamError(1, "[BLOCK_FILTER_ENGINE] Filter input must be rank 1 or 2.")
+        if (frank == 1 and (f_sample != 0 or faxes["batch"] is not None or faxes["channel"] is not None)) or \
+           (frank == 2 and (f_sample != 1 or faxes["batch"] is not None or faxes["channel"] != 0)):
+            raise JetstreamError(1, "[BLOCK_FILTER_ENGINE] Filter coefficients must be [T] with sampleAxis=0 or [C,T] "
+                                    "with channelAxis=0 and sampleAxis=1.")
+        multi = faxes["channel"] is not None
+        if multi and axes["channel"] is not None:
+            raise JetstreamError(1, "[BLOCK_FILTER_ENGINE] Cannot add filter channels to a signal that already "
+                                    "carries channelAxis.")
+        signal_size, filter_size = signal.shape[s_axis], filt.shape[f_sample]
+        heads = filt.shape[0] if multi else 1
+
+        def attr(key):
+            try:
+                return filt.attribute(key)
+            except JetstreamError:
+                return None
+        sr, bw, ctr = attr("sampleRate"), attr("bandwidth"), attr("center")
+        if ctr is not None:
+            ctr = list(ctr) if isinstance(ctr, list) else [ctr]
+            if len(ctr) == 1 and multi and heads > 1:
+                ctr = ctr * heads     # scalar metadata expands across the filter channels (:333-341)
+            elif len(ctr) != heads:
+                raise JetstreamError(1, "[BLOCK_FILTER_ENGINE] Filter center metadata must match the filter channel extent.")
+        if sr is None or bw is None or ctr is None:   # bypass: plain convolution
+            plan = {"padSize": filter_size - 1, "convolutionSize": signal_size + filter_size - 1, "resample": False,
+                    "resamplerOffsets": [], "resamplerSize": 0, "resampledSampleRate": 0.0}
+        else:
+            plan = filter_plan(sr, bw, ctr, filter_size, heads, signal_size)
+        self.plan = plan
+        batch = axes["batch"]
+        out_axes = dict(axes)
+        out_axes["sample"] = s_axis
+        if multi:
+            out_axes = {"sample": s_axis + 1, "channel": s_axis,
+                        "batch": None if batch is None else (batch + 1 if batch >= s_axis else batch)}
+        sample_axis = s_axis + 1 if multi else s_axis
+        p = name + "."
+        self.cast_signal = Module("cast", {"outputType": "CF32"}, {"buffer": signal}, p + "cast_signal")
+        self.cast_filter = Module("cast", {"outputType": "CF32"}, {"buffer": filt}, p + "cast_filter")
+        sig_in = self.cast_signal.output("buffer")
+        self.expand_signal = None
+        if multi:
+            self.expand_signal = Module("expand_dims", {"axis": s_axis}, {"buffer": sig_in}, p + "expand_signal")
+            sig_in = self.expand_signal.output("buffer").set_axes(**out_axes)
+        self.pad_signal = Module("pad", {"size": filter_size - 1, "axis": sample_axis}, {"unpadded": sig_in},
+                                 p + "padSignal")
+        self.pad_filter = Module("pad", {"size": signal_size - 1, "axis": f_sample},
+                                 {"unpadded": self.cast_filter.output("buffer")}, p + "padFilter")
+        self.fft_signal = Module("fft", {"forward": True}, {"signal": self.pad_signal.output("padded")}, p + "fftSignal")
+        self.fft_filter = Module("fft", {"forward": True}, {"signal": self.pad_filter.output("padded")}, p + "fftFilter")
+        fspec = self.fft_filter.output("signal")
+        want = [1] * len(sig_in.shape)
+        if multi:
+            want[s_axis] = heads
+        want[sample_axis] = plan["convolutionSize"]
+        self.reshape_filter = None
+        if list(fspec.shape) != want:
+            self.reshape_filter = Module("reshape", {"shape": want}, {"buffer": fspec}, p + "reshape_filter")
+            fspec = self.reshape_filter.output("buffer")
+        fspec.set_axes(sample=sample_axis, channel=s_axis if multi else None)
+        self.multiply = Module("multiply", {}, {"a": self.fft_signal.output("signal"), "b": fspec}, p + "multiply")
+        product = self.multiply.output("product").set_axes(**out_axes)
+        offsets = [int(o) for o in plan["resamplerOffsets"]]
+        ifft_in, self.fold = product, None
+        if plan["resample"]:
+            if multi:
+                product.set_attribute("channelOffsets", offsets)
+            self.fold = Module("fold", {"offset": 0 if multi else offsets[0], "size": plan["resamplerSize"]},
+                               {"buffer": product}, p + "fold")
+            ifft_in = self.fold.output("buffer")
+        self.ifft = Module("fft", {"forward": False}, {"signal": ifft_in}, p + "ifft")
+        ifft_out = self.ifft.output("signal")
+        self.normalize = Module("multiply_constant",
+                                {"constant": float(np.float32(1.0) / np.float32(ifft_out.shape[sample_axis]))},
+                                {"factor": ifft_out}, p + "normalize")
+        normalized = self.normalize.output("product")
+        self.phase_correction = None
+        if plan["resample"] and any(o != 0 for o in offsets):
+            inc = [math.remainder(2.0 * math.pi * float(o) * float(signal_size) / float(plan["convolutionSize"]),
+                                  2.0 * math.pi) for o in offsets]
+            if multi:
+                normalized.set_attribute("channelPhaseIncrements", inc)
+            self.phase_correction = Module("phase_correction", {"phaseIncrement": 0.0 if multi else inc[0]},
+                                           {"signal": normalized}, p + "phase_correction")
+            normalized = self.phase_correction.output("signal")
+        self.unpad = self.overlap = None
+        if plan["padSize"] == 0:
+            self.buffer = normalized
+        else:
+            self.unpad = Module("unpad", {"size": plan["padSize"], "axis": sample_axis}, {"padded": normalized},
+                                p + "unpad")
+            self.overlap = Module("overlap_add", {}, {"buffer": self.unpad.output("unpadded"),
+                                                      "overlap": self.unpad.output("pad")}, p + "overlap")
+            self.buffer = self.overlap.output("buffer")
+        self.buffer.set_axes(**out_axes)
+        if plan["resample"]:
+            self.buffer.set_attribute("sampleRate", plan["resampledSampleRate"])
+
+    @property
+    def modules(self) -> List[Module]:
+        ms = [self.cast_signal, self.cast_filter, self.expand_signal, self.pad_signal, self.pad_filter,
+              self.fft_signal, self.fft_filter, self.reshape_filter, self.multiply, self.fold, self.ifft,
+              self.normalize, self.phase_correction, self.unpad, self.overlap]
+        return [m for m in ms if m is not None]
+
+
 class Decimator:
     """The decimator BLOCK: reshape [.., S/r, r] -> arithmetic(add, ratio axis) -> squeeze_dims ->
     duplicate (src/domains/dsp/decimator/block_impl.cc:140-207): integrate-and-dump, no divide."""

@@ -533,6 +533,52 @@ def filter_block(x: np.ndarray, plan: dict, sample_rate: float, bandwidth: float
     return out
 
 
+def filter_engine_block(x: np.ndarray, taps: np.ndarray, plan: dict, state: dict) -> np.ndarray:
+    """The filter_engine block's module chain (filter_engine/block_impl.cc:400-673) for a signal [samples] or
+    [batch, samples] and EXTERNAL coefficients [T] (one head: no head axis, scalar fold offset / phase increment) or
+    [C, T] (C heads: output [.., C, out]).  `plan` = the block's candidate plan (resample, offsets, sizes)."""
+    import math
+    x = np.asarray(x, np.complex64)
+    rank1 = x.ndim == 1
+    xb = x.reshape(1, -1) if rank1 else x
+    b, s = xb.shape
+    taps = np.asarray(taps, np.complex64)
+    multi = taps.ndim == 2
+    heads = taps.shape[0] if multi else 1
+    tv = taps.reshape(heads, -1)
+    t = tv.shape[1]
+    conv = plan["convolutionSize"]
+    assert conv == s + t - 1
+    sig = pad(xb.reshape(b, 1, s), t - 1, 2)
+    fsig = fft_c2c(sig, True)
+    ffil = fft_c2c(pad(tv, s - 1, 1), True).reshape(1, heads, conv)
+    spec = multiply(fsig, ffil)
+    offsets = plan["resamplerOffsets"]
+    if plan["resample"]:
+        if multi:
+            spec = fold(spec, 2, plan["resamplerSize"], 0, 1, offsets)
+        else:
+            spec = fold(spec, 2, plan["resamplerSize"], offsets[0])
+    time = fft_c2c(spec, False)
+    c = np.float32(1.0) / np.float32(time.shape[2])
+    norm = (time.real * c + 1j * (time.imag * c)).astype(np.complex64)
+    if plan["resample"] and any(o != 0 for o in offsets):
+        inc = [math.remainder(2.0 * math.pi * float(o) * float(s) / float(conv), 2.0 * math.pi) for o in offsets]
+        phases = state.setdefault("phases", np.zeros(heads, np.float64))
+        norm = phase_correction(norm, inc, phases, batch_axis=0, channel_axis=1)
+    if plan["padSize"] == 0:
+        out = norm
+    else:
+        body, tail = unpad(norm, plan["padSize"], 2)
+        prev = state.get("prev")
+        if prev is None:
+            prev = np.zeros((1,) + tail.shape[1:], np.complex64)
+        out, state["prev"] = overlap_add(body, tail, prev, batch_axis=0)
+    if not multi:
+        out = out[:, 0, :]
+    return out[0] if rank1 else out
+
+
 def lineplot(avg: np.ndarray, x: np.ndarray, averaging: int = 1, decimation: int = 1) -> None:
     """In-place update of the averaged trace avg (F32[width // decimation]); x: F32 [batches, width]."""
     assert x.dtype == np.float32 and x.ndim == 2 and avg.dtype == np.float32
