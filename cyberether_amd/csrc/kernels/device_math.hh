@@ -347,6 +347,7 @@ __device__ __forceinline__ float range_f32_fast(float v, float scale, float offs
 // asserts the bound).  About 4e-4 of the elements take the exact path at height 256.
 struct BinGuard {
     float h0 = 0.0f, h1 = 0.0f;  // consumer heights (0 = none)
+    float t0 = 0.0f, t1 = 0.0f;  // their guard widths h * 7.5e-7 once a kernel has pinned them in VGPRs (0 = form them on use)
 };
 // f = r * h, already formed.  v_fract_f32 (for finite f >= 0 it IS f - floor(f): that difference is exact and below 1, so the
 // instruction's clamp never acts; written as `f - floorf(f)` hipcc emits v_floor + v_sub because it cannot know the sign).
@@ -394,6 +395,45 @@ __device__ __forceinline__ float amplitude_range_lean(float p, const FastRangePo
     const float z = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(q.k3, f, q.k2), f, q.k1), f, tail);
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));  // 2^z = inf -> 0, 2^z = 0 -> 1
 }
+// Round 4: the same lean value by instruction CLASS.  Measured on MI355X (tools/ubench/valu_forms.hip, ns per wave64
+// instruction and SIMD at >= 2 wavefronts per SIMD): add / mul / fma / and-or / shifts 1.1; v_cmp_*, v_cndmask, v_fract,
+// v_frexp_*, v_cvt_*, v_min / v_med3, DPP moves 2.0; v_sqrt / v_exp / v_rcp / v_log 3.5; a v_cmp + v_cndmask pair through
+// VCC 7.  The round-3 epilogue spent ~50 ns per output, more than half of it on the half-rate classes around three
+// unavoidable transcendentals; here
+//   * the mantissa is ONE v_and_or_b32 on the magnitude's bits (instead of v_frexp_mant), the exponent two integer
+//     operations and the conversion -- the same numbers frexpf gives for a normal float;
+//   * the domain test is one v_cmp_class on the magnitude (anything but a positive normal float goes to the exact
+//     arithmetic) instead of an integer add + compare on the power;
+//   * "within thr of a bin edge" is |f - rint(f)| < thr with rint(f) = (f + 1.5 * 2^23) - 1.5 * 2^23 (two full-rate adds,
+//     exact for 0 <= f < 2^22) and ONE compare with an |.| modifier, instead of v_fract + add + two compares; it also
+//     flags f < thr (values below thr / height: the exact path answers them, nothing else changes);
+//   * k2 and k0 live in VGPRs (pinned once per thread: StoreAmplitudeRangeT::pin_constants) -- a VOP3 fma takes one
+//     scalar operand, and hipcc re-materialised the second one with a v_mov per fma.
+// ~36 ns per output.  The VALUE is the round-3 lean value bit for bit on its old domain (same operations on the same
+// numbers); what changed is how mantissa / exponent / guard flags are formed and the wider domain, and the bin guarantee
+// is re-proved by the exhaustive sweep (exact_sweep.hip WHICH 4 calls this very function).
+#ifndef JST_EPI_V2  // A/B switch: 0 = the round-3 form
+#define JST_EPI_V2 1
+#endif
+__device__ __forceinline__ float amplitude_range_lean2(float p, const FastRangePoly& q, bool& special) {
+    const float mag = __builtin_amdgcn_sqrtf(p);
+    special = __builtin_amdgcn_classf(mag, 0x2ff);  // everything but +normal: zero, denormal, inf, NaN (negative cannot occur)
+    const uint32_t mb = f2u(mag);
+    const float f = u2f((mb & 0x007fffffu) | 0x3f000000u);  // frexpf mantissa of a normal float, in [0.5, 1)
+    // frexpf's exponent as a SMALL number (one integer subtract in front of the conversion): with the biased field and
+    // the bias folded into k0 the rounding errors of ke and of the folded constant are multiplied by ~127 instead of
+    // |e| <= 50 -- 33 powers per 2^32 then changed their Spectrogram bin at height 256 (exhaustive sweep, first build)
+    const float e = (float)((int32_t)(mb >> 23) - 126);
+    const float tail = __builtin_fmaf(q.ke, e, q.k0);
+    const float z = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(q.k3, f, q.k2), f, q.k1), f, tail);
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));  // 2^z = inf -> 0, 2^z = 0 -> 1
+}
+// |f - rint(f)| < thr for 0 <= f < 2^22 (f = value * height, height <= 2^16 in every caller)
+__device__ __forceinline__ bool near_integer(float f, float thr) {
+    const float n = (f + 12582912.0f) - 12582912.0f;
+    return __builtin_fabsf(f - n) < thr;
+}
+
 // f0 receives value * g.h0 (the product the first consumer's quantiser forms: the side-output epilogue of fft_lds.hh takes
 // its row index from it instead of multiplying again); undefined when g.h0 == 0.
 __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p, float coeff, float scale,
@@ -403,6 +443,15 @@ __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p
         f0 = 0.5f * g.h0;
         return 0.5f;
     }
+#if JST_EPI_V2
+    bool cold;
+    float r = amplitude_range_lean2(p, q, cold);
+    f0 = r * g.h0;
+    if (g.h0 > 0.0f) {  // wave-uniform
+        cold |= near_integer(f0, g.t0 > 0.0f ? g.t0 : g.h0 * 7.5e-7f);
+        if (g.h1 > 0.0f) cold |= near_integer(r * g.h1, g.t1 > 0.0f ? g.t1 : g.h1 * 7.5e-7f);
+    }
+#else
     float r = amplitude_range_lean(p, q);
     bool cold = (f2u(p) - kPowerLo) > (kPowerHi - kPowerLo);  // zero, subnormal, huge, inf, NaN: the exact ladder
     f0 = r * g.h0;
@@ -410,6 +459,7 @@ __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p
         cold |= near_bin_edge_of(f0, g.h0);
         if (g.h1 > 0.0f) cold |= near_bin_edge(r, g.h1);
     }
+#endif
     // A guard hit (~2.5 % of the wavefront-elements at height 256) goes through the INLINED exact main path, not through a
     // call: with the out-of-line copy every epilogue carried a call site whose ABI (caller-saved v0-v31, live values
     // parked in callee-saved registers around it) cost the whole kernel 1.5 us per launch although the call is rare --
@@ -419,11 +469,18 @@ __device__ __forceinline__ float amplitude_range_fast_guarded_from_power(float p
     if (__builtin_expect(cold, 0)) {
         r = amplitude_range_from_power(p, coeff, scale, offset);
         f0 = r * g.h0;
+#if JST_EPI_V2  // f0 == h0 (value 1.0) is no hit: only an element that came through here can sit ON an integer, so the
+                // test lives here and the side output's index is the plain conversion of f0 (fft_lds.hh)
+        if (!(f0 < g.h0)) f0 = 0.0f;
+#endif
     }
 #else
     if (__builtin_expect(cold, 0)) {
         r = amplitude_range_from_power_cold(p, coeff, scale, offset);
         f0 = r * g.h0;
+#if JST_EPI_V2
+        if (!(f0 < g.h0)) f0 = 0.0f;
+#endif
     }
 #endif
     return r;

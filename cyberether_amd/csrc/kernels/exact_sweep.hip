@@ -68,14 +68,27 @@ __global__ __launch_bounds__(256) void sweep_kernel(float coeff, float scale, fl
             if (bin_of(ref, height) != bin_of(got, height)) note(res, bits);
         } else if constexpr (WHICH == 5) {  // fast provider WITHOUT the guard (shows the sweep can tell: bins do move)
             const float ref = range_f32_general(amplitude_from_power(a, coeff), scale, offset);
+#if JST_EPI_V2
+            bool special;
+            float got = amplitude_range_lean2(a, make_fast_range_poly(coeff, scale, offset), special);
+            if (special) got = ref;
+#else
             float got = amplitude_range_lean(a, make_fast_range_poly(coeff, scale, offset));
             if ((bits - kPowerLo) > (kPowerHi - kPowerLo)) got = ref;
+#endif
             if (bin_of(ref, height) != bin_of(got, height)) note(res, bits);
         } else {  // WHICH == 6: largest |lean fast value - exact value| over the lean form's domain (bits of it in `first`)
+            const float ref = range_f32_general(amplitude_from_power(a, coeff), scale, offset);
+#if JST_EPI_V2  // domain: every power whose magnitude is a positive normal float
+            bool special;
+            const float got = amplitude_range_lean2(a, make_fast_range_poly(coeff, scale, offset), special);
+            if (special) continue;
+            ++main_hits;
+#else
             if ((bits - kPowerLo) > (kPowerHi - kPowerLo)) continue;
             ++main_hits;
-            const float ref = range_f32_general(amplitude_from_power(a, coeff), scale, offset);
             const float got = amplitude_range_lean(a, make_fast_range_poly(coeff, scale, offset));
+#endif
             const float d = __builtin_fabsf(got - ref);
             if (!(d <= 1.0f)) note(res, bits);              // NaN or nonsense: counted as bad
             else atomicMax(&res->pad, f2u(d));              // non-negative floats order like their bits

@@ -350,6 +350,7 @@ using LoadCU8TimesWindow = LoadCITimesWindow<uint16_t, false>;
 // 128 VGPRs + 96 B of scratch, 203 instead of 187 us per 16384-transform launch.
 template <class Pro>
 struct RealOperand : Pro {
+    static constexpr bool kRealOperand = true;  // only the operand's real parts are read (fft_wave.hh loads just those)
     __device__ __forceinline__ float2 apply(typename Pro::raw_t v, float2 w) const { return Pro::apply_real(v, w.x); }
 };
 
@@ -396,6 +397,16 @@ struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_na
     FastRangePoly poly = make_fast_range_poly(coeff, scale, offset);  // FAST only: folded constants, computed on the host
     static constexpr uint32_t kElemBytes = 4;
     __device__ __forceinline__ const void* row(int64_t base) const { return out + base; }
+    // FAST: called once per thread on the kernel's own copy of the functor, before the transform loop.  The second
+    // scalar operand of the polynomial's fused multiply-adds and the guard widths become VGPR residents (an empty asm
+    // "rewrites" them, so they are neither re-materialised from SGPRs per use nor recomputed per output).
+    __device__ __forceinline__ void pin_constants() {
+        if constexpr (FAST) {
+            guard.t0 = guard.h0 * 7.5e-7f;
+            guard.t1 = guard.h1 * 7.5e-7f;
+            __asm__ volatile("" : "+v"(poly.k2), "+v"(poly.k0), "+v"(guard.t0), "+v"(guard.t1));
+        }
+    }
     __device__ __forceinline__ float value(float2 v) const {
         if constexpr (FAST) return amplitude_range_fast_guarded(v, coeff, scale, offset, guard, poly);
 #ifdef JST_EPI_GENERAL  // A/B switch: the class-ladder form of round 1
@@ -454,9 +465,9 @@ struct StoreAmplitudeRangeSideT : StoreAmplitudeRangeT<FAST> {
     // FAST: guard.h0 == side_height (fft_side.hip puts the fed Spectrogram's height first), so the product value * height
     // the bin guard formed IS the quantiser's: the index comes from it, no second multiply.  The index rule
     // `1 <= f < height ? (u32)f : 0` is `f < height ? (u32)f : 0` for f >= 0: the conversion truncates everything below 1 to 0.
-    template <bool IN_BASE>
-    __device__ __forceinline__ void store_buf_side(rsrc_t r, rsrc_t rs, uint32_t voff, uint32_t soff, float2 v) const {
-        float y, f;
+    // the value that is stored and the row index the Spectrogram derives from it (both kernels' epilogues)
+    __device__ __forceinline__ void side_compute(float2 v, float& y, uint32_t& index) const {
+        float f;
         if constexpr (FAST) {
             y = amplitude_range_fast_guarded_from_power((v.x * v.x) + (v.y * v.y), this->coeff, this->scale, this->offset,
                                                         this->guard, this->poly, f);
@@ -464,8 +475,22 @@ struct StoreAmplitudeRangeSideT : StoreAmplitudeRangeT<FAST> {
             y = this->value(v);
             f = y * side_height;
         }
+#if JST_EPI_V2
+        // FAST: 0 <= f < height or f == 0 -- a value ON an integer (f == height included: the one non-hit the conversion
+        // does not map to 0 by itself) only comes out of the guard's exact recomputation, which zeroes it there
+        // (device_math.hh); NaN converts to 0.  No compare, no select on the hot path.
+        if constexpr (FAST) index = (uint32_t)f;
+        else index = (f < side_height) ? (uint32_t)f : 0u;
+#else
+        index = (f < side_height) ? (uint32_t)f : 0u;
+#endif
+    }
+    template <bool IN_BASE>
+    __device__ __forceinline__ void store_buf_side(rsrc_t r, rsrc_t rs, uint32_t voff, uint32_t soff, float2 v) const {
+        float y;
+        uint32_t index;
+        side_compute(v, y, index);
         buf_store_f1(r, voff, soff, y);
-        const uint32_t index = (f < side_height) ? (uint32_t)f : 0u;
         const uint32_t u = voff >> 2;
 #ifdef JST_SIDE_ROW_MAJOR
         (void)IN_BASE;
@@ -954,11 +979,13 @@ constexpr size_t fft_pipe_lds_bytes(int n) {
 // blockIdx.x / gridDim.x, a launch that carries other work beside the transforms passes its own numbering.
 template <int N, bool FWD, bool CONTIG, class Pro, class Epi>
 __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* __restrict__ W, const Pro& pro,
-                                              const Epi& epi, const uint32_t bid, const uint32_t grid) {
+                                              const Epi& epi_arg, const uint32_t bid, const uint32_t grid) {
     constexpr int T = N / 8;
     constexpr Plan plan = make_plan(N);
     constexpr TwPlan tp = make_twplan(N);
     constexpr int NEX = plan.nf - 1;  // LDS exchanges per transform
+    Epi epi = epi_arg;  // this thread's copy: an epilogue may pin constants in VGPRs for the whole transform loop
+    if constexpr (requires { epi.pin_constants(); }) epi.pin_constants();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* bufA = reinterpret_cast<float2*>(smem_raw);
     float2* bufB = bufA + lds_elems(N);

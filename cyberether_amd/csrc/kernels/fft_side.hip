@@ -118,6 +118,11 @@ hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const floa
         (L.ring_transforms % side_batches) != 0 || (L.ring_first % side_batches) != 0)
         return hipErrorInvalidValue;
     const float h = (float)height;
+    // CF32 input, 4096 points: the one-wavefront-per-transform kernel (fft_wave.hip) when it is selected
+    if (n == 4096 && in_format == 0 && spectrum_wave_selected())
+        return launch_spectrum_wave_side(L, W, static_cast<const float2*>(in), window, out, amp_coeff, range_scale,
+                                         range_offset, fast, guard_h0, guard_h1, side, h, (uint32_t)side_batches,
+                                         (uint32_t)side_pitch, real_window && fast, stream);
     const float inv = in_format ? 1.0f / scaler : 1.0f;  // a power of two: x / scaler == x * inv, exactly
     // real_window (host knowledge: every imaginary part of the window is +-0) with provider "fast": the RealOperand
     // instantiations (fft_lds.hh) -- two products per sample instead of std::complex's full product

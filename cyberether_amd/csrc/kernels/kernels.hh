@@ -129,6 +129,13 @@ hipError_t launch_fft_c2c_tiled_scaled_unpad(uint64_t n, bool forward, const Fft
                                              float constant, uint64_t body_len, hipStream_t s);
 
 
+// The 4096-point fused spectrum chain with the side output as ONE WAVEFRONT PER TRANSFORM (fft_wave.hip / fft_wave.hh): dense
+// CF32 rows in, F32 rows + one-byte row indices out (the arguments of launch_spectrum_fused_side).
+bool spectrum_wave_selected();
+hipError_t launch_spectrum_wave_side(const FftLayout& L, const float2* W, const float2* in, const float2* window, float* out,
+                                     float amp_coeff, float range_scale, float range_offset, bool fast, float guard_h0,
+                                     float guard_h1, uint8_t* side, float side_height, uint32_t side_batches,
+                                     uint32_t side_pitch, bool real_window, hipStream_t stream);
 hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const float2* W,
                                        const float2* in, const float2* window,
                                        int64_t window_stride, float* out, float amp_coeff,

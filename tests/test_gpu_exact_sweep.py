@@ -84,7 +84,9 @@ def test_lean_fast_value_deviates_less_than_4e7_on_every_power(js, coeff, scale,
     (1.2e-7) with margin, and is itself proven per height by the exhaustive bin sweep above; BASELINE's float tolerance
     is 1e-5."""
     bad, visited, dev_bits = sweep(js, 6, coeff, scale, offset)
-    assert visited == 0x71800000 - 0x0d800000 + 1 and bad == 0
+    # round 4: the lean form's domain is every power whose magnitude is a positive normal float (one v_cmp_class on
+    # sqrt(p)) -- at least the round-3 domain [2^-100, 2^100], at most every positive normal power
+    assert 0x71800000 - 0x0d800000 + 1 <= visited <= 0x7f800000 - 0x00000001 and bad == 0
     import struct
     dev = struct.unpack("<f", struct.pack("<I", dev_bits))[0]
     print(f"largest |lean - exact| = {dev:.3e} (coeff {coeff:.2f}, scale {scale:.4f})")
