@@ -265,7 +265,8 @@ Result Runtime::planUnits() {
     // Static settlement: a STATIC_OUTPUT module with no inputs, or a STATELESS/STATIC module
     // whose inputs all come from settled producers, runs once
     // (src/scheduler_synchronous.cc:534-546,670-693).
-    std::set<const void*> static_storage;
+    std::set<const void*>& static_storage = static_storage_;
+    static_storage.clear();
     std::vector<bool> is_static(ordered_.size(), false);
     for (size_t i = 0; i < ordered_.size(); ++i) {
         Module* m = ordered_[i];
@@ -332,7 +333,8 @@ bool Runtime::tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed) {
     return modules::TryFuseSpectrum(ordered_, at, unit.name, unit.modules, unit.submit, consumed,
                                     (flags_ & COMBINE) != 0 && (flags_ & PIPELINE) == 0, &unit.flush,
                                     (flags_ & PIPELINE) == 0,
-                                    (flags_ & BATCH) && (flags_ & GRAPH) && !(flags_ & (PIPELINE | COMBINE)) ? &unit.batch : nullptr) ||
+                                    (flags_ & BATCH) && (flags_ & GRAPH) && !(flags_ & (PIPELINE | COMBINE)) ? &unit.batch : nullptr,
+                                    &static_storage_) ||
            modules::TryFuseFilter(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
 }
 
@@ -428,7 +430,20 @@ Result Runtime::planBatch() {
         u.per_cycle_in_span = false;
         if (u.is_static || i == fused) continue;
         for (Module* m : u.modules) {
-            if (!m->launchesKernels() || m->spanCapable()) continue;
+            if (!m->launchesKernels()) continue;
+            // every kernel module of a batched runtime -- span form or sink -- reads what the spectrum unit (or the source
+            // ring) leaves in the rings: it runs BEHIND that unit and every input of it shares storage with them.  Anything
+            // else (a Lineplot of the static window ordered in front of the unit, say) keeps the runtime per cycle.
+            if (i < fused) return Result::SUCCESS;
+            if (m->spanCapable()) {
+                for (const auto& kv : m->inputs()) {
+                    bool from_ring = kv.second.storageId() == b.phase.storageId();
+                    for (Module* prod : units_[fused].modules)
+                        for (const auto& out : prod->outputs()) from_ring |= out.second.storageId() == kv.second.storageId();
+                    if (!from_ring) return Result::SUCCESS;
+                }
+                continue;
+            }
             bool sink = (m->taint() & SURFACE) != 0 && m->outputs().empty() && m->cyclePeriod() == 1 && u.modules.size() == 1;
             for (const auto& kv : m->inputs()) {
                 bool from_ring = kv.second.storageId() == b.phase.storageId();
@@ -678,6 +693,8 @@ Result Runtime::submitAll(bool record_events, U64 slot, bool count_cycles) {
         if (count_cycles)
             for (Module* m : u.modules) m->timing.cycles++;
     }
+    for (auto& u : units_)
+        for (Module* m : u.modules) m->cycleSubmitted(stream_);
     return Result::SUCCESS;
 }
 

@@ -67,6 +67,9 @@ class Module {
     virtual Result computeInitialize() { return Result::SUCCESS; }
     virtual Result computeSubmit(hipStream_t stream) = 0;
     virtual Result computeDeinitialize() { return Result::SUCCESS; }
+    // Called on the compute thread once EVERY unit of the cycle this module's computeSubmit opened has been enqueued on
+    // `stream` (Runtime::submitAll): from here on an event recorded on the stream is behind all of the cycle's readers.
+    virtual void cycleSubmitted(hipStream_t /*stream*/) {}
     // True when computeSubmit touches no device state through the host (graph-capturable).
     virtual bool capturable() const { return true; }
     // Number of consecutive cycles after which this module's host-side state repeats (a ring
@@ -230,6 +233,7 @@ class Runtime {
     void computePeriod();
     Result flushUnits();
     bool tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed);
+    std::set<const void*> static_storage_;  // storage of the tensors statically settled units produce (planUnits)
     // In a captured period only every timingStride()-th cycle carries event-record nodes: a pair
     // costs ~2 us of queue time, sampling keeps Module::Timing live at a quarter of that cost.
     U64 timingStride() const { return period_ >= 8 ? 4 : 1; }

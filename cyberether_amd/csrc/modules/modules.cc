@@ -1222,6 +1222,32 @@ Result RingSource::computeSubmit(hipStream_t stream) {
     return output.ringSelect(cursor);
 }
 
+// Every unit of the cycle that consumed `pendingFreeSlot` is on the stream now: an event recorded here is behind all of
+// the slot's readers (recorded from the producer thread it could land in front of kernels the compute thread had not
+// enqueued yet -- the upload then overwrote the slot under its own cycle).
+void RingSource::cycleSubmitted(hipStream_t stream) {
+    if (!live) return;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (pendingFreeSlot < 0 || slotFree.empty()) return;
+        if (hipEventRecord(slotFree[(size_t)pendingFreeSlot], stream) != hipSuccess) return;  // the next cycle records it
+        slotFreeValid[(size_t)pendingFreeSlot] = 1;
+        pendingFreeSlot = -1;
+    }
+    cycleClosed.notify_all();
+}
+Result RingSource::computeDeinitialize() {  // the runtime (and its stream) go away; producers may keep pushing
+    std::lock_guard<std::mutex> lock(mu);
+    lastComputeStream = nullptr;
+    if (pendingFreeSlot >= 0 && !slotFree.empty()) {
+        // the runtime synchronised its stream before tearing down: the slot's last readers are done
+        slotFreeValid[(size_t)pendingFreeSlot] = 0;
+        pendingFreeSlot = -1;
+    }
+    cycleClosed.notify_all();
+    return Result::SUCCESS;
+}
+
 void RingSource::advanceHostState(U64 cycles) {
     if (live || cycles == 0) return;
     if (first) {  // the first cycle exposes slot 0 without moving
@@ -1276,7 +1302,7 @@ Result RingSource::ringAcquire(void** ptr, U64* max_elements) {
     return Result::SUCCESS;
 }
 
-Result RingSource::publishStagedBatch() {  // mu held; the current staging buffer holds one whole batch
+Result RingSource::publishStagedBatch(std::unique_lock<std::mutex>& lock) {  // mu held; the staging buffer holds one whole batch
     if (published() - consumed >= slots) {
         // every slot holds a published batch no cycle has consumed
         ++overflowCount;
@@ -1284,11 +1310,17 @@ Result RingSource::publishStagedBatch() {  // mu held; the current staging buffe
         ++consumed;  // OverwriteOldest (circular_buffer.cc:151-161): the oldest unconsumed batch is dropped
     }
     const U64 slot = published() % slots;
-    // The cycle that consumed this slot last must have finished before the copy lands.
-    if (pendingFreeSlot == (I64)slot && lastComputeStream) {  // consumed by the latest cycle: record its completion now
-        JST_HIP_CHECK(hipEventRecord(slotFree[slot], lastComputeStream), "hipEventRecord");
-        slotFreeValid[slot] = 1;
-        pendingFreeSlot = -1;
+    // The cycle that consumed this slot last must have finished before the copy lands.  If that cycle is still being
+    // enqueued (its free event is pending), the compute thread records it in cycleSubmitted -- microseconds away; wait
+    // for that (without the lock).  Only a cycle that died half way leaves the slot pending: after the timeout its
+    // completion is recorded here, behind whatever it did enqueue.
+    if (pendingFreeSlot == (I64)slot) {
+        cycleClosed.wait_for(lock, std::chrono::milliseconds(200), [&] { return pendingFreeSlot != (I64)slot; });
+        if (pendingFreeSlot == (I64)slot && lastComputeStream) {
+            JST_HIP_CHECK(hipEventRecord(slotFree[slot], lastComputeStream), "hipEventRecord");
+            slotFreeValid[slot] = 1;
+            pendingFreeSlot = -1;
+        }
     }
     if (slotFreeValid[slot]) JST_HIP_CHECK(hipStreamWaitEvent(uploadStream, slotFree[slot], 0), "hipStreamWaitEvent");
     const size_t batch_bytes = (size_t)(batches * samples) * elementBytes;
@@ -1308,7 +1340,7 @@ Result RingSource::publishStagedBatch() {  // mu held; the current staging buffe
 Result RingSource::ringCommit(U64 elements) {
     Result r = Result::SUCCESS;
     {
-        std::lock_guard<std::mutex> lock(mu);
+        std::unique_lock<std::mutex> lock(mu);
         JST_CHECK(ensureProducer());
         const U64 batch = batches * samples;
         if (elements > batch - stagingFill) {
@@ -1318,7 +1350,7 @@ Result RingSource::ringCommit(U64 elements) {
         }
         stagingFill += elements;
         if (stagingFill == batch) {
-            r = publishStagedBatch();
+            r = publishStagedBatch(lock);
             if (r == Result::INCOMPLETE) stagingFill = batch - elements;  // rejected: the chunk was not taken
         }
     }
@@ -1376,6 +1408,10 @@ Result RingSource::ringClear() {
     stagingFill = 0;
     overflowCount = 0;
     for (U64 i = 0; i < kStaging; ++i) stagingBusy[i] = false;
+    // nothing is published any more: no slot is waiting for a consumer's completion, no upload is outstanding
+    pendingFreeSlot = -1;
+    std::fill(slotFreeValid.begin(), slotFreeValid.end(), 0);
+    std::fill(slotUploadValid.begin(), slotUploadValid.end(), 0);
     return Result::SUCCESS;
 }
 
@@ -1383,7 +1419,7 @@ Result RingSource::ringClear() {
 bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string& name,
                      std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
                      size_t& consumed, bool allow_combine, std::function<Result(hipStream_t)>* flush, bool allow_side,
-                     SpanSupport* batch) {
+                     SpanSupport* batch, const std::set<const void*>* static_storage) {
     if (at + 2 >= ordered.size()) return false;
     auto* mul = dynamic_cast<Multiply*>(ordered[at]);
     auto* fft = dynamic_cast<Fft*>(ordered[at + 1]);
@@ -1622,7 +1658,10 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
     // (kernels.hh: launch_spectrum_fused_side, real_window).  The table is a STATIC tensor that the window chain fills in
     // the first, eager cycle, on this very stream in front of this unit: the first submission outside a capture waits for
     // it, reads it back once (n complex values) and remembers the answer; until then the full product is used.
-    auto window_real = std::make_shared<int>(-1);
+    // Only an operand that a statically SETTLED unit produced keeps its first answer for the lifetime of this unit: any
+    // other producer may hand over imaginary parts in a later cycle, and the real-operand kernel would drop them silently.
+    const bool operand_static = static_storage && static_storage->count(mul->b.storageId()) != 0;
+    auto window_real = std::make_shared<int>(operand_static ? -1 : 0);
     auto know_window = [mul, n, axis, window_real](hipStream_t stream) -> bool {
         if (*window_real >= 0) return *window_real == 1;
         const Tensor& win = mul->b;

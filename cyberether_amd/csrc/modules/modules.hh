@@ -38,7 +38,7 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                      std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
                      size_t& consumed, bool allow_combine = false,
                      std::function<Result(hipStream_t)>* flush = nullptr, bool allow_side = true,
-                     SpanSupport* batch = nullptr);
+                     SpanSupport* batch = nullptr, const std::set<const void*>* static_storage = nullptr);
 
 // Filter-chain fusions (filter_modules.cc): pad -> fft (zeros synthesised in the FFT's first load)
 // and multiply -> fold (the broadcast product is never materialised).  Same contract.
@@ -307,6 +307,8 @@ class RingSource : public Module {
     Result create() override;
     Result destroy() override;
     Result computeSubmit(hipStream_t stream) override;
+    void cycleSubmitted(hipStream_t stream) override;
+    Result computeDeinitialize() override;
     U64 cyclePeriod() const override { return live ? 1 : slots; }
     void advanceHostState(U64 cycles) override;
     bool launchesKernels() const override { return false; }
@@ -331,8 +333,9 @@ class RingSource : public Module {
     // staging memory itself, so a driver can read straight into it; push() is acquire + memcpy + commit); every
     // completed batch goes to ring slot (published % slots) with an asynchronous H2D copy on the source's own upload
     // stream.  The library -- not the caller -- keeps an upload from overwriting a slot whose consuming cycle has not
-    // finished: a cycle's completion is an event on the compute stream, recorded when the NEXT cycle is submitted (or
-    // on demand), and the upload stream waits for it.  A full ring (every slot published and unconsumed) follows the
+    // finished: a cycle's completion is an event on the compute stream, recorded BY THE COMPUTE THREAD once every unit of
+    // the cycle is enqueued (cycleSubmitted; a cycle that failed half way: when the next one is submitted), and the upload
+    // stream waits for it.  A producer that reaches the slot of a cycle still being enqueued waits for that record.  A full ring (every slot published and unconsumed) follows the
     // overflow policy of the reference's buffer: "overwrite" (default, OverwriteOldest: the oldest unconsumed batch is
     // dropped) or "reject" (the push returns INCOMPLETE and nothing of it is taken); both count an overflow.
     Result ringAcquire(void** ptr, U64* max_elements);
@@ -346,10 +349,11 @@ class RingSource : public Module {
 
  private:
     Result ensureProducer();
-    Result publishStagedBatch();  // mu held
+    Result publishStagedBatch(std::unique_lock<std::mutex>& lock);  // mu held (released while waiting for a cycle to close)
     static constexpr U64 kStaging = 4;
     std::mutex mu;
     std::condition_variable dataAvailable;
+    std::condition_variable cycleClosed;  // the compute thread recorded the pending slot's free event
     bool rejectOnOverflow = false;
     hipStream_t uploadStream = nullptr;
     void* staging[kStaging] = {};

@@ -419,7 +419,17 @@ class Module:
         """push(): any number of elements (complex samples of the source's dtype; integer formats as [..., 2]
         arrays).  Returns "success" or "incomplete" (overflow policy reject: nothing was taken)."""
         a = np.ascontiguousarray(samples)
-        count = a.size // 2 if a.dtype.kind in "iu" else a.size
+        # the library reads `count` elements of the SOURCE's sample format from this buffer: the array must be of that
+        # format (an int8 array pushed into a CF32 source would be read four times past its end)
+        fmt = self.output("buffer").dtype
+        want = {"CF32": (np.dtype(np.complex64), 8, False), "CI16": (np.dtype(np.int16), 4, True),
+                "CI8": (np.dtype(np.int8), 2, True), "CU8": (np.dtype(np.uint8), 2, True)}.get(fmt)
+        if want is None:
+            raise JetstreamError(1, f"[MODULE_RING_SOURCE] ring_push: unsupported source format {fmt}")
+        if a.dtype != want[0] or (want[2] and (a.ndim == 0 or a.shape[-1] != 2)):
+            raise JetstreamError(1, f"[MODULE_RING_SOURCE] ring_push: a {fmt} source takes "
+                                    f"{'[..., 2] ' if want[2] else ''}{want[0]} samples, got {a.dtype} {a.shape}")
+        count = a.nbytes // want[1]
         r = _lib.jst_ring_push(self._h, a.ctypes.data_as(C.c_void_p), count)
         if r == 9:
             return "incomplete"
