@@ -422,6 +422,38 @@ def main() -> None:
 
     rt, elapsed = measure(args.provider)
     repeats_main, spread_main = measure.repeats, measure.spread
+
+    # The path's optional exchange step (north_star: "optional RCCL-over-xGMI reduce"), OUTSIDE the timed region -- no
+    # collective sits on the data path.  With RCCL as the control plane's backend every rank builds the LIBRARY's
+    # communicator (csrc/jst/comm.cc: RCCL dlopen'ed behind the C ABI, no torch on the data) and times the two
+    # collectives the path has: the U32[256, 4096] hit counts of the exact multi-GPU Spectrogram (4 MiB) and config 5's
+    # averaged F32[65536] trace (256 KiB).  The line reports how many ranks RCCL saw.
+    collective = None
+    if world > 1 and backend != "gloo":
+        import cyberether_amd.distributed as D
+        comm = D.library_comm()
+        counts = js.Tensor.from_numpy(np.full((HEIGHT, N_FFT), rank + 1, np.uint32))
+        trace = js.Tensor.from_numpy(np.full((65536,), float(rank + 1), np.float32))
+
+        def timed_allreduce(t, average):
+            for _ in range(3):
+                comm.all_reduce(t, "sum", average=average, stream=rt.stream)
+            rt.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                comm.all_reduce(t, "sum", average=average, stream=rt.stream)
+            rt.synchronize()
+            return (time.perf_counter() - t0) / 20 * 1e6
+        counts.copy_from(np.full((HEIGHT, N_FFT), rank + 1, np.uint32))
+        comm.all_reduce(counts, "sum", stream=rt.stream)
+        rt.synchronize()
+        ok = bool(np.all(counts.numpy() == world * (world + 1) // 2))
+        collective = {"library": "RCCL behind the C ABI (jst_comm_allreduce, csrc/jst/comm.cc)", "rccl_ranks": comm.world,
+                      "uses_rccl": comm.uses_rccl, "sum_of_counts_exact": ok,
+                      "allreduce_us": {"u32_counts_4MiB": round(timed_allreduce(counts, False), 1),
+                                       "f32_trace_256KiB_average": round(timed_allreduce(trace, True), 1)},
+                      "in_timed_region": False}
     samples = float(args.steps) * BATCHES * N_FFT * world
     kernel_ms_raw, pair_ms, kernel_ms, achieved = kernel_time(rt)
     cycles_per_launch = kernel_time.cycles
@@ -483,7 +515,8 @@ def main() -> None:
                                             if any(u.endswith("+indices") for u in rt.units) else "values (F32)",
                        "units_ms": {u.split("(")[0]: rt.unit_mean_ms(u) for u in rt.units
                                     if rt.unit_mean_ms(u) > 0},
-                       "sharding": "independent batches per GPU, no data-path collective"},
+                       "sharding": "independent batches per GPU, no data-path collective",
+                       "collective": collective},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,

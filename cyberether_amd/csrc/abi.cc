@@ -6,6 +6,7 @@
 #include <cstring>
 #include <mutex>
 
+#include "jst/comm.hh"
 #include "jst/module.hh"
 #include "modules/modules.hh"
 
@@ -17,6 +18,9 @@ struct jst_tensor_s {
 struct jst_module_s {
     std::shared_ptr<Module> m;  // shared with every runtime the module was handed to
     bool initialized = false;
+};
+struct jst_comm_s {
+    Comm c;
 };
 struct jst_runtime_s {
     Runtime rt;
@@ -479,6 +483,37 @@ jst_result jst_filter_plan(float sample_rate, float bandwidth, const float* cent
     plan->resampled_sample_rate = p.resampledSampleRate;
     for (uint64_t h = 0; h < heads; ++h) offsets[h] = h < p.resamplerOffsets.size() ? p.resamplerOffsets[h] : 0;
     return R(Result::SUCCESS);
+}
+
+// ---- collectives (jst/comm.cc: RCCL over xGMI, dlopen'ed) -------------------------------------------------------
+int jst_comm_available(void) { return Comm::available() ? 1 : 0; }
+jst_result jst_comm_unique_id(uint8_t* id128) {
+    JST_ARG(id128, "null argument");
+    return R(Comm::uniqueId(id128));
+}
+jst_result jst_comm_init(uint32_t rank, uint32_t world, const uint8_t* id128, jst_comm* out) {
+    JST_ARG(out, "null argument");
+    auto* c = new jst_comm_s();
+    const Result r = c->c.create(rank, world, id128);
+    if (r != Result::SUCCESS) {
+        delete c;
+        return R(r);
+    }
+    *out = c;
+    return R(Result::SUCCESS);
+}
+jst_result jst_comm_destroy(jst_comm c) {
+    delete c;
+    return R(Result::SUCCESS);
+}
+uint32_t jst_comm_rank(jst_comm c) { return c ? c->c.rank() : 0; }
+uint32_t jst_comm_world(jst_comm c) { return c ? c->c.world() : 0; }
+uint64_t jst_comm_calls(jst_comm c) { return c ? c->c.calls() : 0; }
+int jst_comm_uses_rccl(jst_comm c) { return c && c->c.usesRccl() ? 1 : 0; }
+jst_result jst_comm_allreduce(jst_comm c, jst_tensor t, int op, int average, void* hip_stream) {
+    JST_ARG(c && t && (op == JST_COMM_SUM || op == JST_COMM_MAX), "invalid all-reduce arguments");
+    return R(c->c.allReduce(t->t, op == JST_COMM_SUM ? Comm::Op::SUM : Comm::Op::MAX, average != 0,
+                            static_cast<hipStream_t>(hip_stream)));
 }
 
 size_t jst_runtime_order(jst_runtime r, char* buffer, size_t capacity) {

@@ -347,6 +347,19 @@ hipError_t launch_fill_ones(void* out, uint64_t count, int elem_bytes, bool pair
     else hipLaunchKernelGGL(fill_kernel<float>, grid, dim3(256), 0, s, (float*)out, words, 1.0f, pair ? 0.0f : 1.0f);
     return hipGetLastError();
 }
+namespace {
+__global__ __launch_bounds__(256) void divide_kernel(float* x, uint64_t count, float divisor) {
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256ull) x[i] = x[i] / divisor;
+}
+}  // namespace
+// x[i] /= divisor in place (the cross-rank average of a summed trace: jst/comm.cc)
+hipError_t launch_divide_f32(float* x, uint64_t count, float divisor, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    (void)hipGetLastError();
+    const uint64_t blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(divide_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, x, count, divisor);
+    return hipGetLastError();
+}
 hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipStream_t s) {
     EwLayout L{};
     L.size = count;

@@ -255,6 +255,7 @@ hipError_t launch_window(float2* out, uint64_t n, hipStream_t stream);
 hipError_t launch_peak_abs(float* peak, const void* in, uint64_t count, bool complex, hipStream_t stream);
 // ones_tensor: count elements of 1 (elem_bytes 4 = F32, 8 with pair = CF32 (1,0), 8 = F64, 16 = CF64 (1,0))
 hipError_t launch_fill_ones(void* out, uint64_t count, int elem_bytes, bool pair, hipStream_t stream);
+hipError_t launch_divide_f32(float* x, uint64_t count, float divisor, hipStream_t stream);
 hipError_t launch_tanhf_probe(float* out, const float* in, uint64_t count, hipStream_t stream);
 // Exhaustive sweeps over all 2^32 float bit patterns (exact_sweep.hip): which = 0 sqrt of the main path, 1 tanhf
 // main path, 2 amplitude->range from the power (main + bail-out) vs the general form, 3 amplitude alone, 4 fast

@@ -48,30 +48,33 @@ def merge_hit_counts(counts: torch.Tensor) -> torch.Tensor:
     return counts
 
 
-_TORCH_OF = {"F32": (torch.float32, "<f4"), "U32": (torch.int32, "<i4"), "I32": (torch.int32, "<i4")}
+_COMM = None
 
 
-def device_view(tensor) -> torch.Tensor:
-    """Zero-copy torch view of a dense HIP jetstream Tensor (F32 / U32) for a collective: the collective then runs
-    in place on the module's own HBM.  U32 hit counts travel as int32 (sums stay far below 2^31)."""
-    if tensor.device != "hip":
-        raise ValueError("device_view needs a HIP tensor")
-    tdtype, typestr = _TORCH_OF[tensor.dtype]
-    shape = tuple(int(v) for v in tensor.shape)
+def library_comm():
+    """The library's own communicator (csrc/jst/comm.cc: RCCL behind the C ABI, no torch on the data path) for the
+    torch.distributed world this process is part of: rank 0 creates the ncclUniqueId, torch.distributed -- the control
+    plane that is already up -- broadcasts its 128 bytes, every rank calls jst_comm_init.  Created once per process."""
+    global _COMM
+    if _COMM is None:
+        import cyberether_amd.jetstream as js
+        world = _world()
+        if world == 1:
+            _COMM = js.Comm(0, 1, None)
+        else:
+            rank = dist.get_rank()
+            ident = [js.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            _COMM = js.Comm(rank, world, ident[0])
+    return _COMM
 
-    class _View:
-        __cuda_array_interface__ = {"shape": shape, "typestr": typestr,
-                                    "data": (int(tensor.data_ptr) + int(tensor.offset) * 4, False), "version": 2}
-    view = torch.as_tensor(_View(), device="cuda")
-    view._jst_keep = tensor   # the jetstream tensor owns the memory
-    return view
 
-
-def merge_spectrogram_counts(counts_tensor, via_host: bool = False) -> None:
+def merge_spectrogram_counts(counts_tensor, via_host: bool = False, stream: int = 0) -> None:
     """The exchange step of the exact multi-GPU spectrogram: sum the U32[H, N] hit counts a
-    `spectrogram{merge=counts}` module wrote this cycle over all ranks, in place on the device (RCCL all-reduce of
-    4 MiB at H = 256, N = 4096); a `spectrogram_merge{batches = all ranks' batches}` module then applies them.
-    via_host: bounce through the host (gloo dry runs where ranks share a device)."""
+    `spectrogram{merge=counts}` module wrote this cycle over all ranks, in place on the device -- jst_comm_allreduce (RCCL
+    all-reduce of 4 MiB at H = 256, N = 4096) on `stream`; a `spectrogram_merge{batches = all ranks' batches}` module
+    then applies them.  via_host: bounce through the host with torch.distributed (gloo dry runs where ranks share a
+    device or have none)."""
     if _world() == 1:
         return
     if via_host:
@@ -79,8 +82,14 @@ def merge_spectrogram_counts(counts_tensor, via_host: bool = False) -> None:
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
         counts_tensor.copy_from(host.numpy().astype(np.uint32))
     else:
-        merge_hit_counts(device_view(counts_tensor))
-        torch.cuda.synchronize()
+        library_comm().all_reduce(counts_tensor, "sum", stream=stream)
+
+
+def average_trace(trace_tensor, stream: int = 0) -> None:
+    """BASELINE config 5's averaged spectrum: the F32[N] trace of every rank becomes the mean over ranks, in place on the
+    device (jst_comm_allreduce with average = 1), one collective per reporting interval."""
+    if _world() > 1:
+        library_comm().all_reduce(trace_tensor, "sum", average=True, stream=stream)
 
 
 def max_over_ranks(seconds: float, device: str = "cpu") -> float:

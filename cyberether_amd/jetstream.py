@@ -142,6 +142,15 @@ _sig("jst_runtime_unit_mean_cycles", C.c_double, _h, C.c_char_p)
 _sig("jst_runtime_batched", C.c_int, _h)
 _sig("jst_runtime_event_overhead_ms", C.c_double, _h)
 _sig("jst_runtime_reset_timing", R, _h)
+_sig("jst_comm_available", C.c_int)
+_sig("jst_comm_unique_id", R, C.c_char_p)
+_sig("jst_comm_init", R, C.c_uint32, C.c_uint32, C.c_char_p, _hp)
+_sig("jst_comm_destroy", R, _h)
+_sig("jst_comm_rank", C.c_uint32, _h)
+_sig("jst_comm_world", C.c_uint32, _h)
+_sig("jst_comm_calls", C.c_uint64, _h)
+_sig("jst_comm_uses_rccl", C.c_int, _h)
+_sig("jst_comm_allreduce", R, _h, _h, C.c_int, C.c_int, C.c_void_p)
 _sig("jst_fft_twiddles", R, C.c_uint64, C.POINTER(C.c_float))
 _sig("jst_probe_tanhf", R, C.c_void_p, C.c_void_p, C.c_uint64)
 _sig("jst_probe_exact_sweep", R, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint64),
@@ -569,6 +578,48 @@ class Runtime:
 
     def reset_timing(self):
         _check(_lib.jst_runtime_reset_timing(self._h))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_available() -> bool:
+    """Can RCCL be loaded in this process (jst_comm_available)?"""
+    return bool(_lib.jst_comm_available())
+
+
+def comm_unique_id() -> bytes:
+    """ncclUniqueId of a new communicator (rank 0 calls this and ships the 128 bytes to the other ranks)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(_lib.jst_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """The path's communicator behind the C ABI (csrc/jst/comm.cc): RCCL over xGMI, one per process; world == 1 needs
+    no RCCL.  all_reduce runs in place on a dense F32 / U32 HIP tensor, on `stream` (default: the null stream)."""
+
+    def __init__(self, rank: int = 0, world: int = 1, unique_id: Optional[bytes] = None):
+        out = C.c_void_p()
+        self._h = None
+        if unique_id is not None and len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        _check(_lib.jst_comm_init(rank, world, unique_id, C.byref(out)))
+        self._h = C.c_void_p(out.value)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.jst_comm_destroy(h)
+
+    rank = property(lambda self: int(_lib.jst_comm_rank(self._h)))
+    world = property(lambda self: int(_lib.jst_comm_world(self._h)))
+    calls = property(lambda self: int(_lib.jst_comm_calls(self._h)))
+    uses_rccl = property(lambda self: bool(_lib.jst_comm_uses_rccl(self._h)))
+
+    def all_reduce(self, tensor: "Tensor", op: str = "sum", average: bool = False, stream: int = 0) -> None:
+        _check(_lib.jst_comm_allreduce(self._h, tensor._h, {"sum": 0, "max": 1}[op], 1 if average else 0,
+                                       C.c_void_p(stream) if stream else None))
 
 
 class SpectrumEngine:

@@ -89,6 +89,7 @@ enum {
 typedef struct jst_tensor_s* jst_tensor;
 typedef struct jst_module_s* jst_module;
 typedef struct jst_runtime_s* jst_runtime;
+typedef struct jst_comm_s* jst_comm;
 
 #define JST_MAX_RANK 8
 
@@ -290,6 +291,31 @@ double jst_runtime_unit_mean_cycles(jst_runtime r, const char* unit_prefix);
 /* 1 when JST_RUNTIME_BATCH took effect (the planner could batch every dynamic unit), else 0 */
 int jst_runtime_batched(jst_runtime r);
 jst_result jst_runtime_reset_timing(jst_runtime r);
+
+/* ---- collectives: one communicator per process (one process per GPU), RCCL over xGMI ----------------
+ * The reference has no multi-device code; a C++ host that runs one device ordinal per process
+ * (include/jetstream/backend/config.hh:39-41) reaches the path's two cross-rank exchanges here, without torch:
+ *   - the exact multi-GPU Spectrogram: `spectrogram{merge=counts}` writes this rank's U32[H, N] hit counts,
+ *     jst_comm_allreduce(counts, JST_COMM_SUM) sums them in place, `spectrogram_merge` applies them (bit-exact);
+ *   - BASELINE config 5's averaged spectrum: jst_comm_allreduce(lineplot average F32[N], JST_COMM_SUM, average = 1)
+ *     once per reporting interval (256 KiB at N = 65536: latency bound -- one collective per interval, never per cycle).
+ * RCCL is dlopen'ed on first use; world = 1 needs no RCCL and reduces nothing.  The 128-byte id is ncclUniqueId: rank 0
+ * creates it (jst_comm_unique_id) and ships it to the other ranks over whatever the host already has (MPI, a file, a
+ * TCP store ...); every rank then calls jst_comm_init with the same bytes.  The all-reduce runs in place on the
+ * tensor's own HBM on `hip_stream` (e.g. jst_runtime_stream(rt)): no host round trip. */
+enum { JST_COMM_SUM = 0, JST_COMM_MAX = 1 };
+#define JST_COMM_ID_BYTES 128
+int jst_comm_available(void); /* 1 when librccl.so can be loaded in this process */
+jst_result jst_comm_unique_id(uint8_t* id128);
+jst_result jst_comm_init(uint32_t rank, uint32_t world, const uint8_t* id128 /* may be NULL when world == 1 */,
+                         jst_comm* out);
+jst_result jst_comm_destroy(jst_comm c);
+uint32_t jst_comm_rank(jst_comm c);
+uint32_t jst_comm_world(jst_comm c);
+uint64_t jst_comm_calls(jst_comm c);  /* all-reduces issued so far */
+int jst_comm_uses_rccl(jst_comm c);   /* 1 when the communicator holds an RCCL communicator (world > 1) */
+/* dense F32 or U32 HIP tensor, in place; average: F32 sums only, divided by the world size behind the reduce */
+jst_result jst_comm_allreduce(jst_comm c, jst_tensor t, int op, int average, void* hip_stream);
 
 /* ---- test/bench probes -------------------------------------------------------------------- */
 /* Host twiddle generator used for the FFT tables: W[k] = exp(+j 2 pi k/n), interleaved. */

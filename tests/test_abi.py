@@ -138,3 +138,15 @@ def test_batching_needs_a_gpu_but_the_flag_is_understood(js):
     lib.jst_runtime_unit_mean_cycles.restype = C.c_double
     assert lib.jst_runtime_batched(None) == 0
     assert lib.jst_runtime_unit_mean_cycles(None, b"spectrum_fused") < 0
+
+
+def test_comm_symbols_and_single_rank_semantics(js):
+    """The collective behind the C ABI (csrc/jst/comm.cc): a one-rank communicator needs no RCCL and no GPU; more ranks
+    without rank 0's id fail loudly with the reason in jst_last_error (operand checks: tests/test_gpu_advice_r04.py)."""
+    assert js.comm_available() in (True, False)
+    c = js.Comm(0, 1, None)
+    assert (c.rank, c.world, c.calls, c.uses_rccl) == (0, 1, 0, False)
+    with pytest.raises(js.JetstreamError, match="unique id"):
+        js.Comm(0, 2, None)
+    with pytest.raises(js.JetstreamError, match="invalid rank"):
+        js.Comm(3, 2, bytes(128))

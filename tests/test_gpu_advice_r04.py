@@ -140,3 +140,23 @@ def test_ring_push_checks_the_sample_format(js):
     with pytest.raises(js.JetstreamError, match="takes"):
         src16.ring_push(np.zeros((4, 256), np.complex64))
     assert src16.ring_push(np.zeros((4, 256, 2), np.int16)) == "success"
+
+
+def test_single_rank_communicator_on_device_tensors(js):
+    """jst_comm_allreduce with world = 1: counted, a no-op on the data (sum and average alike), operand rules enforced."""
+    c = js.Comm(0, 1, None)
+    counts = js.Tensor.from_numpy(np.arange(64 * 128, dtype=np.uint32).reshape(64, 128))
+    trace = js.Tensor.from_numpy(np.linspace(-3, 3, 4096, dtype=np.float32))
+    c.all_reduce(counts, "sum")
+    c.all_reduce(trace, "sum", average=True)
+    c.all_reduce(trace, "max")
+    assert c.calls == 3 and not c.uses_rccl
+    assert np.array_equal(counts.numpy(), np.arange(64 * 128, dtype=np.uint32).reshape(64, 128))
+    assert np.array_equal(trace.numpy(), np.linspace(-3, 3, 4096, dtype=np.float32))
+    with pytest.raises(js.JetstreamError, match="dense F32 or U32 HIP tensor"):
+        c.all_reduce(js.Tensor.from_numpy(np.zeros((4, 8), np.complex64)))
+    with pytest.raises(js.JetstreamError, match="average"):
+        c.all_reduce(counts, "sum", average=True)
+    sliced = js.Tensor.from_numpy(np.zeros((8, 8), np.float32)).slice(1, 0, 4)
+    with pytest.raises(js.JetstreamError, match="dense F32 or U32 HIP tensor"):
+        c.all_reduce(sliced)

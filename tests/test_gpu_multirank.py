@@ -45,6 +45,12 @@ def test_bench_two_ranks_contract():
     assert cpu and cpu["value"] > 0 and cpu["cores"] == 1 and cpu["configs0"]["value"] > 0
     par = line["parity"]
     assert par["checked"] and par["bit_exact"] and par["output_rows"] >= 64 * 16 and par["cycles"] >= 16
+    # the optional exchange step: timed outside the region by the LIBRARY's communicator when RCCL is the backend (one
+    # GPU per rank); on this box the two ranks share a device, the control plane is gloo and the key is null
+    assert "collective" in line["config"]
+    coll = line["config"]["collective"]
+    assert coll is None or (coll["rccl_ranks"] == 2 and coll["uses_rccl"] and coll["sum_of_counts_exact"]
+                            and coll["allreduce_us"]["u32_counts_4MiB"] > 0 and coll["in_timed_region"] is False)
 
 
 def test_config5_two_ranks_psd_reduce_keeps_rank_state():
