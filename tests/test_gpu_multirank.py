@@ -67,3 +67,25 @@ def test_config5_two_ranks_psd_reduce_keeps_rank_state():
     line = _last_json(out.stdout)
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["backend"] == "gloo"
     assert line["merged_trace_is_mean_of_rank_traces"] is True
+
+
+def test_bench_single_gpu_line_carries_the_other_configs():
+    """configs[2..4] ride in the driver-run command's own JSON line, each with its time per cycle, a
+    roofline fraction on SURVEY 8(d)'s bytes and a parity stamp against the oracle on the timed tensors; plus the
+    round-1 definition of the headline (provider generic, per-cycle launches) and the rocprofv3-derived fraction key."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "32", "--warmup", "16",
+                          "--no-cpu-baseline", "--no-host-fed"], cwd=ROOT, env=_env(), capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _last_json(out.stdout)
+    assert line["n_gpus"] == 1 and line["parity"]["bit_exact"]
+    cfgs = line["configs"]
+    assert len(cfgs) == 3
+    for rec in cfgs:
+        assert "error" not in rec and "skipped" not in rec, rec
+        assert rec["parity"]["checked"] and rec["parity"]["bit_exact"], rec
+        assert 0.0 < rec["roofline"]["frac"] < 1.0
+    assert cfgs[0]["ms_per_cycle"] > 0 and cfgs[1]["x_realtime"] > 1 and cfgs[2]["us_per_cycle"] > 0
+    assert cfgs[2]["cycle_batched"]["batched"] is True
+    assert line["value_generic_per_cycle"]["value"] > 0
+    assert "frac_rocprof" in line["roofline"] and "rocprofv3_kernel_us" in line["roofline"]

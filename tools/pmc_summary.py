@@ -45,7 +45,10 @@ if traffic_json:
     cycles = int(sys.argv[7]) if len(sys.argv) > 7 and sys.argv[6] == "--cycles" else 1
     # StoreAmplitudeRangeT<..> or, with the Spectrogram's row indices as a side output, StoreAmplitudeRangeSideT<..>
     tag = "T<true>" if provider == "fast" else "T<false>"
-    pick = [k for k in acc if "fft_pipe_kernel<4096" in k and "LoadCF32TimesWindow" in k and "StoreAmplitudeRange" in k and tag in k]
+    # the fused 4096-point side kernel of either form (pipelined / one wavefront per transform)
+    pick = [k for k in acc if ("fft_pipe_kernel<4096" in k or "fft_wave4096_kernel" in k) and "LoadCF32TimesWindow" in k
+            and "StoreAmplitudeRange" in k and tag in k]
+    kname_tag = "fft_wave4096_kernel" if pick and "fft_wave4096_kernel" in pick[0] else "fft_pipe_kernel<4096"
     if not pick or "FETCH_SIZE" not in acc[pick[0]] or "WRITE_SIZE" not in acc[pick[0]]:
         sys.exit("no FETCH_SIZE / WRITE_SIZE pass for the fused spectrum kernel (" + provider + ") under " + root)
     k = pick[0]
@@ -65,6 +68,13 @@ if traffic_json:
                          "MI355X_MICROARCH.md section HBM; the doubled value reproduces the known 32 MiB input + tables to "
                          "0.1 %), WRITE_SIZE as reported",
            "kernel_sources_sha256": kernel_sources_sha256()}
+    # the rocprofv3 --kernel-trace --stats average of the same kernel, when that pass sits beside the PMC passes
+    # (<root>/trace/**/kernel_stats.csv): bench.py derives roofline.frac_rocprof from it under the same hash guard
+    for path in sorted(glob.glob(os.path.join(root, "trace", "**", "*kernel_stats.csv"), recursive=True)):
+        for row in csv.DictReader(open(path)):
+            if row["Name"][:150] == k[:150] or (kname_tag in row["Name"] and tag in row["Name"] and "LoadCF32TimesWindow" in row["Name"]):
+                rec["rocprofv3_kernel_us_mean"] = float(row["AverageNs"]) / 1e3
+                rec["rocprofv3_kernel_calls"] = int(row["Calls"])
     doc = {}
     if os.path.exists(traffic_json):
         try:
