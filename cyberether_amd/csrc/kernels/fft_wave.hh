@@ -37,6 +37,12 @@
 #define JST_WAVE_PREFETCH 1
 #endif
 
+#ifndef JST_WAVE_PASS_SB_OFF  // A/B switch: no scheduling barrier between the butterflies of passes 0-2
+#define JST_WAVE_PASS_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define JST_WAVE_PASS_SB() do {} while (0)
+#endif
+
 namespace jst::dev {
 
 constexpr int kWaveN = 4096;
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 2) void fft_wave4096_kernel(const 
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) x[b + 8 * c] = y[c];
-            __builtin_amdgcn_sched_barrier(0);
+            JST_WAVE_PASS_SB();
         }
 
         // ---- pass 1: butterfly (lane, k) reads m = b' + 8 k, writes q = k + 8 c, twiddle W[8 c lane] -----------------
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 2) void fft_wave4096_kernel(const 
             twiddle_inplace4<FWD>((unsigned)lane, y[4], y[5], y[6], y[7], tw1[4], tw1[5], tw1[6], tw1[7]);
 #pragma unroll
             for (int c = 0; c < 8; ++c) z[k + 8 * c] = y[c];
-            __builtin_amdgcn_sched_barrier(0);
+            JST_WAVE_PASS_SB();
         }
 
         // ---- transposition: lane i holds (q, i) for all q; lane k receives (k, j) for all j -- real parts, then imaginary
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 2) void fft_wave4096_kernel(const 
                 pin(y[c]);
                 u[c * 8 + i] = y[c];
             }
-            __builtin_amdgcn_sched_barrier(0);
+            JST_WAVE_PASS_SB();
         }
 
         // ---- next transform's loads ride behind the retiring outputs ------------------------------------------------

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
     JST_SPAN_DUMP();
 }
 
+
 }  // namespace
 
 namespace {
@@ -468,6 +469,10 @@ hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64
     // is launch bound and does not care (5.08 / 5.10 / 5.18 us); here the counting is what is left, and every copy is
     // 16 KiB more to read back and zero per cycle: 36.4 us per 16-cycle span with four, 32.2 with two, 32.8 with one (more
     // same-address collisions among the four rows of an atomic instruction) -- profiles/r03_experiments/w_span_kernel_diagnosis.log.
+    // Round 4 tried the collision-free form (U32[index][4 copies][16 columns], two histograms used alternately: one barrier
+    // per cycle): 36.4 us against 31.6 us for this kernel, same box -- what a cycle costs is reading back and zeroing the
+    // copies and the hit update, not the atomics' collisions (tools/ubench/spectrogram_span2_experiment.hh,
+    // profiles/r04_experiments/d_span_kernel_v2.log).
     static const int copies = [] {
         const char* e = getenv("JST_SPEC_SPAN_COPIES");
         const int c = e ? atoi(e) : 2;

@@ -7,6 +7,8 @@
 
 #include <cstdint>
 
+#include "hit_update.hh"
+
 namespace jst::kernels::specdev {
 
 // State stores written through at agent scope (`global_store ... sc1`), like the spectrum kernel's output (fft_lds.hh,
@@ -21,25 +23,16 @@ __device__ __forceinline__ void store_state(float* p, float v) { *p = v; }
 
 constexpr int kThreadsDefault = 1024;
 
-// std::min(val + 0.02f, 1.0f) applied k times to w (spectrogram/module_impl_native_cpu.cc:70-77, once per hit), w in
-// [0, 1], k <= 64.  Without the clamp the additions form a non-decreasing sequence s_n = fl(s_(n-1) + 0.02f); the
-// clamped sequence equals it until it first reaches 1 and is 1.0f from there on (a fixed point: fl(1 + 0.02) > 1).  So
-// the result is min(s_k, 1): k dependent additions and ONE clamp, no clamp or exit test inside the loop (the loop with
-// both cost three dependent operations per hit, and the wavefronts that own the noise-floor rows -- ~30 hits per cell
-// and cycle -- were a quarter of the kernel's life).  A cell whose hits carry it past 1 by a margin far above the
-// rounding of 64 additions (each within 2^-24 of ~1) ends at exactly 1.0f and skips the loop.
-__device__ __forceinline__ float apply_hits(float w, uint32_t k) {
-    if (w + 0.02f * (float)k >= 1.001f) return 1.0f;
-    uint32_t n = 0;
-    for (; n + 4u <= k; n += 4u) {
-        w += 0.02f;
-        w += 0.02f;
-        w += 0.02f;
-        w += 0.02f;
-    }
-    for (; n < k; ++n) w += 0.02f;
-    return fminf(w, 1.0f);
-}
+// The saturating hit update applied k times (kernels/hit_update.hh, host-testable): the k dependent additions and one
+// clamp.  JST_HITS_BINADE selects the binade form (the same floats in at most a dozen integer steps on the bit pattern,
+// proven equal on the host by tests/test_hit_update.py): measured 33.3-33.9 us against 31.8 us per 16-cycle span for the
+// additions (profiles/r04_experiments/e_hit_update_binade.log) -- its per-step conversion, multiply and two corrections cost
+// more than the ~30 dependent additions of a noise-floor cell they replace -- so it is not the default.
+#ifdef JST_HITS_BINADE
+__device__ __forceinline__ float apply_hits(float w, uint32_t k) { return jst::dev::apply_hits_binade(w, k); }
+#else
+__device__ __forceinline__ float apply_hits(float w, uint32_t k) { return jst::dev::apply_hits(w, k); }
+#endif
 
 // Workgroup barrier that orders LDS traffic only: __syncthreads() is a full fence and puts s_waitcnt vmcnt(0)
 // in front of s_barrier, which would drain the input loads in flight across the histogram clear.

@@ -27,7 +27,7 @@ def live_source(js, b, n, slots, **cfg):
 
 def test_two_slot_ring_never_mixes_batches(js, oracle):
     """slots = 2 in steady state: the slot the producer wants next is always the one the latest cycle consumed."""
-    n, b, slots, total = 4096, 64, 2, 60
+    n, b, slots, total = 4096, 32, 2, 60
     src, out = live_source(js, b, n, slots, overflow="reject")
     amp = js.Module("amplitude", {}, {"signal": out}, "amp")
     rge = js.Module("range", {"min": -100.0, "max": 100.0}, {"signal": amp.output("signal")}, "range")
