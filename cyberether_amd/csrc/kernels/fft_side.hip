@@ -83,15 +83,9 @@ hipError_t side_with(uint64_t n, const FftLayout& L, const float2* W, const Pro&
 
 }  // namespace
 
-// Rows a 128-column group of the tile-major side tensor occupies: the batches plus a pad that takes the group stride off
-// the powers of two (JST_SIDE_PAD_ROWS, default 2 rows = 256 bytes of skew per group).
-uint64_t spectrum_side_pitch(uint64_t batches) {
-    static const uint64_t pad = [] {
-        const char* e = getenv("JST_SIDE_PAD_ROWS");
-        return e ? (uint64_t)atoll(e) : 2ull;
-    }();
-    return batches + pad;
-}
+// Rows a 128-column group of the tile-major side tensor occupies: the batches plus two pad rows (256 bytes of skew per
+// group) that take the group stride off the powers of two.
+uint64_t spectrum_side_pitch(uint64_t batches) { return batches + 2; }
 
 bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stride, uint64_t height) {
     const char* k = getenv("JST_FFT_KERNEL");

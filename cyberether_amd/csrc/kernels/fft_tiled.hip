@@ -201,9 +201,7 @@ constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_
 }
 
 bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
-    // A/B switches (read once): lanes per workgroup of the two kernels, powers of two
-    static const uint32_t force_cb = [] { const char* e = getenv("JST_TILED_CB"); return e ? (uint32_t)atoi(e) : 0u; }();
-    static const uint32_t force_ca = [] { const char* e = getenv("JST_TILED_CA"); return e ? (uint32_t)atoi(e) : 0u; }();
+    constexpr uint32_t force_ca = 0, force_cb = 0;  // lanes per workgroup of the two kernels: picked below
     // Lane counts measured per plan with the specialised kernels (rocprofv3, profiles/r03_experiments/k_static_plan_lanes.log):
     // config 5's columns kernel 9.4 -> 7.8 us with 16 columns per workgroup instead of pick_lanes' 8 (128-byte instead of
     // 64-byte runs; the 52-register kernels keep enough workgroups in flight), config 3's 75.3 -> 70.7 us with 32.

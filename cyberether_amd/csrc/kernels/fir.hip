@@ -235,13 +235,6 @@ FirPlan fir_plan(uint32_t Q, uint32_t r) {
     };
     FirPlan p;
     p.J = (size_t)slots(4, 256) * r * sizeof(float2) <= 26 * 1024 ? 4 : 2;
-    if (const char* tune = getenv("JST_FIR_TUNE")) {  // "J,threads": measurement knob (tools/fir_sweep.py)
-        int tj = 0, tt = 0;
-        if (sscanf(tune, "%d,%d", &tj, &tt) == 2 && tj >= 1 && tj <= kFirMaxJ && tt >= 64 && tt <= 256 && tt % 64 == 0) {
-            p.J = tj;
-            p.threads = tt;
-        }
-    }
     constexpr size_t kLdsBudget = 53 * 1024;  // three workgroups per CU
     while ((size_t)slots(p.J, p.threads) * r * sizeof(float2) > kLdsBudget && (p.J > 1 || p.threads > 64)) {
         if (p.threads > 64) p.threads -= 64;

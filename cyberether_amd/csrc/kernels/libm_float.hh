@@ -14,7 +14,7 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define JST_FN __host__ __device__ __forceinline__
 #else
 #define JST_FN static inline

@@ -399,20 +399,15 @@ hipError_t launch_spectrogram(float* bins, const float* in, uint64_t in_offset, 
     // dense-enough input for the one-descriptor form: non-negative strides, rows that do not interleave, < 2 GiB
     const int64_t span = (int64_t)(batches ? batches - 1 : 0) * batch_stride + (int64_t)(width - 1) * elem_stride + 1;
     const bool buf_ok = elem_stride >= 0 && batch_stride >= (int64_t)(width - 1) * elem_stride + 1 && batches > 0 &&
-                        span * 4 < (int64_t)0x7fff0000 && getenv("JST_SPEC_FLAT") == nullptr;
+                        span * 4 < (int64_t)0x7fff0000;
 #define JST_SPEC_LAUNCH(TW, COPIES, THREADS, DEPTH, TILES)                          \
     do {                                                                            \
         if (buf_ok) JST_SPEC_LAUNCH_B(TW, COPIES, THREADS, DEPTH, TILES, true);     \
         else JST_SPEC_LAUNCH_B(TW, COPIES, THREADS, DEPTH, TILES, false);           \
     } while (0)
     if (height <= 256) {
-        static const int threads = [] {  // A/B switch: JST_SPEC_THREADS=512|256 (fewer wavefronts to dispatch)
-            const char* e = getenv("JST_SPEC_THREADS");
-            return e ? atoi(e) : 1024;
-        }();
-        if (threads == 512) JST_SPEC_LAUNCH(16, 4, 512, 32, tiles16);
-        else if (threads == 256) JST_SPEC_LAUNCH(16, 4, 256, 32, tiles16);
-        else JST_SPEC_LAUNCH(16, 4, 1024, 16, tiles16);
+        // 1024 threads: 512- and 256-thread workgroups (fewer wavefronts to dispatch) were +1.2 / +2.9 us per step (round 2)
+        JST_SPEC_LAUNCH(16, 4, 1024, 16, tiles16);
     }
     else if (height <= 512) JST_SPEC_LAUNCH(16, 2, 1024, 16, tiles16);
     else if (height <= 1024) JST_SPEC_LAUNCH(16, 1, 1024, 16, tiles16);
@@ -433,10 +428,6 @@ hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t ba
     if (!spectrogram_index_supported(batches, width, height) || pitch < batches || pitch * width >= (1ull << 31))
         return hipErrorInvalidValue;
     const size_t lds = ((size_t)height * 16 + 16) * 4 * sizeof(uint32_t);  // four copies, 64-byte aligned
-    static const int threads = [] {  // A/B switch: JST_SPEC_INDEX_THREADS = 256 | 512 | 1024
-        const char* e = getenv("JST_SPEC_INDEX_THREADS");
-        return e ? atoi(e) : 1024;
-    }();
     (void)hipGetLastError();
 #define JST_SPEC_INDEX(THREADS)                                                                                      \
     do {                                                                                                             \
@@ -447,9 +438,7 @@ hipError_t launch_spectrogram_index(float* bins, const uint8_t* idx, uint64_t ba
                            stream, bins, idx, (uint32_t)batches, (uint32_t)pitch, (uint32_t)width, (uint32_t)height, \
                            decay JST_SPEC_TL_ARG);                                                                   \
     } while (0)
-    if (threads == 1024) JST_SPEC_INDEX(1024);
-    else if (threads == 512) JST_SPEC_INDEX(512);
-    else JST_SPEC_INDEX(256);
+    JST_SPEC_INDEX(1024);  // 512- / 256-thread workgroups: 6.3 / 8.0 us against 4.9 (profiles/r03_experiments/l_...)
 #undef JST_SPEC_INDEX
     return hipGetLastError();
 }
@@ -465,7 +454,7 @@ hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64
     if (cycles < 1 || cycles >= (1ull << 31) || !spectrogram_index_supported(batches, width, height) || pitch < batches ||
         (ring_slots ? ring_slots : cycles) * pitch * width >= (1ull << 31) || (ring_slots && first_slot >= ring_slots))
         return hipErrorInvalidValue;
-    // Private histogram copies per workgroup (JST_SPEC_SPAN_COPIES = 1 | 2 | 4 is the A/B switch).  The single-cycle kernel
+    // TWO private histogram copies per workgroup.  The single-cycle kernel
     // is launch bound and does not care (5.08 / 5.10 / 5.18 us); here the counting is what is left, and every copy is
     // 16 KiB more to read back and zero per cycle: 36.4 us per 16-cycle span with four, 32.2 with two, 32.8 with one (more
     // same-address collisions among the four rows of an atomic instruction) -- profiles/r03_experiments/w_span_kernel_diagnosis.log.
@@ -473,11 +462,7 @@ hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64
     // per cycle): 36.4 us against 31.6 us for this kernel, same box -- what a cycle costs is reading back and zeroing the
     // copies and the hit update, not the atomics' collisions (tools/ubench/spectrogram_span2_experiment.hh,
     // profiles/r04_experiments/d_span_kernel_v2.log).
-    static const int copies = [] {
-        const char* e = getenv("JST_SPEC_SPAN_COPIES");
-        const int c = e ? atoi(e) : 2;
-        return c == 1 || c == 4 ? c : 2;
-    }();
+    constexpr int copies = 2;
     const size_t lds = ((size_t)height * 16 + 16) * (size_t)copies * sizeof(uint32_t);
     (void)hipGetLastError();
 #define JST_SPEC_SPAN(COPIES)                                                                                             \
@@ -489,9 +474,7 @@ hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64
                            stream, bins, idx, (uint32_t)batches, (uint32_t)pitch, (uint32_t)width, (uint32_t)height,      \
                            decay, (uint32_t)cycles, (uint32_t)first_slot, (uint32_t)ring_slots JST_SPAN_TL_ARG);         \
     } while (0)
-    if (copies == 1) JST_SPEC_SPAN(1);
-    else if (copies == 2) JST_SPEC_SPAN(2);
-    else JST_SPEC_SPAN(4);
+    JST_SPEC_SPAN(2);
 #undef JST_SPEC_SPAN
     return hipGetLastError();
 }

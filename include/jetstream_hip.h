@@ -91,6 +91,12 @@ typedef struct jst_module_s* jst_module;
 typedef struct jst_runtime_s* jst_runtime;
 typedef struct jst_comm_s* jst_comm;
 
+/* Tensors of up to 8 axes.  A NARROWING of the reference's tensor contract, on purpose: its fast iterators take rank <= 16
+ * (include/jetstream/tools/automatic_iterator.hh:182) and the generic path any rank; nothing on the named path -- Soapy
+ * [B, N], the Filter chain's [B, heads, N], FM's [B, lanes.., S, 2], the reference tests' rank-4 non-contiguous cases --
+ * goes beyond rank 4, the descriptor below is passed by value across the ABI, and the device-side layouts (EwLayout,
+ * FftLayout: kernel arguments) are sized by it.  jst_tensor_create / _wrap / _reshape / _expand_dims refuse more axes
+ * with JST_ERROR and a message in jst_last_error(). */
 #define JST_MAX_RANK 8
 
 /* The fields a module reads from a Tensor (tensor.hh:56-79, axis.hh:19-23). axis = -1: unset. */
@@ -106,7 +112,11 @@ typedef struct jst_tensor_desc {
 } jst_tensor_desc;
 
 /* ---- library ---------------------------------------------------------------------------- */
-/* The plugin handshake symbol the reference's loader looks up (plugin.hh:48-87). */
+/* The plugin handshake symbol the reference's loader looks up (plugin.hh:48-87).  HANDSHAKE ONLY: Plugin::load validates
+ * this record and then drains the plugin's JST_REGISTER_MODULE queues (src/plugin.cc:1131-1137) -- C++ objects this C
+ * library cannot fill, so a reference build that dlopens the file as a plugin finds a valid plugin with ZERO
+ * registrations.  Modules reach the reference through the bindings of INTEGRATION.md sections 2-3 (translation units
+ * compiled INTO the reference, or into a plugin of its own, which call the jst_* entry points below). */
 typedef struct JetstreamPluginAbi {
     uint32_t magic;   /* 0x4a535450 "JSTP" */
     uint32_t size;    /* sizeof(JetstreamPluginAbi) */

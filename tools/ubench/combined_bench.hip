@@ -5,7 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -I cyberether_amd/csrc/kernels -I cyberether_amd/csrc
 //         tools/ubench/combined_bench.hip
 #include "../../cyberether_amd/csrc/kernels/spectrogram.hip"
-#include "fft_lds.hh"
+#include "fft_lds_r03_variants.hh"  // the round-3 header with its A/B switches (the product header dropped them)
 
 #include <algorithm>
 #include <chrono>

@@ -110,6 +110,7 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 #define JST_STORE_AUX 16
 #endif
 // The same policy for plain global stores: a relaxed atomic store at agent scope is `global_store ... sc1`, nothing else.
+#ifndef JST_PLAIN_STORES  // A/B switch
 __device__ __forceinline__ void store_agent(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -117,6 +118,10 @@ __device__ __forceinline__ void store_agent(float2* p, float2 v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
+#else
+__device__ __forceinline__ void store_agent(float* p, float v) { *p = v; }
+__device__ __forceinline__ void store_agent(float2* p, float2 v) { *p = v; }
+#endif
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
@@ -147,11 +152,59 @@ __device__ __forceinline__ void buf_store_f1(rsrc_t r, uint32_t voff_bytes, uint
 __device__ __forceinline__ void buf_store_u8(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, uint32_t v) {
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, r, voff_bytes, soff_bytes, JST_SIDE_STORE_AUX);
 }
-// Measured and rejected, kept out of this header (tools/ubench/fft_lds_r03_variants.hh has them as A/B switches, logs in
-// profiles/r03_experiments/): 16-byte loads / stores with quad transposes in front (+0.5..1.0 us per 1024 x 4096 launch:
-// the kernel is bound by its per-workgroup latency chain, not by request count), the device-decided real-operand form
-// (123 VGPRs cost more than the re-requests), exec-branch / select forms of the twiddle multiply, paired LDS reads,
-// the one-pad-per-8 exchange layout, plain (wave-scope) stores.
+// 16-byte forms (A/B switches JST_STORE16 / JST_LOAD16, both OFF by default).  A wavefront's 4-byte store is one
+// 256-byte request per instruction and the epilogue issues eight of them per transform and thread; MI355X_MICROARCH.md
+// prices a scalar sc1 store at ~6x the dwordx4 time per byte and calls such store tails issue-bound.  Measured here
+// (profiles/r03_experiments/a_floor_bisect.log, a_wide_access_variants.log): in the memory-only skeleton of this launch
+// 16-byte stores change nothing (10.10 vs 10.08 us) and 16-byte loads buy 0.5 us (10.10 -> 9.57); in the full kernel the
+// quad transposes in front of the wide stores cost +0.5..1.0 us and the wide loads are neutral (exact 20.0 vs 20.4,
+// fast 18.6 vs 18.6, trivial epilogue 15.7 vs 15.7 us): the kernel is bound by its per-workgroup latency chain
+// (DESIGN.md section 4), not by request count.  Both forms are bit-identical to the narrow ones (the whole -m gpu suite
+// ran green with them switched on).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f buf_load_f4(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes) {
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
+}
+__device__ __forceinline__ void buf_store_f4(rsrc_t r, uint32_t voff_bytes, uint32_t soff_bytes, v4f v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), r, voff_bytes, soff_bytes, JST_STORE_AUX);
+}
+// Lane exchanges inside a quad (DPP quad_perm: no LDS, full rate).  xor1 = [1,0,3,2], xor2 = [2,3,0,1].
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;
+// 4 x 4 transpose across the lanes of a quad: in, lane q holds M[q][0..3]; out, lane q holds M[0..3][q].
+__device__ __forceinline__ void quad_transpose4(float (&a)[4], bool odd, bool hi) {
+    const float n0 = dpp_quad<kQuadXor1>(a[0]), n1 = dpp_quad<kQuadXor1>(a[1]);
+    const float n2 = dpp_quad<kQuadXor1>(a[2]), n3 = dpp_quad<kQuadXor1>(a[3]);
+    const float b0 = odd ? n1 : a[0], b1 = odd ? a[1] : n0;
+    const float b2 = odd ? n3 : a[2], b3 = odd ? a[3] : n2;
+    const float m0 = dpp_quad<kQuadXor2>(b0), m1 = dpp_quad<kQuadXor2>(b1);
+    const float m2 = dpp_quad<kQuadXor2>(b2), m3 = dpp_quad<kQuadXor2>(b3);
+    a[0] = hi ? m2 : b0;
+    a[1] = hi ? m3 : b1;
+    a[2] = hi ? b2 : m0;
+    a[3] = hi ? b3 : m1;
+}
+#ifndef JST_STORE16
+#define JST_STORE16 0
+#endif
+#ifndef JST_LOAD16
+#define JST_LOAD16 0
+#endif
+// JST_OPND_REAL: an operand whose imaginary parts are all +-0 (a window: window -> invert -> reshape, the spectrum_engine
+// block's own wiring) is kept RESIDENT as 8 real parts + one word of signs per thread and never re-requested: each
+// wavefront looks at the 8 elements it loaded for its first transform (they are the same for every transform it takes),
+// and when all 64 lanes agree the re-requests go through a zero-record descriptor (they return 0 without touching
+// memory) and the products use mk(re, +-0) -- the same four multiplications on the same operand bits, so the result is
+// bit-identical; any other operand keeps the re-request path.  Measured (profiles/r03_experiments/s_real_operand_resident.log,
+// same box, 103 chain tests bit-exact either way): 17.16-17.39 vs 16.80 us (fast), 20.97-21.15 vs 20.89 us (exact) -- the
+// kernel grows from 105 / 102 to 123 / 120 VGPRs and loses more in its passes than the re-requests cost.  OFF.
+#ifndef JST_OPND_REAL
+#define JST_OPND_REAL 0
+#endif
 // The Multiply operand of the prologue (the window taps of this thread's eight pass-0 positions) stays in VGPRs across
 // the transforms of a workgroup instead of being re-requested from L2 behind every retired output: a thread visits
 // the same positions in every transform.  Round 2 could not afford the 16 registers (127 VGPRs); the in-place twiddles
@@ -356,7 +409,11 @@ struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_na
     }
     __device__ __forceinline__ float value(float2 v) const {
         if constexpr (FAST) return amplitude_range_fast_guarded(v, coeff, scale, offset, guard, poly);
+#ifdef JST_EPI_GENERAL  // A/B switch: the class-ladder form of round 1
+        else return range_f32_general(amplitude_cf32(v, coeff), scale, offset);
+#else
         else return amplitude_range_exact(v, coeff, scale, offset);
+#endif
     }
     __device__ __forceinline__ void store_buf(rsrc_t r, uint32_t voff, uint32_t soff, float2 v) const {
         buf_store_f1(r, voff, soff, value(v));
@@ -395,8 +452,13 @@ struct StoreAmplitudeRangeSideT : StoreAmplitudeRangeT<FAST> {
     __device__ __forceinline__ rsrc_t side_rsrc(uint64_t transform, uint32_t n, int tid) const {
         const uint32_t t = (uint32_t)transform;
         const uint32_t cycle = t / side_batches, row = t - cycle * side_batches;
+#ifdef JST_SIDE_ROW_MAJOR  // A/B switch: U8[cycle][side_pitch][n], the round-3 layout (spectrogram.hip must be built alike)
+        (void)tid;
+        const uint32_t in_cycle = row * n;
+#else
         const uint32_t group = IN_BASE ? (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 7) : 0u;
         const uint32_t in_cycle = (group * side_pitch + row) * 128u;
+#endif
         return make_rsrc(side + (size_t)cycle * side_pitch * n + in_cycle, side_pitch * n - in_cycle);
     }
     // voff / soff: the F32 store's byte offsets (4 * u, 4 * c * BUT with BUT a multiple of 128).
@@ -430,8 +492,13 @@ struct StoreAmplitudeRangeSideT : StoreAmplitudeRangeT<FAST> {
         side_compute(v, y, index);
         buf_store_f1(r, voff, soff, y);
         const uint32_t u = voff >> 2;
+#ifdef JST_SIDE_ROW_MAJOR
+        (void)IN_BASE;
+        buf_store_u8(rs, u, soff >> 2, index);
+#else
         const uint32_t lane_off = IN_BASE ? (u & 127u) : (u >> 7) * (side_pitch * 128u) + (u & 127u);
         buf_store_u8(rs, lane_off, (soff >> 2) * side_pitch, index);
+#endif
     }
 };
 template <class Epi>
@@ -453,8 +520,13 @@ constexpr int cphys(int q) { return q + (q >> 3); }
 // the contiguous reads keep their one extra cycle per 32-lane group and the ido = 1 reads (stride 8) gain one:
 // 32 conflict cycles instead of 112, no extra instruction (base + compile-time offsets as before: no carry into
 // bit 4 between a base and its in-butterfly offsets for power-of-two plans).
+#ifdef JST_LDS_PAD8  // A/B switch: the one-pad-per-8 layout
+__device__ __forceinline__ int pphys(int p) { return p + (p >> 3); }
+constexpr int pcphys(int q) { return q + (q >> 3); }
+#else
 __device__ __forceinline__ int pphys(int p) { return p + ((p >> 4) << 1); }
 constexpr int pcphys(int q) { return q + ((q >> 4) << 1); }
+#endif
 
 // One butterfly per thread in the last pass (u = tid): the side output's column group is wave-uniform (see
 // StoreAmplitudeRangeSideT); the last pass's butterfly count is a multiple of 128 for every n the side output supports.
@@ -505,12 +577,20 @@ __device__ __forceinline__ void run_passes(float2* lds, const float2* __restrict
         const unsigned i = (unsigned)(u & (IDO - 1));
         butterfly<IP, FWD>(x[j]);
         if constexpr (IDO > 1) {
+#ifdef JST_RP_TW_BRANCH  // A/B switch: exec-masked region instead of selects
+            if (i != 0u) {
+                __asm__ volatile("");
+#pragma unroll
+                for (int c = 1; c < IP; ++c) x[j][c] = special_mul<FWD>(x[j][c], W[(unsigned)(c * L1) * i]);
+            }
+#else
 #pragma unroll
             for (int c = 1; c < IP; ++c) {
                 const float2 w = W[(unsigned)(c * L1) * i];
                 const float2 y = special_mul<FWD>(x[j][c], w);
                 x[j][c] = (i != 0u) ? y : x[j][c];
             }
+#endif
         }
         if constexpr (LAST) {
             if (active) {
@@ -664,6 +744,24 @@ __device__ __forceinline__ void twiddle_inplace4(unsigned i, float2& y0, float2&
 }
 #undef JST_TW1
 
+// Which wide-access forms a pipe-kernel instantiation uses: 16-byte input loads when pass 0 is a radix-8 pass on a dense
+// row (one butterfly per thread: the two lanes of a pair split its eight 16-byte pieces and swap halves), 16-byte
+// stores when the epilogue produces one float per output on a dense row and the last pass is radix 4 or 8.
+template <int N, bool CONTIG, class Pro = LoadCF32>
+constexpr bool pipe_load16() {
+    return JST_LOAD16 && CONTIG && make_plan(N).ip[0] == 8 && Pro::kRawBytes == 8;
+}
+// (not for an epilogue with a side output: with the four indices of a lane packed into one dword store beside the 16-byte
+// store the side kernel measured 196.5 vs 188.6 us per 16384-transform launch, tools/ubench/run_r03v.sh)
+template <int N, bool CONTIG, class Epi>
+constexpr bool pipe_store16() {
+    if constexpr (epi_has_side<Epi>()) return false;
+    else if constexpr (JST_STORE16 && CONTIG && Epi::kElemBytes == 4 && (make_plan(N).ip[make_plan(N).nf - 1] % 4) == 0)
+        return requires(const Epi& e, float2 v) { e.value(v); };
+    else
+        return false;
+}
+
 template <int N, int T, bool FWD, bool CONTIG, int P, class Pro, class Epi>
 __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2* buf1,
                                             const float2 (&twr)[make_twplan(N).regs + 1],
@@ -682,6 +780,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
     // the epilogue is a long barrier-free VALU stream.  With both co-resident workgroups at equal
     // priority the epilogue of one delays the passes of the other; passes at priority 3 and the
     // epilogue at 0 gave 30.8 -> 28.9 us (exact) and 21.0 -> 20.1 us (fast) per 1024 x 4096 launch.
+#ifndef JST_NO_SETPRIO  // A/B switch
 #ifndef JST_PRIO_PA
 #define JST_PRIO_PA 3
 #define JST_PRIO_PB 3
@@ -701,6 +800,7 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
             else __builtin_amdgcn_s_setprio(JST_PRIO_EA);
         }
     }
+#endif
     // x[] holds CC(i,b,k) for butterfly j at x[j*IP + b]
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -714,6 +814,16 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
             // pocketfft multiplies by WA(c-1,i) only when i > 0 (signed zeros and non-finite values survive
             // the i == 0 butterflies untouched).  One exec-masked region around the seven multiplies instead
             // of fourteen compare/select pairs: the lanes with i == 0 sit out, everyone else pays nothing.
+#ifdef JST_TW_SELECT  // A/B switch (tools/ubench/fused_bench.hip): the select form
+#pragma unroll
+            for (int c = 1; c < IP; ++c) {
+                float2 w;
+                if constexpr (tp.reg_off[P] >= 0) w = twr[tp.reg_off[P] + j * (IP - 1) + (c - 1)];
+                else w = twl[tp.lds_off[P] + i * (IP - 1) + (c - 1)];
+                const float2 z = special_mul<FWD>(y[c], w);
+                y[c] = (i != 0u) ? z : y[c];
+            }
+#else
             float2 w[IP];
 #pragma unroll
             for (int c = 1; c < IP; ++c) {
@@ -730,8 +840,53 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                     y[c] = (i != 0u) ? z : y[c];
                 }
             }
+#endif
         }
-        if constexpr (LAST) {
+        if constexpr (LAST && pipe_store16<N, CONTIG, Epi>()) {
+            // Wide stores: the eight outputs of a butterfly sit 4 * BUT bytes apart, one float each.  A 4 x 4 transpose
+            // inside every quad of lanes (two DPP stages) gives lane q the four CONSECUTIVE outputs u0..u0+3 of
+            // segment c = 4g + q: two 16-byte stores per thread and transform instead of eight 4-byte ones.
+            const bool odd = (tid & 1) != 0, hi2 = (tid & 2) != 0;
+            const uint32_t voff = (uint32_t)(((tid & ~3) + (tid & 3) * BUT) * 4);
+#pragma unroll
+            for (int g = 0; g < IP / 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = epi.value(y[4 * g + q]);
+#ifndef JST_NO_EPI_SCHED_BARRIER
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+                quad_transpose4(v, odd, hi2);
+                buf_store_f4(r_out, voff, (uint32_t)((4 * g * BUT + j * T) * 4), v4f{v[0], v[1], v[2], v[3]});
+#ifndef JST_NO_EPI_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                if constexpr (Pro::kHasOperand && !(JST_OPND_RESIDENT && CONTIG)) {
+                    constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
+                    if constexpr (pipe_load16<N, CONTIG, Pro>()) {
+                        const uint32_t vo = (uint32_t)(((tid & ~1) + 4 * IDO0 * (tid & 1)) * 8);
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) {
+                            const int k = (j * IP + 4 * g) / 2 + k2;
+                            const v4f w = buf_load_f4(r_opnd, vo, (uint32_t)(IDO0 * k) * 8u);
+                            opnd[2 * k] = mk(w.x, w.y);
+                            opnd[2 * k + 1] = mk(w.z, w.w);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int e = j * IP + 4 * g + q;
+                            const int u0 = tid + (e / IP0) * T;
+                            const int l0 = (u0 & (IDO0 - 1)) + IDO0 * IP0 * (u0 / IDO0);
+                            opnd[e] = buf_load_f2(r_opnd, (uint32_t)l0 * 8u, (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else if constexpr (LAST) {
 #pragma unroll
             for (int c = 0; c < IP; ++c) {
                 if constexpr (CONTIG && epi_has_side<Epi>())
@@ -744,7 +899,9 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                     epi.template store<CONTIG>(out_base, out_as, u + c * BUT, y[c]);
                 // keep at most two epilogues in flight: interleaving all eight costs ~40 VGPRs
                 // of temporaries and pushes the prefetch registers into scratch
+#ifndef JST_NO_EPI_SCHED_BARRIER  // A/B switch
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 if constexpr (Pro::kHasOperand && !(JST_OPND_RESIDENT && CONTIG)) {
                     // The per-position operand of the prologue (window taps) is not kept live
                     // across the passes: element e is re-requested from L2 as soon as output e
@@ -755,13 +912,23 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
                     if (CONTIG || more) {
                         constexpr int IP0 = plan.ip[0], IDO0 = plan.ido[0];
                         const int e = j * IP + c;  // constant after unrolling
-                        const int u0 = tid + (e / IP0) * T;
-                        const int l0 = (u0 & (IDO0 - 1)) + IDO0 * IP0 * (u0 / IDO0);
-                        if constexpr (CONTIG)
-                            opnd[e] = buf_load_f2(r_opnd, (uint32_t)l0 * 8u,
-                                                  (uint32_t)(IDO0 * (e % IP0)) * 8u);
-                        else
-                            opnd[e] = pro.template load_operand<CONTIG>(IDO0 * (e % IP0), l0);
+                        if constexpr (pipe_load16<N, CONTIG, Pro>()) {
+                            if ((e & 1) == 1) {  // a 16-byte request once both halves have retired (folds after unrolling)
+                                const int k = e >> 1;
+                                const uint32_t vo = (uint32_t)(((tid & ~1) + 4 * IDO0 * (tid & 1)) * 8);
+                                const v4f w = buf_load_f4(r_opnd, vo, (uint32_t)(IDO0 * k) * 8u);
+                                opnd[2 * k] = mk(w.x, w.y);
+                                opnd[2 * k + 1] = mk(w.z, w.w);
+                            }
+                        } else {
+                            const int u0 = tid + (e / IP0) * T;
+                            const int l0 = (u0 & (IDO0 - 1)) + IDO0 * IP0 * (u0 / IDO0);
+                            if constexpr (CONTIG)
+                                opnd[e] = buf_load_f2(r_opnd, (uint32_t)l0 * 8u,
+                                                      (uint32_t)(IDO0 * (e % IP0)) * 8u);
+                            else
+                                opnd[e] = pro.template load_operand<CONTIG>(IDO0 * (e % IP0), l0);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -785,12 +952,16 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
             const float2* rd = buf0 + pphys(i + IDO2 * IP2 * k);
 #pragma unroll
             for (int b = 0; b < IP2; ++b) {
+#ifdef JST_LDS_READ2  // A/B switch: let the compiler pair the reads into ds_read2_b64
+                x[j * IP2 + b] = rd[pcphys(IDO2 * b)];
+#else
                 // One ds_read_b64 per element: the load/store optimiser would pair these into ds_read2_b64, which the
                 // LDS serves at 128 B/clk against 256 B/clk for the single form (tools/ubench/lds_rate.hip: 27 vs 16
                 // clocks per wavefront for the eight elements of a butterfly).  A volatile access is never merged.
                 typedef const volatile __attribute__((address_space(3))) unsigned long long* lds_u64_ptr;
                 const unsigned long long bits = *(lds_u64_ptr)(rd + pcphys(IDO2 * b));
                 x[j * IP2 + b] = __builtin_bit_cast(float2, bits);
+#endif
             }
         }
         pipe_passes<N, T, FWD, CONTIG, P + 1, Pro, Epi>(x, buf1, buf0, twr, twl, tid, out_base,
@@ -876,8 +1047,25 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
     float2 opnd[8];
     constexpr uint32_t RB = Pro::kRawBytes;  // bytes per complex sample of the input stream (8: cf32, 4: ci16, 2: ci8 / cu8)
     const rsrc_t r_opnd = make_rsrc(pro.operand_row(), (uint32_t)N * 8u);
+    // 16-byte loads (pipe_load16): the even lane of a pair requests {i, i+1} x b = 0..3, the odd lane {i-1, i} x b = 4..7
+    // (i = tid: its own butterfly index); raw[2k] / raw[2k+1] hold the two elements of piece k until the halves are swapped.
+    constexpr bool L16 = pipe_load16<N, CONTIG, Pro>();
+    const uint32_t voff16 = (uint32_t)(((tid & ~1) + 4 * IDO0 * (tid & 1)) * 8);
     {
         const rsrc_t r_in = make_rsrc(pro.row(in_base), (uint32_t)N * RB);
+        if constexpr (L16) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (Pro::kHasOperand) {
+                    const v4f w = buf_load_f4(r_opnd, voff16, (uint32_t)(IDO0 * k) * 8u);
+                    opnd[2 * k] = mk(w.x, w.y);
+                    opnd[2 * k + 1] = mk(w.z, w.w);
+                }
+                const v4f v = buf_load_f4(r_in, voff16, (uint32_t)(IDO0 * k) * 8u);
+                raw[2 * k] = mk(v.x, v.y);
+                raw[2 * k + 1] = mk(v.z, v.w);
+            }
+        } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             if constexpr (CONTIG) {
@@ -891,11 +1079,29 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
                                                        IDO0 * (e % IP0), pos0[e / IP0]);
             }
         }
+        }
     }
 #pragma unroll
     for (int q = 0; q < TWL_PER_THREAD; ++q)
         if (tid + q * T < tp.lds_entries) twl[tid + q * T] = twv[q];
     if constexpr (tp.lds_entries > 0 && tp.lds_off[0] >= 0) lds_barrier();  // pass 0 reads the table
+
+    // JST_OPND_REAL (see the switch): is this wavefront's slice of the operand real?
+    constexpr bool REALOP = JST_OPND_REAL && CONTIG && Pro::kHasOperand && !L16 && !JST_OPND_RESIDENT;
+    [[maybe_unused]] float kept[8];
+    [[maybe_unused]] uint32_t kept_signs = 0;
+    [[maybe_unused]] bool wave_real = false;
+    if constexpr (REALOP) {
+        uint32_t imag_or = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            kept[e] = opnd[e].x;
+            const uint32_t b = f2u(opnd[e].y);
+            imag_or |= b;
+            kept_signs |= (b >> 31) << e;
+        }
+        wave_real = __all((imag_or & 0x7fffffffu) == 0u) != 0;
+    }
 
     bool flip = false;
 #ifdef JST_FFT_TIMELINE
@@ -905,8 +1111,29 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
     while (true) {
         JST_STAMP(0);  // iteration start
         float2 x[8];
+        if constexpr (L16) {
+            // products on the pieces as loaded, then the pair swaps halves: the even lane keeps the first element of
+            // every piece (b = 0..3 of butterfly i) and receives the odd lane's first elements (b = 4..7); the odd lane
+            // keeps its second elements (b = 4..7 of butterfly i) and receives the even lane's (b = 0..3).
+            const bool odd = (tid & 1) != 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = pro.apply(raw[e], opnd[e]);
+            for (int k = 0; k < 4; ++k) {
+                const float2 lo = pro.apply(raw[2 * k], opnd[2 * k]), hi = pro.apply(raw[2 * k + 1], opnd[2 * k + 1]);
+                const float2 nlo = mk(dpp_quad<kQuadXor1>(lo.x), dpp_quad<kQuadXor1>(lo.y));
+                const float2 nhi = mk(dpp_quad<kQuadXor1>(hi.x), dpp_quad<kQuadXor1>(hi.y));
+                x[k] = odd ? nhi : lo;
+                x[4 + k] = odd ? hi : nlo;
+            }
+        } else if constexpr (REALOP) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float2 w = wave_real ? mk(kept[e], u2f(((kept_signs >> e) & 1u) << 31)) : opnd[e];
+                x[e] = pro.apply(raw[e], w);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = pro.apply(raw[e], opnd[e]);
+        }
         JST_STAMP(1);  // input arrived + prologue applied
         // prefetch the next transform of this workgroup while this one is computed
         const uint64_t tn = t + grid;
@@ -919,9 +1146,18 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
             // zero records: the loads return 0 without touching memory.
             fft_bases(L, more ? tn : t, nin, nout);
             const rsrc_t r_in = make_rsrc(pro.row(nin), more ? (uint32_t)N * RB : 0u);
+            if constexpr (L16) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                raw[e] = Pro::load_raw_buf(r_in, (uint32_t)pos0[e / IP0] * RB, (uint32_t)(IDO0 * (e % IP0)) * RB);
+                for (int k = 0; k < 4; ++k) {
+                    const v4f v = buf_load_f4(r_in, voff16, (uint32_t)(IDO0 * k) * 8u);
+                    raw[2 * k] = mk(v.x, v.y);
+                    raw[2 * k + 1] = mk(v.z, v.w);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    raw[e] = Pro::load_raw_buf(r_in, (uint32_t)pos0[e / IP0] * RB, (uint32_t)(IDO0 * (e % IP0)) * RB);
+            }
         } else if (more) {
             fft_bases(L, tn, nin, nout);
 #pragma unroll
@@ -929,10 +1165,15 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
                 raw[e] = pro.template load_raw<CONTIG>(nin, L.in_axis_stride, IDO0 * (e % IP0), pos0[e / IP0]);
         }
         const rsrc_t r_out = make_rsrc(epi.row(out_base), (uint32_t)N * Epi::kElemBytes);
-        const rsrc_t r_opnd_next = make_rsrc(pro.operand_row(), more ? (uint32_t)N * 8u : 0u);
+        const rsrc_t r_opnd_next = make_rsrc(pro.operand_row(), (more && !(REALOP && wave_real)) ? (uint32_t)N * 8u : 0u);
         rsrc_t r_side = r_out;  // unused unless the epilogue has a side output
         if constexpr (CONTIG && epi_has_side<Epi>())
             r_side = epi.template side_rsrc<kSideGroupInBase<N, T>>(fft_ring_row(L, t), (uint32_t)N, tid);
+#ifdef JST_FB_SKIP_PASSES  // decomposition experiment (tools/ubench/fused_bench.hip): last pass + epilogue only
+        pipe_passes<N, T, FWD, CONTIG, plan.nf - 1, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
+                                                              L.out_axis_stride, epi, pro, opnd,
+                                                              more, r_out, r_opnd_next, r_side, young JST_TL_PASS);
+#else
         if (flip)
             pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufB, bufA, twr, twl, tid, out_base,
                                                         L.out_axis_stride, epi, pro, opnd,
@@ -941,6 +1182,7 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
             pipe_passes<N, T, FWD, CONTIG, 0, Pro, Epi>(x, bufA, bufB, twr, twl, tid, out_base,
                                                         L.out_axis_stride, epi, pro, opnd,
                                                         more, r_out, r_opnd_next, r_side, young JST_TL_PASS);
+#endif
 #ifdef JST_FFT_TIMELINE
         ++tl_it;
         if (threadIdx.x == 0) jst_tl_base[blockIdx.x * 64 + 63] = wall_clock64();

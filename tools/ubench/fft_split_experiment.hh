@@ -8,7 +8,7 @@
 // stage time -- ~3.9 us per transform against ~2.75 us per transform and CU for the pipelined kernel -- is set by that
 // chain, whatever the epilogue weighs.  Two FFT roles plus an epilogue role per CU would need 217 KiB of LDS.
 #pragma once
-#include "fft_lds.hh"
+#include "fft_lds_r03_variants.hh"  // the round-3 header with its A/B switches (the product header dropped them)
 
 namespace jst::dev {
 

@@ -1,7 +1,7 @@
 // Per-workgroup phase timeline of the pipelined fused spectrum kernel (s_memtime stamps by
 // thread 0).  Diagnostic only.  hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off
 //   -DJST_FFT_TIMELINE -I cyberether_amd/csrc/kernels tools/ubench/fft_timeline.hip
-#include "fft_lds.hh"
+#include "fft_lds_r03_variants.hh"  // the round-3 header with its A/B switches (the product header dropped them)
 #include <cstdio>
 #include <vector>
 #include <algorithm>

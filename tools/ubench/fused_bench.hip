@@ -5,7 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off [-DJST_...] -I cyberether_amd/csrc/kernels \
 //         -I cyberether_amd/csrc tools/ubench/fused_bench.hip -o fused_bench_<variant>
 // Diagnostic only; the product path is cyberether_amd/lib/libjetstream_hip.so.
-#include "fft_lds.hh"
+#include "fft_lds_r03_variants.hh"  // the round-3 header with its A/B switches (the product header dropped them)
 #ifdef FB_SPLIT
 #include "fft_split_experiment.hh"
 #endif
