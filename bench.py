@@ -409,7 +409,8 @@ def main() -> None:
           zero_copy  -- the producer owns the staging memory (a driver's readStream writing into it): acquire + commit,
                         no CPU copy; PCIe-bound
           push_8192  -- jst_ring_push of 8192-sample chunks out of pageable memory, the reference's Soapy loop
-                        verbatim: bound by one core's memcpy
+                        verbatim (the loop in native code, jst_probe_ring_push_chunks): bound by one core's copy into
+                        the pinned staging memory (non-temporal stores since round 4)
         PCIe-inclusive; never `value`."""
         import ctypes as C
         slots = args.slots
@@ -465,8 +466,7 @@ def main() -> None:
             flat = host.reshape(-1, 2) if np_t is not None else host.reshape(-1)
             pushed, t0 = 0, time.perf_counter()
             while time.perf_counter() - t0 < seconds / 2:
-                for off in range(0, batch, 8192):
-                    source.ring_push(flat[off:off + 8192])
+                source.ring_push_chunks(flat, 8192)   # 512 pushes of 8192 samples, the loop itself in native code
                 rt.compute(1, sync=False)
                 pushed += 1
             rt.synchronize()

@@ -383,6 +383,23 @@ jst_result jst_ring_push(jst_module source, const void* samples, uint64_t count)
     auto* r = ring_of(source);
     return r ? R(r->ringPush(samples, count)) : R(Result::ERROR);
 }
+// The reference's producer loop as native code (soapy/module_impl.cc:375-399: read <= chunk samples, push, repeat): `count`
+// elements of `samples` go in as consecutive pushes of at most `chunk` elements.  What bench.py's host_fed times as
+// push_8192 -- a Python loop of 512 ctypes calls per batch measured the interpreter, not the library.
+jst_result jst_probe_ring_push_chunks(jst_module source, const void* samples, uint64_t count, uint64_t chunk) {
+    auto* r = ring_of(source);
+    if (!r || chunk == 0 || (count > 0 && !samples)) return R(Result::ERROR);
+    const size_t eb = r->ringElementBytes();
+    const char* p = static_cast<const char*>(samples);
+    while (count > 0) {
+        const uint64_t n = count < chunk ? count : chunk;
+        const Result res = r->ringPush(p, n);
+        if (res != Result::SUCCESS) return R(res);
+        p += (size_t)n * eb;
+        count -= n;
+    }
+    return R(Result::SUCCESS);
+}
 jst_result jst_ring_acquire(jst_module source, void** ptr, uint64_t* max_count) {
     auto* r = ring_of(source);
     return r ? R(r->ringAcquire(ptr, max_count)) : R(Result::ERROR);

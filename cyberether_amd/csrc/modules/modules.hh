@@ -346,6 +346,7 @@ class RingSource : public Module {
     U64 ringSize();      // elements published and not yet consumed, plus the partial batch in staging
     U64 ringCapacity() const { return slots * batches * samples; }
     U64 ringOverflows();
+    size_t ringElementBytes() const { return elementBytes; }
 
  private:
     Result ensureProducer();

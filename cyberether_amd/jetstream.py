@@ -129,6 +129,7 @@ _sig("jst_runtime_period", C.c_uint64, _h)
 _sig("jst_runtime_graph_active", C.c_int, _h)
 _sig("jst_runtime_order", C.c_size_t, _h, C.c_char_p, C.c_size_t)
 _sig("jst_ring_push", R, _h, C.c_void_p, C.c_uint64)
+_sig("jst_probe_ring_push_chunks", R, _h, C.c_void_p, C.c_uint64, C.c_uint64)
 _sig("jst_ring_acquire", R, _h, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64))
 _sig("jst_ring_commit", R, _h, C.c_uint64)
 _sig("jst_ring_wait", R, _h, C.c_uint64, C.c_uint32)
@@ -427,19 +428,36 @@ class Module:
     def ring_push(self, samples: np.ndarray) -> str:
         """push(): any number of elements (complex samples of the source's dtype; integer formats as [..., 2]
         arrays).  Returns "success" or "incomplete" (overflow policy reject: nothing was taken)."""
-        a = np.ascontiguousarray(samples)
-        # the library reads `count` elements of the SOURCE's sample format from this buffer: the array must be of that
-        # format (an int8 array pushed into a CF32 source would be read four times past its end)
-        fmt = self.output("buffer").dtype
-        want = {"CF32": (np.dtype(np.complex64), 8, False), "CI16": (np.dtype(np.int16), 4, True),
-                "CI8": (np.dtype(np.int8), 2, True), "CU8": (np.dtype(np.uint8), 2, True)}.get(fmt)
-        if want is None:
-            raise JetstreamError(1, f"[MODULE_RING_SOURCE] ring_push: unsupported source format {fmt}")
-        if a.dtype != want[0] or (want[2] and (a.ndim == 0 or a.shape[-1] != 2)):
-            raise JetstreamError(1, f"[MODULE_RING_SOURCE] ring_push: a {fmt} source takes "
-                                    f"{'[..., 2] ' if want[2] else ''}{want[0]} samples, got {a.dtype} {a.shape}")
-        count = a.nbytes // want[1]
+        a, count = self._ring_samples(samples)
         r = _lib.jst_ring_push(self._h, a.ctypes.data_as(C.c_void_p), count)
+        if r == 9:
+            return "incomplete"
+        _check(r)
+        return "success"
+
+    def _ring_samples(self, samples):
+        """(contiguous array, element count) after checking the array against the SOURCE's sample format: the library
+        reads `count` elements of that format from the buffer (an int8 array pushed into a CF32 source would be read four
+        times past its end).  The format is looked up once per module."""
+        a = np.ascontiguousarray(samples)
+        want = getattr(self, "_ring_format", None)
+        if want is None:
+            fmt = self.output("buffer").dtype
+            want = {"CF32": (np.dtype(np.complex64), 8, False, fmt), "CI16": (np.dtype(np.int16), 4, True, fmt),
+                    "CI8": (np.dtype(np.int8), 2, True, fmt), "CU8": (np.dtype(np.uint8), 2, True, fmt)}.get(fmt)
+            if want is None:
+                raise JetstreamError(1, f"[MODULE_RING_SOURCE] ring_push: unsupported source format {fmt}")
+            self._ring_format = want
+        if a.dtype != want[0] or (want[2] and (a.ndim == 0 or a.shape[-1] != 2)):
+            raise JetstreamError(1, f"[MODULE_RING_SOURCE] ring_push: a {want[3]} source takes "
+                                    f"{'[..., 2] ' if want[2] else ''}{want[0]} samples, got {a.dtype} {a.shape}")
+        return a, a.nbytes // want[1]
+
+    def ring_push_chunks(self, samples: np.ndarray, chunk: int = 8192) -> str:
+        """The reference's producer loop in native code (jst_probe_ring_push_chunks): consecutive pushes of <= chunk
+        elements, as the Soapy thread does (soapy/module_impl.cc:375-399)."""
+        a, count = self._ring_samples(samples)
+        r = _lib.jst_probe_ring_push_chunks(self._h, a.ctypes.data_as(C.c_void_p), count, chunk)
         if r == 9:
             return "incomplete"
         _check(r)

@@ -330,6 +330,9 @@ jst_result jst_comm_allreduce(jst_comm c, jst_tensor t, int op, int average, voi
 /* ---- test/bench probes -------------------------------------------------------------------- */
 /* Host twiddle generator used for the FFT tables: W[k] = exp(+j 2 pi k/n), interleaved. */
 jst_result jst_fft_twiddles(uint64_t n, float* interleaved_out);
+/* The Soapy-shaped producer loop in native code: `count` elements of the source's sample format pushed as consecutive
+ * jst_ring_push calls of at most `chunk` elements (soapy/module_impl.cc:375-399).  bench.py: host_fed.push_8192. */
+jst_result jst_probe_ring_push_chunks(jst_module source, const void* samples, uint64_t count, uint64_t chunk);
 /* out[i] = device restatement of libm tanhf(in[i]); both DEVICE pointers. */
 jst_result jst_probe_tanhf(const float* in_device, float* out_device, uint64_t count);
 /* The fused Amplitude -> Range epilogues on arbitrary complex inputs (interleaved re,im; DEVICE
