@@ -565,6 +565,11 @@ jst_result jst_fft_twiddles(uint64_t n, float* out) {
     modules::ComputeTwiddles(n, out);
     return R(Result::SUCCESS);
 }
+int jst_probe_fft_path(uint64_t n) {
+    if (kernels::fft_lds_supported(n)) return JST_FFT_PATH_REGISTER;
+    if (!kernels::fft_tiled_supported(n)) return JST_FFT_PATH_PASSES;
+    return kernels::fft_tiled_needs_scratch(n) ? JST_FFT_PATH_TILE_PAIR : JST_FFT_PATH_TILE;
+}
 jst_result jst_probe_amplitude_range(const float* in, float* out_exact, float* out_fast, uint64_t count,
                                      float amplitude_coeff, float range_scale, float range_offset,
                                      float guard_h0, float guard_h1) {

@@ -1,5 +1,6 @@
 // fft_tiled.hip -- LDS-tiled mixed-radix FFT for lengths the register kernels (fft_lds.hh) do not
-// cover: any n whose cfftp plan (pocketfft.hh:1476-1497) uses radices <= 11, in ONE kernel when a
+// cover: any n whose cfftp plan (pocketfft.hh:1476-1497) uses radices <= 11 or generic odd primes up to
+// kMaxGenericRadix (passg, pocketfft.hh:1314-1421: tile_pass_generic below), in ONE kernel when a
 // transform fits an LDS tile, otherwise in TWO kernels (instead of one launch per pass through HBM,
 // fft_global.hip):
 //
@@ -53,6 +54,19 @@ __shared__ unsigned long long jst_tiled_stamps[16];
 constexpr int kMaxThreads = 1024;  // workgroup size follows the tile: about 4 elements per thread
 constexpr uint32_t kTileElems = 8192;  // upper bound of a tile (64 KiB of LDS, one buffer: passes run in place)
 constexpr uint64_t kWantGroups = 1024; // enough workgroups to cover 256 CUs several times
+constexpr uint32_t kMaxGenericRadix = 127;  // largest prime passg runs on an LDS tile (its wal[] table lives in LDS)
+constexpr bool is_generic_radix(uint32_t ip) { return ip > 11; }
+// tile_pass_generic: a wave owns at most kGenericSlots tasks = (pair of l, chunk of 64 butterflies x lanes)
+constexpr int kGenericSlots = 4;
+constexpr uint32_t generic_pass_tasks(uint32_t ip, uint64_t butterflies_x_lanes) {
+    return (uint32_t)((((ip + 1u) / 2u) / 2u) * ((butterflies_x_lanes + 63u) / 64u));
+}
+constexpr uint64_t generic_pass_threads(uint32_t ip, uint64_t tile_elems) {  // workgroup size the pass needs on this tile
+    return 64ull * ((generic_pass_tasks(ip, tile_elems / ip) + kGenericSlots - 1) / kGenericSlots);
+}
+// entries of pass (ip, global ido) in the per-pass twiddle table: the output twiddles, then -- generic radix only --
+// passg's wal[0..ip-1] = W[m * n/ip] (comp_twiddle's csarr, pocketfft.hh:1526-1531)
+constexpr uint64_t pass_table_entries(uint64_t ip, uint64_t ido) { return (ip - 1) * ido + (is_generic_radix((uint32_t)ip) ? ip : 0); }
 
 // Pad fused into the first load (core/pad/module_impl_native_cpu.cc:75-140): positions at or beyond
 // `valid` along the transform axis read as zero, everything else comes from the unpadded tensor.
@@ -134,7 +148,9 @@ constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_
     const int nf = plan_factors_ce(n, fact);
     if (nf <= 0 || nf > 20) return false;
     for (int i = 0; i < nf; ++i)
-        if (fact[i] > 11) return false;
+        if (fact[i] > kMaxGenericRadix) return false;
+    bool any_generic = false;
+    for (int i = 0; i < nf; ++i) any_generic = any_generic || is_generic_radix(fact[i]);
     p = TiledPlan{};
     p.n = (uint32_t)n;
     p.nf = (uint32_t)nf;
@@ -174,6 +190,11 @@ constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_
         if (force_cb) p.CB = force_cb;
         if (force_ca) p.CA = force_ca;
     }
+    if (any_generic)  // every generic pass fits the slots of a workgroup of at most kMaxThreads threads
+        for (uint32_t q = 0; q < p.nf; ++q)
+            if (is_generic_radix(p.fact[q]) &&
+                generic_pass_threads(p.fact[q], q < p.g ? (uint64_t)p.R1 * p.CA : (uint64_t)p.S * p.CB) > (uint64_t)kMaxThreads)
+                return false;
     p.ca_shift = ilog2(p.CA ? p.CA : 1);
     p.cb_shift = ilog2(p.CB);
     p.grp_w = p.CB;
@@ -194,10 +215,16 @@ constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_
     for (uint32_t q = 0; q < p.nf; ++q) {
         const uint64_t ido = n / (l1 * p.fact[q]);
         p.tw_off[q] = (uint32_t)off;
-        off += (uint64_t)(p.fact[q] - 1) * ido;
+        off += pass_table_entries(p.fact[q], ido);
         l1 *= p.fact[q];
     }
     return true;
+}
+
+// JST_TILED_GENERIC=0: A/B switch (tools/bench_multi_fm.py), plans with a generic radix go back to one launch per pass
+inline bool generic_radix_tiles_enabled() {
+    static const bool on = [] { const char* e = getenv("JST_TILED_GENERIC"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
@@ -216,7 +243,11 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
             ca = 32;
         }
     }
-    return build_tiled_plan(n, transforms, ca, cb, p);
+    if (!build_tiled_plan(n, transforms, ca, cb, p)) return false;
+    if (!generic_radix_tiles_enabled())
+        for (uint32_t q = 0; q < p.nf; ++q)
+            if (is_generic_radix(p.fact[q])) return false;
+    return true;
 }
 
 // The fold epilogue's lane grouping (see FoldProductEpi below): part of the plan.
@@ -396,7 +427,171 @@ __device__ __forceinline__ void tile_pass(float2* __restrict__ buf, const float2
     __syncthreads();  // outputs visible before the next pass (or the store) reads them
 }
 
+// One GENERIC odd-radix pass (any prime 13 <= ip <= kMaxGenericRadix) over an LDS tile, in place: pocketfft's passg
+// (pocketfft.hh:1314-1421) with its CH / CX planes kept in registers.  passg computes, per butterfly,
+//   H[0] = CC[0];  H[j], H[ip-j] = CC[j] +/- CC[ip-j]  (j = 1..ipph-1);   X[0] = H[0] + H[1] + ... + H[ipph-1]
+//   X[l], X[ip-l] from the wal[] sums (terms 1,2 first, then two at a time, then a single one: the association
+//   decides the rounding);   out[l], out[ip-l] = (X[l] +/- X[ip-l]) * twiddle.
+// Work item = (butterfly, PAIR of l): it reads the butterfly's ip inputs once, forms every H on the way (two adds
+// per input, cheaper than a pass over the tile and a barrier), and feeds both l of the pair -- the pass is bound by
+// LDS bandwidth (one item per (butterfly, l) with wal[] in LDS: 35 reads per item, 7.2 of the 8050-point kernel's
+// 24 us; profiles/r04_experiments/h_tiled_timeline_8050.log).  A WAVE owns 64 adjacent butterflies of ONE pair, so
+// l, the wal[] walk and the loop counts are wave-uniform: the walk runs on the scalar unit and the wal[] reads are
+// broadcasts.  Pair 0 also forms X[0].
+// The results (four, five for pair 0) wait in registers for the barrier, then go to their Stockham positions.
+// A wave owns at most kGenericSlots (pair, 64-butterfly chunk) tasks: build_tiled_plan checks that.
+
 template <bool FWD>
+__device__ __forceinline__ void tile_pass_generic(uint32_t ip, float2* __restrict__ buf, const float2* __restrict__ PT,
+                                                  uint32_t len, uint32_t lane_shift, uint32_t live_lanes,
+                                                  uint32_t pitch, uint32_t ido, uint32_t ido_magic,
+                                                  uint32_t l1loc, uint32_t ido_glob, uint32_t tw_is,
+                                                  uint32_t tw_i0, uint32_t tw_lane) {
+    const uint32_t ipph = (ip + 1u) / 2u, but = len / ip, lane_mask = (1u << lane_shift) - 1u;
+    const uint32_t rs = ido * pitch;  // distance of two inputs j, j+1 of a butterfly
+    const uint32_t per_pair = but << lane_shift, chunks = (per_pair + 63u) >> 6;
+    const uint32_t ntask = ((ipph - 1u + 1u) / 2u) * chunks;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = blockDim.x >> 6;
+    // wal[m] = W[m * n/ip] (conjugated for the forward transform), staged in LDS: read at wave-uniform addresses in the
+    // same batch as the inputs -- as scalar loads from the table every wal[] pair was a second and third round trip
+    // per step of the walk (s_load, s_waitcnt lgkmcnt(0)) behind the LDS one
+    __shared__ float2 wal_s[kMaxGenericRadix + 1];
+    if (threadIdx.x < ip) {
+        float2 w = PT[(ip - 1u) * ido_glob + threadIdx.x];
+        if (FWD) w.y = -w.y;
+        wal_s[threadIdx.x] = w;
+    }
+    __syncthreads();
+    float2 o[kGenericSlots][5];  // out[l1], out[ip-l1], out[l2], out[ip-l2], out[0]
+    uint32_t wr_base[kGenericSlots];  // 0xffffffff marks an idle slot
+#pragma unroll
+    for (int r = 0; r < kGenericSlots; ++r) {
+        const uint32_t task = wave + (uint32_t)r * nwaves;  // wave-uniform
+        wr_base[r] = 0xffffffffu;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) o[r][q] = mk(0.0f, 0.0f);
+        if (task >= ntask) continue;
+        const uint32_t pair = task / chunks, chunk = task - pair * chunks;
+        const uint32_t e = (chunk << 6) + (threadIdx.x & 63u);
+        const uint32_t lane = e & lane_mask, u = e >> lane_shift;
+        if (e >= per_pair || lane >= live_lanes) continue;
+        const uint32_t la = 1u + 2u * pair, lb = la + 1u;  // the pair's l (lb may be ipph: then only la is real)
+        const bool two = lb < ipph;
+        const uint32_t k = ido > 1 ? __umulhi(u, ido_magic) : u, i = u - k * ido;
+        const float2* h = buf + (i + ido * ip * k) * pitch + lane;
+        wr_base[r] = (i + ido * k) * pitch + lane;
+        auto wal = [&](uint32_t m) { return wal_s[m]; };
+        // terms 1 and 2
+        const float2 c0 = h[0];
+        float2 t1 = h[rs], t2 = h[2u * rs], u1 = h[(ip - 1u) * rs], u2 = h[(ip - 2u) * rs];
+        float2 h1 = cadd(t1, u1), h2 = cadd(t2, u2), g1 = csub(t1, u1), g2 = csub(t2, u2);  // H[1], H[2], H[ip-1], H[ip-2]
+        float2 x0 = c0;
+        x0.x += h1.x; x0.y += h1.y;
+        x0.x += h2.x; x0.y += h2.y;
+        float2 xa, xac, xb, xbc;
+        uint32_t ia = 2u * la, ib = 2u * lb;
+        {
+            const float2 w1 = wal(la), w2 = wal(ia);
+            xa.x = c0.x + w1.x * h1.x + w2.x * h2.x;
+            xa.y = c0.y + w1.x * h1.y + w2.x * h2.y;
+            xac.x = -w1.y * g1.y - w2.y * g2.y;
+            xac.y = w1.y * g1.x + w2.y * g2.x;
+        }
+        if (two) {
+            const float2 w1 = wal(lb), w2 = wal(ib);
+            xb.x = c0.x + w1.x * h1.x + w2.x * h2.x;
+            xb.y = c0.y + w1.x * h1.y + w2.x * h2.y;
+            xbc.x = -w1.y * g1.y - w2.y * g2.y;
+            xbc.y = w1.y * g1.x + w2.y * g2.x;
+        } else {
+            xb = xbc = mk(0.0f, 0.0f);
+            ib = 0;
+        }
+        auto step = [&](uint32_t& iw, uint32_t l) {  // iwal += l; if (iwal > ip) iwal -= ip;  (never == ip: ip is prime)
+            iw += l;
+            if (iw > ip) iw -= ip;
+            return wal(iw);
+        };
+        uint32_t j = 3u;
+        const float2* hj = h + 3u * rs;          // CC[j]
+        const float2* hjc = h + (ip - 3u) * rs;  // CC[ip - j]
+        for (; j < ipph - 1u; j += 2u, hj += 2u * rs, hjc -= 2u * rs) {
+            t1 = hj[0]; t2 = hj[rs]; u1 = hjc[0]; u2 = *(hjc - rs);
+            h1 = cadd(t1, u1); g1 = csub(t1, u1);  // H[j], H[ip-j]
+            h2 = cadd(t2, u2); g2 = csub(t2, u2);  // H[j+1], H[ip-j-1]
+            x0.x += h1.x; x0.y += h1.y;
+            x0.x += h2.x; x0.y += h2.y;
+            {
+                const float2 xw = step(ia, la);
+                const float2 xw2 = step(ia, la);
+                xa.x += h1.x * xw.x + h2.x * xw2.x;
+                xa.y += h1.y * xw.x + h2.y * xw2.x;
+                xac.x -= g1.y * xw.y + g2.y * xw2.y;
+                xac.y += g1.x * xw.y + g2.x * xw2.y;
+            }
+            if (two) {
+                const float2 xw = step(ib, lb);
+                const float2 xw2 = step(ib, lb);
+                xb.x += h1.x * xw.x + h2.x * xw2.x;
+                xb.y += h1.y * xw.x + h2.y * xw2.x;
+                xbc.x -= g1.y * xw.y + g2.y * xw2.y;
+                xbc.y += g1.x * xw.y + g2.x * xw2.y;
+            }
+        }
+        for (; j < ipph; ++j, hj += rs, hjc -= rs) {
+            t1 = hj[0]; u1 = hjc[0];
+            h1 = cadd(t1, u1); g1 = csub(t1, u1);
+            x0.x += h1.x; x0.y += h1.y;
+            {
+                const float2 xw = step(ia, la);
+                xa.x += h1.x * xw.x;
+                xa.y += h1.y * xw.x;
+                xac.x -= g1.y * xw.y;
+                xac.y += g1.x * xw.y;
+            }
+            if (two) {
+                const float2 xw = step(ib, lb);
+                xb.x += h1.x * xw.x;
+                xb.y += h1.y * xw.x;
+                xbc.x -= g1.y * xw.y;
+                xbc.y += g1.x * xw.y;
+            }
+        }
+        float2 a1 = cadd(xa, xac), a2 = csub(xa, xac), b1 = cadd(xb, xbc), b2 = csub(xb, xbc);
+        const uint32_t st = tw_i0 + lane * tw_lane + tw_is * i;  // the GLOBAL i of the butterfly
+        if (st != 0) {
+            a1 = special_mul<FWD>(a1, PT[(la - 1u) * ido_glob + st]);
+            a2 = special_mul<FWD>(a2, PT[(ip - la - 1u) * ido_glob + st]);
+            if (two) {
+                b1 = special_mul<FWD>(b1, PT[(lb - 1u) * ido_glob + st]);
+                b2 = special_mul<FWD>(b2, PT[(ip - lb - 1u) * ido_glob + st]);
+            }
+        }
+        o[r][0] = a1; o[r][1] = a2; o[r][2] = b1; o[r][3] = b2; o[r][4] = x0;
+    }
+    __syncthreads();  // every input of this pass has been read
+    JST_TSTAMP(13);
+    const uint32_t ws = l1loc * ido * pitch;
+#pragma unroll
+    for (int r = 0; r < kGenericSlots; ++r) {
+        if (wr_base[r] == 0xffffffffu) continue;
+        const uint32_t task = wave + (uint32_t)r * nwaves;
+        const uint32_t pair = task / chunks, la = 1u + 2u * pair, lb = la + 1u;
+        float2* wr = buf + wr_base[r];
+        wr[la * ws] = o[r][0];
+        wr[(ip - la) * ws] = o[r][1];
+        if (lb < ipph) {
+            wr[lb * ws] = o[r][2];
+            wr[(ip - lb) * ws] = o[r][3];
+        }
+        if (pair == 0) wr[0] = o[r][4];
+    }
+    __syncthreads();  // outputs visible before the next pass (or the store) reads them
+}
+
+// GEN: the kernel is compiled for plans that hold a generic radix (a second set of kernels: with the generic pass
+// inlined into the one set, every kernel of this file paid registers / scratch for a pass most plans never run)
+template <bool FWD, bool GEN>
 __device__ __forceinline__ void tile_pass_any(uint32_t ip, float2* buf, const float2* PT, uint32_t len,
                                               uint32_t lane_shift, uint32_t live_lanes, uint32_t pitch,
                                               uint32_t ido, uint32_t ido_magic, uint32_t l1loc,
@@ -412,14 +607,21 @@ __device__ __forceinline__ void tile_pass_any(uint32_t ip, float2* buf, const fl
         case 5: JST_TP(5); break;
         case 7: JST_TP(7); break;
         case 8: JST_TP(8); break;
-        default: JST_TP(11); break;
+        case 11: JST_TP(11); break;
+        default:
+            if constexpr (GEN)
+                tile_pass_generic<FWD>(ip, buf, PT, len, lane_shift, live_lanes, pitch, ido, ido_magic, l1loc,
+                                       ido_glob, tw_is, tw_i0, tw_lane);
+            else
+                __builtin_unreachable();  // build_tiled_plan admits 2,3,4,5,7,8,11 and generic primes only
+            break;
     }
 #undef JST_TP
 }
 
 // ---- kernel A: passes 0..g-1 on CA adjacent columns ---------------------------------------------
-template <bool FWD, class Pro, int SP = 0>
-__global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_columns_kernel(const FftLayout L,
+template <bool FWD, class Pro, int SP = 0, bool GEN = false>
+__global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void fft_tile_columns_kernel(const FftLayout L,
                                                                     const TiledPlan Prt,
                                                                     const float2* __restrict__ W,
                                                                     const Pro pro,
@@ -462,7 +664,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_col
     for (uint32_t p = 0; p < P.g; ++p) {
         const uint32_t ip = P.fact[p];
         m /= ip;  // local ido'
-        tile_pass_any<FWD>(ip, buf0, W + P.tw_off[p], P.R1, P.ca_shift, live, P.CA, m, P.magic[p], l1,
+        tile_pass_any<FWD, GEN>(ip, buf0, W + P.tw_off[p], P.R1, P.ca_shift, live, P.CA, m, P.magic[p], l1,
                            m * P.S, P.S, c0, 1u);
         l1 *= ip;
         JST_TSTAMP(2 + p);  // pass p done
@@ -482,8 +684,8 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_col
 }
 
 // ---- kernel B: passes g..nf-1 on CB adjacent blocks (or whole transforms when g == 0) -----------
-template <bool FWD, class Pro, class Epi, int SP = 0>
-__global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blocks_kernel(const FftLayout L,
+template <bool FWD, class Pro, class Epi, int SP = 0, bool GEN = false>
+__global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void fft_tile_blocks_kernel(const FftLayout L,
                                                                    const TiledPlan Prt,
                                                                    const float2* __restrict__ W,
                                                                    const Pro pro, const Epi epi,
@@ -558,7 +760,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
     for (uint32_t p = P.g; p < P.nf; ++p) {
         const uint32_t ip = P.fact[p];
         ido /= ip;
-        tile_pass_any<FWD>(ip, buf0, W + P.tw_off[p], P.S, P.cb_shift, live, pitch, ido, P.magic[p],
+        tile_pass_any<FWD, GEN>(ip, buf0, W + P.tw_off[p], P.S, P.cb_shift, live, pitch, ido, P.magic[p],
                            l1 / P.R1, ido, 1u, 0u, 0u);
         l1 *= ip;
         JST_TSTAMP(2 + (p - P.g));  // pass done
@@ -575,7 +777,11 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
         const uint32_t groups = P.CB >> P.grp_shift;
         for (uint32_t hd = 0; hd < epi.heads; ++hd) {
         const float2* hh = epi.h + (int64_t)hd * epi.h_head_stride;
-        const bool in_place = hd + 1u == epi.heads;  // the last head may overwrite the spectrum tile with its products
+        // The last head may overwrite the spectrum tile with its products (every thread multiplies, eight operand loads
+        // in flight, then the walk reads finished products).  With several heads that extra pass over the tile only
+        // pays when the walk has few threads to hide its operand loads behind (multi-fm.yml: 805 walkers of 1024
+        // threads, products on the fly 2.0 us against 4.4 us, profiles/r04_experiments/h_tiled_timeline_8050.log).
+        const bool in_place = hd + 1u == epi.heads && (epi.heads == 1u || total * 4u < blockDim.x);
         if (in_place) {
         if (epi.heads > 1) __syncthreads();  // every walk of the earlier heads has read the spectrum tile
         for (uint32_t e0 = threadIdx.x; e0 < elems; e0 += 8 * blockDim.x) {
@@ -596,6 +802,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
                     buf0[slot[k]] = epi.spectrum_first ? cmul_full(buf0[slot[k]], hv[k]) : cmul_full(hv[k], buf0[slot[k]]);
         }
         __syncthreads();
+        JST_TSTAMP(8);  // products of the last head in place
         }
         for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
             const uint32_t kb = e & (P.CB - 1u), q = e >> P.cb_shift;
@@ -677,6 +884,7 @@ __global__ __launch_bounds__(kMaxThreads, JST_TILED_MIN_WAVES) void fft_tile_blo
             }
             epi.out[(t * epi.heads + hd) * F + m] = mk((float)(sr / divisor), (float)(si / divisor));  // 32-byte runs: plain store, merged in L2
         }
+        JST_TSTAMP(9 + (hd & 1u));  // walk of head hd done (threads of wave 0)
         }
     } else
     // store result q of block (t, k) at k + R1*q: block index fastest when R1 > 1 (adjacent k are
@@ -706,6 +914,10 @@ inline uint64_t min_threads_for_passes(const TiledPlan& P, uint32_t first, uint3
     uint64_t need = 64;
     for (uint32_t q = first; q < last; ++q) {
         const uint32_t ip = P.fact[q];
+        if (is_generic_radix(ip)) {
+            need = std::max<uint64_t>(need, generic_pass_threads(ip, tile_elems));
+            continue;
+        }
         const uint64_t per = ip <= 3 ? 4 : (ip <= 7 ? 2 : 1);
         const uint64_t nb = tile_elems / ip;
         need = std::max<uint64_t>(need, (nb + per - 1) / per);
@@ -720,19 +932,28 @@ inline unsigned threads_for(uint64_t tile_elems, const char* override_env = null
     }
     uint64_t t = ((tile_elems / 8 + 255) / 256) * 256;
     if (t < 256) t = 256;
+    if (t < min_threads) t = ((min_threads + 63) / 64) * 64;  // a generic-radix pass may need more (wave-granular tasks)
     if (t > (uint64_t)kMaxThreads) t = kMaxThreads;
     return (unsigned)t;
 }
 
-template <bool FWD, class Pro, class Epi, int SP = 0>
+inline bool plan_has_generic_radix(const TiledPlan& P) {
+    for (uint32_t q = 0; q < P.nf; ++q)
+        if (is_generic_radix(P.fact[q])) return true;
+    return false;
+}
+
+template <bool FWD, class Pro, class Epi, int SP = 0, bool GEN = false>
 hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2* W, const Pro& pro,
                            const Epi& epi, float2* scratch, hipStream_t s) {
     if (L.transforms == 0) return hipSuccess;
+    if constexpr (SP == 0 && !GEN)
+        if (plan_has_generic_radix(P)) return launch_tiled_sp<FWD, Pro, Epi, 0, true>(P, L, W, pro, epi, scratch, s);
     (void)hipGetLastError();
     if (P.g > 0) {
         if (!scratch) return hipErrorInvalidValue;
         const size_t lds_a = (size_t)P.R1 * P.CA * sizeof(float2);
-        auto ka = fft_tile_columns_kernel<FWD, Pro, SP>;
+        auto ka = fft_tile_columns_kernel<FWD, Pro, SP, GEN>;
         {  // tiles never exceed kTileElems
             const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(ka), (int)(kTileElems * sizeof(float2)));
             if (e != hipSuccess) return e;
@@ -743,7 +964,7 @@ hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2*
                            pro, scratch);
     }
     const size_t lds_b = (size_t)P.S * (P.CB | 1u) * sizeof(float2);
-    auto kb = fft_tile_blocks_kernel<FWD, Pro, Epi, SP>;
+    auto kb = fft_tile_blocks_kernel<FWD, Pro, Epi, SP, GEN>;
     {  // pitch CB|1 adds at most one lane of padding per row
         const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kb), (int)(2 * kTileElems * sizeof(float2)));
         if (e != hipSuccess) return e;
@@ -801,13 +1022,14 @@ hipError_t dispatch_dir(bool forward, const TiledPlan& P, const FftLayout& L, co
 }  // namespace
 
 // Per-pass twiddle table for the tiled kernels: pass p occupies (ip-1)*ido entries laid out
-// [c-1][i] with value W[c * l1 * i] (i = 0 is present but never read).  Entry count / filler.
+// [c-1][i] with value W[c * l1 * i] (i = 0 is present but never read); a generic-radix pass is followed by its
+// wal[0..ip-1] = W[m * n/ip] (pass_table_entries).  Entry count / filler.
 uint64_t fft_pass_twiddle_count(uint64_t n) {
     uint32_t fact[64];
     const int nf = fft_plan_factors(n, fact);
     uint64_t total = 0, l1 = 1;
     for (int q = 0; q < nf; ++q) {
-        total += (uint64_t)(fact[q] - 1) * (n / (l1 * fact[q]));
+        total += pass_table_entries(fact[q], n / (l1 * fact[q]));
         l1 *= fact[q];
     }
     return total;
@@ -825,6 +1047,11 @@ void fft_pass_twiddle_fill(uint64_t n, const float* w_interleaved, float* out_in
                 out_interleaved[2 * dst + 1] = w_interleaved[2 * src + 1];
             }
         off += (ip - 1) * ido;
+        if (is_generic_radix((uint32_t)ip))
+            for (uint64_t m = 0; m < ip; ++m, ++off) {
+                out_interleaved[2 * off] = w_interleaved[2 * (m * (n / ip))];
+                out_interleaved[2 * off + 1] = w_interleaved[2 * (m * (n / ip)) + 1];
+            }
         l1 *= ip;
     }
 }

@@ -153,6 +153,7 @@ _sig("jst_comm_calls", C.c_uint64, _h)
 _sig("jst_comm_uses_rccl", C.c_int, _h)
 _sig("jst_comm_allreduce", R, _h, _h, C.c_int, C.c_int, C.c_void_p)
 _sig("jst_fft_twiddles", R, C.c_uint64, C.POINTER(C.c_float))
+_sig("jst_probe_fft_path", C.c_int, C.c_uint64)
 _sig("jst_probe_tanhf", R, C.c_void_p, C.c_void_p, C.c_uint64)
 _sig("jst_probe_exact_sweep", R, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint64),
      C.POINTER(C.c_uint64), C.POINTER(C.c_uint32))
@@ -191,6 +192,14 @@ def fft_twiddles(n: int) -> np.ndarray:
     out = np.empty(n, dtype=np.complex64)
     _check(_lib.jst_fft_twiddles(n, out.ctypes.data_as(C.POINTER(C.c_float))))
     return out
+
+
+FFT_PATHS = ("register", "tile", "tile_pair", "passes")
+
+
+def fft_path(n: int) -> str:
+    """Kernel family a complex transform of (pass) length n runs on: JST_FFT_PATH_* of include/jetstream_hip.h."""
+    return FFT_PATHS[_lib.jst_probe_fft_path(n)]
 
 
 class Tensor:

@@ -330,6 +330,14 @@ jst_result jst_comm_allreduce(jst_comm c, jst_tensor t, int op, int average, voi
 /* ---- test/bench probes -------------------------------------------------------------------- */
 /* Host twiddle generator used for the FFT tables: W[k] = exp(+j 2 pi k/n), interleaved. */
 jst_result jst_fft_twiddles(uint64_t n, float* interleaved_out);
+/* Which kernel family a complex transform of length n (the pass length: Bluestein sizes resolved by the caller) runs on:
+ * JST_FFT_PATH_REGISTER (fft_lds.hh, one workgroup per transform in registers + LDS), _TILE (fft_tiled.hip, one kernel),
+ * _TILE_PAIR (fft_tiled.hip, columns + blocks kernels), _PASSES (fft_global.hip, one launch per pass through HBM). */
+#define JST_FFT_PATH_REGISTER 0
+#define JST_FFT_PATH_TILE 1
+#define JST_FFT_PATH_TILE_PAIR 2
+#define JST_FFT_PATH_PASSES 3
+int jst_probe_fft_path(uint64_t n);
 /* The Soapy-shaped producer loop in native code: `count` elements of the source's sample format pushed as consecutive
  * jst_ring_push calls of at most `chunk` elements (soapy/module_impl.cc:375-399).  bench.py: host_fed.push_8192. */
 jst_result jst_probe_ring_push_chunks(jst_module source, const void* samples, uint64_t count, uint64_t chunk);

@@ -142,6 +142,34 @@ def test_every_pocketfft_plan_bit_exact(js, oracle, n):
         assert_bit_equal(out["signal"], oracle.fft_c2c(x, forward), f"n={n} fwd={forward}")
 
 
+@pytest.mark.parametrize("n,path", [(8050, "tile"), (805, "tile"), (1016, "tile"), (2 * 61 * 61, "tile"),   # 23 | 23 | 127 | 61, 61
+                                    (13 * 4096, "tile_pair"), (23 * 4096, "tile_pair"), (31 * 31 * 32, "tile_pair"),
+                                    (2 * 127 * 127, "tile_pair"), (131 * 8, "passes")])
+def test_generic_radix_runs_on_lds_tiles(js, oracle, n, path):
+    """passg (pocketfft.hh:1314-1421) inside the tiled kernels (fft_tiled.hip: tile_pass_generic) for every prime
+    13..127: one kernel up to 8192 points, columns + blocks kernels beyond -- the generic pass lands in either of the
+    two -- and only a larger prime falls back to one launch per pass.  Bit for bit pocketfft in both directions."""
+    assert js.fft_path(n) == path
+    rng = np.random.default_rng(n)
+    x = csignal(rng, (5, n))
+    for forward in (True, False):
+        _, out = run_module(js, "fft", {"forward": forward}, {"signal": js.Tensor.from_numpy(x, sample=1, batch=0)})
+        assert_bit_equal(out["signal"], oracle.fft_c2c(x, forward), f"n={n} fwd={forward}")
+
+
+def test_generic_radix_tile_with_many_and_strided_transforms(js, oracle):
+    """More transforms than one workgroup's lanes (several transforms per tile, ragged last tile) and a transform axis
+    that is not the innermost one."""
+    rng = np.random.default_rng(77)
+    n = 13 * 16                                              # 208 points: up to 32 transforms per tile
+    x = csignal(rng, (2500, n))
+    _, out = run_module(js, "fft", {}, {"signal": js.Tensor.from_numpy(x, sample=1, batch=0)})
+    assert_bit_equal(out["signal"], oracle.fft_c2c(x))
+    lead = csignal(rng, (17 * 6, 37))                        # transform along axis 0, n = 102 = 2*3*17
+    _, out = run_module(js, "fft", {}, {"signal": js.Tensor.from_numpy(lead, sample=0, batch=1)})
+    assert_bit_equal(out["signal"], np.ascontiguousarray(oracle.fft_c2c(np.ascontiguousarray(lead.T)).T))
+
+
 def test_bluestein_strided_and_special_values(js, oracle):
     rng = np.random.default_rng(5)
     n = 422                                                # 2 * 211 -> Bluestein, n2 = 847 = 7*11*11 (odd)

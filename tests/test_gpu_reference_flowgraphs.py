@@ -64,6 +64,10 @@ def test_multi_fm_example(js, oracle):
     fg.feed("soapy", x)
     rt = fg.runtime(graph=True, fuse=True)
     plan = fg.nodes["flt"].impl.plan
+    # convolution length 8050 = 2*5*5*7*23: the generic radix 23 runs inside the LDS-tiled kernel, so the Filter keeps
+    # its fused Pad -> FFT -> Multiply -> Fold unit (and the 805-point inverse its fused unpad)
+    assert plan["convolutionSize"] == 8050 and js.fft_path(8050) == "tile" and js.fft_path(805) == "tile"
+    assert any(u.startswith("fft_padded_fold(") for u in rt.units), rt.units
     state, lane = {}, oracle.FmLane("narrow", "none", 200e3)
     wide = oracle.spectrum_chain(x, -81.0, 1.0)["range"]
     avg = np.zeros(s, np.float32)
