@@ -529,7 +529,12 @@ class Runtime:
     """One device segment: ordered modules on one HIP stream, optionally as a hipGraph."""
 
     def __init__(self, modules: Iterable[Module], graph: bool = False, fuse: bool = False,
-                 timing: bool = False, pipeline: bool = False, combine: bool = False, batch: bool = False):
+                 timing: bool = False, pipeline: bool = False, combine: bool = False, batch: Optional[bool] = None):
+        # batch=None: cycle batching whenever it can apply (graph + fuse, no per-unit timing; the planner keeps any chain
+        # that is not a resident ring -> spectrum unit -> span-capable readers per cycle, Runtime.batched tells).  What is
+        # visible after compute() is bit-identical either way; pass batch=False for one launch per unit and cycle.
+        if batch is None:
+            batch = bool(graph and fuse and not timing)
         self.modules = list(modules)
         flags = (RUNTIME_GRAPH if graph else 0) | (RUNTIME_FUSE if fuse else 0) | \
                 (RUNTIME_TIMING if timing else 0) | (RUNTIME_PIPELINE if pipeline else 0) | \

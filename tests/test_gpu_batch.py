@@ -109,8 +109,14 @@ def test_planner_stays_per_cycle_when_a_unit_cannot_batch(js, oracle):
     assert_bit_equal(spec.state("frequencyBins").numpy().reshape(-1), bins)
     assert_bit_equal(eng.buffer.numpy(), refs[6 % slots])
     rt.destroy()
-    # no flag: per cycle
+    # batch=False: per cycle; no flag: graph + fuse batch whenever the chain allows it
+    eng, spec, rt = _ring_chain(js, xs, h, batch=False)
+    assert not rt.batched
+    rt.destroy()
     eng, spec, rt = _ring_chain(js, xs, h)
+    assert rt.batched
+    rt.destroy()
+    eng, spec, rt = _ring_chain(js, xs, 512)
     assert not rt.batched
 
 

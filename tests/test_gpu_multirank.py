@@ -86,6 +86,8 @@ def test_bench_single_gpu_line_carries_the_other_configs():
         assert rec["parity"]["checked"] and rec["parity"]["bit_exact"], rec
         assert 0.0 < rec["roofline"]["frac"] < 1.0
     assert cfgs[0]["ms_per_cycle"] > 0 and cfgs[1]["x_realtime"] > 1 and cfgs[2]["us_per_cycle"] > 0
-    assert cfgs[2]["cycle_batched"]["batched"] is True
+    # config 5 runs on a resident ring with the runtime's defaults: cycle-batched; the launch-per-cycle form rides along
+    assert cfgs[2]["cycle_batched"] is True and cfgs[2]["launch_per_cycle"]["bit_exact"]
+    assert cfgs[2]["us_per_cycle"] < cfgs[2]["launch_per_cycle"]["us_per_cycle"]
     assert line["value_generic_per_cycle"]["value"] > 0
     assert "frac_rocprof" in line["roofline"] and "rocprofv3_kernel_us" in line["roofline"]

@@ -105,5 +105,42 @@ int main() {
     hipMemcpy(t.data(), tl, t.size() * 8, hipMemcpyDeviceToHost);
     printf("blocks kernel: %.2f us by events, %u threads, %zu B LDS\n", ms * 1e3, threads_for((uint64_t)P.S * P.CB), lds_b);
     report("blocks", t, gridB, (int)(P.nf - P.g));
+    // the same blocks kernel with the Filter's Multiply -> Fold epilogue (fold 16000, one head), constant plan 8
+    {
+        const uint64_t F = 16000;
+        TiledPlan PF = P;
+        if (!plan_fold_groups(PF, F)) { printf("no fold groups\n"); return 1; }
+        float2 *hf, *folded;
+        hipMalloc(&hf, n * 8); hipMalloc(&folded, B * F * 8);
+        hipMemcpy(hf, h.data(), n * 8, hipMemcpyHostToDevice);
+        FoldProductEpi fe{folded, hf, 1, (uint32_t)F, (uint32_t)(n / F), 0u, nullptr, 1u, 1u, true, 0, 0, 0, 0, 1u, 0};
+        fe.dq = (uint32_t)(F / PF.R1);
+        fe.dk = (uint32_t)(F % PF.R1);
+        fe.nq = PF.n / PF.R1;
+        fe.grp_step = PF.grp_stride ? fe.dk / PF.grp_stride : 0;
+        printf("fold plan: grp_w %u grp_stride %u CB %u dq %u dk %u grp_step %u\n", PF.grp_w, PF.grp_stride, PF.CB, fe.dq, fe.dk, fe.grp_step);
+        auto kf = fft_tile_blocks_kernel<true, LoadCF32Padded, FoldProductEpi, 8>;
+        hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileElems * 8));
+        const bool is_static = same_plan(PF, static_plan(8));
+        printf("constant plan 8 %s the run-time plan\n", is_static ? "equals" : "DIFFERS FROM");
+        const unsigned gridF = (unsigned)(B * ((PF.R1 + PF.CB - 1) / PF.CB));
+        for (int rep = 0; rep < 3; ++rep) {
+            hipMemset(tl, 0, (size_t)gmax * 16 * 8);
+            hipEventRecord(e0);
+            kf<<<gridF, threads_for((uint64_t)PF.S * PF.CB), (size_t)PF.S * (PF.CB | 1u) * 8>>>(L, PF, Wp, pro, fe, scratch);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+        }
+        hipEventElapsedTime(&ms, e0, e1);
+        hipMemcpy(t.data(), tl, t.size() * 8, hipMemcpyDeviceToHost);
+        printf("blocks kernel + fold epilogue: %.2f us by events\n", ms * 1e3);
+        const int np = (int)(PF.nf - PF.g);
+        double acc[16] = {0};
+        for (unsigned b = 0; b < gridF; ++b) for (int q = 0; q < 16; ++q) acc[q] += (double)(t[(size_t)b * 16 + q] - t[(size_t)b * 16]) * 0.01 / gridF;
+        printf("   mean us since workgroup start: loaded %.2f | last pass %.2f | products in place %.2f | walk %.2f | end %.2f\n",
+               acc[1], acc[1 + np], acc[8], acc[9], acc[15]);
+        unsigned long long w0 = ~0ull, w1 = 0;
+        for (unsigned b = 0; b < gridF; ++b) { w0 = std::min(w0, t[(size_t)b * 16]); w1 = std::max(w1, t[(size_t)b * 16 + 15]); }
+        printf("   %u workgroups, device span %.2f us\n", gridF, (w1 - w0) * 0.01);
+    }
     return 0;
 }
