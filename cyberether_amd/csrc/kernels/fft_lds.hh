@@ -548,12 +548,16 @@ __device__ __forceinline__ void run_passes(float2* lds, const float2* __restrict
 //     4096-pt transform instead of 6;
 //   * 2 x 36 KiB LDS, <=128 VGPR -> 2 workgroups = 16 waves per CU.
 // Same arithmetic, same order as the slot kernel above (bit-identical results).
-// Timeline instrumentation for tools/ubench/fft_timeline.hip only (never defined in the product).
+// Timeline instrumentation for tools/ubench/fft_timeline_batched.hip only (never defined in the product).  The stamps
+// of the last three transforms of a workgroup collect in LDS and reach memory in one piece when the workgroup ends: a
+// global store per stamp sits in the one vmcnt in front of the kernel's own waits and stretched a transform from 5.4
+// to 7.2 us.
 #ifdef JST_FFT_TIMELINE
 __device__ unsigned long long* jst_tl_base;
+__shared__ unsigned long long jst_tl_lds[64];
 #define JST_STAMP(slot)                                                                   \
     do {                                                                                  \
-        if (threadIdx.x == 0) jst_tl_base[blockIdx.x * 64 + tl_it * 16 + (slot)] = clock64(); \
+        if (threadIdx.x == 0) jst_tl_lds[(tl_it % 3) * 16 + (slot)] = clock64();          \
     } while (0)
 #define JST_TL_ARG , int tl_it
 #define JST_TL_PASS , tl_it
@@ -900,7 +904,7 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
     bool flip = false;
 #ifdef JST_FFT_TIMELINE
     int tl_it = 0;
-    if (threadIdx.x == 0) jst_tl_base[blockIdx.x * 64 + 62] = wall_clock64();
+    if (threadIdx.x == 0) jst_tl_lds[62] = wall_clock64();
 #endif
     while (true) {
         JST_STAMP(0);  // iteration start
@@ -943,13 +947,17 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
                                                         more, r_out, r_opnd_next, r_side, young JST_TL_PASS);
 #ifdef JST_FFT_TIMELINE
         ++tl_it;
-        if (threadIdx.x == 0) jst_tl_base[blockIdx.x * 64 + 63] = wall_clock64();
+        if (threadIdx.x == 0) jst_tl_lds[63] = wall_clock64();
 #endif
         if (!more) break;
         if constexpr (NEX & 1) flip = !flip;  // next transform starts on the buffer written longest ago
         t = tn;
         out_base = nout;
     }
+#ifdef JST_FFT_TIMELINE
+    if (threadIdx.x == 0)
+        for (int q = 0; q < 64; ++q) jst_tl_base[blockIdx.x * 64 + q] = jst_tl_lds[q];
+#endif
 }
 
 template <int N, bool FWD, bool CONTIG, class Pro, class Epi>
