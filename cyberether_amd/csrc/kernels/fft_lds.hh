@@ -686,6 +686,15 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
     // the epilogue is a long barrier-free VALU stream.  With both co-resident workgroups at equal
     // priority the epilogue of one delays the passes of the other; passes at priority 3 and the
     // epilogue at 0 gave 30.8 -> 28.9 us (exact) and 21.0 -> 20.1 us (fast) per 1024 x 4096 launch.
+// Epilogue priority leapfrog (see the last pass below): switch point in outputs (0 = off) and the lift.  Same-box A/B per
+// 16384-transform launch (profiles/r04_experiments/n_epilogue_leapfrog.log): off 171.9 / 169.8 us, 4 outputs + 1: 168.4 /
+// 165.9, 4 outputs + 2: 166.7 / 165.7, every 2 outputs or every output: no gain.
+#ifndef JST_EPI_LEAPFROG
+#define JST_EPI_LEAPFROG 4
+#endif
+#ifndef JST_EPI_LIFT
+#define JST_EPI_LIFT 2
+#endif
 #ifndef JST_PRIO_PA
 #define JST_PRIO_PA 3
 #define JST_PRIO_PB 3
@@ -738,6 +747,23 @@ __device__ __forceinline__ void pipe_passes(float2 (&x)[8], float2* buf0, float2
         if constexpr (LAST) {
 #pragma unroll
             for (int c = 0; c < IP; ++c) {
+#if JST_EPI_LEAPFROG
+                // The two wavefronts of a workgroup that share a SIMD (w and w + 4 of eight) take turns at the higher
+                // priority through the barrier-free epilogue (every JST_EPI_LEAPFROG outputs): the arbiter's oldest-first
+                // rule otherwise lets the older one run ahead for the whole stretch and the next barrier waits for the
+                // younger.
+                if (c % JST_EPI_LEAPFROG == 0) {
+                    const bool upper = (tid >> 8) & 1;  // wavefronts 4..7 of the 512-thread workgroup
+                    const bool lift = ((c / JST_EPI_LEAPFROG) & 1) ? !upper : upper;
+                    if (young) {
+                        if (lift) __builtin_amdgcn_s_setprio(JST_PRIO_EB + JST_EPI_LIFT);
+                        else __builtin_amdgcn_s_setprio(JST_PRIO_EB);
+                    } else {
+                        if (lift) __builtin_amdgcn_s_setprio(JST_PRIO_EA + JST_EPI_LIFT);
+                        else __builtin_amdgcn_s_setprio(JST_PRIO_EA);
+                    }
+                }
+#endif
                 if constexpr (CONTIG && epi_has_side<Epi>())
                     epi.template store_buf_side<kSideGroupInBase<N, T>>(r_out, r_side, (uint32_t)u * Epi::kElemBytes,
                                        (uint32_t)(c * BUT) * Epi::kElemBytes, y[c]);
