@@ -1,13 +1,13 @@
 #!/bin/bash
-# round 4, call n (second run: the first compared the base library with itself, the variant had not built): same-box A/B of the fused kernel with the epilogue priority leapfrog (-DJST_EPI_LEAPFROG=1)
+# round 4, call o: same-box A/B on top of the leapfrog default (base = 4 outputs, lift 2): lift 3; pass 0 at a low / middle priority
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-O=$ROOT/gpurun_out/r04n
+O=$ROOT/gpurun_out/r04o
 mkdir -p $O
 cd $ROOT
 LIB=cyberether_amd/lib/libjetstream_hip.so
 cp $LIB /tmp/base.so
 for round in 1 2; do
-  for v in base lf4 lf2 lf1 lf4x2; do
+  for v in base lift3 p0low p0mid; do
     if [ $v = base ]; then cp /tmp/base.so $LIB; else cp cyberether_amd/lib/variants/$v.so $LIB; fi
     python bench.py --no-cpu-baseline --no-host-fed --no-configs 2>/dev/null | python -c "
 import sys,json
