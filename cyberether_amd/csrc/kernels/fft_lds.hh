@@ -555,9 +555,14 @@ __device__ __forceinline__ void run_passes(float2* lds, const float2* __restrict
 #ifdef JST_FFT_TIMELINE
 __device__ unsigned long long* jst_tl_base;
 __shared__ unsigned long long jst_tl_lds[64];
+__shared__ unsigned long long jst_tl_wave[8 * 16];  // per wavefront, transform JST_TL_WAVE_IT of the workgroup
+#ifndef JST_TL_WAVE_IT
+#define JST_TL_WAVE_IT 30
+#endif
 #define JST_STAMP(slot)                                                                   \
     do {                                                                                  \
         if (threadIdx.x == 0) jst_tl_lds[(tl_it % 3) * 16 + (slot)] = clock64();          \
+        if ((threadIdx.x & 63) == 0 && tl_it == JST_TL_WAVE_IT) jst_tl_wave[(threadIdx.x >> 6) * 16 + (slot)] = clock64(); \
     } while (0)
 #define JST_TL_ARG , int tl_it
 #define JST_TL_PASS , tl_it
@@ -981,8 +986,10 @@ __device__ __forceinline__ void fft_pipe_body(const FftLayout& L, const float2* 
         out_base = nout;
     }
 #ifdef JST_FFT_TIMELINE
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         for (int q = 0; q < 64; ++q) jst_tl_base[blockIdx.x * 64 + q] = jst_tl_lds[q];
+        for (int q = 0; q < 128; ++q) jst_tl_base[(size_t)gridDim.x * 64 + (size_t)blockIdx.x * 128 + q] = jst_tl_wave[q];
+    }
 #endif
 }
 

@@ -16,7 +16,7 @@ int main() {
     const uint64_t B = 16384, batches = 1024, H = 256;
     float2 *in, *win, *W; float* out; uint8_t* side; unsigned long long* tl;
     hipMalloc(&in, B * N * 8); hipMalloc(&win, N * 8); hipMalloc(&W, N * 8); hipMalloc(&out, B * N * 4); hipMalloc(&side, B * N);
-    hipMalloc(&tl, 512 * 64 * 8); hipMemset(tl, 0, 512 * 64 * 8);
+    hipMalloc(&tl, 512 * (64 + 128) * 8); hipMemset(tl, 0, 512 * (64 + 128) * 8);
     std::vector<float2> h(N);
     for (int i = 0; i < N; ++i) h[i] = make_float2(cosf(6.283185307f * i / N), sinf(6.283185307f * i / N));
     hipMemcpy(W, h.data(), N * 8, hipMemcpyHostToDevice);
@@ -84,6 +84,48 @@ int main() {
         double a = 0;
         for (int b = 0; b < 512; ++b) a += (double)(t[b * 64 + 0 * 16 + 0] - t[b * 64 + 2 * 16 + 8]);
         printf("gap end of transform 30 -> start of 31: %.0f ticks\n", a / 512);
+    }
+    {   // per wavefront, transform 31 of 32 (tl_it == 30): arrival at each stamp relative to the workgroup's EARLIEST wavefront at
+        // that stamp, mean over the workgroups; and which wavefront is last at barrier 0 (slot 2 = pass 0 done)
+        std::vector<unsigned long long> tw(512 * 128);
+        hipMemcpy(tw.data(), tl + 512 * 64, tw.size() * 8, hipMemcpyDeviceToHost);
+        const int slots[] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+        printf("per wavefront (transform 31 of 32): mean lag in ticks behind the workgroup's first wavefront at each stamp\n");
+        printf("  stamp:            ");
+        for (int s : slots) printf(" %9s", (const char*[]){"it start", "in ready", "p0 done", "bar0", "p1 done", "bar1", "p2 done", "bar2", "epi done"}[s]);
+        printf("\n");
+        int last_hist[8] = {0};
+        for (int w = 0; w < 8; ++w) {
+            printf("  wavefront %d:      ", w);
+            for (int s : slots) {
+                double a = 0;
+                for (int b = 0; b < 512; ++b) {
+                    unsigned long long mn = ~0ull;
+                    for (int v = 0; v < 8; ++v) mn = std::min(mn, tw[(size_t)b * 128 + v * 16 + s]);
+                    a += (double)(tw[(size_t)b * 128 + w * 16 + s] - mn);
+                }
+                printf(" %9.0f", a / 512);
+            }
+            printf("\n");
+        }
+        for (int b = 0; b < 512; ++b) {
+            int lw = 0;
+            for (int v = 1; v < 8; ++v) if (tw[(size_t)b * 128 + v * 16 + 2] > tw[(size_t)b * 128 + lw * 16 + 2]) lw = v;
+            ++last_hist[lw];
+        }
+        printf("  last wavefront at barrier 0, count over 512 workgroups:");
+        for (int w = 0; w < 8; ++w) printf(" w%d=%d", w, last_hist[w]);
+        printf("\n");
+        // spread of arrivals at barrier 0 and at the end of the epilogue
+        for (int s : {8, 0, 1, 2}) {
+            double a = 0;
+            for (int b = 0; b < 512; ++b) {
+                unsigned long long mn = ~0ull, mx = 0;
+                for (int v = 0; v < 8; ++v) { mn = std::min(mn, tw[(size_t)b * 128 + v * 16 + s]); mx = std::max(mx, tw[(size_t)b * 128 + v * 16 + s]); }
+                a += (double)(mx - mn);
+            }
+            printf("  spread (last - first wavefront) at stamp %d: %.0f ticks\n", s, a / 512);
+        }
     }
     return 0;
 }
