@@ -380,8 +380,7 @@ def main() -> None:
             torch.cuda.synchronize()
             barrier()
             t0 = time.perf_counter()
-            rt.compute(args.steps, sync=False)
-            rt.synchronize()
+            rt.compute(args.steps, sync=True)   # submit + hipStreamSynchronize of the runtime's stream in one call
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             barrier()
