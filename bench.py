@@ -4,15 +4,16 @@
 Workload (BASELINE.json configs[1]): Window -> 4096-pt FFT -> Amplitude -> Range -> Spectrogram on
 1024 batches of cf32 IQ per compute cycle, the whole cycle captured in a hipGraph.  One "step" =
 one compute cycle over one batch tensor CF32[1024, 4096] that is ALREADY RESIDENT IN HBM: a ring
-of `--slots` distinct batches (default 16 x 32 MiB = 512 MiB, larger than the 256 MiB Infinity
+of `--slots` distinct batches (default 32 x 32 MiB = 1 GiB, four times the 256 MiB Infinity
 Cache, so every step's input really comes from HBM).
 
-Cycle batching (default; `--no-batch` and `alt_per_cycle_launch` are the other form): the runtime captures a ring period of 16
-cycles into its graph anyway, and with all 16 slots resident it submits them as ONE launch per unit -- the persistent fused
-kernel over 16 x 1024 transforms, the Spectrogram over the 16 index tensors with its state in registers -- instead of 16
-launches each (JST_RUNTIME_BATCH).  Every step is still one pass over one CF32[1024, 4096] batch: its
+Cycle batching (default; `--no-batch` and `alt_per_cycle_launch` are the other form): the runtime captures a ring period of R
+(= slots) cycles into its graph anyway, and with all R slots resident it submits them as ONE launch per unit -- the persistent
+fused kernel over R x 1024 transforms, the Spectrogram over the R index tensors with its state in registers -- instead of R
+launches each (JST_RUNTIME_BATCH; R = 32 since round 4: same-box 12.78 -> 12.36 us per step against
+R = 16, profiles/r04_experiments/s_ring_period_and_value_store_policy.log).  Every step is still one pass over one CF32[1024, 4096] batch: its
 range output lands in its slot of the output ring, the Spectrogram state takes that cycle's decay and hit update, and the
-parity leg checks both per cycle; what changes is that the kernel's ramp, cold start and tail are paid once per 16 steps.
+parity leg checks both per cycle; what changes is that the kernel's ramp, cold start and tail are paid once per R steps.
 `roofline` prices the launch that is timed: cycles_per_launch x 50.33 MB over its event-pair duration.
 
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
@@ -264,7 +265,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=320)
     ap.add_argument("--warmup", type=int, default=48)
-    ap.add_argument("--slots", type=int, default=16)
+    ap.add_argument("--slots", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-fuse", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -278,7 +279,7 @@ def main() -> None:
     ap.add_argument("--no-batch", action="store_true",
                     help="one launch per unit and CYCLE (the round-2 form) instead of cycle batching (JST_RUNTIME_BATCH: the "
                          "cycles of a captured ring period run as one launch per unit -- the persistent fused kernel over all "
-                         "16 resident slots, the Spectrogram over their 16 index tensors); the per-cycle form is measured and "
+                         "resident slots, the Spectrogram over their index tensors); the per-cycle form is measured and "
                          "reported beside the headline either way (alt_per_cycle_launch)")
     ap.add_argument("--pipeline", action="store_true",
                     help="run the spectrogram as its own graph on a second stream, one ring period behind "
@@ -642,7 +643,7 @@ def main() -> None:
                                              "absolute of the reference CPU path (north_star: 1e-5)" if args.provider == "fast"
                                              else "every output bit-identical to the reference CPU path"),
                        "pipelined": args.pipeline, "combined": args.combine,
-                       # cycle batching (JST_RUNTIME_BATCH): the 16 resident ring slots of a period run as ONE launch per
+                       # cycle batching (JST_RUNTIME_BATCH): the resident ring slots of a period run as ONE launch per
                        # unit; every step is still one pass over one CF32[1024, 4096] batch (its output in its ring slot,
                        # its own decay + hit update of the Spectrogram state); alt_per_cycle_launch is the other form
                        "cycle_batching": bool(rt.batched), "cycles_per_launch": cycles_per_launch,

@@ -12,6 +12,18 @@
 #ifndef JST_LOAD_AUX
 #define JST_LOAD_AUX 2
 #endif
+// Round 4: the F32 VALUE stores are `sc1 nt` (written through at agent scope AND streaming), the one-byte index stores stay
+// `sc1`: nobody in this chain comes back for the values (the Spectrogram reads the indices), and without `nt` the 16 MiB of
+// values per cycle push the 4 MiB of indices out of the Infinity Cache before the span Spectrogram reads them.  Same box,
+// bench.py (tools/ubench/run_r04s.sh): ring period 16: step 12.94 -> 12.78 us; ring period 32 (one launch = 32 cycles):
+// 12.92 -> 12.36 us, fused kernel 161.8 -> 165.9 us per 16 cycles but the span Spectrogram no longer reads cold indices
+// (`nt` alone: 12.81 / 12.51 us).
+#ifndef JST_STORE_AUX
+#define JST_STORE_AUX 18
+#endif
+#ifndef JST_SIDE_STORE_AUX
+#define JST_SIDE_STORE_AUX 16
+#endif
 // The window operand stays RESIDENT in 16 VGPRs instead of being re-requested from L2 behind every retired output
 // (fft_lds.hh: JST_OPND_RESIDENT).  Per 1024-transform launch that was a wash (the launch is bound by its ramp and tail,
 // DESIGN.md section 4); in the steady state of a cycle-batched launch it is not: 188.6 -> 178.0 us per 16384 transforms

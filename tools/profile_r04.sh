@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 evidence run (via gpurun, ONE box): the default bench line (parity stamp, alt_per_cycle_launch,
 # alt_provider, host_fed, cpu_baseline), the --steps 20 and --provider generic lines, rocprofv3 kernel stats and the separate
-# PMC passes for both providers, the HBM-traffic file with its provenance (cycles_per_launch = 16), the default line again
+# PMC passes for both providers, the HBM-traffic file with its provenance (cycles_per_launch = 32: the ring period of the default line), the default line again
 # quoting that traffic.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 O=$ROOT/gpurun_out/prof_r04
@@ -26,8 +26,8 @@ for v in fast generic; do
 done
 cd $ROOT
 rm -f $O/pmc_traffic.json
-python tools/pmc_summary.py $O/generic --traffic-json $O/pmc_traffic.json --provider generic --cycles 16 > $O/pmc_traffic.log 2>&1
-python tools/pmc_summary.py $O/fast --traffic-json $O/pmc_traffic.json --provider fast --cycles 16 >> $O/pmc_traffic.log 2>&1
+python tools/pmc_summary.py $O/generic --traffic-json $O/pmc_traffic.json --provider generic --cycles 32 > $O/pmc_traffic.log 2>&1
+python tools/pmc_summary.py $O/fast --traffic-json $O/pmc_traffic.json --provider fast --cycles 32 >> $O/pmc_traffic.log 2>&1
 cp $O/pmc_traffic.json $ROOT/profiles/pmc_traffic.json   # so that the default line below quotes this run's own counters
 python bench.py --no-cpu-baseline --no-alt --no-parity > $O/bench_default_with_traffic.json 2>> $O/bench_default.err
 # the other BASELINE configs (each with its roofline object) and rocprofv3 kernel stats of configs 3 and 5 and of multi-fm.yml
