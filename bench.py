@@ -265,7 +265,9 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=320)
     ap.add_argument("--warmup", type=int, default=48)
-    ap.add_argument("--slots", type=int, default=32)
+    ap.add_argument("--slots", type=int, default=0,
+                    help="ring slots = cycles of a ring period (0 = 32, or 16 when --steps is shorter than 32: a timed region "
+                         "holds at least one whole period, which is what the kernel's event pair brackets)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-fuse", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -298,6 +300,8 @@ def main() -> None:
     ap.add_argument("--min-time", type=float, default=0.25,
                     help="repeat the K-step timed region until this many seconds have been timed (0: once)")
     args = ap.parse_args()
+    if args.slots <= 0:
+        args.slots = 32 if args.steps >= 32 else 16
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`
@@ -606,7 +610,9 @@ def main() -> None:
         if os.path.exists(pmc):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             from kernel_hash import kernel_sources_sha256
-            rec = json.load(open(pmc)).get(args.provider, {})
+            doc = json.load(open(pmc))
+            # one record per (provider, launch form): "<provider>@<cycles per launch>", the bare provider key = the default form
+            rec = doc.get(f"{args.provider}@{int(round(cycles_per_launch))}", doc.get(args.provider, {}))
             if rec.get("kernel_sources_sha256") == kernel_sources_sha256() and \
                     int(rec.get("cycles_per_launch", 1)) == int(round(cycles_per_launch)):
                 traffic = rec.get("spectrum_fused_hbm_bytes_per_launch")

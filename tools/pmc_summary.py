@@ -83,7 +83,10 @@ if traffic_json:
             doc = {}
         if "spectrum_fused_hbm_bytes_per_launch" in doc:  # the one-provider layout of earlier rounds
             doc = {}
-    doc[provider] = rec
+    # one record per (provider, launch form); the bare provider key keeps the form with the most cycles per launch
+    doc[f"{provider}@{cycles}"] = rec
+    if provider not in doc or int(doc[provider].get("cycles_per_launch", 1)) <= cycles:
+        doc[provider] = rec
     with open(traffic_json, "w") as f:
         json.dump(doc, f, indent=1)
     print("wrote", traffic_json, provider, rec["spectrum_fused_hbm_bytes_per_launch"], "bytes per launch")

@@ -24,12 +24,21 @@ for v in fast generic; do
   cp $(ls $O/$v/trace/*/*kernel_stats.csv | head -1) $O/rocprofv3_kernel_stats_$v.csv
   grep -E '^\{' $O/$v/trace.log | tail -1 > $O/bench_under_rocprofv3_$v.json   # the line the profiled run itself printed
 done
+# the launch form of a run that is shorter than 32 steps (the driver's --steps 20): ring period 16, provider fast
+B16="python $ROOT/bench.py --slots 16 --no-cpu-baseline --no-alt --no-parity --no-configs --no-host-fed --min-time 0.05"
+mkdir -p $O/fast16
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fast16/trace -- $B16 > $O/fast16/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/fast16/pmc_fetch -- $B16 > $O/fast16/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/fast16/pmc_write -- $B16 > $O/fast16/pmc_write.log 2>&1
+python $ROOT/tools/kstats.py $O/fast16/trace > $O/kernel_stats_fast_period16.txt 2>&1
 cd $ROOT
 rm -f $O/pmc_traffic.json
+python tools/pmc_summary.py $O/fast16 --traffic-json $O/pmc_traffic.json --provider fast --cycles 16 > $O/pmc_traffic16.log 2>&1
 python tools/pmc_summary.py $O/generic --traffic-json $O/pmc_traffic.json --provider generic --cycles 32 > $O/pmc_traffic.log 2>&1
 python tools/pmc_summary.py $O/fast --traffic-json $O/pmc_traffic.json --provider fast --cycles 32 >> $O/pmc_traffic.log 2>&1
 cp $O/pmc_traffic.json $ROOT/profiles/pmc_traffic.json   # so that the default line below quotes this run's own counters
 python bench.py --no-cpu-baseline --no-alt --no-parity > $O/bench_default_with_traffic.json 2>> $O/bench_default.err
+python bench.py --steps 20 --warmup 5 > $O/bench_driver_form.json 2>> $O/bench_default.err   # the driver's invocation, quoting fast@16
 # the other BASELINE configs (each with its roofline object) and rocprofv3 kernel stats of configs 3 and 5 and of multi-fm.yml
 python tools/bench_configs.py > $O/bench_configs.jsonl 2> $O/bench_configs.err
 python tools/bench_multi_fm.py 400 > $O/multi_fm.json 2>> $O/bench_configs.err
@@ -46,7 +55,7 @@ head -n 4 $O/kernel_stats_generic.txt $O/kernel_stats_fast.txt
 cat $O/pmc_traffic.log; tail -c 400 $O/bench_default.err
 python - <<'PY'
 import json
-for f in ('bench_default','bench_steps20','bench_generic','bench_per_cycle','bench_default_with_traffic'):
+for f in ('bench_default','bench_steps20','bench_generic','bench_per_cycle','bench_default_with_traffic','bench_driver_form'):
     try:
         d=json.loads(open(f'gpurun_out/prof_r04/{f}.json').read().strip().splitlines()[-1])
         print(f, round(d['value']), 'MS/s', round(d['ms_per_step']*1e3,2),'us/step kernel', round(d['roofline']['kernel_ms']*1e3,2), 'cycles/launch', d['roofline']['cycles_per_launch'], 'frac', round(d['roofline']['frac'],4), 'step_frac', round(d['roofline']['step_frac'],4), 'parity', d['parity'].get('bit_exact'), 'traffic', d['roofline']['traffic'], d['config']['provider'])
