@@ -794,6 +794,18 @@ Result Runtime::abortCapture(Result r) {
 
 Result Runtime::launchSpan(U64 n, bool timing) {
     const U64 phase = cycles_ % period_;
+    // A cycle-batched span is one launch per unit: two or three kernels.  JST_RUNTIME_EAGER_SPANS=1 (A/B switch) submits
+    // them directly instead of replaying a graph of them.
+    static const bool eager_spans = getenv("JST_RUNTIME_EAGER_SPANS") != nullptr;
+    if (eager_spans && batched_) {
+        JST_CHECK(submitBatched(n, false));
+        for (auto& u : units_) {
+            if (u.is_static && u.settled) continue;
+            for (Module* m : u.modules) m->timing.cycles += n;
+        }
+        cycles_ += n;
+        return Result::SUCCESS;
+    }
     auto key = std::make_pair(phase, n);
     auto it = span_graphs_.find(key);
     if (it == span_graphs_.end()) {
