@@ -70,6 +70,22 @@ constexpr uint64_t pass_table_entries(uint64_t ip, uint64_t ido) { return (ip - 
 
 // Pad fused into the first load (core/pad/module_impl_native_cpu.cc:75-140): positions at or beyond
 // `valid` along the transform axis read as zero, everything else comes from the unpadded tensor.
+// A load of data that is read ONCE (the transform's input, the scratch image behind the columns kernel): `nt`, so that it does
+// not displace what comes back -- config 3 moves 128 MB of input and 128 MB of scratch through a 256 MB Infinity Cache.
+// JST_TILED_STREAM_LOADS=0: A/B switch (plain loads).
+#ifndef JST_TILED_STREAM_LOADS
+#define JST_TILED_STREAM_LOADS 1
+#endif
+__device__ __forceinline__ float2 stream_load(const float2* p) {
+#if JST_TILED_STREAM_LOADS
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p));
+    return mk(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+
 struct LoadCF32Padded {
     const float2* in;
     uint32_t valid;
@@ -78,7 +94,7 @@ struct LoadCF32Padded {
         // branch-free: a conditional load is a branch, and hipcc drains vmcnt at every such branch when eight of them
         // are unrolled back to back (one HBM round trip per element); load a clamped position, select afterwards
         const uint32_t p = (uint32_t)pos < valid ? (uint32_t)pos : (valid ? valid - 1u : 0u);
-        const float2 v = in[base + (int64_t)p * axis_stride];
+        const float2 v = stream_load(in + (base + (int64_t)p * axis_stride));
         return (uint32_t)pos < valid ? v : mk(0.0f, 0.0f);
     }
 };
@@ -741,7 +757,7 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
                 const uint32_t idx = i0 + (uint32_t)k * blockDim.x;
                 const uint32_t cidx = idx < tile ? idx : tile - 1u;
                 const uint32_t kb = cidx / P.S, x = cidx - kb * P.S;
-                if constexpr (decltype(from_scratch)::value) v[k] = blk[cidx + (kb >> P.grp_shift) * grp_gap * P.S];
+                if constexpr (decltype(from_scratch)::value) v[k] = stream_load(blk + (cidx + (kb >> P.grp_shift) * grp_gap * P.S));
                 else v[k] = pro.template load<false>(lane_in[kb], L.in_axis_stride, (int)x);
                 slot[k] = idx < tile ? x * pitch + kb : 0xffffffffu;
             }
