@@ -36,3 +36,25 @@ def test_traffic_takes_the_full_launches(tmp_path):
     expect = (2.0 * sum(fetch[3:]) / 40 + full_write) * 1024.0
     assert abs(rec["spectrum_fused_hbm_bytes_per_launch"] - expect) <= 1.0
     assert len(rec["kernel_sources_sha256"]) == 64
+
+
+def test_one_record_per_launch_form(tmp_path):
+    """A second pass with another launch form (cycles per launch) lands beside the first: "<provider>@<cycles>"; the bare
+    provider key keeps the form with the most cycles per launch (bench.py looks the run's own form up first)."""
+    out = str(tmp_path / "traffic.json")
+    for cycles, scale in ((16, 1.0), (32, 2.0), (16, 1.0)):
+        root = tmp_path / f"form{cycles}"
+        _write(str(root / "pmc_fetch" / "x_counter_collection.csv"), "FETCH_SIZE", [262500.0 * scale] * 12)
+        _write(str(root / "pmc_write" / "x_counter_collection.csv"), "WRITE_SIZE", [327680.0 * scale] * 12)
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), str(root), "--traffic-json", out,
+                               "--provider", "fast", "--cycles", str(cycles)], stdout=subprocess.DEVNULL)
+    doc = json.load(open(out))
+    assert set(doc) == {"fast", "fast@16", "fast@32"}
+    assert doc["fast"]["cycles_per_launch"] == 32 and doc["fast@16"]["cycles_per_launch"] == 16
+    assert doc["fast@32"]["spectrum_fused_hbm_bytes_per_launch"] == 2 * doc["fast@16"]["spectrum_fused_hbm_bytes_per_launch"]
+
+
+def test_bench_picks_the_ring_period_from_the_run_length():
+    """bench.py: 32 ring slots, 16 when the run is shorter than 32 steps (a timed region holds a whole period)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "args.slots = 32 if args.steps >= 32 else 16" in src
