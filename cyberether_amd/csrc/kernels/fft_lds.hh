@@ -354,6 +354,15 @@ struct StoreAmplitudeRangeT {  // Amplitude -> Range fused (range/module_impl_na
             __asm__ volatile("" : "+v"(poly.k2), "+v"(poly.k0), "+v"(guard.t0), "+v"(guard.t1));
         }
     }
+    // the same with the second guard width left where it is (fft_quad.hh, at its VGPR limit: a second consumer height is the
+    // rare case, and without one the width is never read)
+    __device__ __forceinline__ void pin_constants_lean() {
+        if constexpr (FAST) {
+            guard.t0 = guard.h0 * 7.5e-7f;
+            guard.t1 = guard.h1 * 7.5e-7f;
+            __asm__ volatile("" : "+v"(poly.k2), "+v"(poly.k0), "+v"(guard.t0));
+        }
+    }
     __device__ __forceinline__ float value(float2 v) const {
         if constexpr (FAST) return amplitude_range_fast_guarded(v, coeff, scale, offset, guard, poly);
         else return amplitude_range_exact(v, coeff, scale, offset);
@@ -396,6 +405,13 @@ struct StoreAmplitudeRangeSideT : StoreAmplitudeRangeT<FAST> {
         const uint32_t t = (uint32_t)transform;
         const uint32_t cycle = t / side_batches, row = t - cycle * side_batches;
         const uint32_t group = IN_BASE ? (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 7) : 0u;
+        const uint32_t in_cycle = (group * side_pitch + row) * 128u;
+        return make_rsrc(side + (size_t)cycle * side_pitch * n + in_cycle, side_pitch * n - in_cycle);
+    }
+    // the same descriptor for an explicit (wave-uniform) column group: fft_quad.hh, two butterflies per thread
+    __device__ __forceinline__ rsrc_t side_rsrc_group(uint64_t transform, uint32_t n, uint32_t group) const {
+        const uint32_t t = (uint32_t)transform;
+        const uint32_t cycle = t / side_batches, row = t - cycle * side_batches;
         const uint32_t in_cycle = (group * side_pitch + row) * 128u;
         return make_rsrc(side + (size_t)cycle * side_pitch * n + in_cycle, side_pitch * n - in_cycle);
     }

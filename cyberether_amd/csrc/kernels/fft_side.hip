@@ -32,7 +32,7 @@
 #ifndef JST_OPND_RESIDENT
 #define JST_OPND_RESIDENT 1
 #endif
-#include "fft_lds.hh"
+#include "fft_quad.hh"
 #include "kernels.hh"
 
 #include <cstdlib>
@@ -70,15 +70,44 @@ hipError_t launch_side(const FftLayout& L, const float2* W, const Pro& pro, cons
     return hipGetLastError();
 }
 
+// Round 5: 4096 points, CF32 rows, provider fast with a real window -- fft_quad_kernel (fft_quad.hh): 256 threads per transform,
+// in-place exchange, rows by LDS-DMA, four workgroups per CU.  Same box, alternating launches of 16384 transforms
+// (tools/ubench/run_r05e.sh): 166-168 us against 180-183 for fft_pipe_kernel (0.92), every value and index byte identical.
+// JST_FFT_KERNEL=pipe keeps the pipelined kernel (A/B, tests run both).
+bool quad_selected() {  // read per call, like use_pipe_kernel (fft_kernels.hip): the tests switch kernels inside one process
+    const char* k = getenv("JST_FFT_KERNEL");
+    return !(k && (k[0] == 'p' || k[0] == 'w' || k[0] == 's'));
+}
+
+template <class Pro, class Epi>
+hipError_t launch_side_quad(const FftLayout& L, const float2* W, const Pro& pro, const Epi& epi, uint32_t* sched, hipStream_t stream) {
+    constexpr size_t lds = fft_quad_lds_bytes();
+    static_assert(lds <= 64 * 1024, "no opt-in needed for the dynamic LDS size");
+    if (L.transforms == 0) return hipSuccess;
+    const uint64_t resident = 4ull * (uint64_t)side_compute_units();
+    const uint64_t blocks = L.transforms < resident ? L.transforms : resident;
+    // Claimed rounds only for launches of eight rounds and more (a cycle-batched span): with fewer, the claims of a whole
+    // round arrive at the counters at once -- a 1024-transform launch took 32 us instead of 20 (i_hybrid_eight_counters.log).
+    // JST_QUAD_STATIC=1: the static round robin throughout (A/B).
+    const bool all_static = getenv("JST_QUAD_STATIC") != nullptr;
+    if (all_static || L.transforms < 8 * resident) sched = nullptr;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((fft_quad_kernel<true, Pro, Epi>), dim3((unsigned)blocks), dim3(kQuadT), lds, stream, L, W, pro, epi, sched);
+    return hipGetLastError();
+}
+
 template <class Pro>
 hipError_t side_with(uint64_t n, const FftLayout& L, const float2* W, const Pro& pro, float* out, float amp_coeff,
                      float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1, uint8_t* side,
-                     float side_height, uint32_t side_batches, uint32_t side_pitch, hipStream_t stream) {
+                     float side_height, uint32_t side_batches, uint32_t side_pitch, uint32_t* sched, hipStream_t stream) {
     // the fed Spectrogram's height first in the guard (the epilogue takes the row index from the guard's own product
     // value * h0), the other consumer height -- if any -- second
     const float other = guard_h0 != side_height ? guard_h0 : (guard_h1 != side_height ? guard_h1 : 0.0f);
     const StoreAmplitudeRangeSideT<true> ef{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{side_height, other}}, side, side_height, side_batches, side_pitch};
     const StoreAmplitudeRangeSideT<false> ee{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}}, side, side_height, side_batches, side_pitch};
+    if constexpr (Pro::kRawBytes == 8 && requires { Pro::kRealOperand; }) {
+        if (n == 4096 && fast && quad_selected()) return launch_side_quad(L, W, pro, ef, sched, stream);
+    }
     switch (n) {
 #define JST_SIDE_CASE(NN)                                                  \
     case NN:                                                               \
@@ -98,6 +127,7 @@ hipError_t side_with(uint64_t n, const FftLayout& L, const float2* W, const Pro&
 // Rows a 128-column group of the tile-major side tensor occupies: the batches plus two pad rows (256 bytes of skew per
 // group) that take the group stride off the powers of two.
 uint64_t spectrum_side_pitch(uint64_t batches) { return batches + 2; }
+uint64_t spectrum_sched_words() { return kQuadSchedWords; }
 
 bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stride, uint64_t height) {
     const char* k = getenv("JST_FFT_KERNEL");
@@ -116,7 +146,7 @@ hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const floa
                                       float scaler, const float2* window, float* out, float amp_coeff,
                                       float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1,
                                       uint8_t* side, uint64_t height, uint64_t side_batches, uint64_t side_pitch, bool real_window,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, uint32_t* sched) {
     // side_batches: the rows of ONE index tensor (a compute cycle's batches); L.transforms is a whole number of them
     if (!spectrum_side_supported(n, L, 1, height) || !side || side_batches == 0 || L.transforms % side_batches != 0 ||
         side_pitch < side_batches ||
@@ -135,9 +165,9 @@ hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const floa
     const bool real = real_window && fast;
 #define JST_SIDE_WITH(PRO)                                                                                             \
     (real ? side_with(n, L, W, RealOperand<decltype(PRO)>{PRO}, out, amp_coeff, range_scale, range_offset, fast, guard_h0, \
-                      guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, stream)                          \
+                      guard_h1, side, h, (uint32_t)side_batches, (uint32_t)side_pitch, sched, stream)                   \
           : side_with(n, L, W, PRO, out, amp_coeff, range_scale, range_offset, fast, guard_h0, guard_h1, side, h,       \
-                      (uint32_t)side_batches, (uint32_t)side_pitch, stream))
+                      (uint32_t)side_batches, (uint32_t)side_pitch, sched, stream))
     switch (in_format) {
         case 0:
             return JST_SIDE_WITH((LoadCF32TimesWindow{static_cast<const float2*>(in), window, 1}));

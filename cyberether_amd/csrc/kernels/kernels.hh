@@ -197,7 +197,11 @@ hipError_t launch_spectrum_fused_side(uint64_t n, const FftLayout& L, const floa
                                       float scaler, const float2* window, float* out, float amp_coeff,
                                       float range_scale, float range_offset, bool fast, float guard_h0, float guard_h1,
                                       uint8_t* side, uint64_t height, uint64_t side_batches, uint64_t side_pitch, bool real_window,
-                                      hipStream_t stream);
+                                      hipStream_t stream, uint32_t* sched = nullptr);
+// sched: spectrum_sched_words() zeroed U32 words of device memory that belong to the calling unit (launches that share them
+// must be ordered on one stream), or null.  With them the 4096-point kernel (fft_quad.hh) hands the last rounds of a long
+// launch out dynamically; it leaves the words zeroed behind every launch.
+uint64_t spectrum_sched_words();
 // guard_h0/h1 (fast + range only): heights of the Spectrogram modules that will quantise the output;
 // elements whose value * height lies within the fast path's error of a bin edge are computed with the
 // exact arithmetic instead, so the bins equal the exact provider's (dev::BinGuard, device_math.hh).

@@ -1674,7 +1674,9 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
             (!cast || sig.stride(1) == 1) &&
             ((only->rowIndices.valid() && only->rowIndices.shape() == Shape{kernels::spectrum_side_pitch(sig.shape(0)), n} &&
               only->rowIndices.ringSlots() == rng->output.ringSlots()) ||
-             only->rowIndices.create(DeviceType::HIP, DataType::U8, {kernels::spectrum_side_pitch(sig.shape(0)), n}) == Result::SUCCESS)) {
+             only->rowIndices.create(DeviceType::HIP, DataType::U8, {kernels::spectrum_side_pitch(sig.shape(0)), n}) == Result::SUCCESS) &&
+            (only->schedWords.valid() ||
+             only->schedWords.create(DeviceType::HIP, DataType::U32, {kernels::spectrum_sched_words()}) == Result::SUCCESS)) {
             fed = only;
             fed->indexFed = true;
             name += "+indices";
@@ -1775,7 +1777,8 @@ bool TryFuseSpectrum(const std::vector<Module*>& ordered, size_t at, std::string
                         static_cast<const float2*>(win.data()) + win.offset(), static_cast<float*>(out.ringSlotData(0)),
                         amp->scalingCoeff, rng->scalingCoeff, rng->offsetCoeff, fast, guard0, guard1,
                         static_cast<uint8_t*>(fed->rowIndices.ringSlotData(0)), fed->height, sig.shape(0),
-                        fed->rowIndices.shape(0), fast && know_window(stream), stream),
+                        fed->rowIndices.shape(0), fast && know_window(stream), stream,
+                        static_cast<uint32_t*>(fed->schedWords.data())),
                     "fused spectrum kernel (+ row indices, cycle-batched span)"));
                 const U64 slot = (first + cycles) % ring;
                 const U64 last = (slot + ring - 1) % ring;

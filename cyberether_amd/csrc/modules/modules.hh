@@ -236,6 +236,9 @@ class Spectrogram : public Module {
     // (kernels::launch_spectrogram_index).  Same state, bit for bit; a decision of the runtime's planner, reset by it.
     bool indexFed = false;
     Tensor rowIndices;
+    // Device words of the feeding unit's 4096-point kernel (kernels::spectrum_sched_words(): the counters its long launches
+    // hand their last rounds out from); owned here because this module is the unit's partner for the lifetime of the plan.
+    Tensor schedWords;
     // Cycle batching (Runtime::planBatch): rowIndices is then a ring of as many slots as the source has, and a span of n
     // cycles is ONE launch over n consecutive index tensors with the state tile in registers in between
     // (kernels::launch_spectrogram_index_span; cycle c of the span reads slot (first + c) mod R: one launch whatever the span).

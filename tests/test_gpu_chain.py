@@ -9,9 +9,10 @@ from util import assert_bit_equal, csignal
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["pipe", "slot"])
+@pytest.fixture(autouse=True, params=["pipe", "slot", "quad"])
 def fft_kernel_variant(request, monkeypatch):
-    """Every test here runs against both FFT kernel variants (pipelined / slot), same bits."""
+    """Every test here runs against the FFT kernel variants (pipelined / slot / quad: the round-5 4096-point side kernel,
+    the default when the variable is unset), same bits."""
     monkeypatch.setenv("JST_FFT_KERNEL", request.param)
     yield
 

@@ -8,8 +8,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = ("void jst::dev::fft_pipe_kernel<4096, true, true, jst::dev::LoadCF32TimesWindow, "
-          "jst::dev::StoreAmplitudeRangeSideT<true> >(jst::dev::FftLayout)")
+KERNEL = ("void jst::dev::fft_quad_kernel<true, jst::dev::RealOperand<jst::dev::LoadCF32TimesWindow>, "
+          "jst::dev::StoreAmplitudeRangeSideT<true> >(jst::dev::FftLayout, HIP_vector_type<float, 2u> const*, ...)")
 
 
 def _write(path, counter, values):

@@ -5,7 +5,7 @@ import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ("fft_lds.hh", "fft_kernels.hip", "fft_side.hip", "fft_radix.hh", "device_math.hh", "libm_float.hh",
+KERNEL_SOURCES = ("fft_lds.hh", "fft_quad.hh", "fft_kernels.hip", "fft_side.hip", "fft_radix.hh", "device_math.hh", "libm_float.hh",
                   "kernels.hh", "spectrogram_body.hh")
 
 

@@ -45,10 +45,12 @@ if traffic_json:
     cycles = int(sys.argv[7]) if len(sys.argv) > 7 and sys.argv[6] == "--cycles" else 1
     # StoreAmplitudeRangeT<..> or, with the Spectrogram's row indices as a side output, StoreAmplitudeRangeSideT<..>
     tag = "T<true>" if provider == "fast" else "T<false>"
-    # the fused 4096-point side kernel of either form (pipelined / one wavefront per transform)
-    pick = [k for k in acc if ("fft_pipe_kernel<4096" in k or "fft_wave4096_kernel" in k) and "LoadCF32TimesWindow" in k
+    # the fused 4096-point side kernel of any form (round 5: fft_quad_kernel; pipelined; one wavefront per transform)
+    forms = ("fft_quad_kernel<", "fft_pipe_kernel<4096", "fft_wave4096_kernel")
+    pick = [k for k in acc if any(f in k for f in forms) and "LoadCF32TimesWindow" in k
             and "StoreAmplitudeRange" in k and tag in k]
-    kname_tag = "fft_wave4096_kernel" if pick and "fft_wave4096_kernel" in pick[0] else "fft_pipe_kernel<4096"
+    pick.sort(key=lambda k: [f in k for f in forms].index(True))
+    kname_tag = next((f for f in forms if pick and f in pick[0]), forms[0])
     if not pick or "FETCH_SIZE" not in acc[pick[0]] or "WRITE_SIZE" not in acc[pick[0]]:
         sys.exit("no FETCH_SIZE / WRITE_SIZE pass for the fused spectrum kernel (" + provider + ") under " + root)
     k = pick[0]
