@@ -41,7 +41,8 @@ Rccl& rccl() {
             if (r.handle) break;
         }
         if (!r.handle) {
-            r.error = std::string("RCCL is not loadable (") + (dlerror() ? dlerror() : "librccl.so not found") + ")";
+            const char* why = dlerror();  // ONE call: dlerror() clears the message it returns, a second call answers NULL
+            r.error = std::string("RCCL is not loadable (") + (why ? why : "librccl.so not found") + ")";
             return;
         }
         const auto sym = [&](const char* s) { return dlsym(r.handle, s); };

@@ -1130,6 +1130,12 @@ class Lineplot : public Module {
         input = inputs_.at("signal");
         JST_CHECK(signalPoints.create(device(), DataType::F32, {numberOfElements, 2}));
         JST_CHECK(averagingBuffer.create(device(), DataType::F32, {numberOfElements}));
+        // the X coordinates of the points, once, with the reference's F32 expression
+        // (lineplot/module_impl_native_cpu.cc:64-69: i * 2.0f / (numberOfElements - 1) - 1.0f); Y starts at 0
+        std::vector<F32> xy(2 * numberOfElements, 0.0f);
+        for (U64 i = 0; i < numberOfElements; ++i) xy[2 * i] = i * 2.0f / (numberOfElements - 1) - 1.0f;
+        JST_CHECK(hip_result(hipMemcpy(ptr<float>(signalPoints), xy.data(), xy.size() * sizeof(F32), hipMemcpyHostToDevice),
+                             "lineplot X coordinates"));
         return Result::SUCCESS;
     }
     Result computeSubmit(hipStream_t s) override {

@@ -69,12 +69,22 @@ def library_comm():
     return _COMM
 
 
+def _order_against_producer(stream: int, when: str) -> None:
+    """Without an explicit stream the collective goes to the legacy null stream, which is NOT ordered against a runtime's
+    stream (created hipStreamNonBlocking): the producer of the reduced tensor must have finished before the collective and
+    the collective before the consumer's next cycle.  Pass the producing runtime's stream (Runtime.stream) to keep the
+    exchange asynchronous; stream=0 keeps the round-3 contract instead -- device-wide synchronisation on both sides."""
+    if stream == 0:
+        torch.cuda.synchronize()
+
+
 def merge_spectrogram_counts(counts_tensor, via_host: bool = False, stream: int = 0) -> None:
     """The exchange step of the exact multi-GPU spectrogram: sum the U32[H, N] hit counts a
     `spectrogram{merge=counts}` module wrote this cycle over all ranks, in place on the device -- jst_comm_allreduce (RCCL
     all-reduce of 4 MiB at H = 256, N = 4096) on `stream`; a `spectrogram_merge{batches = all ranks' batches}` module
     then applies them.  via_host: bounce through the host with torch.distributed (gloo dry runs where ranks share a
-    device or have none)."""
+    device or have none).  stream: the stream of the runtime that produced the counts (ordered there, asynchronous); 0 =
+    synchronise the device before and after (see _order_against_producer)."""
     if _world() == 1:
         return
     if via_host:
@@ -82,14 +92,18 @@ def merge_spectrogram_counts(counts_tensor, via_host: bool = False, stream: int 
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
         counts_tensor.copy_from(host.numpy().astype(np.uint32))
     else:
+        _order_against_producer(stream, "before")
         library_comm().all_reduce(counts_tensor, "sum", stream=stream)
+        _order_against_producer(stream, "after")
 
 
 def average_trace(trace_tensor, stream: int = 0) -> None:
     """BASELINE config 5's averaged spectrum: the F32[N] trace of every rank becomes the mean over ranks, in place on the
-    device (jst_comm_allreduce with average = 1), one collective per reporting interval."""
+    device (jst_comm_allreduce with average = 1), one collective per reporting interval.  stream: as merge_spectrogram_counts."""
     if _world() > 1:
+        _order_against_producer(stream, "before")
         library_comm().all_reduce(trace_tensor, "sum", average=True, stream=stream)
+        _order_against_producer(stream, "after")
 
 
 def max_over_ranks(seconds: float, device: str = "cpu") -> float:

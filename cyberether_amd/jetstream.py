@@ -885,11 +885,14 @@ class FilterEngine:
                 return None
         sr, bw, ctr = attr("sampleRate"), attr("bandwidth"), attr("center")
         if ctr is not None:
-            ctr = list(ctr) if isinstance(ctr, list) else [ctr]
-            if len(ctr) == 1 and multi and heads > 1:
-                ctr = ctr * heads     # scalar metadata expands across the filter channels (:333-341)
-            elif len(ctr) != heads:
-                raise JetstreamError(1, "[BLOCK_FILTER_ENGINE] Filter center metadata must match the filter channel extent.")
+            # a SCALAR F32 attribute expands across the filter channels (filter_engine/block_impl.cc:333-341); a vector -- of
+            # length 1 included -- must match the channel extent (:342-345)
+            if not isinstance(ctr, (list, tuple)):
+                ctr = [ctr] * heads
+            else:
+                ctr = list(ctr)
+                if len(ctr) != heads:
+                    raise JetstreamError(1, "[BLOCK_FILTER_ENGINE] Filter center metadata must match the filter channel extent.")
         if sr is None or bw is None or ctr is None:   # bypass: plain convolution
             plan = {"padSize": filter_size - 1, "convolutionSize": signal_size + filter_size - 1, "resample": False,
                     "resamplerOffsets": [], "resamplerSize": 0, "resampledSampleRate": 0.0}

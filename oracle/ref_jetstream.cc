@@ -31,6 +31,11 @@
 #include "jetstream/runtime.hh"
 #include "jetstream/runtime_context_native_cpu.hh"
 #include "jetstream/scheduler_context.hh"
+// the visualization modules' state tensors are protected members: read as the reference's own tests read them
+// (spectrogram/module_tests.cc:22-41, waterfall/module_tests.cc:24-47, lineplot/module_tests.cc:25-44)
+#include "domains/visualization/lineplot/module_impl.hh"
+#include "domains/visualization/spectrogram/module_impl.hh"
+#include "domains/visualization/waterfall/module_impl.hh"
 
 namespace Jetstream {
 
@@ -176,6 +181,17 @@ struct ModSession {
     }
 };
 
+struct SpectrogramAccess : Modules::SpectrogramImpl {
+    static auto bins() { return &SpectrogramAccess::frequencyBins; }
+};
+struct WaterfallAccess : Modules::WaterfallImpl {
+    static auto bins() { return &WaterfallAccess::frequencyBins; }
+    static auto ring() { return &WaterfallAccess::ringState; }
+};
+struct LineplotAccess : Modules::LineplotImpl {
+    static auto points() { return &LineplotAccess::signalPoints; }
+};
+
 struct FgSession {
     std::unique_ptr<Flowgraph> fg;
     ~FgSession() {
@@ -278,6 +294,36 @@ uint64_t ref_mod_output_attr(void* h, const char* port, const char* key, int kin
     if (kind == 2) { if (const auto* p = std::any_cast<std::vector<F32>>(&a)) { uint64_t n = p->size() < cap ? p->size() : cap; for (uint64_t i = 0; i < n; ++i) v[i] = (*p)[i]; return n; } }
     if (kind == 3) { if (const auto* p = std::any_cast<std::vector<U64>>(&a)) { uint64_t n = p->size() < cap ? p->size() : cap; for (uint64_t i = 0; i < n; ++i) v[i] = (double)(*p)[i]; return n; } }
     return 0;
+}
+// state of a visualization module: "frequencyBins" (spectrogram F32[width, height] as created -- row-major words
+// bins[x + idx * width] --, waterfall F32[height, width]) or "signalPoints" (lineplot F32[width, 2]); waterfall also
+// "writeIndex" through ref_mod_state_scalar
+int ref_mod_state(void* h, const char* name, Desc* out) {
+    auto* s = static_cast<ModSession*>(h);
+    if (!s->module) return 1;
+    const std::string n(name);
+    if (s->type == "spectrogram" && n == "frequencyBins") {
+        const auto* impl = s->module->getImpl<Modules::SpectrogramImpl>();
+        return impl ? fill_desc(impl->*SpectrogramAccess::bins(), out) : 1;
+    }
+    if (s->type == "waterfall" && n == "frequencyBins") {
+        const auto* impl = s->module->getImpl<Modules::WaterfallImpl>();
+        return impl ? fill_desc(impl->*WaterfallAccess::bins(), out) : 1;
+    }
+    if (s->type == "lineplot" && n == "signalPoints") {
+        const auto* impl = s->module->getImpl<Modules::LineplotImpl>();
+        return impl ? fill_desc(impl->*LineplotAccess::points(), out) : 1;
+    }
+    return 1;
+}
+int64_t ref_mod_state_scalar(void* h, const char* name) {
+    auto* s = static_cast<ModSession*>(h);
+    if (!s->module) return -1;
+    if (s->type == "waterfall" && std::string(name) == "writeIndex") {
+        const auto* impl = s->module->getImpl<Modules::WaterfallImpl>();
+        return impl ? (int64_t)(impl->*WaterfallAccess::ring()).writeIndex : -1;
+    }
+    return -1;
 }
 void ref_mod_free(void* h) { delete static_cast<ModSession*>(h); }
 

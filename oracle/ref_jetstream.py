@@ -192,6 +192,17 @@ class RefModule:
         r = self.start()
         return r if r != RESULT_SUCCESS else self.compute()
 
+    def state(self, name: str) -> np.ndarray:
+        """A visualization module's state tensor (spectrogram / waterfall "frequencyBins", lineplot "signalPoints"), read the
+        way the reference's own tests read it (a derived accessor for the protected member): numpy copy."""
+        d = _Desc()
+        assert self._l.ref_mod_state(self._h, name.encode(), C.byref(d)) == 0, f"no state {name}"
+        return np.array(_view(d))
+
+    def state_scalar(self, name: str) -> int:
+        self._l.ref_mod_state_scalar.restype = C.c_int64
+        return int(self._l.ref_mod_state_scalar(self._h, name.encode()))
+
 
 class RefFlowgraph:
     """A Flowgraph of the reference's BLOCKS (Flowgraph::blockCreate / compute, as tests/support/flowgraph_fixture.hh)."""

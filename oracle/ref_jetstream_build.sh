@@ -8,6 +8,10 @@
 # render / compositor / viewport / remote instance / YAML parser (rapidyaml is a network wrap) / python runtime /
 # non-CPU devices -- none of them is on the path; oracle/ref_jetstream.cc provides the three symbols the core still
 # asks for (PythonRuntimeFactory and two Platform helpers) and the extern "C" harness the tests drive.
+# Round 5: the visualization modules (spectrogram / waterfall / lineplot) are compiled in place too -- their COMPUTE halves
+# are on the path (a10, a11, f2).  Their translation units also hold the present halves: oracle/ref_shim
+# carries empty stand-ins for the shader tables the reference's build generates (resources/shaders/*_shaders.hh) and a
+# few glm types; oracle/ref_render_stubs.cc the Render:: symbols those halves reference (aborting if ever reached).
 #   usage: oracle/ref_jetstream_build.sh [-j N]   (REF=/root/reference by default)
 set -u
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -34,6 +38,7 @@ MODULES="core/add core/arithmetic core/cast core/duplicate core/expand_dims core
          core/slice core/squeeze_dims core/unpad
          dsp/agc dsp/am dsp/amplitude dsp/fft dsp/filter_taps dsp/fm dsp/fold dsp/invert dsp/overlap_add
          dsp/phase_correction dsp/signal_generator dsp/squelch dsp/window
+         visualization/spectrogram visualization/waterfall visualization/lineplot
 "
 BLOCKS="$MODULES dsp/filter dsp/filter_engine dsp/spectrum_engine dsp/decimator"
 
@@ -59,5 +64,6 @@ compile_one() {
 export -f compile_one; export OBJ REF CXXFLAGS
 xargs -a "$LIST" -P "$JOBS" -I{} bash -c 'compile_one {}' || { echo "libref_jetstream.so: some units failed"; exit 1; }
 g++ $CXXFLAGS -c "$HERE/ref_jetstream.cc" -o "$OBJ/harness.o" || exit 1
+g++ $CXXFLAGS -c "$HERE/ref_render_stubs.cc" -o "$OBJ/render_stubs.o" || exit 1
 OBJS=$(sed 's|/|_|g; s|\.cc$|.o|' "$LIST" | sed "s|^|$OBJ/|")
-g++ -shared -fPIC -o "$OUT/libref_jetstream.so" $OBJS "$OBJ/harness.o" -Wl,--no-undefined -lpthread && echo "built _ref/libref_jetstream.so from $REF"
+g++ -shared -fPIC -o "$OUT/libref_jetstream.so" $OBJS "$OBJ/harness.o" "$OBJ/render_stubs.o" -Wl,--no-undefined -lpthread ${EXTRA_LINK:-} && echo "built _ref/libref_jetstream.so from $REF"

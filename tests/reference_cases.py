@@ -143,6 +143,24 @@ def run_oracle(oracle, case):
             audio = lane(filt.reshape(-1))
             n = audio.shape[0] // p["ratio"]
             outs.append(oracle.arithmetic_add(np.ascontiguousarray(audio.reshape(1, n, p["ratio"], 2)), 2).reshape(1, n, 2))
+    elif kind == "spectrogram":
+        bins = np.zeros(case["ins"][0].shape[1] * p["height"], np.float32)
+        for x in case["ins"]:
+            oracle.spectrogram(bins, x, p["height"])
+            outs.append(bins.reshape(case["outs"][0].shape).copy())
+    elif kind == "waterfall":
+        bins, st = np.zeros((p["height"], case["ins"][0].shape[1]), np.float32), (0, 0)
+        for x in case["ins"]:
+            st = oracle.waterfall(bins, st, x, p["height"])
+            outs.append(bins.reshape(case["outs"][0].shape).copy())
+    elif kind == "lineplot":
+        width = case["ins"][0].shape[1] // p["decimation"]
+        trace = np.zeros(width, np.float32)
+        for c, x in enumerate(case["ins"]):
+            oracle.lineplot(trace, x, p["averaging"], p["decimation"])
+            pts = case["outs"][c].copy()     # x coordinates are the reference's (i * 2 / (width - 1) - 1): compare y only
+            pts.reshape(-1, 2)[:, 1] = trace
+            outs.append(pts)
     else:
         raise KeyError(kind)
     return outs
@@ -193,6 +211,18 @@ def run_hip(js, case, **rt_flags):
         dec = js.Decimator(fm.output("signal"), p["ratio"])
         mods, out_t = flt.modules + [sq, fm] + dec.modules, dec.buffer
         feed = lambda x: src.copy_from(x)
+    elif kind in ("spectrogram", "waterfall", "lineplot"):
+        src = js.Tensor.from_numpy(ins[0], sample=1, batch=0)
+        m = js.Module(kind, dict(p), {"signal": src}, kind)
+        rt = js.Runtime([m], **rt_flags)
+        for c, x in enumerate(ins):
+            if c:
+                src.copy_from(x)
+            rt.compute(1)
+            st = m.state("signalPoints" if kind == "lineplot" else "frequencyBins").numpy()
+            outs.append(st.reshape(case["outs"][c].shape))
+        rt.destroy()
+        return outs
     else:
         raise KeyError(kind)
     rt = js.Runtime(mods, **rt_flags)

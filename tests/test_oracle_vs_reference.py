@@ -358,3 +358,94 @@ def test_config4_chain_filter_fm_decimator_two_cycles():
             same(np.array(fg.tensor("fm", "signal")).reshape(-1, 2), audio)
             dec = oracle.arithmetic_add(np.ascontiguousarray(audio.reshape(1, 101, 4, 2)), 2)
             same(np.array(fg.tensor("dec", "buffer")), dec.reshape(1, 101, 2))
+
+
+# ------------------------------------------------------------- visualization modules' COMPUTE halves (a10, a11, f2)
+# Round 5: spectrogram / waterfall / lineplot are compiled in place too (oracle/ref_jetstream_build.sh; their present halves
+# are never created: no render window).  State tensors are read as the reference's own tests read them
+# (spectrogram/module_tests.cc:22-41, waterfall/module_tests.cc:24-47, lineplot/module_tests.cc:25-44).
+def _range_like(rng, b, n, lo=-0.1, hi=1.1):
+    """Values around [0, 1] incl. out-of-range, exact bin edges, +-0, and a NaN: what a Range output can hold."""
+    x = rng.uniform(lo, hi, (b, n)).astype(np.float32)
+    x[0, :8] = [0.0, -0.0, 1.0, 0.5, 1.0 / 256, 255.0 / 256, np.nextafter(np.float32(1.0), np.float32(0)), np.nan]
+    return x
+
+
+@pytest.mark.parametrize("b,n,h", [(1024, 4096, 256), (7, 100, 37), (300, 64, 2048)])
+def test_spectrogram_state_over_cycles(b, n, h):
+    """spectrogram/module_impl_native_cpu.cc:61-87 over three cycles of changing input (decay powf(0.999, B), index
+    (U64)(v * H), saturating +0.02): BASELINE config 2's shape first."""
+    rng = np.random.default_rng(41)
+    xs = [_range_like(rng, b, n) for _ in range(3)]
+    bins = np.zeros(n * h, np.float32)
+    with rj.RefModule("spectrogram", {"height": h}) as m:
+        m.input("signal", xs[0], sample=1, batch=0)
+        assert m.start() == 0
+        for k, x in enumerate(xs):
+            m.write("signal", x)
+            assert m.compute() == 0
+            oracle.spectrogram(bins, x, h)
+            same(m.state("frequencyBins").reshape(-1), bins)
+    assert bins.max() > 0.03  # hits accumulated over cycles
+
+
+def test_spectrogram_leading_sample_axis_and_rank1():
+    """The element axis first ([N, B], spectrogram/module_tests.cc:281-329's layouts) and an input without a batch axis."""
+    rng = np.random.default_rng(42)
+    x = _range_like(rng, 6, 50).T.copy()          # [N=50, B=6]: sampleAxis 0, batchAxis 1
+    h = 64
+    bins = np.zeros(50 * h, np.float32)
+    with rj.RefModule("spectrogram", {"height": h}) as m:
+        m.input("signal", x, sample=0, batch=1)
+        assert m.run() == 0
+        oracle.spectrogram(bins, x, h, batch_axis=1, elem_axis=0)
+        same(m.state("frequencyBins").reshape(-1), bins)
+    v = _range_like(rng, 1, 333)[0]
+    bins = np.zeros(333 * h, np.float32)
+    with rj.RefModule("spectrogram", {"height": h}) as m:
+        m.input("signal", v, sample=0)
+        assert m.run() == 0 and m.compute() == 0
+        oracle.spectrogram(bins, v, h)
+        oracle.spectrogram(bins, v, h)
+        same(m.state("frequencyBins").reshape(-1), bins)
+
+
+@pytest.mark.parametrize("b,n,h", [(3, 64, 8), (8, 32, 8), (13, 16, 5), (1024, 4096, 512)])
+def test_waterfall_ring_over_cycles(b, n, h):
+    """waterfall/module_impl_native_cpu.cc:53-78 + ring_state.hh:16-56: fewer batches than rows, as many, MORE (only the
+    newest `height` rows land), and config 2's batch on the default height -- four cycles each, the write index too."""
+    rng = np.random.default_rng(43)
+    bins = np.zeros((h, n), np.float32)
+    state = (0, 0)
+    with rj.RefModule("waterfall", {"height": h}) as m:
+        x0 = rng.standard_normal((b, n)).astype(np.float32)
+        m.input("signal", x0, sample=1, batch=0)
+        assert m.start() == 0
+        for k in range(4):
+            x = rng.standard_normal((b, n)).astype(np.float32)
+            m.write("signal", x)
+            assert m.compute() == 0
+            state = oracle.waterfall(bins, state, x, h)
+            same(m.state("frequencyBins").reshape(h, n), bins)
+            assert m.state_scalar("writeIndex") == state[0]
+
+
+@pytest.mark.parametrize("b,n,avg,dec", [(16, 65536, 1, 1), (5, 4096, 4, 1), (3, 1000, 2, 4), (1, 64, 8, 3)])
+def test_lineplot_trace_over_cycles(b, n, avg, dec):
+    """lineplot/module_impl_native_cpu.cc:80-118: left-to-right batch sum per bin, normalisation, fmin / fmax clamp, the moving
+    average's two divisions -- config 5's shape first, then averaging and decimation."""
+    rng = np.random.default_rng(44)
+    width = n // dec
+    trace = np.zeros(width, np.float32)
+    with rj.RefModule("lineplot", {"averaging": avg, "decimation": dec}) as m:
+        x0 = rng.uniform(-0.2, 1.2, (b, n)).astype(np.float32)
+        m.input("signal", x0, sample=1, batch=0)
+        assert m.start() == 0
+        for k in range(3):
+            x = rng.uniform(-0.2, 1.2, (b, n)).astype(np.float32)
+            m.write("signal", x)
+            assert m.compute() == 0
+            oracle.lineplot(trace, x, avg, dec)
+            pts = m.state("signalPoints").reshape(-1, 2)
+            assert pts.shape[0] == width
+            same(np.ascontiguousarray(pts[:, 1]), trace)

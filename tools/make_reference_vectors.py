@@ -230,5 +230,41 @@ with rj.RefFlowgraph() as fg:
 record("config4_chain", "c4", {"sampleRate": sr, "bandwidth": bw, "taps": taps, "ratio": 4}, xs, outs,
        "SURVEY section 8(d) C4 at 20400 samples per cycle: filter -> squeeze_dims -> fm(wide, 75us) -> decimator(4)")
 
+
+# ------------------------------------------------------------------------ visualization modules' compute halves (round 5)
+def run_visual(mtype, cfg, cycles, state):
+    outs = []
+    with rj.RefModule(mtype, cfg) as m:
+        v = m.input("signal", cycles[0], sample=1, batch=0)
+        assert m.start() == 0
+        for x in cycles:
+            v[...] = x
+            assert m.compute() == 0
+            outs.append(m.state(state))
+    return outs
+
+
+rng = np.random.default_rng(1237)
+b, n, h = 48, 512, 256
+xs = []
+for c in range(3):
+    x = rng.uniform(-0.1, 1.1, (b, n)).astype(F32)
+    x[0, :8] = [0.0, -0.0, 1.0, 0.5, 1.0 / 256, 255.0 / 256, np.nextafter(F32(1.0), F32(0)), np.nan]
+    xs.append(x)
+cfg = {"height": h}
+record("spectrogram_three_cycles", "spectrogram", cfg, xs, run_visual("spectrogram", cfg, xs, "frequencyBins"),
+       "src/domains/visualization/spectrogram/module_impl_native_cpu.cc:61-87: decay + saturating hits over three cycles, "
+       "out-of-range values, exact edges, NaN")
+b, n, h = 13, 64, 5   # more batches than rows: only the newest five land
+xs = [rng.standard_normal((b, n)).astype(F32) for _ in range(4)]
+cfg = {"height": h}
+record("waterfall_batches_exceed_height", "waterfall", cfg, xs, run_visual("waterfall", cfg, xs, "frequencyBins"),
+       "src/domains/visualization/waterfall/module_impl_native_cpu.cc:53-78 + ring_state.hh:16-56, B > H, four cycles")
+b, n = 5, 1000
+xs = [rng.uniform(-0.2, 1.2, (b, n)).astype(F32) for _ in range(3)]
+cfg = {"averaging": 2, "decimation": 4}
+record("lineplot_decimation_averaging", "lineplot", cfg, xs, run_visual("lineplot", cfg, xs, "signalPoints"),
+       "src/domains/visualization/lineplot/module_impl_native_cpu.cc:80-118, decimation 4, averaging 2, three cycles")
+
 np.savez_compressed(OUT, manifest=np.frombuffer(json.dumps(cases, sort_keys=True).encode(), np.uint8), **arrays)
 print(f"wrote {OUT}: {len(cases)} cases, {os.path.getsize(OUT) / 1024:.0f} KiB")
