@@ -1,0 +1,29 @@
+// integration/mi355x_provider/amplitude.cc -- REFERENCE-SIDE code: would live at src/domains/dsp/amplitude/module_impl_native_cpu_mi355x.cc
+// (INTEGRATION.md section 2).  The reference's own AmplitudeImpl (validate / define / create) with computeSubmit() forwarded to
+// libjetstream_hip.so through the host-staging bridge; registered under provider "mi355x".
+#include <jetstream/runtime_context_native_cpu.hh>
+#include <jetstream/scheduler_context.hh>
+#include <jetstream/module_context.hh>
+#include <jetstream/registry.hh>
+
+#include "module_impl.hh"
+#include "mi355x_bridge.hh"
+
+namespace Jetstream::Modules {
+
+struct AmplitudeImplMi355x : public AmplitudeImpl, public NativeCpuRuntimeContext, public Scheduler::Context {
+    Result create() override {
+        JST_CHECK(AmplitudeImpl::create());
+        return bridge.create("MODULE_AMPLITUDE_MI355X", "amplitude", name(), {}, {{"signal", &input}}, "signal");
+    }
+    Result computeSubmit() override { return bridge.run(output); }
+    Result destroy() override {
+        (void)bridge.destroy();
+        return AmplitudeImpl::destroy();
+    }
+    Mi355x::Bridge bridge;
+};
+
+JST_REGISTER_MODULE(AmplitudeImplMi355x, DeviceType::CPU, RuntimeType::NATIVE, "mi355x");
+
+}  // namespace Jetstream::Modules

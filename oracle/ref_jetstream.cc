@@ -170,6 +170,7 @@ int set_attr(Tensor& t, const char* key, int kind, const double* v, uint64_t n) 
 
 // ---- one module + one runtime, alive across computes (TestContext::start / compute / stop) --------------------
 struct ModSession {
+    std::string provider = "generic";  // the registry's 4th key (src/registry.cc:605-618): "mi355x" selects integration/mi355x_provider
     std::string type;
     Parser::Map config;
     std::unordered_map<std::string, Tensor> inputs;
@@ -253,7 +254,7 @@ int ref_mod_input_view(void* h, const char* port, int op, const uint64_t* v, uin
 int ref_mod_start(void* h) {
     auto* s = static_cast<ModSession*>(h);
     if (s->module || s->runtime) return (int)Result::ERROR;
-    Result r = Registry::BuildModule(s->type, DeviceType::CPU, RuntimeType::NATIVE, "generic", s->module);
+    Result r = Registry::BuildModule(s->type, DeviceType::CPU, RuntimeType::NATIVE, s->provider, s->module);
     if (r != Result::SUCCESS) return (int)r;
     TensorMap in;
     for (auto& [name, t] : s->inputs) {
@@ -266,6 +267,15 @@ int ref_mod_start(void* h) {
     r = s->runtime->create({{"test", s->module}});
     if (r != Result::SUCCESS) { (void)s->module->destroy(); s->module.reset(); s->runtime.reset(); }
     return (int)r;
+}
+int ref_mod_set_provider(void* h, const char* provider) {
+    static_cast<ModSession*>(h)->provider = provider;
+    return 0;
+}
+// 1 when the registry holds (type, CPU, NATIVE, provider)
+int ref_registry_has(const char* type, const char* provider) {
+    std::shared_ptr<Module> probe;
+    return Registry::BuildModule(type, DeviceType::CPU, RuntimeType::NATIVE, provider, probe) == Result::SUCCESS ? 1 : 0;
 }
 int ref_mod_compute(void* h) {
     auto* s = static_cast<ModSession*>(h);
@@ -349,6 +359,24 @@ int ref_fg_block(void* h, const char* name, const char* type, const char* config
         }
     }
     return (int)s->fg->blockCreate(name, std::string(type), parse_config(config_lines), in);
+}
+// the same with the registry's provider key: every module the block creates is built with it (src/block_impl.cc:46-53)
+int ref_fg_block_provider(void* h, const char* name, const char* type, const char* config_lines, const char* inputs_lines,
+                          const char* provider) {
+    auto* s = static_cast<FgSession*>(h);
+    TensorMap in;
+    if (inputs_lines) {
+        std::istringstream is(inputs_lines);
+        std::string line;
+        while (std::getline(is, line)) {
+            const auto eq = line.find('=');
+            const auto colon = line.find(':', eq == std::string::npos ? 0 : eq);
+            if (eq == std::string::npos || colon == std::string::npos) continue;
+            in[line.substr(0, eq)].requested(line.substr(eq + 1, colon - eq - 1), line.substr(colon + 1));
+        }
+    }
+    return (int)s->fg->blockCreate(name, std::string(type), parse_config(config_lines), in, DeviceType::CPU, RuntimeType::NATIVE,
+                                   std::string(provider));
 }
 // state of a block: Block::State value, or -1 when the block does not exist
 int ref_fg_block_state(void* h, const char* name) {

@@ -22,6 +22,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PATH = os.path.join(_HERE, "_ref", "libref_jetstream.so")
+# the same reference objects + integration/mi355x_provider, linked against cyberether_amd/lib/libjetstream_hip.so
+# (oracle/ref_jetstream_build.sh): select with use_hip_library() BEFORE the first call, one library per process
+_PATH_HIP = os.path.join(_HERE, "_ref", "libref_jetstream_hip.so")
 
 RESULT_SUCCESS = 0
 
@@ -53,10 +56,26 @@ def available() -> bool:
     return os.path.exists(_PATH)
 
 
+def hip_library_available() -> bool:
+    return os.path.exists(_PATH_HIP)
+
+
+def use_hip_library() -> None:
+    """The reference linked against the HIP library (provider "mi355x" registered): for tests/test_gpu_reference_drives_library.py."""
+    global _PATH
+    assert _lib is None or _PATH == _PATH_HIP, "the CPU-only reference library is already loaded in this process"
+    _PATH = _PATH_HIP
+
+
+def registry_has(mtype: str, provider: str) -> bool:
+    return bool(lib().ref_registry_has(mtype.encode(), provider.encode()))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()
+        if _PATH != _PATH_HIP:
+            build()
         _lib = C.CDLL(_PATH)
         assert _lib.ref_jst_desc_size() == C.sizeof(_Desc)
         for n in ("ref_mod_new", "ref_fg_new"):
@@ -110,9 +129,11 @@ ATTR_INDEX, ATTR_F32, ATTR_VEC_F32, ATTR_VEC_U64, ATTR_VEC_F64, ATTR_F64 = range
 class RefModule:
     """One module of the reference behind Registry::BuildModule / Module::create / Runtime::compute."""
 
-    def __init__(self, mtype: str, config: Optional[Dict] = None):
+    def __init__(self, mtype: str, config: Optional[Dict] = None, provider: str = "generic"):
         self._l = lib()
         self._h = C.c_void_p(self._l.ref_mod_new(mtype.encode(), _cfg(config)))
+        if provider != "generic":
+            self._l.ref_mod_set_provider(self._h, provider.encode())
         self._in: Dict[str, np.ndarray] = {}
         self._in_desc: Dict[str, _Desc] = {}
 
@@ -235,8 +256,11 @@ class RefFlowgraph:
                 self.set_attr(name, "signal", key, ATTR_INDEX, val)
         return v
 
-    def block(self, name: str, btype: str, config: Optional[Dict] = None, inputs: Optional[Dict[str, str]] = None) -> int:
+    def block(self, name: str, btype: str, config: Optional[Dict] = None, inputs: Optional[Dict[str, str]] = None,
+              provider: str = "generic") -> int:
         ins = "\n".join(f"{port}={src}" for port, src in (inputs or {}).items()).encode()
+        if provider != "generic":
+            return int(self._l.ref_fg_block_provider(self._h, name.encode(), btype.encode(), _cfg(config), ins, provider.encode()))
         return int(self._l.ref_fg_block(self._h, name.encode(), btype.encode(), _cfg(config), ins))
 
     def state(self, name: str) -> int:

@@ -67,3 +67,27 @@ g++ $CXXFLAGS -c "$HERE/ref_jetstream.cc" -o "$OBJ/harness.o" || exit 1
 g++ $CXXFLAGS -c "$HERE/ref_render_stubs.cc" -o "$OBJ/render_stubs.o" || exit 1
 OBJS=$(sed 's|/|_|g; s|\.cc$|.o|' "$LIST" | sed "s|^|$OBJ/|")
 g++ -shared -fPIC -o "$OUT/libref_jetstream.so" $OBJS "$OBJ/harness.o" "$OBJ/render_stubs.o" -Wl,--no-undefined -lpthread ${EXTRA_LINK:-} && echo "built _ref/libref_jetstream.so from $REF"
+
+# ---- the reference DRIVING the library (round 5) --------------------------------------------------------------------------
+# A second library, oracle/_ref/libref_jetstream_hip.so: the same reference objects plus the `provider: mi355x` modules of
+# integration/mi355x_provider/ (reference-side code: the reference's own Impl classes with computeSubmit() forwarded to
+# libjetstream_hip.so), linked against cyberether_amd/lib/libjetstream_hip.so.  The reference's registry, Module::create,
+# runtime, scheduler and the spectrum_engine BLOCK then run the HIP kernels (tests/test_gpu_reference_drives_library.py).
+# Kept apart from libref_jetstream.so so that the CPU checker above never depends on the product.
+REPO=$(cd "$HERE/.." && pwd)
+HIPLIB=$REPO/cyberether_amd/lib/libjetstream_hip.so
+if [ -f "$HIPLIB" ]; then
+  SHIM=$REPO/integration/mi355x_provider
+  SHIM_OBJS=""
+  for pair in fft:dsp/fft amplitude:dsp/amplitude range:core/range multiply:core/multiply invert:dsp/invert window:dsp/window \
+              reshape:core/reshape cast:core/cast spectrogram:visualization/spectrogram; do
+    f=${pair%%:*}; d=${pair##*:}
+    o=$OBJ/mi355x_$f.o
+    if [ ! -f "$o" ] || [ "$SHIM/$f.cc" -nt "$o" ] || [ "$SHIM/mi355x_bridge.hh" -nt "$o" ]; then
+      g++ $CXXFLAGS -I"$REF/src/domains/$d" -I"$SHIM" -I"$REPO/include" -c "$SHIM/$f.cc" -o "$o" || { echo "FAILED integration/mi355x_provider/$f.cc"; exit 1; }
+    fi
+    SHIM_OBJS="$SHIM_OBJS $o"
+  done
+  g++ -shared -fPIC -o "$OUT/libref_jetstream_hip.so" $OBJS "$OBJ/harness.o" "$OBJ/render_stubs.o" $SHIM_OBJS -L"$REPO/cyberether_amd/lib" -l:libjetstream_hip.so \
+      -Wl,--no-undefined -Wl,-rpath,'$ORIGIN/../../cyberether_amd/lib' -lpthread && echo "built _ref/libref_jetstream_hip.so (reference + mi355x provider -> libjetstream_hip.so)"
+fi
