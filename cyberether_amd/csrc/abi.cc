@@ -157,6 +157,10 @@ jst_result jst_tensor_wrap(void* ptr, size_t bytes, uint8_t device, uint8_t dtyp
     *out = h.release();
     return R(Result::SUCCESS);
 }
+jst_result jst_tensor_rebind(jst_tensor t, void* ptr, size_t bytes) {
+    JST_ARG(t && ptr, "null tensor or pointer");
+    return R(t->t.rebind(ptr, bytes));
+}
 jst_result jst_tensor_clone(jst_tensor t, jst_tensor* out) {
     JST_ARG(t && out, "null tensor");
     auto h = std::make_unique<jst_tensor_s>();

@@ -96,6 +96,29 @@ Buffer::~Buffer() {
     else if (device == DeviceType::CPU) (void)hipHostFree(ptr);
 }
 
+Result Tensor::rebind(void* ptr, size_t bytes) {
+    if (!buffer_ || !ptr) {
+        JST_ERROR("[MEMORY:TENSOR] Cannot rebind an unallocated tensor (or to a null pointer).");
+        return Result::ERROR;
+    }
+    if (buffer_->slots != 1) {
+        JST_ERROR("[MEMORY:TENSOR] Cannot rebind ring storage.");
+        return Result::ERROR;
+    }
+    if (bytes < buffer_->bytes) {
+        JST_ERROR("[MEMORY:TENSOR] External buffer of %llu bytes is smaller than the storage it replaces (%llu bytes).",
+                  (unsigned long long)bytes, (unsigned long long)buffer_->bytes);
+        return Result::ERROR;
+    }
+    if (buffer_->owned && buffer_->ptr) {
+        if (buffer_->device == DeviceType::HIP) (void)hipFree(buffer_->ptr);
+        else if (buffer_->device == DeviceType::CPU) (void)hipHostFree(buffer_->ptr);
+    }
+    buffer_->ptr = ptr;
+    buffer_->owned = false;
+    return Result::SUCCESS;
+}
+
 std::vector<U64> DenseStrides(const Shape& shape) {
     std::vector<U64> s(shape.size(), 1);
     for (size_t i = shape.size(); i-- > 1;) s[i - 1] = s[i] * shape[i];

@@ -58,6 +58,12 @@ class Tensor {
     Result wrap(void* ptr, size_t bytes, DeviceType device, DataType dtype, const Shape& shape,
                 const std::vector<U64>& stride = {}, U64 offset = 0);
 
+    // Move this tensor's STORAGE -- and with it every view of that storage -- onto external memory of at least the same
+    // size (no ownership; what was owned is freed, contents are dropped).  For a host framework that has already
+    // allocated the buffer a module is to write (the reference's Impl::create() allocates `output` before a device
+    // binding gets a say: integration/device_hip/fft_module_impl_native_hip.cc).  Single-slot storage only, and before
+    // the first compute (a captured graph holds addresses).
+    Result rebind(void* ptr, size_t bytes);
     bool valid() const { return static_cast<bool>(buffer_); }
     bool validShape() const { return !shape_.empty(); }
     DeviceType device() const { return buffer_ ? buffer_->device : DeviceType::None; }

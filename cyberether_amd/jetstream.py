@@ -90,6 +90,7 @@ _sig("jst_tensor_create", R, C.c_uint8, C.c_uint8, C.c_uint32, _u64p, _hp)
 _sig("jst_tensor_create_ring", R, C.c_uint8, C.c_uint8, C.c_uint32, _u64p, C.c_uint64, _hp)
 _sig("jst_tensor_wrap", R, C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint8, C.c_uint32, _u64p, _u64p,
      C.c_uint64, _hp)
+_sig("jst_tensor_rebind", R, _h, C.c_void_p, C.c_size_t)
 _sig("jst_tensor_clone", R, _h, _hp)
 _sig("jst_tensor_destroy", R, _h)
 _sig("jst_tensor_describe", R, _h, C.POINTER(_Desc))
@@ -251,6 +252,12 @@ class Tensor:
         out = C.c_void_p()
         _check(_lib.jst_tensor_clone(self._h, C.byref(out)))
         return Tensor(out.value)
+
+    def rebind(self, ptr: int, nbytes: int) -> "Tensor":
+        """jst_tensor_rebind: move this tensor's storage (and every view of it, e.g. a module's output) onto external
+        memory the caller owns -- a host framework that allocated the buffer itself."""
+        _check(_lib.jst_tensor_rebind(self._h, C.c_void_p(ptr), nbytes))
+        return self
 
     # -- introspection --------------------------------------------------------------------
     def _desc(self) -> _Desc:

@@ -142,6 +142,12 @@ jst_result jst_tensor_create_ring(uint8_t device, uint8_t dtype, uint32_t rank,
 jst_result jst_tensor_wrap(void* ptr, size_t bytes, uint8_t device, uint8_t dtype, uint32_t rank,
                            const uint64_t* shape, const uint64_t* stride, uint64_t offset,
                            jst_tensor* out);
+/* Move the STORAGE of t -- and every view of it, e.g. the output tensor a module handed out -- onto caller-owned memory
+ * of at least the same size (no ownership, contents dropped).  For a host framework that has already allocated the
+ * buffer a module is to write into: the reference's Impl::create() allocates `output` before a device binding gets a
+ * say (Tensor::create(device(), ..), e.g. fft/module_impl.cc:80-83; integration/device_hip/).  Single-slot storage,
+ * before the first compute. */
+jst_result jst_tensor_rebind(jst_tensor t, void* ptr, size_t bytes);
 jst_result jst_tensor_clone(jst_tensor t, jst_tensor* out); /* new view, shared storage */
 jst_result jst_tensor_destroy(jst_tensor t);
 jst_result jst_tensor_describe(jst_tensor t, jst_tensor_desc* out);
