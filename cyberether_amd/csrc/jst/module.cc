@@ -796,7 +796,8 @@ Result Runtime::launchSpan(U64 n, bool timing) {
     const U64 phase = cycles_ % period_;
     // A cycle-batched span is one launch per unit: two or three kernels.  JST_RUNTIME_EAGER_SPANS=1 (A/B switch) submits
     // them directly instead of replaying a graph of them.
-    static const bool eager_spans = getenv("JST_RUNTIME_EAGER_SPANS") != nullptr;
+    // (read per call: bench.py measures both forms in one process -- `alt_eager_spans`)
+    const bool eager_spans = getenv("JST_RUNTIME_EAGER_SPANS") != nullptr;
     if (eager_spans && batched_) {
         JST_CHECK(submitBatched(n, false));
         for (auto& u : units_) {

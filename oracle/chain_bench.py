@@ -52,6 +52,34 @@ def run(rows: int, epoch_s: float, epochs: int, use_ref: bool = True, seed: int 
             "epoch_rates_MSps": [round(r / 1e6, 2) for r in rates]}
 
 
+def run_reference_runtime(rows: int, epoch_s: float, epochs: int, spectrogram: bool = True, seed: int = 4321) -> dict:
+    """The SAME chain through the REFERENCE'S OWN RUNTIME: oracle/_ref/libref_jetstream.so is the reference's core, scheduler,
+    native-CPU runtime, modules and blocks compiled in place (oracle/ref_jetstream_build.sh).  A Flowgraph holds a source,
+    the `spectrum_engine` block (cast -> window -> invert -> reshape -> multiply -> fft -> amplitude -> range: its own
+    module_impl_native_cpu.cc files, AutomaticIterator and all) and the `spectrogram` block; Flowgraph::compute() is timed
+    nanobench-style in a C loop (src/benchmark.cc:100-106,175-186 shape).  Returns None when the library is absent."""
+    from oracle import ref_jetstream as rj
+    if not rj.available():
+        return None
+    rng = np.random.default_rng(seed)
+    n = np.arange(N_FFT, dtype=np.float64)
+    bins_ = (100.25 + np.arange(rows, dtype=np.float64)) % N_FFT
+    phase = 2.0 * np.pi * bins_[:, None] * n[None, :] / N_FFT
+    x = np.empty((rows, N_FFT), np.complex64)
+    x.real = np.cos(phase) + rng.standard_normal((rows, N_FFT)).astype(np.float32) * np.float32(1e-3)
+    x.imag = np.sin(phase) + rng.standard_normal((rows, N_FFT)).astype(np.float32) * np.float32(1e-3)
+    with rj.RefFlowgraph() as fg:
+        fg.source("src", x, sample=1, batch=0)
+        assert fg.block("eng", "spectrum_engine", {"enableScale": True, "rangeMin": -100.0, "rangeMax": 0.0},
+                        {"buffer": "src:signal"}) == 0 and fg.state("eng") == 2
+        if spectrogram:
+            assert fg.block("spec", "spectrogram", {"height": HEIGHT}, {"signal": "eng:buffer"}) == 0 and fg.state("spec") == 2
+        rates = fg.compute_timed(epoch_s, epochs)
+    per_s = sorted(rates)[len(rates) // 2] * rows * N_FFT
+    return {"samples_per_s": float(per_s), "kind": "reference-runtime", "rows": rows, "epochs": epochs, "epoch_s": epoch_s,
+            "spectrogram": spectrogram, "epoch_rates_MSps": [round(r * rows * N_FFT / 1e6, 2) for r in rates]}
+
+
 def run_configs0(epoch_s: float = 0.1, epochs: int = 11, use_ref: bool = True) -> dict:
     """BASELINE configs[0], like for like: ONE batch of 4096 cf32 (an off-bin CW tone) through
     FFT -> Amplitude, one op per compute(), nanobench-style (epochs >= 100 ms, median) as src/benchmark.cc:100-106,
@@ -84,5 +112,6 @@ if __name__ == "__main__":
     ap.add_argument("--epochs", type=int, default=5)
     ap.add_argument("--no-ref", action="store_true")
     ap.add_argument("--seed", type=int, default=4321)
+    ap.add_argument("--reference-runtime", action="store_true", help="time the chain through the compiled reference's own runtime")
     a = ap.parse_args()
     print(json.dumps(run(a.rows, a.epoch_s, a.epochs, not a.no_ref, a.seed)), flush=True)

@@ -8,6 +8,7 @@
 // counterpart of the reference's test-only flowgraph_test_source, with a dtype and a shape), and three symbols the
 // core references from subsystems that are not built (python runtime, YAML parser).
 #include <any>
+#include <chrono>
 #include <complex>
 #include <cstdint>
 #include <cstring>
@@ -431,6 +432,26 @@ uint64_t ref_fg_tensor_attr_get(void* h, const char* block, const char* port, co
     return 0;
 }
 int ref_fg_compute(void* h) { return (int)static_cast<FgSession*>(h)->fg->compute(); }
+// nanobench-style timing of Flowgraph::compute() (src/benchmark.cc:100-106,175-186: warm-up, epochs of a minimum duration,
+// the caller takes the median): rates[e] = computes per second of epoch e; returns the Result of the last compute
+int ref_fg_compute_timed(void* h, double epoch_s, uint32_t epochs, double* rates) {
+    auto* s = static_cast<FgSession*>(h);
+    Result r = s->fg->compute();
+    if (r != Result::SUCCESS) return (int)r;
+    for (uint32_t e = 0; e < epochs; ++e) {
+        const auto t0 = std::chrono::steady_clock::now();
+        uint64_t n = 0;
+        double dt = 0.0;
+        do {
+            r = s->fg->compute();
+            ++n;
+            dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        } while (r == Result::SUCCESS && dt < epoch_s);
+        if (r != Result::SUCCESS) return (int)r;
+        rates[e] = (double)n / dt;
+    }
+    return (int)r;
+}
 void ref_fg_free(void* h) { delete static_cast<FgSession*>(h); }
 
 }  // extern "C"

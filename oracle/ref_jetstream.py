@@ -290,6 +290,13 @@ class RefFlowgraph:
             return None
         return buf[:n].tolist() if kind in (ATTR_VEC_F32, ATTR_VEC_U64) else buf[0]
 
+    def compute_timed(self, epoch_s: float, epochs: int):
+        """Flowgraph::compute() in a C loop, nanobench-style: computes per second of every epoch."""
+        rates = (C.c_double * epochs)()
+        rc = int(self._l.ref_fg_compute_timed(self._h, C.c_double(epoch_s), C.c_uint32(epochs), rates))
+        assert rc == 0, f"Flowgraph::compute failed ({rc})"
+        return [float(r) for r in rates]
+
     def view(self, block: str, port: str, op: str, values: Sequence[int]):
         code = {"permute": 0, "reshape": 1, "expand_dims": 2}[op]
         v = (C.c_uint64 * max(len(values), 1))(*values)

@@ -91,3 +91,11 @@ def test_lean_fast_value_deviates_less_than_4e7_on_every_power(js, coeff, scale,
     dev = struct.unpack("<f", struct.pack("<I", dev_bits))[0]
     print(f"largest |lean - exact| = {dev:.3e} (coeff {coeff:.2f}, scale {scale:.4f})")
     assert 0.0 < dev <= 4.0e-7, dev
+
+
+def test_libm_pinned_on_this_box():
+    """The bit-exact float comparisons of this suite take their STRICT branch only where the host libm is the one the parity is
+    stated against (glibc 2.35 x86-64, tests/golden/libm_pin.json); elsewhere tests/util.py: assert_bit_equal falls back to
+    1e-5 of the peak with a warning.  This test FAILS on such a box, so that a green GPU run records which branch ran."""
+    from util import libm_pinned
+    assert libm_pinned(), "host libm differs from the pinned glibc 2.35: float parity was judged at 1e-5 of the peak, not bit for bit"
