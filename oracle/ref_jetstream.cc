@@ -25,6 +25,7 @@
 #include "jetstream/flowgraph.hh"
 #include "jetstream/flowgraph_view.hh"
 #include "jetstream/logger.hh"
+#include "jetstream/memory/token.hh"
 #include "jetstream/module.hh"
 #include "jetstream/module_context.hh"
 #include "jetstream/parser.hh"
@@ -237,7 +238,8 @@ int ref_mod_input_attr(void* h, const char* port, const char* key, int kind, con
     if (it == s->inputs.end()) return 1;
     return set_attr(it->second, key, kind, v, n);
 }
-// layout edits of an input before start(): op 0 permute(axes), 1 reshape(shape), 2 expandDims(axis), 3 broadcastTo(shape)
+// layout edits of an input before start(): op 0 permute(axes), 1 reshape(shape), 2 expandDims(axis), 3 broadcastTo(shape),
+// 4 slice(tokens): four numbers per axis {kind, a, b, c}: kind 0 = ':' (all), 1 = index a (the axis goes), 2 = a:b:c
 int ref_mod_input_view(void* h, const char* port, int op, const uint64_t* v, uint64_t n, Desc* out) {
     auto* s = static_cast<ModSession*>(h);
     const auto it = s->inputs.find(port);
@@ -248,6 +250,15 @@ int ref_mod_input_view(void* h, const char* port, int op, const uint64_t* v, uin
     else if (op == 1) r = it->second.reshape(sh);
     else if (op == 2) r = it->second.expandDims((Index)v[0]);
     else if (op == 3) r = it->second.broadcastTo(sh);
+    else if (op == 4 && n % 4 == 0) {
+        std::vector<Token> tokens;
+        for (uint64_t a = 0; a < n; a += 4) {
+            if (v[a] == 0) tokens.emplace_back();
+            else if (v[a] == 1) tokens.emplace_back((U64)v[a + 1]);
+            else tokens.emplace_back((U64)v[a + 1], (U64)v[a + 2], (U64)v[a + 3], true);
+        }
+        r = it->second.slice(tokens);
+    }
     if (r != Result::SUCCESS) return 1;
     return fill_desc(it->second, out);
 }

@@ -104,8 +104,19 @@ def _view(d: _Desc) -> np.ndarray:
     rank = int(d.rank)
     shape = [int(d.shape[a]) for a in range(rank)]
     stride = [int(d.stride[a]) for a in range(rank)]
+    ci = {c: t for t, c in _CI.values()}
     if code in _DTYPES:
         dt = np.dtype(_DTYPES[code])
+    elif code in ci:  # complex integer samples: an integer array whose last axis holds (re, im)
+        dt = np.dtype(ci[code])
+        shape, stride = shape + [2], [2 * st for st in stride] + [1]
+        d_off = 2 * int(d.offset)
+        extent = 1 + sum((s - 1) * st for s, st in zip(shape, stride)) if all(shape) else 0
+        if extent == 0:
+            return np.empty(shape, dt)
+        base = np.ctypeslib.as_array(C.cast(C.c_void_p(d.data + 0), C.POINTER(C.c_uint8)), ((d_off + extent) * dt.itemsize,))
+        flat = base.view(dt)[d_off:]
+        return np.lib.stride_tricks.as_strided(flat, shape=shape, strides=[st * dt.itemsize for st in stride])
     else:
         raise TypeError(f"dtype code {code}")
     extent = 1 + sum((s - 1) * st for s, st in zip(shape, stride)) if all(shape) else 0
@@ -164,6 +175,19 @@ class RefModule:
             self.input_attr(port, key, kind, val)
         return v
 
+    def input_ci(self, port: str, x: np.ndarray, dtype: str):
+        """A complex-integer input ("CI8", "CI16", "CU8", "CU16"): x is an integer array whose last axis holds (re, im)."""
+        x = np.ascontiguousarray(x, dtype=_CI[dtype][0])
+        assert x.shape[-1] == 2
+        shape = (C.c_uint64 * max(x.ndim - 1, 1))(*x.shape[:-1])
+        d = _Desc()
+        assert self._l.ref_mod_input(self._h, port.encode(), dtype.encode(), x.ndim - 1, shape, C.byref(d)) == 0
+        v = _view(d)
+        v[...] = x
+        self._in[port] = v
+        self._in_desc[port] = d
+        return v
+
     def input_attr(self, port: str, key: str, kind: int, value):
         arr, n = _attr_args(value)
         assert self._l.ref_mod_input_attr(self._h, port.encode(), key.encode(), kind,
@@ -171,7 +195,7 @@ class RefModule:
 
     def input_view(self, port: str, op: str, values: Sequence[int]):
         """permute / reshape / expand_dims / broadcast of an input before start() (Tensor::permute etc.)."""
-        code = {"permute": 0, "reshape": 1, "expand_dims": 2, "broadcast": 3}[op]
+        code = {"permute": 0, "reshape": 1, "expand_dims": 2, "broadcast": 3, "slice": 4}[op]
         v = (C.c_uint64 * max(len(values), 1))(*values)
         d = _Desc()
         assert self._l.ref_mod_input_view(self._h, port.encode(), code, v, C.c_uint64(len(values)), C.byref(d)) == 0
