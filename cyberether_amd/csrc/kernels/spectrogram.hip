@@ -130,8 +130,19 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_kernel(float* __re
     const uint32_t rot = tid & 15u;  // this lane's first column
     // LDS byte address of (row i, column c) in this lane group's copy: base + 64 i + 4 c.  Index 0 (no hit) is NOT
     // predicated away: it counts into row 0, which no sample can hit (0 < index) and which the update below skips.
+    // JST_SPAN_INTERLEAVED (two copies): U32[index][copy][16 columns] instead of two histograms one behind the other.  The 32
+    // lanes of a half wavefront then hit 32 DIFFERENT banks whatever the indices are (lanes 0-15: copy 0, sixteen rotated
+    // columns; lanes 16-31: copy 1): with separate histograms the bank is 16 x (index parity ^ copy) + column, and two lanes
+    // of a half collide whenever their index parities differ the wrong way (every second pair).  Measured, same box, three
+    // alternating bench.py runs each (tools/ubench/run_r05m.sh, profiles/r05_experiments/m_span_interleaved_copies.log): 31.5-31.8
+    // us per 16-cycle span against 31.0-31.3 for the separate histograms -- the atomics are bound by the LDS atomic unit's
+    // own rate (~12 clocks per wavefront instruction), not by bank conflicts.  Off.
+#ifndef JST_SPAN_INTERLEAVED
+#define JST_SPAN_INTERLEAVED 0
+#endif
+    constexpr bool kInterleaved = JST_SPAN_INTERLEAVED && COPIES == 2;
     const uint32_t my_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)hist +
-                             ((tid >> 4) % COPIES) * copy_stride * 4u;
+                             (kInterleaved ? ((tid >> 4) & 1u) * 64u : ((tid >> 4) % COPIES) * copy_stride * 4u);
     typedef __attribute__((address_space(3))) uint32_t* lds_u32;
     for (uint32_t first = 0; first < batches; first += 1024u) {
         if (first != 0u) request(first);
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_kernel(float* __re
 #pragma unroll
             for (uint32_t j = 0; j < 16; ++j) {
                 const uint32_t i = (g[j >> 2] >> (8u * (j & 3u))) & 0xffu;  // the index at column (rot + j) % 16
-                const uint32_t addr = (i << 6) + ((((rot + j) & 15u) << 2) | my_base);
+                const uint32_t addr = (kInterleaved ? (i << 7) : (i << 6)) + ((((rot + j) & 15u) << 2) + my_base);
                 __hip_atomic_fetch_add((lds_u32)(uintptr_t)addr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
@@ -268,8 +279,19 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
     lds_only_barrier();
 
     const uint32_t rot = tid & 15u;
+    // JST_SPAN_INTERLEAVED (two copies): U32[index][copy][16 columns] instead of two histograms one behind the other.  The 32
+    // lanes of a half wavefront then hit 32 DIFFERENT banks whatever the indices are (lanes 0-15: copy 0, sixteen rotated
+    // columns; lanes 16-31: copy 1): with separate histograms the bank is 16 x (index parity ^ copy) + column, and two lanes
+    // of a half collide whenever their index parities differ the wrong way (every second pair).  Measured, same box, three
+    // alternating bench.py runs each (tools/ubench/run_r05m.sh, profiles/r05_experiments/m_span_interleaved_copies.log): 31.5-31.8
+    // us per 16-cycle span against 31.0-31.3 for the separate histograms -- the atomics are bound by the LDS atomic unit's
+    // own rate (~12 clocks per wavefront instruction), not by bank conflicts.  Off.
+#ifndef JST_SPAN_INTERLEAVED
+#define JST_SPAN_INTERLEAVED 0
+#endif
+    constexpr bool kInterleaved = JST_SPAN_INTERLEAVED && COPIES == 2;
     const uint32_t my_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)hist +
-                             ((tid >> 4) % COPIES) * copy_stride * 4u;
+                             (kInterleaved ? ((tid >> 4) & 1u) * 64u : ((tid >> 4) % COPIES) * copy_stride * 4u);
     typedef __attribute__((address_space(3))) uint32_t* lds_u32;
     auto count_rows = [&](const v4u (&cur)[kRows]) {
 #pragma unroll
@@ -284,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
 #pragma unroll
             for (uint32_t j = 0; j < 16; ++j) {
                 const uint32_t i = (g[j >> 2] >> (8u * (j & 3u))) & 0xffu;
-                const uint32_t addr = (i << 6) + ((((rot + j) & 15u) << 2) | my_base);
+                const uint32_t addr = (kInterleaved ? (i << 7) : (i << 6)) + ((((rot + j) & 15u) << 2) + my_base);
 #if defined(JST_SPAN_DIAG_NOATOMICS)  // timing diagnostics only
                 if (addr == 0xffffffffu) hist[j] = i;
 #else
@@ -307,8 +329,9 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
             uint32_t n = 0;
 #pragma unroll
             for (int cp = 0; cp < COPIES; ++cp) {
-                n += hist[cp * copy_stride + e];
-                hist[cp * copy_stride + e] = 0u;
+                const uint32_t at = kInterleaved ? (e >> 4) * 32u + (uint32_t)cp * 16u + (e & 15u) : cp * copy_stride + e;
+                n += hist[at];
+                hist[at] = 0u;
             }
             if (e < TW) n = 0u;
             k[j] = n < 64u ? n : 64u;
