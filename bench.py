@@ -328,7 +328,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=320)
     ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--slots", type=int, default=0,
-                    help="ring slots = cycles of a ring period (0 = 32, or 16 when --steps is shorter than 32: a timed region "
+                    help="ring slots = cycles of a ring period (0 = the run's steps between 16 and 32 -- the driver's --steps 20: 20: a timed region "
                          "holds at least one whole period, which is what the kernel's event pair brackets)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-fuse", action="store_true")
@@ -363,7 +363,7 @@ def main() -> None:
                     help="repeat the K-step timed region until this many seconds have been timed (0: once)")
     args = ap.parse_args()
     if args.slots <= 0:
-        args.slots = 32 if args.steps >= 32 else 16
+        args.slots = min(32, max(16, args.steps))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`

@@ -55,6 +55,7 @@ def test_one_record_per_launch_form(tmp_path):
 
 
 def test_bench_picks_the_ring_period_from_the_run_length():
-    """bench.py: 32 ring slots, 16 when the run is shorter than 32 steps (a timed region holds a whole period)."""
+    """bench.py: as many ring slots as the run has steps, between 16 and 32 (a timed region holds a whole period; the driver's
+    --steps 20 is one 20-cycle launch per unit)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "args.slots = 32 if args.steps >= 32 else 16" in src
+    assert "args.slots = min(32, max(16, args.steps))" in src
