@@ -335,7 +335,9 @@ bool Runtime::tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed) {
                                     (flags_ & PIPELINE) == 0,
                                     (flags_ & BATCH) && (flags_ & GRAPH) && !(flags_ & (PIPELINE | COMBINE)) ? &unit.batch : nullptr,
                                     &static_storage_) ||
-           modules::TryFuseFilter(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
+           modules::TryFuseFilter(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
+           modules::TryFuseMultiplyFft(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
+           modules::TryFuseAmplitudeRange(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
 }
 
 Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {

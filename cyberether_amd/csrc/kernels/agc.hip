@@ -11,6 +11,8 @@
 // stages the per-sample powers in LDS with coalesced loads and lane 0 adds them in order.  The
 // tile chain (LimitGainChange) is one thread per lane; the gain application is one thread per
 // sample.  Three launches; all state is recomputed every call (the module is STATELESS).
+#include <cstdlib>
+
 #include "device_math.hh"
 #include "kernels.hh"
 
@@ -139,10 +141,56 @@ __global__ __launch_bounds__(kBlock) void agc_apply_kernel(const AgcParams p, T*
     }
 }
 
+// ONE launch when every lane is a single tile (the spectrum_engine block's AGC: one RMS tile per spectrum,
+// spectrum_engine/block_impl.cc:186-190).  start = end = raw(0): no gain ramp and no neighbour tile to look at, so the
+// workgroup that summed the tile's power applies the gain to it right away -- same F64 operations in the same order as the
+// three kernels below (power in sample order, then ApplyGain with step = (g - g) / len = +0 and gain = g + 0 * k = g).
+template <class T>
+__global__ __launch_bounds__(kBlock) void agc_single_tile_kernel(const AgcParams p, T* __restrict__ out, const T* __restrict__ in,
+                                                                 double* __restrict__ gains) {
+    __shared__ double powers[kChunk];
+    __shared__ double tile_gain;
+    const uint64_t lane = blockIdx.x;
+    int64_t in_base, out_base;
+    lane_bases(p, lane, in_base, out_base);
+    const uint64_t len = p.samples;
+    double sum = 0.0;
+    for (uint64_t c0 = 0; c0 < len; c0 += kChunk) {
+        const uint64_t n = (len - c0 < (uint64_t)kChunk) ? (len - c0) : (uint64_t)kChunk;
+        for (uint64_t i = threadIdx.x; i < n; i += kBlock)
+            powers[i] = sample_power(in[in_base + (int64_t)(c0 + i) * p.in_sample_stride]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll 8
+            for (uint64_t i = 0; i < n; ++i) sum += powers[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = sum / (double)len;
+        const double g = clampd(p.reference / sqrt(mean + p.epsilon), p.min_gain, p.max_gain);
+        gains[lane * 2] = g;      // (start, end) of the lane's only tile, as agc_chain_kernel leaves them
+        gains[lane * 2 + 1] = g;
+        tile_gain = g;
+    }
+    __syncthreads();
+    const double g0 = tile_gain;
+    const double step = (g0 - g0) / (double)len;
+    for (uint64_t k = threadIdx.x; k < len; k += kBlock) {
+        const double gain = g0 + step * (double)k;
+        out[out_base + (int64_t)k * p.out_sample_stride] = apply_gain(in[in_base + (int64_t)k * p.in_sample_stride], gain);
+    }
+}
+
 template <class T>
 hipError_t run(T* out, const T* in, double* gains, const AgcParams& p, hipStream_t s) {
     if (p.lanes == 0 || p.samples == 0) return hipSuccess;
     (void)hipGetLastError();
+    static const bool three_kernels = getenv("JST_AGC_THREE_KERNELS") != nullptr;  // A/B and tests
+    if (p.tiles == 1 && !three_kernels) {
+        hipLaunchKernelGGL((agc_single_tile_kernel<T>), dim3((unsigned)p.lanes), dim3(kBlock), 0, s, p, out, in, gains);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((agc_power_kernel<T>), dim3((unsigned)(p.lanes * p.tiles)), dim3(kBlock), 0,
                        s, p, in, gains);
     hipLaunchKernelGGL(agc_chain_kernel, dim3((unsigned)((p.lanes + kBlock - 1) / kBlock)),

@@ -110,6 +110,20 @@ struct RangeF32 {
     float scale, offset;
     __device__ float operator()(uint64_t, float v) const { return range_f32(v, scale, offset); }
 };
+// Amplitude -> Range in one pass (amplitude/module_impl_native_cpu.cc:73-86 then range/module_impl_native_cpu.cc:67-82): the
+// F32 level is formed and consumed in a register instead of going through memory between two launches.
+struct AmpRangeCF32 {
+    float coeff, scale, offset;
+    __device__ float operator()(uint64_t, float2 v) const { return range_f32(amplitude_exact(v, coeff), scale, offset); }
+};
+struct AmpRangeCF32Fast {
+    float coeff, scale, offset;
+    __device__ float operator()(uint64_t, float2 v) const { return range_f32_fast(amplitude_cf32_fast(v, coeff), scale, offset); }
+};
+struct AmpRangeF32 {
+    float coeff, scale, offset;
+    __device__ float operator()(uint64_t, float v) const { return range_f32(amplitude_f32(v, coeff), scale, offset); }
+};
 // multiply_constant/module_impl_native_cpu.cc:92-100: CF32 * F32 scalar = (re*c, im*c).
 struct MulConstCF32 {
     float c;
@@ -210,6 +224,12 @@ hipError_t launch_range_f32(const EwLayout& L, float* out, const float* in, floa
                             float offset, bool fast, hipStream_t s) {
     if (fast) return run_unary(L, out, in, RangeF32Fast{scale, offset}, s);
     return run_unary(L, out, in, RangeF32{scale, offset}, s);
+}
+hipError_t launch_amplitude_range(const EwLayout& L, float* out, const void* in, bool in_is_complex, float coeff, float scale,
+                                  float offset, bool fast, hipStream_t s) {
+    if (!in_is_complex) return run_unary(L, out, static_cast<const float*>(in), AmpRangeF32{coeff, scale, offset}, s);
+    if (fast) return run_unary(L, out, static_cast<const float2*>(in), AmpRangeCF32Fast{coeff, scale, offset}, s);
+    return run_unary(L, out, static_cast<const float2*>(in), AmpRangeCF32{coeff, scale, offset}, s);
 }
 hipError_t launch_multiply_constant_cf32(const EwLayout& L, float2* out, const float2* in,
                                          float constant, hipStream_t s) {

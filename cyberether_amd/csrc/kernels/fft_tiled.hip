@@ -1088,6 +1088,16 @@ hipError_t launch_fft_c2c_tiled(uint64_t n, bool forward, const FftLayout& L, co
     return dispatch_dir(forward, p, L, W, LoadCF32{in}, StoreCF32{out}, scratch, s);
 }
 
+// Multiply (broadcast window) -> forward FFT with the product formed in the transform's first load and the spectrum
+// stored as it is: the spectrum_engine block's chain when something other than Amplitude reads the spectrum (its AGC).
+hipError_t launch_fft_c2c_tiled_windowed(uint64_t n, const FftLayout& L, const float2* W, const float2* in,
+                                         const float2* window, int64_t window_stride, float2* out, float2* scratch,
+                                         hipStream_t s) {
+    TiledPlan p;
+    if (!make_tiled_plan(n, L.transforms, p)) return hipErrorInvalidValue;
+    return launch_tiled<true>(p, L, W, LoadCF32TimesWindow{in, window, window_stride}, StoreCF32{out}, scratch, s);
+}
+
 hipError_t launch_fft_c2c_tiled_padded(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,
                                        const float2* W, const float2* in, float2* out,
                                        float2* scratch, hipStream_t s) {

@@ -96,6 +96,9 @@ hipError_t launch_fft_c2c_tiled(uint64_t n, bool forward, const FftLayout& L, co
                                 const float2* in, float2* out, float2* scratch, hipStream_t stream);
 // Pad (zeros appended along the transform axis) fused into the first load: `in` is the UNPADDED
 // tensor (L.in_* describe it), `valid` its extent along the axis, n the padded transform length.
+hipError_t launch_fft_c2c_tiled_windowed(uint64_t n, const FftLayout& L, const float2* W, const float2* in,
+                                         const float2* window, int64_t window_stride, float2* out, float2* scratch,
+                                         hipStream_t stream);
 hipError_t launch_fft_c2c_tiled_padded(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,
                                        const float2* W, const float2* in, float2* out,
                                        float2* scratch, hipStream_t stream);
@@ -221,6 +224,8 @@ hipError_t launch_amplitude_f32(const EwLayout& L, float* out, const float* in, 
                                 hipStream_t stream);
 hipError_t launch_range_f32(const EwLayout& L, float* out, const float* in, float scale,
                             float offset, bool fast, hipStream_t stream);
+hipError_t launch_amplitude_range(const EwLayout& L, float* out, const void* in, bool in_is_complex, float coeff, float scale,
+                                  float offset, bool fast, hipStream_t stream);
 hipError_t launch_multiply_constant_cf32(const EwLayout& L, float2* out, const float2* in,
                                          float constant, hipStream_t stream);
 hipError_t launch_multiply_constant_f32(const EwLayout& L, float* out, const float* in,

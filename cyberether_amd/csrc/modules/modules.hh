@@ -46,6 +46,13 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
                    std::vector<Module*>& members, std::function<Result(hipStream_t)>& submit,
                    size_t& consumed);
 
+// Small-chain fusions (chain_fusions.cc): multiply(window) -> fft when no Amplitude follows (an AGC in between), and
+// amplitude -> range as one elementwise pass.  Same contract.
+bool TryFuseMultiplyFft(const std::vector<Module*>& ordered, size_t at, std::string& name, std::vector<Module*>& members,
+                        std::function<Result(hipStream_t)>& submit, size_t& consumed);
+bool TryFuseAmplitudeRange(const std::vector<Module*>& ordered, size_t at, std::string& name, std::vector<Module*>& members,
+                           std::function<Result(hipStream_t)>& submit, size_t& consumed);
+
 // The Filter block's plan (src/domains/dsp/filter/block_impl.cc:40-168, CalculateCandidatePlan): how long the
 // convolution is, whether the block resamples by spectral folding and, if so, each head's fold offset.  Host logic of
 // the block, kept next to the modules it wires so that a C / C++ consumer of the C ABI does not have to re-derive it.
