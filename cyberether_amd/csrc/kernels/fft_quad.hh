@@ -83,6 +83,13 @@ static_assert(4 * ((fft_quad_lds_bytes() + 1279) / 1280) * 1280 <= 160 * 1024, "
 #define JST_QUAD_STATIC_NUM 3
 #define JST_QUAD_STATIC_DEN 4
 #endif
+// A workgroup whose claim counter has run out tries the partner counters (see fft_quad_body).  Measured, same box, three
+// alternating runs (tools/ubench/run_r05p.sh, profiles/r05_experiments/p_claim_stealing.log): 162.5-165.4 us against
+// 163.6-165.2 without -- the eight shares end 6 us apart either way, and what remains of the tail is the last transform of
+// every workgroup.  Off.
+#ifndef JST_QUAD_STEAL
+#define JST_QUAD_STEAL 0
+#endif
 #ifndef JST_QUAD_SPREAD  // outputs between two LDS-DMA pieces in the epilogue (0: all nine back to back in front of it)
 #define JST_QUAD_SPREAD 1
 #endif
@@ -247,7 +254,8 @@ __device__ __forceinline__ void fft_quad_body(const FftLayout& L, const float2* 
     // vmcnt(0)` in front of their reloads, in the middle of the epilogue's stores.
     const bool young = bid >= (grid >> 1);
     // the first transform's pieces: everything issued so far (window taps, twiddles, pieces, the counter's answer) has landed
-    if (wv == 0 && 1u >= srounds) fetched = srounds * grid + 8u * quad_claim_and_wait<0>(sched + kQuadSchedStride * (bid & 7u)) + (bid & 7u);
+    uint32_t home = bid & 7u;  // the claim counter this workgroup asks (its own share first)
+    if (wv == 0 && 1u >= srounds) fetched = srounds * grid + 8u * quad_claim_and_wait<0>(sched + kQuadSchedStride * home) + home;
     else JST_WAIT_VMCNT(0);
     if (tid == 0) *handover = fetched;
 #ifdef JST_QUAD_TIMELINE
@@ -403,8 +411,23 @@ __device__ __forceinline__ void fft_quad_body(const FftLayout& L, const float2* 
         // ... and, wavefront 0, the transform after the next (the other wavefronts read the word behind the next barrier, and read
         // it last behind the top barrier of THIS transform, four barriers ago)
         ++rnd;  // the round of transform tn; `fetched` (tn + grid so far) is for round rnd + 1
-        if (wv == 0 && rnd + 1u >= srounds) fetched = srounds * grid + 8u * quad_claim_and_wait<kAfter * STORES>(sched + kQuadSchedStride * (bid & 7u)) + (bid & 7u);
-        else JST_WAIT_VMCNT(kAfter * STORES);
+        if (wv == 0 && rnd + 1u >= srounds) {
+            fetched = srounds * grid + 8u * quad_claim_and_wait<kAfter * STORES>(sched + kQuadSchedStride * home) + home;
+#if JST_QUAD_STEAL
+            // this counter's share is handed out: look at the partner counters (b ^ 4, then ^ 2, then ^ 1: the eight shares
+            // end pairwise, then in fours, then together) and stay with the first that still has work
+            for (uint32_t hop = 4u; fetched >= total && hop != 0u; hop >>= 1) {
+                const uint32_t other = home ^ hop;
+                const uint32_t got = srounds * grid + 8u * quad_claim_and_wait<63>(sched + kQuadSchedStride * other) + other;
+                if (got < total) {
+                    fetched = got;
+                    home = other;
+                }
+            }
+#endif
+        } else {
+            JST_WAIT_VMCNT(kAfter * STORES);
+        }
         JST_QSTAMP(10);  // own pieces landed
         if (tid == 0) *handover = fetched;
         t = tn;
