@@ -17,6 +17,8 @@ _LIB_PATH = os.path.join(_HERE, "libjst_oracle.so")
 _REF_PATH = os.path.join(_HERE, "_ref", "libref_pocketfft.so")
 _REF_HELPERS_PATH = os.path.join(_HERE, "_ref", "libref_helpers.so")
 _REF_JETSTREAM_PATH = os.path.join(_HERE, "_ref", "libref_jetstream.so")
+# the same reference objects linked with integration/mi355x_provider/ against cyberether_amd/lib/libjetstream_hip.so
+_REF_JETSTREAM_HIP_PATH = os.path.join(_HERE, "_ref", "libref_jetstream_hip.so")
 
 _u64p = C.POINTER(C.c_uint64)
 _i64p = C.POINTER(C.c_int64)
@@ -30,7 +32,7 @@ def build(force: bool = False) -> None:
     ):
         subprocess.check_call(["make", "-C", _HERE, "libjst_oracle.so"], stdout=subprocess.DEVNULL)
     if (force or not os.path.exists(_REF_PATH) or not os.path.exists(_REF_HELPERS_PATH)
-            or not os.path.exists(_REF_JETSTREAM_PATH)) and os.path.exists(
+            or not os.path.exists(_REF_JETSTREAM_PATH) or not os.path.exists(_REF_JETSTREAM_HIP_PATH)) and os.path.exists(
         "/root/reference/src/domains/dsp/fft/pocketfft.hh"
     ):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
