@@ -557,6 +557,7 @@ double jst_runtime_unit_mean_cycles(jst_runtime r, const char* prefix) {
     return -1.0;
 }
 int jst_runtime_batched(jst_runtime r) { return r && r->rt.batched() ? 1 : 0; }
+int jst_runtime_branches(jst_runtime r) { return r ? (int)r->rt.branches() : 0; }
 jst_result jst_runtime_reset_timing(jst_runtime r) {
     JST_ARG(r, "null runtime");
     r->rt.resetTiming();

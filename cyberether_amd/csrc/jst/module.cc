@@ -323,6 +323,74 @@ Result Runtime::planUnits() {
             }
         }
     }
+    return planBranches();
+}
+
+// Which units may run side by side inside a captured cycle.  Unit i runs behind unit j < i when one of them writes storage
+// the other touches (the members' declared inputs and outputs; views share their storage's id; a unit that launches nothing
+// -- a view, a bypass cast, a host-side cursor -- and a settled static unit write nothing during a cycle).  Branch
+// assignment: a unit continues the branch of its latest dependency that is still that branch's tail, else it opens a
+// new branch (the first unit of all takes branch 0 = the runtime's stream); at most kMaxBranches, then it queues behind
+// its latest dependency.  JST_RUNTIME_NO_BRANCHES=1: one serial chain (A/B).
+Result Runtime::planBranches() {
+    int kMaxBranches = 6;
+    if (const char* e = getenv("JST_RUNTIME_MAX_BRANCHES")) kMaxBranches = std::atoi(e) > 0 ? std::atoi(e) : 1;
+    for (auto& u : units_) {
+        u.deps.clear();
+        u.branch = 0;
+    }
+    if (getenv("JST_RUNTIME_NO_BRANCHES") != nullptr || (flags_ & PIPELINE)) return Result::SUCCESS;
+    std::vector<std::set<const void*>> reads(units_.size()), writes(units_.size());
+    for (size_t i = 0; i < units_.size(); ++i) {
+        const Unit& u = units_[i];
+        if (u.is_static || !u.has_kernels) continue;
+        for (Module* m : u.modules) {
+            for (const auto& kv : m->inputs()) reads[i].insert(kv.second.storageId());
+            for (const auto& kv : m->outputs()) writes[i].insert(kv.second.storageId());
+        }
+    }
+    auto meets = [](const std::set<const void*>& a, const std::set<const void*>& b) {
+        for (const void* x : a)
+            if (b.count(x)) return true;
+        return false;
+    };
+    std::vector<long> tail;  // tail[b] = last unit on branch b
+    for (size_t i = 0; i < units_.size(); ++i) {
+        Unit& u = units_[i];
+        if (u.is_static || !u.has_kernels) continue;
+        for (size_t j = 0; j < i; ++j)
+            if (meets(writes[j], reads[i]) || meets(writes[j], writes[i]) || meets(reads[j], writes[i])) u.deps.push_back(j);
+        int pick = -1;
+        for (size_t k = u.deps.size(); k-- > 0 && pick < 0;) {
+            const int b = units_[u.deps[k]].branch;
+            if (tail[(size_t)b] == (long)u.deps[k]) pick = b;
+        }
+        if (pick < 0) {
+            if ((int)tail.size() < kMaxBranches) {
+                pick = (int)tail.size();
+                tail.push_back(-1);
+            } else {
+                pick = u.deps.empty() ? 0 : units_[u.deps.back()].branch;
+            }
+        }
+        u.branch = pick;
+        tail[(size_t)pick] = (long)i;
+    }
+    if (tail.size() < 2) {
+        for (auto& u : units_) u.branch = 0;
+        return Result::SUCCESS;
+    }
+    while (branch_streams_.size() < tail.size()) {
+        hipStream_t s = stream_;
+        if (!branch_streams_.empty()) JST_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+        branch_streams_.push_back(s);
+        hipEvent_t e = nullptr;
+        JST_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+        branch_join_.push_back(e);
+    }
+    if (!branch_fork_) JST_HIP_CHECK(hipEventCreateWithFlags(&branch_fork_, hipEventDisableTiming), "hipEventCreate");
+    for (auto& u : units_)
+        if (!u.done) JST_HIP_CHECK(hipEventCreateWithFlags(&u.done, hipEventDisableTiming), "hipEventCreate");
     return Result::SUCCESS;
 }
 
@@ -648,8 +716,18 @@ Result Runtime::destroy() {
     for (auto& u : units_) {
         for (hipEvent_t e : u.span.begin) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : u.span.end) if (e) (void)hipEventDestroy(e);
+        if (u.done) (void)hipEventDestroy(u.done);
     }
     units_.clear();
+    for (size_t b = 1; b < branch_streams_.size(); ++b) {
+        (void)hipStreamSynchronize(branch_streams_[b]);
+        (void)hipStreamDestroy(branch_streams_[b]);
+    }
+    branch_streams_.clear();
+    for (hipEvent_t e : branch_join_) if (e) (void)hipEventDestroy(e);
+    branch_join_.clear();
+    if (branch_fork_) (void)hipEventDestroy(branch_fork_);
+    branch_fork_ = nullptr;
     for (size_t i = ordered_.size(); i-- > 0;)  // reverse order (native/cuda/impl.cc:126-137)
         (void)ordered_[i]->computeDeinitialize();
     ordered_.clear();
@@ -661,12 +739,15 @@ Result Runtime::destroy() {
 // The result convention of src/runtime/native/cpu/impl.cc:98-148: SUCCESS | RELOAD continue; SKIP marks the
 // unit's outputs skipped for this cycle and every unit reading a skipped tensor is skipped in turn;
 // YIELD | TIMEOUT end the cycle quietly (a source without data); anything else fails the cycle.
-Result Runtime::submitAll(bool record_events, U64 slot, bool count_cycles) {
+Result Runtime::submitAll(bool record_events, U64 slot, bool count_cycles, bool fork) {
     std::set<U64> skipped;  // producers (ProducerAttribute) whose outputs do not exist this cycle
     auto producer_of = [](const Tensor& t) -> U64 {
         const AttrValue* a = t.attribute(ProducerAttribute);
         return a && std::holds_alternative<U64>(*a) ? std::get<U64>(*a) : 0;
     };
+    fork = fork && branch_streams_.size() > 1 && !record_events;
+    std::vector<char> started(branch_streams_.size(), 0);
+    if (fork) JST_HIP_CHECK(hipEventRecord(branch_fork_, stream_), "hipEventRecord");
     for (auto& u : units_) {
         if (u.is_static && u.settled) continue;
         bool starved = false;
@@ -676,9 +757,22 @@ Result Runtime::submitAll(bool record_events, U64 slot, bool count_cycles) {
             for (Module* m : u.modules) skipped.insert((U64)reinterpret_cast<uintptr_t>(m));
             continue;
         }
+        hipStream_t on = stream_;
+        if (fork && u.has_kernels) {
+            on = branch_streams_[(size_t)u.branch];
+            if (u.branch != 0 && !started[(size_t)u.branch]) {  // the branch joins the capture behind the cycle's start
+                JST_HIP_CHECK(hipStreamWaitEvent(on, branch_fork_, 0), "hipStreamWaitEvent");
+                started[(size_t)u.branch] = 1;
+            }
+            for (size_t d : u.deps) {
+                const Unit& p = units_[d];
+                if (p.branch != u.branch && p.done_epoch == capture_epoch_)  // (not recorded: it did not run in this capture)
+                    JST_HIP_CHECK(hipStreamWaitEvent(on, p.done, 0), "hipStreamWaitEvent");
+            }
+        }
         const bool rec = record_events && slot < u.span.begin.size();
         if (rec) JST_HIP_CHECK(hipEventRecord(u.span.begin[slot], stream_), "hipEventRecord");
-        const Result r = u.submit(stream_);
+        const Result r = u.submit(on);
         if (r == Result::YIELD || r == Result::TIMEOUT) return r;
         if (r == Result::SKIP) {
             for (Module* m : u.modules) skipped.insert((U64)reinterpret_cast<uintptr_t>(m));
@@ -686,6 +780,10 @@ Result Runtime::submitAll(bool record_events, U64 slot, bool count_cycles) {
             JST_ERROR("[RUNTIME] computeSubmit failed in '%s' (%s): %s", u.name.c_str(),
                       ResultName(r), last_error());
             return r;
+        }
+        if (fork && u.has_kernels) {
+            JST_HIP_CHECK(hipEventRecord(u.done, on), "hipEventRecord");
+            u.done_epoch = capture_epoch_;
         }
         if (rec) {
             JST_HIP_CHECK(hipEventRecord(u.span.end[slot], stream_), "hipEventRecord");
@@ -695,6 +793,12 @@ Result Runtime::submitAll(bool record_events, U64 slot, bool count_cycles) {
         if (count_cycles)
             for (Module* m : u.modules) m->timing.cycles++;
     }
+    if (fork)  // every branch back into the runtime's stream: the next cycle (and the end of the capture) sits behind all of them
+        for (size_t b = 1; b < branch_streams_.size(); ++b) {
+            if (!started[b]) continue;
+            JST_HIP_CHECK(hipEventRecord(branch_join_[b], branch_streams_[b]), "hipEventRecord");
+            JST_HIP_CHECK(hipStreamWaitEvent(stream_, branch_join_[b], 0), "hipStreamWaitEvent");
+        }
     for (auto& u : units_)
         for (Module* m : u.modules) m->cycleSubmitted(stream_);
     return Result::SUCCESS;
@@ -828,8 +932,9 @@ Result Runtime::launchSpan(U64 n, bool timing) {
         // No event-record nodes in span graphs: the unit timers live in the period graph (every timingStride()-th
         // cycle) and in eager cycles; a span is a head or a tail of at most period - 1 cycles.
         if (batched_) r = submitBatched(n, false);
+        ++capture_epoch_;
         for (U64 c = 0; !batched_ && c < n && r == Result::SUCCESS; ++c)
-            r = submitAll(false, (phase + c) % period_, false);  // advances the host cursors
+            r = submitAll(false, (phase + c) % period_, false, true);  // advances the host cursors
         if (r != Result::SUCCESS) return abortCapture(r);
         SpanGraph sg;
         if (hipStreamEndCapture(stream_, &sg.graph) != hipSuccess || !sg.graph) return abortCapture(Result::ERROR);
@@ -907,8 +1012,9 @@ Result Runtime::compute(U64 cycles, bool sync) {
                               "hipStreamBeginCapture");
                 Result r = Result::SUCCESS;
                 if (batched_) r = submitBatched(period_, false);  // one launch per unit for the whole period
+                ++capture_epoch_;
                 for (U64 c = 0; !batched_ && c < period_ && r == Result::SUCCESS; ++c)
-                    r = submitAll(false, c, false);  // event records under capture record nothing on replay (see above)
+                    r = submitAll(false, c, false, true);  // event records under capture record nothing on replay (see above)
                 if (r != Result::SUCCESS) return abortCapture(r);
                 hipGraph_t g = nullptr;
                 if (hipStreamEndCapture(stream_, &g) != hipSuccess || !g) return abortCapture(Result::ERROR);

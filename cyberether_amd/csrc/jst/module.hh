@@ -211,6 +211,7 @@ class Runtime {
     // cycle-batched runtime (whose timed launches carry a whole period each); <0 if unknown.
     F64 unitMeanCycles(const std::string& name);
     bool batched() const { return batched_; }
+    size_t branches() const { return branch_streams_.size() > 1 ? branch_streams_.size() : 1; }
     void resetTiming();
 
  private:
@@ -227,6 +228,12 @@ class Runtime {
         SpanSupport batch;                 // BATCH: the fused spectrum unit's multi-cycle launch
         bool per_cycle_in_span = false;    // BATCH: a sink that reads the batched unit's rings: n per-cycle submissions inside a span
         KernelSpan span;
+        // BRANCHES (planBranches): the units this one must run behind (a tensor one writes and the other reads or writes)
+        // and the capture stream it is submitted on
+        std::vector<size_t> deps;
+        int branch = 0;
+        hipEvent_t done = nullptr;         // recorded behind the unit under capture (an edge of the graph, nothing at run time)
+        U64 done_epoch = 0;                // the capture that recorded it
     };
     Result planOrder(const std::vector<Module*>& modules);
     Result planUnits();
@@ -237,7 +244,16 @@ class Runtime {
     // In a captured period only every timingStride()-th cycle carries event-record nodes: a pair
     // costs ~2 us of queue time, sampling keeps Module::Timing live at a quarter of that cost.
     U64 timingStride() const { return period_ >= 8 ? 4 : 1; }
-    Result submitAll(bool record_events, U64 event_slot, bool count_cycles);
+    Result submitAll(bool record_events, U64 event_slot, bool count_cycles, bool fork = false);
+    // BRANCHES: a flowgraph with independent chains behind one source (the reference's multi-fm.yml: three spectrum chains,
+    // a Filter and a demodulator, every kernel a handful of workgroups) is captured as a graph with PARALLEL branches --
+    // the units of a chain on one capture stream, forks and joins as event edges -- instead of one serial chain of
+    // launch-floor kernels.  Only under capture, only when the plan has more than one branch.
+    Result planBranches();
+    std::vector<hipStream_t> branch_streams_;  // [0] = stream_
+    std::vector<hipEvent_t> branch_join_;
+    hipEvent_t branch_fork_ = nullptr;
+    U64 capture_epoch_ = 0;
     Result harvestTiming();
     Result eagerCycle(bool& needs_sync, bool overwrite_samples);
     // 'n' < period() cycles starting at the current phase as a hipGraph of their own (captured on first use, cached

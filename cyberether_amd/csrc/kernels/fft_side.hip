@@ -73,10 +73,16 @@ hipError_t launch_side(const FftLayout& L, const float2* W, const Pro& pro, cons
 // Round 5: 4096 points, CF32 rows, provider fast with a real window -- fft_quad_kernel (fft_quad.hh): 256 threads per transform,
 // in-place exchange, rows by LDS-DMA, four workgroups per CU.  Same box, alternating launches of 16384 transforms
 // (tools/ubench/run_r05e.sh): 166-168 us against 180-183 for fft_pipe_kernel (0.92), every value and index byte identical.
-// JST_FFT_KERNEL=pipe keeps the pipelined kernel (A/B, tests run both).
-bool quad_selected() {  // read per call, like use_pipe_kernel (fft_kernels.hip): the tests switch kernels inside one process
+// SHORT launches keep fft_pipe_kernel: its 512 workgroups start in half the time of the quad kernel's 1024 (the dispatcher
+// hands out ~85 workgroups per us), and a launch of one round has nothing to pipeline in either -- 1024 transforms 17.5 us
+// against 20.3, 4096 transforms 52.7 = 52.9, 8192 transforms 93.0 against 92.0 (r05_experiments/q_small_launches.log); the
+// quad kernel takes launches of eight rounds and more (where its claimed rounds start, too).
+// JST_FFT_KERNEL=pipe keeps the pipelined kernel throughout, =quad the quad kernel at every size (A/B, tests run both).
+bool quad_selected(uint64_t transforms) {  // read per call, like use_pipe_kernel (fft_kernels.hip): the tests switch kernels inside one process
     const char* k = getenv("JST_FFT_KERNEL");
-    return !(k && (k[0] == 'p' || k[0] == 'w' || k[0] == 's'));
+    if (k && (k[0] == 'p' || k[0] == 'w' || k[0] == 's')) return false;
+    if (k && k[0] == 'q') return true;
+    return transforms >= 8ull * 4ull * (uint64_t)side_compute_units();
 }
 
 template <class Pro, class Epi>
@@ -106,7 +112,7 @@ hipError_t side_with(uint64_t n, const FftLayout& L, const float2* W, const Pro&
     const StoreAmplitudeRangeSideT<true> ef{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{side_height, other}}, side, side_height, side_batches, side_pitch};
     const StoreAmplitudeRangeSideT<false> ee{{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}}, side, side_height, side_batches, side_pitch};
     if constexpr (Pro::kRawBytes == 8 && requires { Pro::kRealOperand; }) {
-        if (n == 4096 && fast && quad_selected()) return launch_side_quad(L, W, pro, ef, sched, stream);
+        if (n == 4096 && fast && quad_selected(L.transforms)) return launch_side_quad(L, W, pro, ef, sched, stream);
     }
     switch (n) {
 #define JST_SIDE_CASE(NN)                                                  \

@@ -364,6 +364,28 @@ struct StoreScaledUnpad {
     }
 };
 
+// ... with phase_correction between the scale and the unpad (filter/block_impl.cc:499-560 with a frequency-shifted head:
+// ifft -> normalize -> phase_correction -> unpad): every sample of transform `base` times the correction of its
+// (channel, batch) cell, dsp/phase_correction/module_impl_native_cpu.cc:95-115 -- the table the module keeps, read here
+// (written for THIS cycle by the previous cycle's overlap kernel, see launch_overlap_heads_phase).
+struct StoreScaledPhaseUnpad {
+    float2* body;
+    float2* tail;
+    float c;
+    uint32_t body_len, tail_len;
+    const float2* corr;  // [channels, batches]
+    uint32_t batches, batch_div, channels, chan_div;  // cell of transform t: batch (t / batch_div) % batches, channel (t / chan_div) % channels
+    template <bool CONTIG>
+    __device__ __forceinline__ void store(int64_t base, int64_t, int pos, float2 v) const {
+        const uint32_t t = (uint32_t)base;
+        const uint32_t b = batches == 1 ? 0u : (t / batch_div) % batches;
+        const uint32_t ch = channels == 1 ? 0u : (t / chan_div) % channels;
+        const float2 r = cmul_full(mk(v.x * c, v.y * c), corr[ch * batches + b]);
+        if ((uint32_t)pos < body_len) body[base * (int64_t)body_len + pos] = r;
+        else tail[base * (int64_t)tail_len + ((uint32_t)pos - body_len)] = r;
+    }
+};
+
 // Workgroup b runs on XCD b % 8 (observed placement, used for speed only) and every XCD has an L2 of its own.
 // Neighbouring tiles share cache lines (a column tile's 128-byte runs start 8 bytes off the line grid whenever the
 // row length is odd in elements; a block tile writes 64-byte halves of 128-byte lines), so XCD k takes a CONTIGUOUS
@@ -1149,6 +1171,26 @@ hipError_t launch_fft_c2c_tiled_scaled_unpad(uint64_t n, bool forward, const Fft
     const StoreScaledUnpad unpad{body, tail, constant, (uint32_t)body_len, (uint32_t)(n - body_len)};
     if (!forward) return launch_tiled<false, LoadCF32, StoreScaledUnpad, 3>(p, T, W, LoadCF32{in}, unpad, scratch, s);
     return dispatch_dir(forward, p, T, W, LoadCF32{in}, unpad, scratch, s);
+}
+
+hipError_t launch_fft_c2c_tiled_scaled_phase_unpad(uint64_t n, const FftLayout& L, const float2* W, const float2* in,
+                                                   float2* scratch, float2* body, float2* tail, float constant,
+                                                   uint64_t body_len, const float2* corr, uint64_t batches,
+                                                   uint64_t batch_div, uint64_t channels, uint64_t chan_div, hipStream_t s) {
+    TiledPlan p;
+    if (body_len > n || !make_tiled_plan(n, L.transforms, p) || L.transforms >> 32 || batch_div == 0 || chan_div == 0)
+        return hipErrorInvalidValue;
+    FftLayout T = L;  // output side: `base` = transform index (as launch_fft_c2c_tiled_scaled_unpad)
+    int64_t stride = 1;
+    for (int a = T.outer_rank - 1; a >= 0; --a) {
+        T.out_outer_stride[a] = stride;
+        stride *= (int64_t)T.outer_shape[a];
+    }
+    T.out_offset = 0;
+    T.out_axis_stride = 0;
+    const StoreScaledPhaseUnpad epi{body, tail, constant, (uint32_t)body_len, (uint32_t)(n - body_len), corr,
+                                    (uint32_t)batches, (uint32_t)batch_div, (uint32_t)channels, (uint32_t)chan_div};
+    return launch_tiled<false>(p, T, W, LoadCF32{in}, epi, scratch, s);  // the Filter's inverse transform only
 }
 
 hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const float2* W,

@@ -189,10 +189,35 @@ __global__ __launch_bounds__(kBlock) void overlap_state_kernel(T* __restrict__ p
 // The overlap region only: `out` already holds the buffer values (the fused inverse transform wrote them there).
 // One thread per overlap element; the thread of a first-batch element is the only one that touches its state entry,
 // so it reads it for the sum and then replaces it with the last batch's overlap.
+// PhaseNext (the fused Filter tail, filter_modules.cc TryFuseFilter): the transform's epilogue of THIS cycle has read the
+// correction table; the first workgroup advances the phase state exactly as phase_table_kernel does at the end of a cycle and
+// writes the table of the NEXT cycle from the advanced state -- the same F64 operations on the same stored values, one
+// cycle earlier in wall time.
+struct PhaseNext {
+    float2* corr = nullptr;
+    double* phases = nullptr;
+    const double* increments = nullptr;
+    uint64_t channels = 0, batches = 0;
+};
+__device__ __forceinline__ void phase_table_row(float2* corr, double ph0, double wrapped, uint64_t c, uint64_t batches) {
+    for (uint64_t b = 0; b < batches; ++b) {
+        const double ph = ph0 + wrapped * (double)b;
+        corr[c * batches + b] = mk((float)cos(ph), (float)sin(ph));
+    }
+}
 template <class T>
 __global__ __launch_bounds__(kBlock) void overlap_heads_kernel(T* __restrict__ out, const T* __restrict__ ovl,
                                                                T* __restrict__ prev, const OlaLayout L,
-                                                               uint64_t total) {
+                                                               uint64_t total, const PhaseNext pn) {
+    if (pn.corr != nullptr && blockIdx.x == 0) {
+        const double two_pi = 2.0 * 3.14159265358979323846;
+        for (uint64_t c = threadIdx.x; c < pn.channels; c += blockDim.x) {
+            const double wrapped = remainder(pn.increments[c], two_pi);
+            const double next = remainder(pn.phases[c] + wrapped * (double)pn.batches, two_pi);
+            pn.phases[c] = next;
+            phase_table_row(pn.corr, next, wrapped, c, pn.batches);
+        }
+    }
     JST_GRID_STRIDE(e, total) {  // e indexes the overlap tensor
         uint64_t c[kMaxRank], rem = e;
         for (int d = (int)L.rank - 1; d >= 0; --d) {
@@ -223,17 +248,14 @@ __global__ __launch_bounds__(kBlock) void overlap_heads_kernel(T* __restrict__ o
 // ---- PhaseCorrection (dsp/phase_correction/module_impl_native_cpu.cc:60-115) -----------------
 __global__ void phase_table_kernel(float2* __restrict__ corr, double* __restrict__ phases,
                                    const double* __restrict__ increments, uint64_t channels,
-                                   uint64_t batches) {
+                                   uint64_t batches, bool advance) {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= channels) return;
     const double two_pi = 2.0 * 3.14159265358979323846;
     const double wrapped = remainder(increments[c], two_pi);
     const double ph0 = phases[c];
-    for (uint64_t b = 0; b < batches; ++b) {
-        const double ph = ph0 + wrapped * (double)b;
-        corr[c * batches + b] = mk((float)cos(ph), (float)sin(ph));
-    }
-    phases[c] = remainder(ph0 + wrapped * (double)batches, two_pi);
+    phase_table_row(corr, ph0, wrapped, c, batches);
+    if (advance) phases[c] = remainder(ph0 + wrapped * (double)batches, two_pi);
 }
 __global__ __launch_bounds__(kBlock) void phase_mul_kernel(const EwLayout L, float2* __restrict__ out,
                                                            const float2* __restrict__ in,
@@ -879,9 +901,11 @@ __global__ __launch_bounds__(kFmThreads) void am_kernel(float* __restrict__ out,
     }
 }
 
+// One launch: the thread that takes a lane's FIRST sample is the only reader of that lane's state, so it is also the one
+// that replaces it with the lane's LAST sample (read, then written, in one thread's program order; the input is not
+// written by this kernel) -- no second kernel to order the state update behind the readers.
 __global__ __launch_bounds__(kBlock) void fm_narrow_parallel_kernel(
-    float* __restrict__ out, const float2* __restrict__ in, const FmState* __restrict__ states,
-    const FmCoeffs k, const FmLayout L) {
+    float* __restrict__ out, const float2* __restrict__ in, FmState* states, const FmCoeffs k, const FmLayout L) {
     const uint64_t per_lane = L.batches * L.samples, total = L.lanes * per_lane;
     JST_GRID_STRIDE(e, total) {
         const uint64_t lane = e / per_lane, n = e % per_lane, b = n / L.samples, s = n % L.samples;
@@ -894,6 +918,11 @@ __global__ __launch_bounds__(kBlock) void fm_narrow_parallel_kernel(
         if (n == 0) {
             prev = mk(states[lane].prev_re, states[lane].prev_im);
             has = states[lane].has_prev != 0;
+            const float2 last = in[in_off + (int64_t)(L.batches - 1) * L.in_batch_stride +
+                                   (int64_t)(L.samples - 1) * L.in_sample_stride];
+            states[lane].prev_re = last.x;
+            states[lane].prev_im = last.y;
+            states[lane].has_prev = 1;
         } else {
             const uint64_t pb = (n - 1) / L.samples, ps = (n - 1) % L.samples;
             prev = in[in_off + (int64_t)pb * L.in_batch_stride + (int64_t)ps * L.in_sample_stride];
@@ -901,18 +930,6 @@ __global__ __launch_bounds__(kBlock) void fm_narrow_parallel_kernel(
         out[out_off + (int64_t)b * L.out_batch_stride + (int64_t)s * L.out_sample_stride] =
             fm_discriminate(prev, cur, has, k.ref);
     }
-}
-__global__ void fm_narrow_state_kernel(const float2* __restrict__ in, FmState* __restrict__ states,
-                                       const FmLayout L) {
-    const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= L.lanes) return;
-    int64_t in_off, out_off;
-    fm_lane_offsets(L, lane, in_off, out_off);
-    const float2 last = in[in_off + (int64_t)(L.batches - 1) * L.in_batch_stride +
-                           (int64_t)(L.samples - 1) * L.in_sample_stride];
-    states[lane].prev_re = last.x;
-    states[lane].prev_im = last.y;
-    states[lane].has_prev = 1;
 }
 
 // ---- SignalGenerator, cosine / sine (dsp/signal_generator/module_impl_native_cpu.cc:20-23,
@@ -1198,9 +1215,25 @@ hipError_t launch_overlap_add(void* out, const void* buf, const void* ovl, void*
     }
     return hipGetLastError();
 }
+// the table of the coming cycle from the state as it stands (no advance): primes the fused Filter tail at plan time
+hipError_t launch_phase_table_prime(float2* corr, double* phases, const double* increments, uint64_t channels,
+                                    uint64_t batches, hipStream_t s) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((channels + 63) / 64)), dim3(64), 0, s, corr, phases,
+                       increments, channels, batches, false);
+    return hipGetLastError();
+}
 hipError_t launch_overlap_heads(void* out, const void* ovl, void* prev, bool complex, uint32_t rank,
                                 int32_t batch_axis, const uint64_t* buf_shape, const uint64_t* ovl_shape,
                                 hipStream_t s) {
+    return launch_overlap_heads_phase(out, ovl, prev, complex, rank, batch_axis, buf_shape, ovl_shape, nullptr, nullptr,
+                                      nullptr, 0, 0, s);
+}
+hipError_t launch_overlap_heads_phase(void* out, const void* ovl, void* prev, bool complex, uint32_t rank,
+                                      int32_t batch_axis, const uint64_t* buf_shape, const uint64_t* ovl_shape,
+                                      float2* corr, double* phases, const double* increments, uint64_t channels,
+                                      uint64_t batches, hipStream_t s) {
+    const PhaseNext pn{corr, phases, increments, channels, batches};
     OlaLayout L{};
     L.rank = rank;
     L.batch_axis = batch_axis;
@@ -1211,13 +1244,14 @@ hipError_t launch_overlap_heads(void* out, const void* ovl, void* prev, bool com
         total *= ovl_shape[d];
     }
     (void)hipGetLastError();
-    if (total == 0) return hipSuccess;
+    if (total == 0 && corr == nullptr) return hipSuccess;
+    const unsigned grid = total ? grid_for(total) : 1u;
     if (complex)
-        hipLaunchKernelGGL(overlap_heads_kernel<float2>, dim3(grid_for(total)), dim3(kBlock), 0, s, (float2*)out,
-                           (const float2*)ovl, (float2*)prev, L, total);
+        hipLaunchKernelGGL(overlap_heads_kernel<float2>, dim3(grid), dim3(kBlock), 0, s, (float2*)out,
+                           (const float2*)ovl, (float2*)prev, L, total, pn);
     else
-        hipLaunchKernelGGL(overlap_heads_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, (float*)out,
-                           (const float*)ovl, (float*)prev, L, total);
+        hipLaunchKernelGGL(overlap_heads_kernel<float>, dim3(grid), dim3(kBlock), 0, s, (float*)out,
+                           (const float*)ovl, (float*)prev, L, total, pn);
     return hipGetLastError();
 }
 hipError_t launch_phase_correction(const EwLayout& L, float2* out, const float2* in, float2* corr,
@@ -1226,7 +1260,7 @@ hipError_t launch_phase_correction(const EwLayout& L, float2* out, const float2*
                                    hipStream_t s) {
     (void)hipGetLastError();
     hipLaunchKernelGGL(phase_table_kernel, dim3((unsigned)((channels + 63) / 64)), dim3(64), 0, s,
-                       corr, phases, increments, channels, batches);
+                       corr, phases, increments, channels, batches, true);
     hipLaunchKernelGGL(phase_mul_kernel, dim3(grid_for(L.size)), dim3(kBlock), 0, s, L, out, in,
                        (const float2*)corr, batches, batch_inner, channels, channel_inner);
     return hipGetLastError();
@@ -1281,10 +1315,9 @@ hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs&
     }
     if (!k.wide && !k.deemph_enabled) {
         const uint64_t total = L.lanes * L.batches * L.samples;
+        if (total == 0) return hipSuccess;
         hipLaunchKernelGGL(fm_narrow_parallel_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, out,
-                           in, (const FmState*)states, k, L);
-        hipLaunchKernelGGL(fm_narrow_state_kernel, dim3((unsigned)((L.lanes + 63) / 64)), dim3(64),
-                           0, s, in, (FmState*)states, L);
+                           in, (FmState*)states, k, L);
     } else {
         hipLaunchKernelGGL(fm_kernel, dim3((unsigned)((L.lanes + 63) / 64)), dim3(64), 0, s, out, in,
                            (FmState*)states, k, L);

@@ -130,6 +130,12 @@ hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool for
 hipError_t launch_fft_c2c_tiled_scaled_unpad(uint64_t n, bool forward, const FftLayout& L, const float2* W,
                                              const float2* in, float2* scratch, float2* body, float2* tail,
                                              float constant, uint64_t body_len, hipStream_t s);
+// ... with phase_correction between multiply_constant and unpad (inverse transforms only): `corr` is the module's
+// [channels, batches] table; transform t belongs to batch (t / batch_div) % batches, channel (t / chan_div) % channels
+hipError_t launch_fft_c2c_tiled_scaled_phase_unpad(uint64_t n, const FftLayout& L, const float2* W, const float2* in,
+                                                   float2* scratch, float2* body, float2* tail, float constant,
+                                                   uint64_t body_len, const float2* corr, uint64_t batches,
+                                                   uint64_t batch_div, uint64_t channels, uint64_t chan_div, hipStream_t s);
 
 
 // The 4096-point fused spectrum chain with the side output as ONE WAVEFRONT PER TRANSFORM (fft_wave.hip / fft_wave.hh): dense
@@ -364,6 +370,13 @@ hipError_t launch_overlap_add(void* out, const void* buf, const void* ovl, void*
 hipError_t launch_overlap_heads(void* out, const void* ovl, void* prev, bool complex, uint32_t rank,
                                 int32_t batch_axis, const uint64_t* buf_shape, const uint64_t* ovl_shape,
                                 hipStream_t s);
+// the same launch also advances a phase_correction state and writes the NEXT cycle's correction table (corr != nullptr)
+hipError_t launch_overlap_heads_phase(void* out, const void* ovl, void* prev, bool complex, uint32_t rank,
+                                      int32_t batch_axis, const uint64_t* buf_shape, const uint64_t* ovl_shape,
+                                      float2* corr, double* phases, const double* increments, uint64_t channels,
+                                      uint64_t batches, hipStream_t s);
+hipError_t launch_phase_table_prime(float2* corr, double* phases, const double* increments, uint64_t channels,
+                                    uint64_t batches, hipStream_t s);
 
 hipError_t launch_phase_correction(const EwLayout& L, float2* out, const float2* in, float2* corr,
                                    double* phases, const double* increments, uint64_t batches,

@@ -1544,14 +1544,19 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
         };
         return true;
     }
-    // fft(inverse, tiled) -> multiply_constant -> unpad(same axis) -> overlap_add: the scale and the body / tail split
-    // ride on the transform's last store (the body lands in overlap_add's output), one small kernel then patches the
-    // overlap region and rolls the state
+    // fft(inverse, tiled) -> multiply_constant [-> phase_correction] -> unpad(same axis) -> overlap_add: the scale, the
+    // phase correction and the body / tail split ride on the transform's last store (the body lands in overlap_add's
+    // output), one small kernel then patches the overlap region, rolls the state and -- with a phase_correction -- advances
+    // its phases and writes the next cycle's correction table (filter/block_impl.cc:499-582)
     if (auto* fft = dynamic_cast<Fft*>(ordered[at])) {
         if (at + 3 >= ordered.size()) return false;
         auto* norm = dynamic_cast<MultiplyConstant*>(ordered[at + 1]);
-        auto* unpad = dynamic_cast<Unpad*>(ordered[at + 2]);
-        auto* ola = dynamic_cast<OverlapAdd*>(ordered[at + 3]);
+        auto* phase = dynamic_cast<PhaseCorrection*>(ordered[at + 2]);
+        static const bool no_phase_epilogue = std::getenv("JST_NO_PHASE_EPILOGUE") != nullptr;
+        if (phase && (no_phase_epilogue || at + 4 >= ordered.size())) return false;
+        const size_t tail_at = at + (phase ? 3 : 2);
+        auto* unpad = dynamic_cast<Unpad*>(ordered[tail_at]);
+        auto* ola = dynamic_cast<OverlapAdd*>(ordered[tail_at + 1]);
         if (!norm || !unpad || !ola || no_unpad_epilogue) return false;
         const Index axis = fft->resolvedAxis;
         if (fft->realInput || !fft->useTiled || fft->bluesteinSize != 0 || axis + 1 != fft->input.rank()) return false;
@@ -1560,7 +1565,27 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
         if (norm->input.shape() != fft->output.shape() || norm->input.offset() != fft->output.offset() ||
             !norm->input.contiguous() || norm->output.dtype() != DataType::CF32)
             return false;
-        if (unpad->input.storageId() != norm->output.storageId() || !sole_consumer(ordered, norm->output, unpad)) return false;
+        const Tensor* scaled = &norm->output;
+        Module* scaled_reader = unpad;
+        U64 batchDiv = 1, chanDiv = 1;
+        if (phase) {
+            if (fft->forward) return false;  // the epilogue is compiled for the Filter's inverse transform
+            if (phase->input.storageId() != norm->output.storageId() || !sole_consumer(ordered, norm->output, phase)) return false;
+            if (phase->input.shape() != fft->output.shape() || phase->input.offset() != 0 || !phase->input.contiguous() ||
+                !phase->output.contiguous())
+                return false;
+            // the (batch, channel) cell of a TRANSFORM: both axes in front of the transform axis
+            const U64 n = fft->input.shape(axis);
+            if ((phase->batchAxis && *phase->batchAxis == axis) || (phase->channelAxis && *phase->channelAxis == axis)) return false;
+            if (phase->batchInner % n || phase->channelInner % n) return false;
+            batchDiv = phase->batchAxis ? phase->batchInner / n : 1;
+            chanDiv = phase->channelAxis ? phase->channelInner / n : 1;
+            if ((fft->input.size() / n) >> 32) return false;
+            scaled = &phase->output;
+            scaled_reader = phase;
+        }
+        (void)scaled_reader;
+        if (unpad->input.storageId() != scaled->storageId() || !sole_consumer(ordered, *scaled, unpad)) return false;
         if (unpad->resolvedAxis != axis || unpad->input.shape() != fft->output.shape() || !unpad->input.contiguous()) return false;
         if (ola->buffer.storageId() != unpad->body.storageId() || ola->overlap.storageId() != unpad->tail.storageId()) return false;
         if (!sole_consumer(ordered, unpad->body, ola) || !sole_consumer(ordered, unpad->tail, ola)) return false;
@@ -1568,13 +1593,43 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
             ola->buffer.offset() != 0 || ola->overlap.offset() != 0 || !ola->buffer.contiguous() ||
             !ola->overlap.contiguous() || !ola->output.contiguous() || ola->output.offset() != 0)
             return false;
-        members = {fft, norm, unpad, ola};
-        consumed = 4;
-        name = "ifft_unpad_overlap(" + fft->name() + "+" + norm->name() + "+" + unpad->name() + "+" + ola->name() + ")";
-        submit = [fft, norm, unpad, ola, axis](hipStream_t stream) -> Result {
+        if (phase) {
+            // the table this cycle's epilogue reads: from the state as it stands now (the standalone module writes it at the
+            // top of its own compute; from here on the overlap kernel of cycle k leaves the table of cycle k + 1)
+            if (hip_result(kernels::launch_phase_table_prime(ptr<float2>(phase->corrections), ptr<double>(phase->phases),
+                                                             ptr<const double>(phase->devIncrements), phase->channelCount,
+                                                             phase->batchCount, nullptr),
+                           "phase_correction (table) kernel") != Result::SUCCESS ||
+                hipStreamSynchronize(nullptr) != hipSuccess)
+                return false;
+            members = {fft, norm, phase, unpad, ola};
+            consumed = 5;
+            name = "ifft_phase_unpad_overlap(" + fft->name() + "+" + norm->name() + "+" + phase->name() + "+" + unpad->name() +
+                   "+" + ola->name() + ")";
+        } else {
+            members = {fft, norm, unpad, ola};
+            consumed = 4;
+            name = "ifft_unpad_overlap(" + fft->name() + "+" + norm->name() + "+" + unpad->name() + "+" + ola->name() + ")";
+        }
+        submit = [fft, norm, phase, unpad, ola, axis, batchDiv, chanDiv](hipStream_t stream) -> Result {
             dev::FftLayout L;
             JST_CHECK(fft->layout(L));
             const U64 n = fft->input.shape(axis);
+            if (phase) {
+                JST_CHECK(hip_result(kernels::launch_fft_c2c_tiled_scaled_phase_unpad(
+                                         n, L, fft->twiddles, ptr<const float2>(fft->input), ptr<float2>(fft->scratchA),
+                                         ptr<float2>(ola->output), ptr<float2>(unpad->tail), norm->constant,
+                                         unpad->body.shape(axis), ptr<const float2>(phase->corrections), phase->batchCount,
+                                         batchDiv, phase->channelCount, chanDiv, stream),
+                                     "fft (tiled, multiply_constant + phase_correction + unpad epilogue) kernel"));
+                return hip_result(kernels::launch_overlap_heads_phase(
+                                      ptr<char>(ola->output), ptr<char>(ola->overlap), ptr<char>(ola->previousOverlap), true,
+                                      (uint32_t)ola->buffer.rank(), ola->batchAxis ? (int32_t)*ola->batchAxis : -1,
+                                      ola->buffer.shape().data(), ola->overlap.shape().data(),
+                                      ptr<float2>(phase->corrections), ptr<double>(phase->phases),
+                                      ptr<const double>(phase->devIncrements), phase->channelCount, phase->batchCount, stream),
+                                  "overlap_add (overlap region) + phase_correction (state) kernel");
+            }
             JST_CHECK(hip_result(kernels::launch_fft_c2c_tiled_scaled_unpad(
                                      n, fft->forward, L, fft->twiddles, ptr<const float2>(fft->input),
                                      ptr<float2>(fft->scratchA), ptr<float2>(ola->output), ptr<float2>(unpad->tail),

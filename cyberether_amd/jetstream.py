@@ -142,6 +142,7 @@ _sig("jst_runtime_units", C.c_size_t, _h, C.c_char_p, C.c_size_t)
 _sig("jst_runtime_unit_mean_ms", C.c_double, _h, C.c_char_p)
 _sig("jst_runtime_unit_mean_cycles", C.c_double, _h, C.c_char_p)
 _sig("jst_runtime_batched", C.c_int, _h)
+_sig("jst_runtime_branches", C.c_int, _h)
 _sig("jst_runtime_event_overhead_ms", C.c_double, _h)
 _sig("jst_runtime_reset_timing", R, _h)
 _sig("jst_comm_available", C.c_int)
@@ -599,6 +600,11 @@ class Runtime:
     @property
     def units(self) -> List[str]:
         return self._lines(_lib.jst_runtime_units)
+
+    @property
+    def branches(self) -> int:
+        """Parallel branches of a captured cycle (1 = one serial chain)."""
+        return int(_lib.jst_runtime_branches(self._h))
 
     def unit_mean_ms(self, prefix: str) -> float:
         return float(_lib.jst_runtime_unit_mean_ms(self._h, prefix.encode()))

@@ -71,3 +71,60 @@ def test_amplitude_range_pair_on_its_own(js, oracle):
         want = oracle.range_(oracle.amplitude(x, x.shape[-1]), -80.0, 10.0)
         assert_bit_equal(rg.output("signal").numpy(), want, f"amplitude + range on {x.dtype}")
         rt.destroy()
+
+
+def _filter_input(rng, b, s, sr):
+    t = np.arange(b * s).reshape(b, s) / sr
+    return (0.6 * np.exp(2j * np.pi * 0.3e6 * t) + 0.3 * np.exp(2j * np.pi * 4.0e6 * t)
+            + 0.02 * (rng.standard_normal((b, s)) + 1j * rng.standard_normal((b, s)))).astype(np.complex64)
+
+
+@pytest.mark.parametrize("case", [
+    dict(sr=20e6, bw=2e6, center=[0.0, 3.0e6, -5.0e6], taps=101, s=900, b=2),
+    dict(sr=2e6, bw=0.2e6, center=[400e3, -400e3], taps=101, s=7950, b=8),      # multi-fm.yml's Filter: 8050 -> 805 per head
+])
+def test_filter_tail_with_phase_correction_is_one_unit(js, oracle, case):
+    """ifft -> normalize -> phase_correction -> unpad -> overlap_add (filter/block_impl.cc:499-582) as
+    `ifft_phase_unpad_overlap`: the correction rides on the inverse transform's last store, the overlap kernel advances the
+    phase state and leaves the NEXT cycle's table.  Same output bits and the same F64 phase state as the module-by-module
+    submission and the oracle -- also when a fused runtime takes over modules an unfused one has already advanced (the table
+    is primed from the state as it stands) and the other way round."""
+    sr, bw, center, taps, s, b = (case[k] for k in ("sr", "bw", "center", "taps", "s", "b"))
+    rng = np.random.default_rng(99)
+    xs = [_filter_input(rng, b, s, sr) for _ in range(7)]
+    src = js.Tensor.create("hip", "CF32", (b, s)).set_axes(batch=0, sample=1)
+    blk = js.Filter(src, sr, bw, center, taps, len(center))
+    assert blk.phase_correction is not None
+    state = {}
+    done = 0
+    for fuse, cycles in ((False, 2), (True, 3), (False, 1), (True, 1)):
+        rt = js.Runtime(blk.modules, graph=True, fuse=fuse)
+        assert any(u.startswith("ifft_phase_unpad_overlap(") for u in rt.units) == fuse, rt.units
+        for _ in range(cycles):
+            src.copy_from(xs[done])
+            rt.compute()
+            ref = oracle.filter_block(xs[done], blk.plan, sr, bw, center, taps, state)
+            assert_bit_equal(blk.buffer.numpy(), ref, f"cycle {done} (fuse={fuse})")
+            assert_bit_equal(blk.phase_correction.state("phases").numpy(), state["phases"], f"phase state after cycle {done}")
+            done += 1
+        rt.destroy()
+
+
+def test_fm_narrow_state_rides_in_the_demodulator_launch(js, oracle):
+    """fm (narrow, no de-emphasis): the lane's previous sample is replaced by the thread that read it -- one launch, replayed
+    from a hipGraph; the stream over several cycles must equal the oracle's (fm/module_impl_native_cpu.cc:93-139) bit for bit."""
+    rng = np.random.default_rng(5)
+    b, lanes, s = 8, 2, 805
+    src = js.Tensor.create("hip", "CF32", (b, lanes, s)).set_axes(batch=0, channel=1, sample=2)
+    fm = js.Module("fm", {"mode": "narrow", "deemphasis": "none", "sampleRate": 200e3}, {"signal": src})
+    rt = js.Runtime([fm], graph=True)
+    refs = [oracle.FmLane("narrow", "none", 200e3) for _ in range(lanes)]
+    for cycle in range(5):
+        ph = np.cumsum(rng.uniform(-0.4, 0.4, b * lanes * s)).reshape(b, lanes, s)
+        x = (np.exp(1j * ph) * rng.uniform(0.5, 1.5, (b, lanes, s))).astype(np.complex64)
+        src.copy_from(x)
+        rt.compute()
+        got = fm.output("signal").numpy()
+        for lane in range(lanes):
+            assert_bit_equal(got[:, lane].reshape(-1), np.asarray(refs[lane](x[:, lane, :]), np.float32), f"cycle {cycle} lane {lane}")
+    rt.destroy()

@@ -45,8 +45,11 @@ def test_filter_block_matches_oracle_chain(js, oracle, case, fuse):
         # ifft -> normalize -> unpad -> overlap_add ride on the inverse transform's last store (no phase correction
         # in between, mixed-radix length)
         n_ifft = plan["resamplerSize"] if plan["resample"] else plan["convolutionSize"]
-        tail_unit = all(c == 0.0 for c in center) and n_ifft & (n_ifft - 1) != 0
-        assert any(u.startswith("ifft_unpad_overlap(") for u in units) == tail_unit, units
+        mixed = n_ifft & (n_ifft - 1) != 0
+        centred = all(c == 0.0 for c in center)
+        assert any(u.startswith("ifft_unpad_overlap(") for u in units) == (centred and mixed), units
+        # ... and with a frequency-shifted head the phase_correction rides there too (round 5)
+        assert any(u.startswith("ifft_phase_unpad_overlap(") for u in units) == (not centred and mixed), units
     else:
         assert not any("(" in u for u in units)
     state = {}

@@ -16,7 +16,7 @@ from util import assert_bit_equal
 pytestmark = pytest.mark.gpu
 
 
-def _run(js, xs, h, calls, monkeypatch, kernel=None, static=False, batch=True):
+def _run(js, xs, h, calls, monkeypatch, kernel="quad", static=False, batch=True):
     if kernel:
         monkeypatch.setenv("JST_FFT_KERNEL", kernel)
     else:
@@ -81,6 +81,9 @@ def test_quad_claimed_rounds_equal_static_and_pipe(js, oracle, monkeypatch):
     _same(sta, dyn, "claimed rounds vs static round robin")
     pipe = _run(js, xs, h, calls, monkeypatch, kernel="pipe")
     _same(pipe, dyn, "claimed rounds vs fft_pipe_kernel")
+    # the library's own choice (no JST_FFT_KERNEL): fft_pipe_kernel for the short launches, the quad kernel from eight rounds
+    auto = _run(js, xs, h, calls, monkeypatch, kernel=None)
+    _same(pipe, auto, "the default selection by launch size")
     # ... and the bins are the reference's (provider generic = every float of the CPU path), the floats within tolerance
     ref = oracle.spectrum_chain(xs[(sum(calls) - 1) % slots], -100.0, 0.0)["range"]
     got = dyn[-1][0]

@@ -68,6 +68,9 @@ def test_multi_fm_example(js, oracle):
     # its fused Pad -> FFT -> Multiply -> Fold unit (and the 805-point inverse its fused unpad)
     assert plan["convolutionSize"] == 8050 and js.fft_path(8050) == "tile" and js.fft_path(805) == "tile"
     assert any(u.startswith("fft_padded_fold(") for u in rt.units), rt.units
+    assert any(u.startswith("ifft_phase_unpad_overlap(") for u in rt.units), rt.units
+    # independent chains behind the source: the captured cycle is a graph with parallel branches (jst/module.cc planBranches)
+    assert rt.branches > 1
     state, lane = {}, oracle.FmLane("narrow", "none", 200e3)
     wide = oracle.spectrum_chain(x, -81.0, 1.0)["range"]
     avg = np.zeros(s, np.float32)

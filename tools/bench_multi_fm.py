@@ -28,7 +28,7 @@ def main():
     dt = time.perf_counter() - t0
     print(json.dumps({"flowgraph": "multi-fm.yml", "cycles": cycles, "us_per_cycle": 1e6 * dt / cycles,
                       "fft_path_8050": js.fft_path(8050), "fft_path_805": js.fft_path(805),
-                      "generic_radix_tiles": os.environ.get("JST_TILED_GENERIC", "1") != "0", "units": list(rt.units)}))
+                      "generic_radix_tiles": os.environ.get("JST_TILED_GENERIC", "1") != "0", "branches": rt.branches, "units": list(rt.units)}))
     rt.destroy()
 
 
