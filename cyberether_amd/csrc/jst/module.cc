@@ -331,15 +331,18 @@ Result Runtime::planUnits() {
 // -- a view, a bypass cast, a host-side cursor -- and a settled static unit write nothing during a cycle).  Branch
 // assignment: a unit continues the branch of its latest dependency that is still that branch's tail, else it opens a
 // new branch (the first unit of all takes branch 0 = the runtime's stream); at most kMaxBranches, then it queues behind
-// its latest dependency.  JST_RUNTIME_NO_BRANCHES=1: one serial chain (A/B).
+// its latest dependency.
 Result Runtime::planBranches() {
-    int kMaxBranches = 6;
+    // MEASURED (r05 experiments s): multi-fm.yml 154-177 us per cycle with 2-5 branches against 136 us as one chain -- this
+    // ROCm's graph executor pays more for a cross-branch edge than the overlap of launch-floor kernels returns.  The plan
+    // stays (JST_RUNTIME_MAX_BRANCHES=n opts in); the default is one chain.
+    int kMaxBranches = 1;
     if (const char* e = getenv("JST_RUNTIME_MAX_BRANCHES")) kMaxBranches = std::atoi(e) > 0 ? std::atoi(e) : 1;
     for (auto& u : units_) {
         u.deps.clear();
         u.branch = 0;
     }
-    if (getenv("JST_RUNTIME_NO_BRANCHES") != nullptr || (flags_ & PIPELINE)) return Result::SUCCESS;
+    if (flags_ & PIPELINE) return Result::SUCCESS;
     std::vector<std::set<const void*>> reads(units_.size()), writes(units_.size());
     for (size_t i = 0; i < units_.size(); ++i) {
         const Unit& u = units_[i];
@@ -405,6 +408,7 @@ bool Runtime::tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed) {
                                     &static_storage_) ||
            modules::TryFuseFilter(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
            modules::TryFuseMultiplyFft(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
+           modules::TryFuseAgcChain(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
            modules::TryFuseAmplitudeRange(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
 }
 
@@ -773,14 +777,24 @@ Result Runtime::submitAll(bool record_events, U64 slot, bool count_cycles, bool 
         const bool rec = record_events && slot < u.span.begin.size();
         if (rec) JST_HIP_CHECK(hipEventRecord(u.span.begin[slot], stream_), "hipEventRecord");
         const Result r = u.submit(on);
-        if (r == Result::YIELD || r == Result::TIMEOUT) return r;
-        if (r == Result::SKIP) {
-            for (Module* m : u.modules) skipped.insert((U64)reinterpret_cast<uintptr_t>(m));
-        } else if (r != Result::SUCCESS && r != Result::RELOAD) {
-            JST_ERROR("[RUNTIME] computeSubmit failed in '%s' (%s): %s", u.name.c_str(),
-                      ResultName(r), last_error());
+        if (r == Result::YIELD || r == Result::TIMEOUT || (r != Result::SUCCESS && r != Result::RELOAD && r != Result::SKIP)) {
+            // The cycle ends here; whatever it did enqueue is behind stream_.  Modules that ran still hear that their cycle
+            // is closed (a live ring source records the slot's free event there: without it the producer's next push to
+            // that slot sat out its 200 ms timeout).  Under a forked capture the branches go back into stream_ first.
+            if (fork)
+                for (size_t b = 1; b < branch_streams_.size(); ++b) {
+                    if (!started[b]) continue;
+                    (void)hipEventRecord(branch_join_[b], branch_streams_[b]);
+                    (void)hipStreamWaitEvent(stream_, branch_join_[b], 0);
+                }
+            for (auto& w : units_)
+                for (Module* m : w.modules) m->cycleSubmitted(stream_);
+            if (r != Result::YIELD && r != Result::TIMEOUT)
+                JST_ERROR("[RUNTIME] computeSubmit failed in '%s' (%s): %s", u.name.c_str(), ResultName(r), last_error());
             return r;
         }
+        if (r == Result::SKIP)
+            for (Module* m : u.modules) skipped.insert((U64)reinterpret_cast<uintptr_t>(m));
         if (fork && u.has_kernels) {
             JST_HIP_CHECK(hipEventRecord(u.done, on), "hipEventRecord");
             u.done_epoch = capture_epoch_;

@@ -145,12 +145,17 @@ __global__ __launch_bounds__(kBlock) void agc_apply_kernel(const AgcParams p, T*
 // spectrum_engine/block_impl.cc:186-190).  start = end = raw(0): no gain ramp and no neighbour tile to look at, so the
 // workgroup that summed the tile's power applies the gain to it right away -- same F64 operations in the same order as the
 // three kernels below (power in sample order, then ApplyGain with step = (g - g) / len = +0 and gain = g + 0 * k = g).
-template <class T>
+template <class T, bool TAIL = false>
 __global__ __launch_bounds__(kBlock) void agc_single_tile_kernel(const AgcParams p, T* __restrict__ out, const T* __restrict__ in,
-                                                                 double* __restrict__ gains) {
+                                                                 double* __restrict__ gains, const AgcTail tail = AgcTail{}) {
     __shared__ double powers[kChunk];
     __shared__ double tile_gain;
     const uint64_t lane = blockIdx.x;
+    // TAIL with a Waterfall: the ring cursor as waterfall_kernel reads it (kernels/waterfall.hip; PlanWaterfallWrite,
+    // waterfall/ring_state.hh:16-28) -- every workgroup at entry, the last one to finish advances it
+    uint64_t write_index = 0;
+    if constexpr (TAIL)
+        if (tail.ring) write_index = __hip_atomic_load(&tail.ring_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int64_t in_base, out_base;
     lane_bases(p, lane, in_base, out_base);
     const uint64_t len = p.samples;
@@ -176,9 +181,43 @@ __global__ __launch_bounds__(kBlock) void agc_single_tile_kernel(const AgcParams
     __syncthreads();
     const double g0 = tile_gain;
     const double step = (g0 - g0) / (double)len;
-    for (uint64_t k = threadIdx.x; k < len; k += kBlock) {
-        const double gain = g0 + step * (double)k;
-        out[out_base + (int64_t)k * p.out_sample_stride] = apply_gain(in[in_base + (int64_t)k * p.in_sample_stride], gain);
+    if constexpr (!TAIL) {
+        for (uint64_t k = threadIdx.x; k < len; k += kBlock) {
+            const double gain = g0 + step * (double)k;
+            out[out_base + (int64_t)k * p.out_sample_stride] = apply_gain(in[in_base + (int64_t)k * p.in_sample_stride], gain);
+        }
+    } else {
+        const uint64_t batches = p.lanes, height = tail.height;
+        const uint64_t retained = tail.ring ? (batches < height ? batches : height) : 0;
+        const uint64_t source_row = batches - retained;
+        const bool kept = tail.ring && lane >= source_row;
+        float* ring_row = nullptr;
+        if (kept) ring_row = tail.ring + ((write_index + (source_row % height)) % height + (lane - source_row)) % height * len;
+        float* level_row = tail.level + lane * len;
+        for (uint64_t k = threadIdx.x; k < len; k += kBlock) {
+            const double gain = g0 + step * (double)k;
+            const T y = apply_gain(in[in_base + (int64_t)k * p.in_sample_stride], gain);
+            if (out) out[out_base + (int64_t)k * p.out_sample_stride] = y;
+            const float level = tail.fast ? jst::dev::range_f32_fast(jst::dev::amplitude_cf32_fast(y, tail.coeff), tail.scale, tail.offset)
+                                          : jst::dev::range_f32(jst::dev::amplitude_exact(y, tail.coeff), tail.scale, tail.offset);
+            level_row[k] = level;
+            if (kept) ring_row[k] = level;
+        }
+        if (tail.ring) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint64_t ticket = __hip_atomic_fetch_add(&tail.ring_state[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (ticket == (uint64_t)gridDim.x - 1) {  // WaterfallRingState::advance (ring_state.hh:40-43)
+                    const uint64_t dirty = __hip_atomic_load(&tail.ring_state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint64_t room = height - dirty;
+                    __hip_atomic_store(&tail.ring_state[0], (write_index + (batches % height)) % height, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&tail.ring_state[1], dirty + (batches < room ? batches : room), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&tail.ring_state[2], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
 }
 
@@ -188,7 +227,7 @@ hipError_t run(T* out, const T* in, double* gains, const AgcParams& p, hipStream
     (void)hipGetLastError();
     static const bool three_kernels = getenv("JST_AGC_THREE_KERNELS") != nullptr;  // A/B and tests
     if (p.tiles == 1 && !three_kernels) {
-        hipLaunchKernelGGL((agc_single_tile_kernel<T>), dim3((unsigned)p.lanes), dim3(kBlock), 0, s, p, out, in, gains);
+        hipLaunchKernelGGL((agc_single_tile_kernel<T, false>), dim3((unsigned)p.lanes), dim3(kBlock), 0, s, p, out, in, gains, AgcTail{});
         return hipGetLastError();
     }
     hipLaunchKernelGGL((agc_power_kernel<T>), dim3((unsigned)(p.lanes * p.tiles)), dim3(kBlock), 0,
@@ -204,6 +243,15 @@ hipError_t run(T* out, const T* in, double* gains, const AgcParams& p, hipStream
 }
 
 }  // namespace
+
+hipError_t launch_agc_tail(void* out, const void* in, double* gains, const AgcParams& p, const AgcTail& tail, hipStream_t s) {
+    if (p.tiles != 1 || p.lanes == 0 || p.samples == 0 || p.lanes > 0x7fffffffull || !tail.level || (tail.ring && (!tail.ring_state || tail.height == 0)))
+        return hipErrorInvalidValue;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((agc_single_tile_kernel<float2, true>), dim3((unsigned)p.lanes), dim3(kBlock), 0, s, p, static_cast<float2*>(out),
+                       static_cast<const float2*>(in), gains, tail);
+    return hipGetLastError();
+}
 
 hipError_t launch_agc(void* out, const void* in, bool complex, double* gains, const AgcParams& p,
                       hipStream_t s) {

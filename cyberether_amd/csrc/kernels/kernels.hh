@@ -263,6 +263,21 @@ struct AgcParams {
 };
 hipError_t launch_agc(void* out, const void* in, bool complex, double* gains, const AgcParams& p,
                       hipStream_t stream);
+// What follows a one-tile-per-lane CF32 AGC in the spectrum_engine block (block_impl.cc:183-217: agc -> amplitude -> range,
+// then a Waterfall reads the block's output) in the AGC's own launch: the workgroup that found a lane's gain forms the
+// level of every sample it scales (amplitude/module_impl_native_cpu.cc:73-86, range/module_impl_native_cpu.cc:67-82, the
+// functions of device_math.hh the standalone kernels use), stores it dense [lanes, samples], and -- with `ring` -- copies
+// the row into the Waterfall's ring as waterfall_kernel would (device cursor, last workgroup advances it).
+struct AgcTail {
+    float* level = nullptr;  // dense [lanes, samples]
+    float coeff = 0, scale = 0, offset = 0;
+    int fast = 0;
+    float* ring = nullptr;       // Waterfall ring [height, samples] (nullptr: no Waterfall rides along)
+    uint64_t* ring_state = nullptr;
+    uint64_t height = 0;
+};
+// `out` may be nullptr when nobody but the tail reads the scaled signal.  p.tiles must be 1.
+hipError_t launch_agc_tail(void* out, const void* in, double* gains, const AgcParams& p, const AgcTail& tail, hipStream_t stream);
 // Window: Blackman taps evaluated in F64 (window/module_impl_native_cpu.cc:20-37).
 hipError_t launch_window(float2* out, uint64_t n, hipStream_t stream);
 // libm-faithful tanhf sweep helper for the parity tests (out[i] = libm_tanhf(in[i])).

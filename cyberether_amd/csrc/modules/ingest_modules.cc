@@ -4,7 +4,9 @@
 // Integer-format cast and add live next to their float siblings in modules.cc.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <functional>
 
 #include "modules.hh"
 
@@ -294,8 +296,7 @@ class Agc : public Module {
         produced("signal", output);
         return Result::SUCCESS;
     }
-    Result computeSubmit(hipStream_t s) override {
-        kernels::AgcParams p;
+    void params(kernels::AgcParams& p) const {
         std::memset(&p, 0, sizeof(p));
         p.lanes = laneCount;
         p.samples = input.shape(sampleAxis);
@@ -319,6 +320,10 @@ class Agc : public Module {
         p.min_gain = minGain;
         p.max_gain = maxGain;
         p.max_gain_change = maxGainChange;
+    }
+    Result computeSubmit(hipStream_t s) override {
+        kernels::AgcParams p;
+        params(p);
         return hip_result(kernels::launch_agc(output.data(), input.data(),
                                               input.dtype() == DataType::CF32,
                                               static_cast<double*>(gains.data()), p, s),
@@ -397,6 +402,73 @@ class Squelch : public Module {
     F32 threshold = 0.1f;
     bool passing = false;
 };
+
+// agc (one tile per lane, CF32) -> amplitude -> range [-> waterfall]: the spectrum_engine block behind its transform when the
+// AGC is enabled (spectrum_engine/block_impl.cc:183-217), and the Waterfall that usually reads the block's output.  The
+// workgroup that found a lane's gain also forms the level of every sample it scales and -- with a Waterfall -- puts the row
+// into its ring (kernels/agc.hip agc_single_tile_kernel<.., TAIL>): three (four) launch-floor kernels become one.  Same
+// contract as the other fusions: the amplitude has no other reader and is not written; the scaled signal and the Range's
+// output are.  JST_NO_CHAIN_FUSION=1 keeps the modules apart.
+bool TryFuseAgcChain(const std::vector<Module*>& ordered, size_t at, std::string& name, std::vector<Module*>& members,
+                     std::function<Result(hipStream_t)>& submit, size_t& consumed) {
+    static const bool off = std::getenv("JST_NO_CHAIN_FUSION") != nullptr;
+    if (off || at + 2 >= ordered.size()) return false;
+    auto* agc = dynamic_cast<Agc*>(ordered[at]);
+    auto* amp = dynamic_cast<Amplitude*>(ordered[at + 1]);
+    auto* rng = dynamic_cast<Range*>(ordered[at + 2]);
+    if (!agc || !amp || !rng || agc->tiles != 1 || agc->input.dtype() != DataType::CF32) return false;
+    auto sole_reader = [&](const Tensor& t, const Module* consumer) {
+        for (const Module* m : ordered) {
+            if (m == consumer) continue;
+            if (const auto* c = dynamic_cast<const Cast*>(m); c && c->bypass) continue;
+            for (const auto& kv : m->inputs())
+                if (kv.second.storageId() == t.storageId()) return false;
+        }
+        return true;
+    };
+    if (amp->input.storageId() != agc->output.storageId() || rng->input.storageId() != amp->output.storageId()) return false;
+    if (!sole_reader(amp->output, rng)) return false;  // (the scaled signal is still written: the AGC's output port stays valid)
+    // dense tensors of one shape all the way, the sample axis last: a lane of the AGC is a row of the Range's output
+    if (agc->sampleAxis + 1 != agc->input.rank() || !agc->output.contiguous() || agc->output.offset() != 0) return false;
+    if (amp->input.shape() != agc->output.shape() || !amp->input.contiguous() || amp->input.offset() != 0) return false;
+    if (!amp->output.contiguous() || rng->input.shape() != amp->output.shape() || !rng->input.contiguous() ||
+        rng->input.offset() != amp->output.offset() || !rng->output.contiguous() || rng->output.offset() != 0 ||
+        rng->output.shape() != agc->output.shape())
+        return false;
+    const bool fast = amp->provider() == "fast";
+    if ((rng->provider() == "fast") != fast) return false;
+    Waterfall* wf = at + 3 < ordered.size() ? dynamic_cast<Waterfall*>(ordered[at + 3]) : nullptr;
+    if (wf && (wf->input.storageId() != rng->output.storageId() || wf->input.offset() != 0 || !wf->input.contiguous() ||
+               wf->input.rank() != 2 || wf->numberOfBatches != agc->laneCount ||
+               wf->numberOfElements != agc->input.shape(agc->sampleAxis) || wf->frequencyBins.offset() != 0))
+        wf = nullptr;
+    members = {agc, amp, rng};
+    name = "agc_amplitude_range(" + agc->name() + "+" + amp->name() + "+" + rng->name();
+    if (wf) {
+        members.push_back(wf);
+        name = "agc_amplitude_range_waterfall(" + agc->name() + "+" + amp->name() + "+" + rng->name() + "+" + wf->name();
+    }
+    name += ")";
+    consumed = members.size();
+    submit = [agc, amp, rng, wf, fast](hipStream_t stream) -> Result {
+        kernels::AgcParams p;
+        agc->params(p);
+        kernels::AgcTail t;
+        t.level = static_cast<float*>(rng->output.data());
+        t.coeff = amp->scalingCoeff;
+        t.scale = rng->scalingCoeff;
+        t.offset = rng->offsetCoeff;
+        t.fast = fast ? 1 : 0;
+        if (wf) {
+            t.ring = static_cast<float*>(wf->frequencyBins.data());
+            t.ring_state = static_cast<uint64_t*>(wf->ringState.data());
+            t.height = wf->height;
+        }
+        return hip_result(kernels::launch_agc_tail(agc->output.data(), agc->input.data(), static_cast<double*>(agc->gains.data()), p, t, stream),
+                          "agc + amplitude + range kernel");
+    };
+    return true;
+}
 
 JST_REGISTER_MODULE(Slice, "slice", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Agc, "agc", DeviceType::HIP, RuntimeType::NATIVE, "generic");

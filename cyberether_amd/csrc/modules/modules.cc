@@ -1319,7 +1319,12 @@ Result RingSource::publishStagedBatch(std::unique_lock<std::mutex>& lock) {  // 
     // for that (without the lock).  Only a cycle that died half way leaves the slot pending: after the timeout its
     // completion is recorded here, behind whatever it did enqueue.
     if (pendingFreeSlot == (I64)slot) {
+        const U64 epoch = clearEpoch, fill = stagingFill, index = stagingIndex, before = published();
         cycleClosed.wait_for(lock, std::chrono::milliseconds(200), [&] { return pendingFreeSlot != (I64)slot; });
+        // `mu` was released while waiting: a ringClear() has dropped the staged batch with everything else, a second producer
+        // thread may have published this staging buffer itself -- in both cases there is nothing left to upload from here
+        // (the slot, the staging index and the fill computed above are stale).
+        if (clearEpoch != epoch || stagingFill != fill || stagingIndex != index || published() != before) return Result::SUCCESS;
         if (pendingFreeSlot == (I64)slot && lastComputeStream) {
             JST_HIP_CHECK(hipEventRecord(slotFree[slot], lastComputeStream), "hipEventRecord");
             slotFreeValid[slot] = 1;
@@ -1440,6 +1445,7 @@ Result RingSource::ringClear() {
     consumed = published();
     stagingFill = 0;
     overflowCount = 0;
+    ++clearEpoch;  // a producer that waits inside publishStagedBatch (lock released) sees that its batch is gone
     for (U64 i = 0; i < kStaging; ++i) stagingBusy[i] = false;
     // nothing is published any more: no slot is waiting for a consumer's completion, no upload is outstanding
     pendingFreeSlot = -1;

@@ -52,6 +52,9 @@ bool TryFuseMultiplyFft(const std::vector<Module*>& ordered, size_t at, std::str
                         std::function<Result(hipStream_t)>& submit, size_t& consumed);
 bool TryFuseAmplitudeRange(const std::vector<Module*>& ordered, size_t at, std::string& name, std::vector<Module*>& members,
                            std::function<Result(hipStream_t)>& submit, size_t& consumed);
+// agc (one tile per lane) -> amplitude -> range [-> waterfall] in the AGC's launch (ingest_modules.cc).  Same contract.
+bool TryFuseAgcChain(const std::vector<Module*>& ordered, size_t at, std::string& name, std::vector<Module*>& members,
+                     std::function<Result(hipStream_t)>& submit, size_t& consumed);
 
 // The Filter block's plan (src/domains/dsp/filter/block_impl.cc:40-168, CalculateCandidatePlan): how long the
 // convolution is, whether the block resamples by spectral folding and, if so, each head's fold offset.  Host logic of
@@ -377,6 +380,7 @@ class RingSource : public Module {
     I64 pendingFreeSlot = -1;                // consumed by the latest cycle; its completion event is still to be recorded
     hipStream_t lastComputeStream = nullptr;
     U64 overflowCount = 0;
+    U64 clearEpoch = 0;                      // ringClear() calls so far (publishStagedBatch re-validates across its unlocked wait)
     size_t elementBytes = 8;
 };
 

@@ -306,10 +306,10 @@ double jst_runtime_event_overhead_ms(jst_runtime r);
 double jst_runtime_unit_mean_cycles(jst_runtime r, const char* unit_prefix);
 /* 1 when JST_RUNTIME_BATCH took effect (the planner could batch every dynamic unit), else 0 */
 int jst_runtime_batched(jst_runtime r);
-/* number of parallel branches a captured cycle is laid out on (1 = one serial chain): independent chains behind one source --
- * the reference's multi-fm.yml -- are captured as a hipGraph with forks and joins instead of one chain of launch-floor
- * kernels (the reference's scheduler, src/scheduler_synchronous.cc:574-696, runs them one after the other).
- * JST_RUNTIME_NO_BRANCHES=1 keeps the serial chain. */
+/* number of parallel branches a captured cycle is laid out on (1 = one serial chain, the default).  With
+ * JST_RUNTIME_MAX_BRANCHES=n independent chains behind one source -- the reference's multi-fm.yml -- are captured as a hipGraph
+ * with forks and joins instead of one chain (the reference's scheduler, src/scheduler_synchronous.cc:574-696, runs them one
+ * after the other); measured slower on ROCm 7.2 (cross-branch edges cost more than the overlap returns), hence opt-in. */
 int jst_runtime_branches(jst_runtime r);
 jst_result jst_runtime_reset_timing(jst_runtime r);
 

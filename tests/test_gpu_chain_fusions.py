@@ -1,7 +1,8 @@
 """The small-chain fusions of round 5 (cyberether_amd/csrc/modules/chain_fusions.cc) and the one-launch AGC (kernels/agc.hip):
 the spectrum_engine block's chain WITH its AGC (spectrum_engine/block_impl.cc:183-197: multiply -> fft -> agc -> amplitude ->
 range, one RMS tile per spectrum) on the lengths the reference's multi-fm.yml uses (8000 = 2^6 5^3: the LDS-tiled kernels).
-Fused -- `fft_windowed(multiply + fft)`, the AGC as one launch, `amplitude_range(amplitude + range)` -- the chain must leave
+Fused -- `fft_windowed(multiply + fft)` and `agc_amplitude_range(agc + amplitude + range)` (with a Waterfall behind it: its ring
+row too), two launches -- the chain must leave
 exactly what the module-by-module submission leaves and what the oracle computes (window, pocketfft, F64 AGC, libm-exact
 amplitude / range), bit for bit."""
 import numpy as np
@@ -41,7 +42,7 @@ def test_agc_spectrum_chain_fused_equals_unfused_and_the_oracle(js, oracle, n, b
         units = rt.units
         if fuse:
             assert any(u.startswith("fft_windowed(") for u in units), units
-            assert any(u.startswith("amplitude_range(") for u in units), units
+            assert any(u.startswith("agc_amplitude_range(") for u in units), units   # the AGC takes amplitude -> range along
         else:
             assert not any("(" in u for u in units), units
         rt.compute(3)
@@ -128,3 +129,34 @@ def test_fm_narrow_state_rides_in_the_demodulator_launch(js, oracle):
         for lane in range(lanes):
             assert_bit_equal(got[:, lane].reshape(-1), np.asarray(refs[lane](x[:, lane, :]), np.float32), f"cycle {cycle} lane {lane}")
     rt.destroy()
+
+
+@pytest.mark.parametrize("n,b,h", [(805, 8, 512), (6000, 5, 3), (8000, 2, 2)])
+def test_agc_chain_takes_the_waterfall_along(js, oracle, n, b, h):
+    """agc -> amplitude -> range -> waterfall as ONE launch (ingest_modules.cc TryFuseAgcChain): the block's output, the AGC's
+    own output and the Waterfall's ring + cursor after several cycles equal the module-by-module submission and the oracle
+    (waterfall/ring_state.hh:16-56) -- also with fewer ring rows than batches (h < b: only the newest rows are kept)."""
+    rng = np.random.default_rng(n + h)
+    xs = [(rng.standard_normal((b, n)) + 1j * rng.standard_normal((b, n))).astype(np.complex64) * np.float32(0.1 * (c + 1)) for c in range(4)]
+    rings = {}
+    for fuse in (False, True):
+        src = js.Tensor.from_numpy(xs[0], sample=1, batch=0)
+        eng = js.SpectrumEngine(src, enable_scale=True, range_min=-100.0, range_max=0.0, enable_agc=True)
+        wf = js.Module("waterfall", {"height": h}, {"signal": eng.buffer}, "wf")
+        rt = js.Runtime(eng.modules + [wf], graph=True, fuse=fuse)
+        assert any(u.startswith("agc_amplitude_range_waterfall(") for u in rt.units) == fuse, rt.units
+        bins = np.zeros((h, n), np.float32)
+        wstate = [0, 0]
+        for c, x in enumerate(xs):
+            src.copy_from(x)
+            rt.compute(1 if c % 2 else 2)
+            want, level = _oracle(oracle, x)
+            for _ in range(1 if c % 2 else 2):
+                wstate = oracle.waterfall(bins, wstate, want, h)
+            assert_bit_equal(eng.buffer.numpy(), want, f"block output, input {c} (fuse={fuse})")
+            assert_bit_equal(eng.agc.output("signal").numpy(), level, f"AGC output, input {c} (fuse={fuse})")
+            assert_bit_equal(wf.state("frequencyBins").numpy().reshape(h, n), bins, f"waterfall ring, input {c} (fuse={fuse})")
+        rings[fuse] = (wf.state("frequencyBins").numpy().copy(), wf.state("ringState").numpy().copy())
+        rt.destroy()
+    assert_bit_equal(rings[True][0], rings[False][0], "ring: fused vs module by module")
+    assert np.array_equal(rings[True][1][:2], rings[False][1][:2]), "ring cursor / dirty rows"

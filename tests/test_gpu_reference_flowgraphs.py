@@ -69,8 +69,7 @@ def test_multi_fm_example(js, oracle):
     assert plan["convolutionSize"] == 8050 and js.fft_path(8050) == "tile" and js.fft_path(805) == "tile"
     assert any(u.startswith("fft_padded_fold(") for u in rt.units), rt.units
     assert any(u.startswith("ifft_phase_unpad_overlap(") for u in rt.units), rt.units
-    # independent chains behind the source: the captured cycle is a graph with parallel branches (jst/module.cc planBranches)
-    assert rt.branches > 1
+    assert rt.branches == 1  # one chain by default; the branch-parallel capture is test_multi_fm_example_on_parallel_branches
     state, lane = {}, oracle.FmLane("narrow", "none", 200e3)
     wide = oracle.spectrum_chain(x, -81.0, 1.0)["range"]
     avg = np.zeros(s, np.float32)
@@ -93,3 +92,32 @@ def test_multi_fm_example(js, oracle):
     got_audio = fg.output("fm", "signal").numpy()
     assert_bit_equal(got_audio.reshape(-1), np.asarray(audio, np.float32).reshape(-1), "fm audio (bit-exact)")
     rt.destroy()
+
+
+def test_multi_fm_example_on_parallel_branches(js, oracle, monkeypatch):
+    """JST_RUNTIME_MAX_BRANCHES=4 (jst/module.cc planBranches): the same flowgraph captured as a hipGraph with forks and joins
+    -- the wide-band engine, the Filter and the two station chains on their own capture streams -- leaves the bytes of the
+    serial chain in every sink, cycle after cycle (opt-in: measured slower than one chain on this ROCm)."""
+    from cyberether_amd.flowgraph import Flowgraph
+    rng = np.random.default_rng(8)
+    xs = [csignal(rng, (8, 8000), 0.05) for _ in range(3)]
+    sinks = {}
+    for branches in ("1", "4"):
+        monkeypatch.setenv("JST_RUNTIME_MAX_BRANCHES", branches)
+        fg = Flowgraph(os.path.join(FIXTURES, "multi-fm.yml"), ring_slots=1)
+        rt = fg.runtime(graph=True, fuse=True)
+        assert rt.branches == (1 if branches == "1" else 4)
+        out = []
+        for x in xs:
+            fg.feed("soapy", x)
+            rt.compute(2)
+            out.append([fg.output("fm", "signal").numpy().copy(), fg.output("spe23", "buffer").numpy().copy(),
+                        fg.output("spectrum_engine", "buffer").numpy().copy(), fg.output("spe33", "buffer").numpy().copy(),
+                        fg.module("lineplot").state("averagingBuffer").numpy().copy(),
+                        fg.module("waterfall").state("frequencyBins").numpy().copy(),
+                        fg.module("wtf_output").state("frequencyBins").numpy().copy()])
+        sinks[branches] = out
+        rt.destroy()
+    for c, (a, b) in enumerate(zip(sinks["1"], sinks["4"])):
+        for i, (u, v) in enumerate(zip(a, b)):
+            assert_bit_equal(v, u, f"input {c}, sink {i}: branches vs one chain")

@@ -179,3 +179,43 @@ def test_no_upload_lands_in_a_slot_its_cycle_is_still_reading(js, oracle):
         assert np.all(rows[k] == want), f"batch {k}: {np.unique(rows[k])[:4]} instead of {want}"
     assert src.ring_overflows > 0          # the producer did run ahead: the ring was full at times
     rt.destroy()
+
+
+def test_a_cycle_that_ends_early_still_closes_its_slot(js):
+    """a cycle that ends in YIELD behind the source's computeSubmit (here: a SECOND live source without
+    data) used to leave the first source's slot waiting for a completion nobody recorded -- the producer's next push to
+    that slot sat out the 200 ms timeout.  The runtime now closes the cycle on its early returns (jst/module.cc submitAll)."""
+    n, b = 1024, 2
+    a = js.Module("ring_source", {"batches": b, "samples": n, "slots": 1, "live": True}, {}, "a")
+    bsrc = js.Module("ring_source", {"batches": b, "samples": n, "slots": 1, "live": True}, {}, "b")
+    amp_a = js.Module("amplitude", {}, {"signal": a.output("buffer")}, "amp_a")
+    amp_b = js.Module("amplitude", {}, {"signal": bsrc.output("buffer")}, "amp_b")
+    rt = js.Runtime([a, bsrc, amp_a, amp_b])
+    x = np.ones((b, n), np.complex64)
+    assert a.ring_push(x) == "success"
+    assert rt.compute(1) == "yield"       # `a` took its slot, `b` has nothing: the cycle ends there
+    rt.synchronize()
+    t0 = time.perf_counter()
+    assert a.ring_push(x) == "success"    # the only slot again
+    assert time.perf_counter() - t0 < 0.1, "the push waited for a cycle that had already ended"
+    rt.destroy()
+
+
+def test_clear_while_a_push_waits_for_its_slot(js):
+    """publishStagedBatch releases the ring's mutex while it waits for the slot's cycle to close; a
+    ringClear() in that window resets what it computed before.  The staged batch must go with the rest of the ring
+    (nothing uploaded, nothing counted), and the ring must keep working afterwards."""
+    n, b = 1024, 2
+    src, out = make(js, b, n, 1)
+    amp = js.Module("amplitude", {}, {"signal": out}, "amp")
+    rt = js.Runtime([src, amp])
+    x = np.full((b, n), 3, np.complex64)
+    assert src.ring_push(x) == "success"
+    assert src.ring_size == b * n
+    src.ring_clear()
+    assert src.ring_size == 0 and rt.compute(1) == "yield"
+    y = np.full((b, n), 5, np.complex64)
+    assert src.ring_push(y) == "success" and rt.compute(1) == "success"
+    got = amp.output("signal").numpy()
+    assert np.all(got == got[0, 0]) and got[0, 0] != 0
+    rt.destroy()
