@@ -158,7 +158,25 @@ constexpr int plan_factors_ce(uint64_t n, uint32_t* fact) {
 // The plan as a constant expression: the generic launch path calls it at run time (with the A/B lane overrides), the
 // per-plan specialisations evaluate it at compile time (static_plan below) and the kernels then see every radix,
 // stride, shift and magic number as a literal.
-constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_ca, uint32_t force_cb, TiledPlan& p) {
+constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_ca, uint32_t force_cb, TiledPlan& p, bool,
+                                bool force_two);
+// split_small: a transform that WOULD fit one tile (n <= 8192) still takes the two-kernel form when there are too few
+// transforms to fill the chip with one workgroup each -- 8 x 8000 points (the reference's multi-fm.yml) is 8 workgroups of
+// one 8000-point transform each, 18.8 us; as column + block workgroups the same passes (same order, same bits) take two
+// short launches.  Not for the fold epilogue (its lane groups are planned for the one-kernel form of such lengths).
+constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_ca, uint32_t force_cb, TiledPlan& p,
+                                bool split_small = false) {
+    if (split_small && n <= kTileElems && n >= 4096 && transforms != 0 && transforms <= 32) {
+        TiledPlan two{};
+        if (build_tiled_plan(n, transforms, force_ca, force_cb, two, false, true)) {
+            p = two;
+            return true;
+        }
+    }
+    return build_tiled_plan(n, transforms, force_ca, force_cb, p, false, false);
+}
+constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_ca, uint32_t force_cb, TiledPlan& p, bool,
+                                bool force_two) {
     if (n < 2 || n > (1ull << 26)) return false;
     uint32_t fact[64] = {};
     const int nf = plan_factors_ce(n, fact);
@@ -172,7 +190,7 @@ constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_
     p.nf = (uint32_t)nf;
     for (int i = 0; i < nf; ++i) p.fact[i] = fact[i];
     if (transforms == 0) transforms = 1;
-    if (n <= kTileElems) {  // one kernel, whole transforms per workgroup
+    if (n <= kTileElems && !force_two) {  // one kernel, whole transforms per workgroup
         p.g = 0;
         p.R1 = 1;
         p.S = (uint32_t)n;
@@ -243,7 +261,13 @@ inline bool generic_radix_tiles_enabled() {
     return on;
 }
 
-bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
+// JST_TILED_SPLIT=0: A/B switch, lengths that fit a tile always run as one kernel
+inline bool small_split_enabled() {
+    static const bool on = [] { const char* e = getenv("JST_TILED_SPLIT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p, bool allow_split = true) {
     constexpr uint32_t force_ca = 0, force_cb = 0;  // lanes per workgroup of the two kernels: picked below
     // Lane counts measured per plan with the specialised kernels (rocprofv3, profiles/r03_experiments/k_static_plan_lanes.log):
     // config 5's columns kernel 9.4 -> 7.8 us with 16 columns per workgroup instead of pick_lanes' 8 (128-byte instead of
@@ -259,7 +283,7 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p) {
             ca = 32;
         }
     }
-    if (!build_tiled_plan(n, transforms, ca, cb, p)) return false;
+    if (!build_tiled_plan(n, transforms, ca, cb, p, allow_split && small_split_enabled())) return false;
     if (!generic_radix_tiles_enabled())
         for (uint32_t q = 0; q < p.nf; ++q)
             if (is_generic_radix(p.fact[q])) return false;
@@ -1098,9 +1122,13 @@ bool fft_tiled_supported(uint64_t n) {
     TiledPlan p;
     return make_tiled_plan(n, 1, p);
 }
-bool fft_tiled_needs_scratch(uint64_t n) {
+bool fft_tiled_needs_scratch(uint64_t n) {  // two kernels whatever the transform count
     TiledPlan p;
-    return make_tiled_plan(n, 1, p) && p.g > 0;
+    return make_tiled_plan(n, 1, p, false) && p.g > 0;
+}
+bool fft_tiled_may_use_scratch(uint64_t n) {  // ... or for a handful of transforms only (build_tiled_plan: split_small)
+    TiledPlan p;
+    return make_tiled_plan(n, 1, p, true) && p.g > 0;
 }
 
 hipError_t launch_fft_c2c_tiled(uint64_t n, bool forward, const FftLayout& L, const float2* W,
@@ -1130,14 +1158,14 @@ hipError_t launch_fft_c2c_tiled_padded(uint64_t n, uint64_t valid, bool forward,
 
 bool fft_tiled_fold_supported(uint64_t n, uint64_t transforms, uint64_t fold) {
     TiledPlan p;
-    return make_tiled_plan(n, transforms, p) && plan_fold_groups(p, fold);
+    return make_tiled_plan(n, transforms, p, false) && plan_fold_groups(p, fold);
 }
 
 hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,
                                             const float2* W, const float2* in, float2* scratch,
                                             const FoldProductArgs& f, hipStream_t s) {
     TiledPlan p;
-    if (valid > n || !make_tiled_plan(n, L.transforms, p) || !plan_fold_groups(p, f.fold)) return hipErrorInvalidValue;
+    if (valid > n || !make_tiled_plan(n, L.transforms, p, false) || !plan_fold_groups(p, f.fold)) return hipErrorInvalidValue;
     FoldProductEpi epi{f.out, f.h, f.h_stride, (uint32_t)f.fold, (uint32_t)(n / f.fold), (uint32_t)(f.offset % n),
                        f.chan_offsets, (uint32_t)f.chan_count, (uint32_t)f.chan_div, f.spectrum_first, 0, 0, 0, 0,
                        (uint32_t)(f.heads ? f.heads : 1), f.h_head_stride};

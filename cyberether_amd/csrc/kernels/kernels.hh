@@ -86,12 +86,14 @@ hipError_t launch_fft_c2c_global(uint64_t n, bool forward, const FftLayout& L, c
                                  float2* scratch_b, float2* scratch_h, hipStream_t stream);
 // LDS-tiled mixed-radix path (fft_tiled.hip): plans with radices <= 11; one kernel when a
 // transform fits an LDS tile (n <= 8192), two kernels (columns, then blocks) up to 2^26 points.
-// scratch: dense CF32[transforms * n], needed when fft_tiled_needs_scratch(n).
+// scratch: dense CF32[transforms * n], needed when fft_tiled_may_use_scratch(n).
 // NOTE: the tiled launchers take the PER-PASS twiddle table (fft_pass_twiddle_*), not W.
 uint64_t fft_pass_twiddle_count(uint64_t n);
 void fft_pass_twiddle_fill(uint64_t n, const float* w_interleaved, float* out_interleaved);
 bool fft_tiled_supported(uint64_t n);
 bool fft_tiled_needs_scratch(uint64_t n);
+// true also for lengths that fit one tile but run as columns + blocks kernels when a launch has only a few transforms
+bool fft_tiled_may_use_scratch(uint64_t n);
 hipError_t launch_fft_c2c_tiled(uint64_t n, bool forward, const FftLayout& L, const float2* W,
                                 const float2* in, float2* out, float2* scratch, hipStream_t stream);
 // Pad (zeros appended along the transform axis) fused into the first load: `in` is the UNPADDED

@@ -679,7 +679,7 @@ Result Fft::computeInitialize() {
     useTiled = !kernels::fft_lds_supported(m) && kernels::fft_tiled_supported(m);
     if (useTiled) JST_CHECK(GetPassTwiddles(m, &twiddles));  // the tiled kernels' table layout
     useGlobalPasses = !kernels::fft_lds_supported(m) && !useTiled;
-    if (useTiled && kernels::fft_tiled_needs_scratch(m))
+    if (useTiled && kernels::fft_tiled_may_use_scratch(m))
         JST_CHECK(scratchA.create(device(), DataType::CF32, {transforms * m}));
     if (useGlobalPasses) {  // ping-pong scratch for the pass-per-launch path
         uint32_t fact[64];
