@@ -48,11 +48,44 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) {
     return (v < lo) ? lo : ((hi < v) ? hi : v);  // std::clamp
 }
 
+// The tile's power, summed in SAMPLE ORDER by one thread (agc/module_impl_native_cpu.cc: a plain F64 accumulation; no other
+// order gives the reference's bits).  What can be taken off the chain is everything but the additions: sixteen addends come
+// out of LDS as eight 16-byte reads issued one block AHEAD of the additions that consume them, so the chain runs at the F64
+// add latency instead of an LDS round trip per eight elements (a lane of 805 samples: ~6 us -> ~3 us of the kernel's 11).
+__device__ __forceinline__ double ordered_sum(const double* powers, uint64_t n, double sum) {
+    const double2* pw = reinterpret_cast<const double2*>(powers);
+    const uint64_t nb = n / 16;  // whole blocks of sixteen addends
+    double2 a[8], c[8];
+    auto load = [&](double2 (&dst)[8], uint64_t block) {  // (a block index past the end re-reads the last block: never added)
+        const double2* q = pw + (block < nb ? block : nb - 1) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = q[k];
+    };
+    auto add = [&](const double2 (&src)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sum += src[k].x;
+            sum += src[k].y;
+        }
+    };
+    uint64_t blk = 0;
+    if (nb > 0) load(a, 0);
+    for (; blk + 2 <= nb; blk += 2) {  // two register sets in turn: no copies, the loads of one set fly over the other's additions
+        load(c, blk + 1);
+        add(a);
+        load(a, blk + 2);
+        add(c);
+    }
+    if (blk < nb) add(a);  // an odd number of blocks: the last one is in `a`
+    for (uint64_t i = nb * 16; i < n; ++i) sum += powers[i];
+    return sum;
+}
+
 template <class T>
 __global__ __launch_bounds__(kBlock) void agc_power_kernel(const AgcParams p,
                                                            const T* __restrict__ in,
                                                            double* __restrict__ gains) {
-    __shared__ double powers[kChunk];
+    __shared__ __attribute__((aligned(16))) double powers[kChunk];
     const uint64_t lane = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
     int64_t in_base, out_base;
     lane_bases(p, lane, in_base, out_base);
@@ -64,10 +97,7 @@ __global__ __launch_bounds__(kBlock) void agc_power_kernel(const AgcParams p,
         for (uint64_t i = threadIdx.x; i < n; i += kBlock)
             powers[i] = sample_power(in[in_base + (int64_t)(start + c0 + i) * p.in_sample_stride]);
         __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll 8
-            for (uint64_t i = 0; i < n; ++i) sum += powers[i];
-        }
+        if (threadIdx.x == 0) sum = ordered_sum(powers, n, sum);
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -145,10 +175,12 @@ __global__ __launch_bounds__(kBlock) void agc_apply_kernel(const AgcParams p, T*
 // spectrum_engine/block_impl.cc:186-190).  start = end = raw(0): no gain ramp and no neighbour tile to look at, so the
 // workgroup that summed the tile's power applies the gain to it right away -- same F64 operations in the same order as the
 // three kernels below (power in sample order, then ApplyGain with step = (g - g) / len = +0 and gain = g + 0 * k = g).
+constexpr int kSingleThreads = 1024;  // a lane of the spectrum_engine's AGC is one spectrum: one or two samples per thread
 template <class T, bool TAIL = false>
-__global__ __launch_bounds__(kBlock) void agc_single_tile_kernel(const AgcParams p, T* __restrict__ out, const T* __restrict__ in,
-                                                                 double* __restrict__ gains, const AgcTail tail = AgcTail{}) {
-    __shared__ double powers[kChunk];
+__global__ __launch_bounds__(kSingleThreads) void agc_single_tile_kernel(const AgcParams p, T* __restrict__ out, const T* __restrict__ in,
+                                                                         double* __restrict__ gains, const AgcTail tail = AgcTail{}) {
+    constexpr int kPer = kChunk / kSingleThreads;  // samples per thread and chunk
+    __shared__ __attribute__((aligned(16))) double powers[kChunk];
     __shared__ double tile_gain;
     const uint64_t lane = blockIdx.x;
     // TAIL with a Waterfall: the ring cursor as waterfall_kernel reads it (kernels/waterfall.hip; PlanWaterfallWrite,
@@ -159,16 +191,26 @@ __global__ __launch_bounds__(kBlock) void agc_single_tile_kernel(const AgcParams
     int64_t in_base, out_base;
     lane_bases(p, lane, in_base, out_base);
     const uint64_t len = p.samples;
+    // a lane of at most one chunk (2048 samples) is read ONCE: the samples wait in registers for the gain
+    const bool resident = len <= (uint64_t)kChunk;
+    T held[kPer];
     double sum = 0.0;
     for (uint64_t c0 = 0; c0 < len; c0 += kChunk) {
         const uint64_t n = (len - c0 < (uint64_t)kChunk) ? (len - c0) : (uint64_t)kChunk;
-        for (uint64_t i = threadIdx.x; i < n; i += kBlock)
-            powers[i] = sample_power(in[in_base + (int64_t)(c0 + i) * p.in_sample_stride]);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll 8
-            for (uint64_t i = 0; i < n; ++i) sum += powers[i];
+        T v[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {  // all of a thread's loads first
+            const uint64_t i = threadIdx.x + (uint64_t)j * kSingleThreads;
+            v[j] = in[in_base + (int64_t)(c0 + (i < n ? i : 0)) * p.in_sample_stride];
         }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const uint64_t i = threadIdx.x + (uint64_t)j * kSingleThreads;
+            if (i < n) powers[i] = sample_power(v[j]);
+            held[j] = v[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sum = ordered_sum(powers, n, sum);
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -181,28 +223,37 @@ __global__ __launch_bounds__(kBlock) void agc_single_tile_kernel(const AgcParams
     __syncthreads();
     const double g0 = tile_gain;
     const double step = (g0 - g0) / (double)len;
-    if constexpr (!TAIL) {
-        for (uint64_t k = threadIdx.x; k < len; k += kBlock) {
-            const double gain = g0 + step * (double)k;
-            out[out_base + (int64_t)k * p.out_sample_stride] = apply_gain(in[in_base + (int64_t)k * p.in_sample_stride], gain);
-        }
-    } else {
-        const uint64_t batches = p.lanes, height = tail.height;
-        const uint64_t retained = tail.ring ? (batches < height ? batches : height) : 0;
-        const uint64_t source_row = batches - retained;
-        const bool kept = tail.ring && lane >= source_row;
-        float* ring_row = nullptr;
-        if (kept) ring_row = tail.ring + ((write_index + (source_row % height)) % height + (lane - source_row)) % height * len;
-        float* level_row = tail.level + lane * len;
-        for (uint64_t k = threadIdx.x; k < len; k += kBlock) {
-            const double gain = g0 + step * (double)k;
-            const T y = apply_gain(in[in_base + (int64_t)k * p.in_sample_stride], gain);
+    // TAIL
+    const uint64_t batches = p.lanes, height = tail.height;
+    const uint64_t retained = (TAIL && tail.ring) ? (batches < height ? batches : height) : 0;
+    const uint64_t source_row = batches - retained;
+    const bool kept = TAIL && tail.ring && lane >= source_row;
+    float* ring_row = nullptr;
+    if (kept) ring_row = tail.ring + ((write_index + (source_row % height)) % height + (lane - source_row)) % height * len;
+    float* level_row = TAIL ? tail.level + lane * len : nullptr;
+    auto finish = [&](uint64_t k, T x) {
+        const double gain = g0 + step * (double)k;
+        const T y = apply_gain(x, gain);
+        if constexpr (!TAIL) {
+            out[out_base + (int64_t)k * p.out_sample_stride] = y;
+        } else {
             if (out) out[out_base + (int64_t)k * p.out_sample_stride] = y;
             const float level = tail.fast ? jst::dev::range_f32_fast(jst::dev::amplitude_cf32_fast(y, tail.coeff), tail.scale, tail.offset)
                                           : jst::dev::range_f32(jst::dev::amplitude_exact(y, tail.coeff), tail.scale, tail.offset);
             level_row[k] = level;
             if (kept) ring_row[k] = level;
         }
+    };
+    if (resident) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const uint64_t k = threadIdx.x + (uint64_t)j * kSingleThreads;
+            if (k < len) finish(k, held[j]);
+        }
+    } else {
+        for (uint64_t k = threadIdx.x; k < len; k += kSingleThreads) finish(k, in[in_base + (int64_t)k * p.in_sample_stride]);
+    }
+    if constexpr (TAIL) {
         if (tail.ring) {
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -227,7 +278,7 @@ hipError_t run(T* out, const T* in, double* gains, const AgcParams& p, hipStream
     (void)hipGetLastError();
     static const bool three_kernels = getenv("JST_AGC_THREE_KERNELS") != nullptr;  // A/B and tests
     if (p.tiles == 1 && !three_kernels) {
-        hipLaunchKernelGGL((agc_single_tile_kernel<T, false>), dim3((unsigned)p.lanes), dim3(kBlock), 0, s, p, out, in, gains, AgcTail{});
+        hipLaunchKernelGGL((agc_single_tile_kernel<T, false>), dim3((unsigned)p.lanes), dim3(kSingleThreads), 0, s, p, out, in, gains, AgcTail{});
         return hipGetLastError();
     }
     hipLaunchKernelGGL((agc_power_kernel<T>), dim3((unsigned)(p.lanes * p.tiles)), dim3(kBlock), 0,
@@ -248,7 +299,7 @@ hipError_t launch_agc_tail(void* out, const void* in, double* gains, const AgcPa
     if (p.tiles != 1 || p.lanes == 0 || p.samples == 0 || p.lanes > 0x7fffffffull || !tail.level || (tail.ring && (!tail.ring_state || tail.height == 0)))
         return hipErrorInvalidValue;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((agc_single_tile_kernel<float2, true>), dim3((unsigned)p.lanes), dim3(kBlock), 0, s, p, static_cast<float2*>(out),
+    hipLaunchKernelGGL((agc_single_tile_kernel<float2, true>), dim3((unsigned)p.lanes), dim3(kSingleThreads), 0, s, p, static_cast<float2*>(out),
                        static_cast<const float2*>(in), gains, tail);
     return hipGetLastError();
 }

@@ -159,7 +159,7 @@ constexpr int plan_factors_ce(uint64_t n, uint32_t* fact) {
 // per-plan specialisations evaluate it at compile time (static_plan below) and the kernels then see every radix,
 // stride, shift and magic number as a literal.
 constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_ca, uint32_t force_cb, TiledPlan& p, bool,
-                                bool force_two);
+                                bool force_two, uint32_t force_g = 0);
 // split_small: a transform that WOULD fit one tile (n <= 8192) still takes the two-kernel form when there are too few
 // transforms to fill the chip with one workgroup each -- 8 x 8000 points (the reference's multi-fm.yml) is 8 workgroups of
 // one 8000-point transform each, 18.8 us; as column + block workgroups the same passes (same order, same bits) take two
@@ -176,7 +176,7 @@ constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_
     return build_tiled_plan(n, transforms, force_ca, force_cb, p, false, false);
 }
 constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_ca, uint32_t force_cb, TiledPlan& p, bool,
-                                bool force_two) {
+                                bool force_two, uint32_t force_g) {
     if (n < 2 || n > (1ull << 26)) return false;
     uint32_t fact[64] = {};
     const int nf = plan_factors_ce(n, fact);
@@ -206,6 +206,12 @@ constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_
         for (int g = 1; g < nf; ++g) {
             r1 *= fact[g - 1];
             const uint64_t s = n / r1;
+            if (force_g) {  // the caller names the split (and the lanes): only the tile bound is checked here
+                if ((uint32_t)g != force_g || r1 * (force_ca ? force_ca : 8) > kTileElems || s * (force_cb ? force_cb : 8) > kTileElems)
+                    continue;
+                best = (uint32_t)g;
+                break;
+            }
             if (r1 * 8 > kTileElems || s * 8 > kTileElems) continue;
             const double score = r1 > s ? (double)r1 / (double)s : (double)s / (double)r1;
             if (score < best_score) {
@@ -1156,16 +1162,47 @@ hipError_t launch_fft_c2c_tiled_padded(uint64_t n, uint64_t valid, bool forward,
     return dispatch_dir(forward, p, L, W, LoadCF32Padded{in, (uint32_t)valid}, StoreCF32{out}, scratch, s);
 }
 
+// The plan of a transform with the fold epilogue.  Lengths beyond a tile: the balanced split, as everywhere.  A length that
+// fits one tile with only a handful of transforms (the reference's multi-fm.yml: 8 x 8050 points folded to 805 -- eight
+// workgroups, 29.7 us): the split and the block lanes are SEARCHED for a pair the fold's alias orbits allow
+// (plan_fold_groups: 8050 = 10 x 805 with two blocks per workgroup, 40 block workgroups), the one with the most block
+// workgroups -- up to 128, then the largest tile -- wins; none: one kernel.
+bool make_tiled_fold_plan(uint64_t n, uint64_t transforms, uint64_t fold, TiledPlan& p) {
+    if (small_split_enabled() && generic_radix_tiles_enabled() && n <= kTileElems && n >= 4096 && transforms != 0 && transforms <= 32) {
+        uint32_t fact[64] = {};
+        const int nf = plan_factors_ce(n, fact);
+        uint64_t best_groups = 0;
+        TiledPlan best{};
+        for (int g = 1; g < nf; ++g)
+            for (uint32_t cb = 2; cb <= 32; cb *= 2) {
+                TiledPlan q{};
+                if (!build_tiled_plan(n, transforms, 0, cb, q, false, true, (uint32_t)g) || !plan_fold_groups(q, fold)) continue;
+                uint64_t groups = transforms * ((q.R1 + q.CB - 1) / q.CB);
+                if (groups <= transforms) continue;  // no more workgroups than the one-kernel form has
+                if (groups > 128) groups = 128;      // enough to fill the chip: beyond that, the larger tile (later, larger cb)
+                if (groups >= best_groups) {
+                    best_groups = groups;
+                    best = q;
+                }
+            }
+        if (best_groups) {
+            p = best;
+            return true;
+        }
+    }
+    return make_tiled_plan(n, transforms, p, false) && plan_fold_groups(p, fold);
+}
+
 bool fft_tiled_fold_supported(uint64_t n, uint64_t transforms, uint64_t fold) {
     TiledPlan p;
-    return make_tiled_plan(n, transforms, p, false) && plan_fold_groups(p, fold);
+    return make_tiled_fold_plan(n, transforms, fold, p);
 }
 
 hipError_t launch_fft_c2c_tiled_padded_fold(uint64_t n, uint64_t valid, bool forward, const FftLayout& L,
                                             const float2* W, const float2* in, float2* scratch,
                                             const FoldProductArgs& f, hipStream_t s) {
     TiledPlan p;
-    if (valid > n || !make_tiled_plan(n, L.transforms, p, false) || !plan_fold_groups(p, f.fold)) return hipErrorInvalidValue;
+    if (valid > n || !make_tiled_fold_plan(n, L.transforms, f.fold, p)) return hipErrorInvalidValue;
     FoldProductEpi epi{f.out, f.h, f.h_stride, (uint32_t)f.fold, (uint32_t)(n / f.fold), (uint32_t)(f.offset % n),
                        f.chan_offsets, (uint32_t)f.chan_count, (uint32_t)f.chan_div, f.spectrum_first, 0, 0, 0, 0,
                        (uint32_t)(f.heads ? f.heads : 1), f.h_head_stride};
