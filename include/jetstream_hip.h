@@ -278,10 +278,14 @@ jst_result jst_filter_plan(float sample_rate, float bandwidth, const float* cent
  *                                       (any number of heads: one operand row and one fold offset per head) and
  *                                       the fold's aliases fit one workgroup: neither the spectrum nor the
  *                                       product is written
- *       fft{forward=false} -> multiply_constant -> unpad -> overlap_add     ONE unit "ifft_unpad_overlap(..)" (tiled
- *                                       transform, no phase_correction in between): scale and body / tail split on
- *                                       the transform's last store, one small kernel for the overlap region + state
- *       [multiply_constant -> phase_correction ->] unpad -> overlap_add otherwise
+ *       fft{forward=false} -> multiply_constant [-> phase_correction] -> unpad -> overlap_add     ONE unit
+ *                                       "ifft_unpad_overlap(..)" / "ifft_phase_unpad_overlap(..)" (tiled transform): scale,
+ *                                       phase correction and body / tail split on the transform's last store, one small
+ *                                       kernel for the overlap region + state (+ the next cycle's correction table)
+ *       multiply_constant [-> phase_correction] -> unpad -> overlap_add as modules otherwise
+ *   around an AGC (spectrum_engine with enableAgc): multiply -> fft "fft_windowed(..)", and
+ *       agc (one tile per lane) -> amplitude -> range [-> waterfall]  ONE unit "agc_amplitude_range[_waterfall](..)";
+ *       amplitude -> range on their own: "amplitude_range(..)"
  *     provider "fast" on a single head centred on 0 Hz replaces the whole chain by fir_taps + fir_decimate.
  * jst_runtime_units reports what was fused. */
 jst_result jst_runtime_create(const jst_module* modules, uint32_t n, uint32_t flags,
