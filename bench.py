@@ -442,14 +442,19 @@ def main() -> None:
         rt.compute((-args.steps) % period, sync=True)
         rt.reset_timing()
 
+        sync_in_compute = os.environ.get("JST_BENCH_SYNC_IN_COMPUTE") == "1"
+
         def region() -> float:
             """EXACTLY K steps bracketed by barrier + synchronize on both sides; max over ranks."""
             torch.cuda.synchronize()
             barrier()
             t0 = time.perf_counter()
-            rt.compute(args.steps, sync=True)   # submit + hipStreamSynchronize of the runtime's stream in one call
+            # submit, then ONE device-wide wait: torch.cuda.synchronize() covers the runtime's stream too (a second
+            # hipStreamSynchronize inside compute() cost ~0.1 us per step of a 20-step region; JST_BENCH_SYNC_IN_COMPUTE=1: A/B)
+            rt.compute(args.steps, sync=sync_in_compute)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
+            rt.synchronize()   # untimed: the unit timers of the region's eager cycles are harvested here
             barrier()
             if world > 1:
                 t = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
