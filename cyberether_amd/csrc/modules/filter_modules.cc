@@ -1577,7 +1577,7 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
             // the (batch, channel) cell of a TRANSFORM: both axes in front of the transform axis
             const U64 n = fft->input.shape(axis);
             if ((phase->batchAxis && *phase->batchAxis == axis) || (phase->channelAxis && *phase->channelAxis == axis)) return false;
-            if (phase->batchInner % n || phase->channelInner % n) return false;
+            if ((phase->batchAxis && phase->batchInner % n) || (phase->channelAxis && phase->channelInner % n)) return false;
             batchDiv = phase->batchAxis ? phase->batchInner / n : 1;
             chanDiv = phase->channelAxis ? phase->channelInner / n : 1;
             if ((fft->input.size() / n) >> 32) return false;
