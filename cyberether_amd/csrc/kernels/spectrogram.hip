@@ -675,17 +675,26 @@ hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64
     }
     constexpr int copies = 2;
     const size_t lds = ((size_t)height * 16 + 16) * (size_t)copies * sizeof(uint32_t);
-#define JST_SPEC_SPAN(COPIES, PAIRED)                                                                                            \
+#define JST_SPEC_SPAN(COPIES, PAIRED, THREADS)                                                                                       \
     do {                                                                                                                         \
-        const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(spectrogram_index_span_kernel<COPIES, 1024, PAIRED>), \
+        const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(spectrogram_index_span_kernel<COPIES, THREADS, PAIRED>), \
                                                80 * 1024);                                                                       \
         if (e != hipSuccess) return e;                                                                                           \
-        hipLaunchKernelGGL((spectrogram_index_span_kernel<COPIES, 1024, PAIRED>), dim3((unsigned)(width / 16)), dim3(1024), lds,  \
+        hipLaunchKernelGGL((spectrogram_index_span_kernel<COPIES, THREADS, PAIRED>), dim3((unsigned)(width / 16)), dim3(THREADS), lds, \
                            stream, bins, idx, (uint32_t)batches, (uint32_t)pitch, (uint32_t)width, (uint32_t)height,             \
                            decay, (uint32_t)cycles, (uint32_t)first_slot, (uint32_t)ring_slots JST_SPAN_TL_ARG);                \
     } while (0)
-    if (batches < 65536 && cycles > 1 && !(which && which[0] == '2')) JST_SPEC_SPAN(2, true);
-    else JST_SPEC_SPAN(2, false);
+    // JST_SPAN_THREADS (A/B): threads per workgroup of the paired form -- 1024: 34.3 us per 20-cycle span, 512: 44.5, 256: 68.3
+    // (profiles/r05_experiments/w_span_threads.log): the 4096 wavefronts take ~12 us to start, but the tile's work needs them
+    const char* th = getenv("JST_SPAN_THREADS");
+    const int threads = th ? atoi(th) : 1024;
+    if (batches < 65536 && cycles > 1 && !(which && which[0] == '2')) {
+        if (threads == 512) JST_SPEC_SPAN(2, true, 512);
+        else if (threads == 256) JST_SPEC_SPAN(2, true, 256);
+        else JST_SPEC_SPAN(2, true, 1024);
+    } else {
+        JST_SPEC_SPAN(2, false, 1024);
+    }
 #undef JST_SPEC_SPAN
     return hipGetLastError();
 }
