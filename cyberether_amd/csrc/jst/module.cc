@@ -409,6 +409,7 @@ bool Runtime::tryFuseSpectrum(size_t at, Unit& unit, size_t& consumed) {
            modules::TryFuseFilter(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
            modules::TryFuseMultiplyFft(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
            modules::TryFuseAgcChain(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
+           modules::TryElideDuplicate(ordered_, at, unit.name, unit.modules, unit.submit, consumed) ||
            modules::TryFuseAmplitudeRange(ordered_, at, unit.name, unit.modules, unit.submit, consumed);
 }
 

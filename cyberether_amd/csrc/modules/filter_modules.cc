@@ -1682,6 +1682,59 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
     return false;
 }
 
+// duplicate (the dense copy a `slice` block puts behind its view, core/slice/block_impl.cc with `contiguous: true`) whose EVERY
+// reader addresses its input through strides anyway -- a Multiply that fuses into `fft_windowed` (the transform's first load
+// walks the operand's strides) or an Fm (lane / batch / sample strides): the readers are pointed at the view itself and the copy
+// is not made.  The duplicate's own output tensor is then an intermediate nobody reads (the contract of every fusion here);
+// pointing a reader at the source is also right when a later, unfused runtime runs the copy again -- same bytes either way.
+// JST_NO_CHAIN_FUSION=1 keeps the copy.
+bool TryElideDuplicate(const std::vector<Module*>& ordered, size_t at, std::string& name, std::vector<Module*>& members,
+                       std::function<Result(hipStream_t)>& submit, size_t& consumed) {
+    static const bool off = std::getenv("JST_NO_CHAIN_FUSION") != nullptr;
+    auto* dup = dynamic_cast<Duplicate*>(ordered[at]);
+    if (off || !dup || dup->input.dtype() != DataType::CF32 || dup->input.shape() != dup->output.shape()) return false;
+    if (dup->input.storageId() == dup->output.storageId()) return false;
+    std::vector<Multiply*> muls;
+    std::vector<Fm*> fms;
+    for (size_t i = 0; i < ordered.size(); ++i) {
+        Module* m = ordered[i];
+        if (m == dup) continue;
+        if (const auto* c = dynamic_cast<const Cast*>(m); c && c->bypass) continue;  // a pure alias reads nothing
+        bool reads = false;
+        for (const auto& kv : m->inputs()) reads |= kv.second.storageId() == dup->output.storageId();
+        if (!reads) continue;
+        if (i < at) return false;
+        if (auto* mul = dynamic_cast<Multiply*>(m)) {
+            if (std::string(mul->type()) != "multiply" || mul->a.storageId() != dup->output.storageId() ||
+                mul->b.storageId() == dup->output.storageId() || mul->a.shape() != dup->output.shape() || mul->a.offset() != 0 ||
+                !mul->a.contiguous())
+                return false;
+            // (a chain multiply -> fft -> amplitude belongs to TryFuseSpectrum, which wants its dense operand: leave it alone)
+            if (i + 2 < ordered.size() && dynamic_cast<Amplitude*>(ordered[i + 2])) return false;
+            std::string n2;
+            std::vector<Module*> mem2;
+            std::function<Result(hipStream_t)> sub2;
+            size_t cons2 = 0;
+            if (!TryFuseMultiplyFft(ordered, i, n2, mem2, sub2, cons2)) return false;  // only the fused unit walks strides in its load
+            muls.push_back(mul);
+        } else if (auto* fm = dynamic_cast<Fm*>(m)) {
+            if (fm->input.storageId() != dup->output.storageId() || fm->input.shape() != dup->output.shape() || fm->input.offset() != 0)
+                return false;
+            fms.push_back(fm);
+        } else {
+            return false;
+        }
+    }
+    if (muls.empty() && fms.empty()) return false;  // nobody inside the runtime reads it: somebody outside may
+    for (Multiply* mul : muls) mul->a = dup->input;
+    for (Fm* fm : fms) fm->input = dup->input;
+    members = {dup};
+    consumed = 1;
+    name = dup->name() + "(elided)";
+    submit = [](hipStream_t) -> Result { return Result::SUCCESS; };
+    return true;
+}
+
 JST_REGISTER_MODULE(SignalGenerator, "signal_generator", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Lineplot, "lineplot", DeviceType::HIP, RuntimeType::NATIVE, "generic");
 JST_REGISTER_MODULE(Pad, "pad", DeviceType::HIP, RuntimeType::NATIVE, "generic");

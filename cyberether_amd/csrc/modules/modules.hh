@@ -52,6 +52,10 @@ bool TryFuseMultiplyFft(const std::vector<Module*>& ordered, size_t at, std::str
                         std::function<Result(hipStream_t)>& submit, size_t& consumed);
 bool TryFuseAmplitudeRange(const std::vector<Module*>& ordered, size_t at, std::string& name, std::vector<Module*>& members,
                            std::function<Result(hipStream_t)>& submit, size_t& consumed);
+// duplicate whose readers all walk strides themselves (fft_windowed's Multiply, Fm): the readers take the view, no copy
+// (filter_modules.cc).
+bool TryElideDuplicate(const std::vector<Module*>& ordered, size_t at, std::string& name, std::vector<Module*>& members,
+                       std::function<Result(hipStream_t)>& submit, size_t& consumed);
 // agc (one tile per lane) -> amplitude -> range [-> waterfall] in the AGC's launch (ingest_modules.cc).  Same contract.
 bool TryFuseAgcChain(const std::vector<Module*>& ordered, size_t at, std::string& name, std::vector<Module*>& members,
                      std::function<Result(hipStream_t)>& submit, size_t& consumed);

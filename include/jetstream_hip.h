@@ -286,6 +286,8 @@ jst_result jst_filter_plan(float sample_rate, float bandwidth, const float* cent
  *   around an AGC (spectrum_engine with enableAgc): multiply -> fft "fft_windowed(..)", and
  *       agc (one tile per lane) -> amplitude -> range [-> waterfall]  ONE unit "agc_amplitude_range[_waterfall](..)";
  *       amplitude -> range on their own: "amplitude_range(..)"
+ *   duplicate (the dense copy behind a `slice` block's view) whose every reader walks strides itself (the Multiply of an
+ *       "fft_windowed(..)", an fm): "<name>(elided)" -- the readers take the view, the copy's output tensor is not written
  *     provider "fast" on a single head centred on 0 Hz replaces the whole chain by fir_taps + fir_decimate.
  * jst_runtime_units reports what was fused. */
 jst_result jst_runtime_create(const jst_module* modules, uint32_t n, uint32_t flags,

@@ -160,3 +160,44 @@ def test_agc_chain_takes_the_waterfall_along(js, oracle, n, b, h):
         rt.destroy()
     assert_bit_equal(rings[True][0], rings[False][0], "ring: fused vs module by module")
     assert np.array_equal(rings[True][1][:2], rings[False][1][:2]), "ring cursor / dirty rows"
+
+
+def test_duplicate_is_elided_only_when_every_reader_walks_strides(js, oracle):
+    """A `slice` block's dense copy (slice -> duplicate) in front of an AGC spectrum engine and an fm (the reference's
+    multi-fm.yml): fused, the copy is not made -- `fft_windowed` and the fm read the view -- and the results are those of the
+    module-by-module run; with one more reader that wants the dense tensor (here a standalone amplitude) the copy stays and its
+    output is valid."""
+    rng = np.random.default_rng(77)
+    b, heads, n = 4, 2, 805
+    ph = np.cumsum(rng.uniform(-0.3, 0.3, b * heads * n)).reshape(b, heads, n)
+    x = (np.exp(1j * ph) * rng.uniform(0.2, 1.0, (b, heads, n))).astype(np.complex64)
+    results = {}
+    for extra_reader in (False, True):
+        for fuse in (False, True):
+            src = js.Tensor.from_numpy(x, batch=0, channel=1, sample=2)
+            sl = js.Module("slice", {"slice": "[:, 1, :]"}, {"buffer": src}, "st.slice")
+            dup = js.Module("duplicate", {}, {"buffer": sl.output("buffer")}, "st.duplicate")
+            station = dup.output("buffer")
+            eng = js.SpectrumEngine(station, enable_scale=True, range_min=-100.0, range_max=0.0, enable_agc=True)
+            fm = js.Module("fm", {"mode": "narrow", "deemphasis": "none", "sampleRate": 200e3}, {"signal": station}, "fm")
+            mods = [sl, dup] + eng.modules + [fm]
+            tap = None
+            if extra_reader:
+                tap = js.Module("amplitude", {}, {"signal": station}, "tap")
+                mods.append(tap)
+            rt = js.Runtime(mods, graph=True, fuse=fuse)
+            elided = any(u == "st.duplicate(elided)" for u in rt.units)
+            assert elided == (fuse and not extra_reader), rt.units
+            rt.compute(3)
+            results[(extra_reader, fuse)] = (eng.buffer.numpy().copy(), fm.output("signal").numpy().copy())
+            if not elided:
+                assert_bit_equal(station.numpy(), np.ascontiguousarray(x[:, 1, :]), "the dense copy")
+            if tap is not None:
+                assert_bit_equal(tap.output("signal").numpy(), oracle.amplitude(np.ascontiguousarray(x[:, 1, :]), n))
+            rt.destroy()
+    base = results[(False, False)]
+    for key, got in results.items():
+        assert_bit_equal(got[0], base[0], f"engine output {key}")
+        assert_bit_equal(got[1], base[1], f"fm output {key}")
+    want, _ = _oracle(oracle, np.ascontiguousarray(x[:, 1, :]))
+    assert_bit_equal(base[0], want, "engine output vs the oracle")

@@ -69,6 +69,8 @@ def test_multi_fm_example(js, oracle):
     assert plan["convolutionSize"] == 8050 and js.fft_path(8050) == "tile" and js.fft_path(805) == "tile"
     assert any(u.startswith("fft_padded_fold(") for u in rt.units), rt.units
     assert any(u.startswith("ifft_phase_unpad_overlap(") for u in rt.units), rt.units
+    # the `slice` blocks' dense copies are not made: their readers (fft_windowed, fm) walk the view's strides themselves
+    assert "slice.duplicate(elided)" in rt.units and "sli23.duplicate(elided)" in rt.units, rt.units
     assert rt.branches == 1  # one chain by default; the branch-parallel capture is test_multi_fm_example_on_parallel_branches
     state, lane = {}, oracle.FmLane("narrow", "none", 200e3)
     wide = oracle.spectrum_chain(x, -81.0, 1.0)["range"]
