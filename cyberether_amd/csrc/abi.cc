@@ -157,6 +157,17 @@ jst_result jst_tensor_wrap(void* ptr, size_t bytes, uint8_t device, uint8_t dtyp
     *out = h.release();
     return R(Result::SUCCESS);
 }
+jst_result jst_tensor_view(jst_tensor base, uint32_t rank, const uint64_t* shape, const uint64_t* stride, uint64_t offset,
+                           jst_tensor* out) {
+    JST_ARG(base && out && (shape || rank == 0) && rank <= JST_MAX_RANK, "invalid tensor arguments");
+    auto h = std::make_unique<jst_tensor_s>();
+    std::vector<U64> st;
+    if (stride) st.assign(stride, stride + rank);
+    const Result r = h->t.view(base->t, Shape(shape, shape + rank), st, offset);
+    if (r != Result::SUCCESS) return R(r);
+    *out = h.release();
+    return R(Result::SUCCESS);
+}
 jst_result jst_tensor_rebind(jst_tensor t, void* ptr, size_t bytes) {
     JST_ARG(t && ptr, "null tensor or pointer");
     return R(t->t.rebind(ptr, bytes));

@@ -94,7 +94,10 @@ Result Comm::create(uint32_t rank, uint32_t world, const uint8_t* id) {
     }
     rank_ = rank;
     world_ = world;
-    if (world == 1) return Result::SUCCESS;  // a one-rank communicator reduces nothing: no RCCL needed
+    // a one-rank communicator reduces nothing and needs no RCCL -- unless the caller hands over an id: then a REAL one-rank
+    // RCCL communicator is opened (ncclCommInitRank(nranks = 1) is legal), and every all-reduce goes through the library,
+    // the dtype / op enum slice above and the caller's stream exactly as it does at world > 1
+    if (world == 1 && !id) return Result::SUCCESS;
     if (!id) {
         JST_ERROR("[COMM] a communicator of %u ranks needs rank 0's unique id.", world);
         return Result::ERROR;
@@ -124,7 +127,7 @@ Result Comm::allReduce(Tensor& t, Op op, bool average, hipStream_t stream) {
         return Result::ERROR;
     }
     ++calls_;
-    if (world_ == 1) return Result::SUCCESS;
+    if (!comm_) return Result::SUCCESS;  // world 1 without RCCL
     char* base = static_cast<char*>(t.data()) + t.offset() * 4;
     JST_CHECK(rccl_check(rccl().AllReduce(base, base, (size_t)t.size(), t.dtype() == DataType::F32 ? kNcclFloat32 : kNcclUint32,
                                            op == Op::SUM ? kNcclSum : kNcclMax, comm_, stream),

@@ -165,16 +165,19 @@ Result Tensor::ringSelect(U64 slot) {
 }
 
 Result Tensor::promoteToRing(U64 slots) {
-    if (!buffer_ || !buffer_->owned || buffer_->device != DeviceType::HIP || buffer_->slots != 1 ||
-        slots < 2) {
-        JST_ERROR("[MEMORY] Only an owned single-slot HBM buffer can be promoted to a ring.");
+    if (!buffer_ || buffer_->device != DeviceType::HIP || buffer_->slots != 1 || slots < 2) {
+        JST_ERROR("[MEMORY] Only a single-slot HBM buffer can be promoted to a ring.");
         return Result::ERROR;
     }
+    // Borrowed storage (jst_tensor_rebind: a host framework's buffer) is left where it is and the ring becomes the
+    // library's own allocation: the host's buffer no longer receives the cycles' results -- a host that batches cycles
+    // publishes the latest slot itself (integration/device_hip/runtime_native_hip_impl.cc: publishLatest).
     const size_t slot_bytes = buffer_->bytes;
     void* fresh = nullptr;
     JST_HIP_CHECK(hipMalloc(&fresh, slot_bytes * slots), "hipMalloc");
     JST_HIP_CHECK(hipMemset(fresh, 0, slot_bytes * slots), "hipMemset");
-    (void)hipFree(buffer_->ptr);
+    if (buffer_->owned) (void)hipFree(buffer_->ptr);
+    buffer_->owned = true;
     buffer_->ptr = fresh;
     buffer_->bytes = slot_bytes * slots;
     buffer_->slot_bytes = slot_bytes;
@@ -250,6 +253,30 @@ Result Tensor::wrap(void* ptr, size_t bytes, DeviceType device, DataType dtype, 
         buffer_.reset();
         return Result::ERROR;
     }
+    return Result::SUCCESS;
+}
+
+Result Tensor::view(const Tensor& base, const Shape& shape, const std::vector<U64>& stride, U64 offset) {
+    if (!base.buffer_ || (!stride.empty() && stride.size() != shape.size())) {
+        JST_ERROR("[MEMORY] A view needs an allocated tensor and one stride per axis.");
+        return Result::ERROR;
+    }
+    const std::vector<U64> st = stride.empty() ? DenseStrides(shape) : stride;
+    U64 last = offset;
+    bool empty = shape.empty();
+    for (size_t i = 0; i < shape.size(); ++i) {
+        if (shape[i] == 0) empty = true;
+        else last += (shape[i] - 1) * st[i];
+    }
+    const size_t slot_bytes = base.buffer_->slots > 1 ? base.buffer_->slot_bytes : base.buffer_->bytes;
+    if (!empty && (last + 1) * DataTypeSize(base.dtype_) > slot_bytes) {
+        JST_ERROR("[MEMORY] View exceeds the %zu-byte storage.", slot_bytes);
+        return Result::ERROR;
+    }
+    *this = base;  // shares the storage; the attributes come along as a copy
+    shape_ = shape;
+    stride_ = st;
+    offset_ = offset;
     return Result::SUCCESS;
 }
 

@@ -64,6 +64,11 @@ class Tensor {
     // binding gets a say: integration/device_hip/fft_module_impl_native_hip.cc).  Single-slot storage only, and before
     // the first compute (a captured graph holds addresses).
     Result rebind(void* ptr, size_t bytes);
+    // This tensor becomes a view {shape, stride, offset} (elements; stride empty = dense) of `base`'s STORAGE: what the
+    // reference's Tensor copies are once slice / permute / broadcastTo have edited them (src/memory/tensor.cc:196-306) --
+    // for a host framework whose consumer sees a producer's tensor through a geometry of its own.  Storage identity (and
+    // with it the runtime's data-flow edges) is kept; bounds are checked against one ring slot.
+    Result view(const Tensor& base, const Shape& shape, const std::vector<U64>& stride, U64 offset);
     bool valid() const { return static_cast<bool>(buffer_); }
     bool validShape() const { return !shape_.empty(); }
     DeviceType device() const { return buffer_ ? buffer_->device : DeviceType::None; }

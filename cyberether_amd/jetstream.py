@@ -92,6 +92,7 @@ _sig("jst_tensor_wrap", R, C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint8, C.c_uin
      C.c_uint64, _hp)
 _sig("jst_tensor_rebind", R, _h, C.c_void_p, C.c_size_t)
 _sig("jst_tensor_clone", R, _h, _hp)
+_sig("jst_tensor_view", R, _h, C.c_uint32, _u64p, _u64p, C.c_uint64, _hp)
 _sig("jst_tensor_destroy", R, _h)
 _sig("jst_tensor_describe", R, _h, C.POINTER(_Desc))
 _sig("jst_tensor_ring_select", R, _h, C.c_uint64)
@@ -252,6 +253,14 @@ class Tensor:
     def clone(self) -> "Tensor":
         out = C.c_void_p()
         _check(_lib.jst_tensor_clone(self._h, C.byref(out)))
+        return Tensor(out.value)
+
+    def view(self, shape: Sequence[int], stride: Optional[Sequence[int]] = None, offset: int = 0) -> "Tensor":
+        """jst_tensor_view: a new handle on this tensor's STORAGE with the caller's geometry (elements; stride None =
+        dense) -- storage identity, and with it the runtime's data-flow edges, is kept (unlike wrap)."""
+        out = C.c_void_p()
+        _check(_lib.jst_tensor_view(self._h, len(shape), _arr(shape), _arr(stride) if stride else None, offset,
+                                    C.byref(out)))
         return Tensor(out.value)
 
     def rebind(self, ptr: int, nbytes: int) -> "Tensor":

@@ -149,6 +149,12 @@ jst_result jst_tensor_wrap(void* ptr, size_t bytes, uint8_t device, uint8_t dtyp
  * before the first compute. */
 jst_result jst_tensor_rebind(jst_tensor t, void* ptr, size_t bytes);
 jst_result jst_tensor_clone(jst_tensor t, jst_tensor* out); /* new view, shared storage */
+/* A new handle on `base`'s STORAGE with a geometry of the caller's (elements; stride NULL = dense): a reference Tensor copy
+ * after slice / permute / broadcastTo (src/memory/tensor.cc:196-306), e.g. the input a consumer module sees.  Unlike
+ * jst_tensor_wrap the storage identity -- what the runtime derives its data-flow edges and fusions from -- is kept.
+ * Attributes are copied from `base`.  Bounds are checked against one ring slot. */
+jst_result jst_tensor_view(jst_tensor base, uint32_t rank, const uint64_t* shape, const uint64_t* stride, uint64_t offset,
+                           jst_tensor* out);
 jst_result jst_tensor_destroy(jst_tensor t);
 jst_result jst_tensor_describe(jst_tensor t, jst_tensor_desc* out);
 jst_result jst_tensor_ring_select(jst_tensor t, uint64_t slot);
