@@ -198,19 +198,41 @@ Result Runtime::planOrder(const std::vector<Module*>& modules) {
     // (src/scheduler_synchronous.cc:574-696).  Ties keep insertion order; with FUSE a ready
     // consumer of the module placed last goes first, so that producer/consumer chains end up
     // adjacent and the fusion hooks (which look at neighbours) can see them.
+    // The edges do not depend on the order the caller lists the modules in (a host framework may hand them over from a
+    // hash map: integration/device_hip/runtime_native_hip_impl.cc).  An input handle remembers the module that published
+    // it (ProducerAttribute travels with every clone / view of the handle): that is the exact edge, also through view
+    // modules (reshape, a bypassing cast) whose output shares its input's storage.  A tensor without that attribute falls
+    // back to storage identity, where a module that WRITES the storage goes before one that merely re-publishes a view.
     const size_t n = modules.size();
+    std::map<const Module*, size_t> index_of;
+    for (size_t i = 0; i < n; ++i) index_of.emplace(modules[i], i);
+    auto republishes = [&](size_t i, const void* storage) {
+        for (const auto& kv : modules[i]->inputs())
+            if (kv.second.storageId() == storage) return true;
+        return false;
+    };
     std::map<const void*, size_t> producer;
-    for (size_t i = 0; i < n; ++i)
-        for (const auto& kv : modules[i]->outputs()) {
-            if (kv.second.storageId()) producer.emplace(kv.second.storageId(), i);
-        }
+    for (int pass = 0; pass < 2; ++pass)
+        for (size_t i = 0; i < n; ++i)
+            for (const auto& kv : modules[i]->outputs()) {
+                const void* storage = kv.second.storageId();
+                if (storage && republishes(i, storage) == (pass == 1)) producer.emplace(storage, i);
+            }
     std::vector<std::set<size_t>> deps(n);
     std::vector<std::vector<size_t>> users(n);
     for (size_t i = 0; i < n; ++i)
         for (const auto& kv : modules[i]->inputs()) {
-            auto it = producer.find(kv.second.storageId());
-            if (it != producer.end() && it->second != i && deps[i].insert(it->second).second)
-                users[it->second].push_back(i);
+            size_t from = n;
+            const AttrValue* tag = kv.second.attribute(ProducerAttribute);
+            if (const U64* address = tag ? std::get_if<U64>(tag) : nullptr) {
+                const auto it = index_of.find(reinterpret_cast<const Module*>(static_cast<uintptr_t>(*address)));
+                if (it != index_of.end()) from = it->second;
+            }
+            if (from == n) {
+                const auto it = producer.find(kv.second.storageId());
+                if (it != producer.end()) from = it->second;
+            }
+            if (from != n && from != i && deps[i].insert(from).second) users[from].push_back(i);
         }
     std::vector<size_t> indeg(n);
     for (size_t i = 0; i < n; ++i) indeg[i] = deps[i].size();

@@ -15,6 +15,14 @@ struct NativeHipRuntimeContext : Runtime::Context {
     virtual Result computeInitialize() { return Result::SUCCESS; }
     virtual Result computeSubmit(void* hipStream) = 0;
     virtual Result computeDeinitialize() { return Result::SUCCESS; }
+    // The jst_module (include/jetstream_hip.h of libjetstream_hip.so) standing behind this module, or null for a module with
+    // kernels of its own.  A runtime segment made ONLY of library modules is handed to one jst_runtime, which captures the
+    // cycle into a hipGraph, fuses module chains into single kernels and batches cycles (src/runtime/native/hip/impl.cc);
+    // a mixed segment runs module by module on the segment's stream.
+    virtual void* libraryModule() const { return nullptr; }
+    // Deferred cycles only: outputs the library keeps in rings of its own are copied (latest slot, on `hipStream`) into the
+    // tensors this module published.
+    virtual Result publishOutputs(void* /*hipStream*/) { return Result::SUCCESS; }
 };
 
 }  // namespace Jetstream

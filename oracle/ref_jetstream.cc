@@ -19,6 +19,11 @@
 #include <unordered_set>
 #include <vector>
 
+#ifdef JETSTREAM_BACKEND_HIP_AVAILABLE
+#include <hip/hip_runtime_api.h>
+#include "hip_library_module.hh"  // integration/device_hip: the library tensors behind the reference's HIP modules
+#endif
+
 #include "jetstream/block.hh"
 #include "jetstream/detail/block_impl.hh"
 #include "jetstream/detail/module_impl.hh"
@@ -130,6 +135,8 @@ struct Desc {  // what the Python side reads back: element strides / offset like
     uint64_t shape[8];
     uint64_t stride[8];
     int64_t sample_axis, batch_axis, channel_axis;
+    uint64_t device;      // DeviceType value: anything but CPU is read / written through ref_dev_read / ref_dev_write
+    uint64_t buffer_bytes;
 };
 
 int64_t axis_attr(const Tensor& t, const char* key) {
@@ -152,6 +159,8 @@ int fill_desc(const Tensor& t, Desc* d) {
     d->sample_axis = axis_attr(t, "sampleAxis");
     d->batch_axis = axis_attr(t, "batchAxis");
     d->channel_axis = axis_attr(t, "channelAxis");
+    d->device = (uint64_t)t.device();
+    d->buffer_bytes = d->data ? t.buffer().sizeBytes() : 0;
     return 0;
 }
 
@@ -173,6 +182,7 @@ int set_attr(Tensor& t, const char* key, int kind, const double* v, uint64_t n) 
 // ---- one module + one runtime, alive across computes (TestContext::start / compute / stop) --------------------
 struct ModSession {
     std::string provider = "generic";  // the registry's 4th key (src/registry.cc:605-618): "mi355x" selects integration/mi355x_provider
+    DeviceType device = DeviceType::CPU;  // the registry's 2nd key: "hip" in the libref_jetstream_devhip.so build (integration/device_hip)
     std::string type;
     Parser::Map config;
     std::unordered_map<std::string, Tensor> inputs;
@@ -228,7 +238,7 @@ int ref_mod_input(void* h, const char* port, const char* dtype, uint32_t rank, c
     auto* s = static_cast<ModSession*>(h);
     Shape sh(shape, shape + rank);
     Tensor t;
-    if (t.create(DeviceType::CPU, NameToDataType(dtype), sh) != Result::SUCCESS) return 1;
+    if (t.create(s->device, NameToDataType(dtype), sh) != Result::SUCCESS) return 1;
     s->inputs[port] = t;
     return fill_desc(t, out);
 }
@@ -266,7 +276,7 @@ int ref_mod_input_view(void* h, const char* port, int op, const uint64_t* v, uin
 int ref_mod_start(void* h) {
     auto* s = static_cast<ModSession*>(h);
     if (s->module || s->runtime) return (int)Result::ERROR;
-    Result r = Registry::BuildModule(s->type, DeviceType::CPU, RuntimeType::NATIVE, s->provider, s->module);
+    Result r = Registry::BuildModule(s->type, s->device, RuntimeType::NATIVE, s->provider, s->module);
     if (r != Result::SUCCESS) return (int)r;
     TensorMap in;
     for (auto& [name, t] : s->inputs) {
@@ -275,7 +285,7 @@ int ref_mod_start(void* h) {
     }
     r = s->module->create("test", s->config, in);
     if (r != Result::SUCCESS) { s->module.reset(); return (int)r; }
-    s->runtime = std::make_unique<Runtime>("test", DeviceType::CPU, RuntimeType::NATIVE);
+    s->runtime = std::make_unique<Runtime>("test", s->device, RuntimeType::NATIVE);
     r = s->runtime->create({{"test", s->module}});
     if (r != Result::SUCCESS) { (void)s->module->destroy(); s->module.reset(); s->runtime.reset(); }
     return (int)r;
@@ -284,10 +294,82 @@ int ref_mod_set_provider(void* h, const char* provider) {
     static_cast<ModSession*>(h)->provider = provider;
     return 0;
 }
+// "cpu" | "hip" (the latter only where the core was built with core_hip_device.patch); before the inputs are allocated
+int ref_mod_set_device(void* h, const char* device) {
+    if (!IsDeviceName(device)) return 1;
+    static_cast<ModSession*>(h)->device = StringToDevice(device);
+    return 0;
+}
+int ref_device_known(const char* device) { return IsDeviceName(device) ? 1 : 0; }
+// device tensors: the bytes [0, bytes) of the buffer at `device_ptr`, through the HIP runtime's copy engine (synchronous)
+int ref_dev_read(const void* device_ptr, void* host, uint64_t bytes) {
+#ifdef JETSTREAM_BACKEND_HIP_AVAILABLE
+    return hipMemcpy(host, device_ptr, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+#else
+    (void)device_ptr; (void)host; (void)bytes;
+    return 1;
+#endif
+}
+int ref_dev_write(void* device_ptr, const void* host, uint64_t bytes) {
+#ifdef JETSTREAM_BACKEND_HIP_AVAILABLE
+    return hipMemcpy(device_ptr, host, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+#else
+    (void)device_ptr; (void)host; (void)bytes;
+    return 1;
+#endif
+}
+// The library tensor standing behind output `port` (or "state:<key>") of the reference's HIP module `module` (flowgraph
+// modules are named "<block>-<module>", src/block_impl.cc:64): where it lives NOW -- for a ring, the selected slot.
+int ref_hip_directory(const char* module, const char* port, Desc* out) {
+#ifdef JETSTREAM_BACKEND_HIP_AVAILABLE
+    jst_tensor t = Hip::TensorDirectory::Get().find(module, port);
+    jst_tensor_desc d{};
+    if (!t || jst_tensor_describe(t, &d) != JST_SUCCESS || d.rank > 8) return 1;
+    static const DataType kinds[] = {DataType::None, DataType::F32, DataType::CF32, DataType::F64, DataType::U64, DataType::I8, DataType::CI8,
+                                     DataType::I16, DataType::CI16, DataType::U8, DataType::CU8, DataType::U16, DataType::CU16, DataType::I32,
+                                     DataType::CI32, DataType::U32, DataType::CU32, DataType::CF64};
+    std::memset(out, 0, sizeof(*out));
+    out->data = d.data;
+    out->offset = d.offset;
+    out->dtype = d.dtype < sizeof(kinds) / sizeof(kinds[0]) ? (uint32_t)kinds[d.dtype] : 0;
+    out->rank = d.rank;
+    uint64_t last = d.offset;
+    for (uint32_t a = 0; a < d.rank; ++a) {
+        out->shape[a] = d.shape[a];
+        out->stride[a] = d.stride[a];
+        if (d.shape[a]) last += (d.shape[a] - 1) * d.stride[a];
+    }
+    out->sample_axis = d.sample_axis;
+    out->batch_axis = d.batch_axis;
+    out->channel_axis = d.channel_axis;
+    out->device = (uint64_t)DeviceType::HIP;
+    out->buffer_bytes = (last + 1) * DataTypeSize(out->dtype ? (DataType)out->dtype : DataType::F32);
+    return 0;
+#else
+    (void)module; (void)port; (void)out;
+    return 1;
+#endif
+}
+// 2 = device memory (HBM), 1 = host memory registered with / allocated by the HIP runtime, 0 = unknown to it, -1 = not a HIP build
+int ref_dev_pointer_kind(const void* ptr) {
+#ifdef JETSTREAM_BACKEND_HIP_AVAILABLE
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, ptr) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return a.type == hipMemoryTypeDevice ? 2 : (a.type == hipMemoryTypeHost ? 1 : 0);
+#else
+    (void)ptr;
+    return -1;
+#endif
+}
 // 1 when the registry holds (type, CPU, NATIVE, provider)
 int ref_registry_has(const char* type, const char* provider) {
     std::shared_ptr<Module> probe;
     return Registry::BuildModule(type, DeviceType::CPU, RuntimeType::NATIVE, provider, probe) == Result::SUCCESS ? 1 : 0;
+}
+int ref_registry_has_on(const char* type, const char* provider, const char* device) {
+    if (!IsDeviceName(device)) return 0;
+    std::shared_ptr<Module> probe;
+    return Registry::BuildModule(type, StringToDevice(device), RuntimeType::NATIVE, provider, probe) == Result::SUCCESS ? 1 : 0;
 }
 int ref_mod_compute(void* h) {
     auto* s = static_cast<ModSession*>(h);
@@ -388,6 +470,26 @@ int ref_fg_block_provider(void* h, const char* name, const char* type, const cha
         }
     }
     return (int)s->fg->blockCreate(name, std::string(type), parse_config(config_lines), in, DeviceType::CPU, RuntimeType::NATIVE,
+                                   std::string(provider));
+}
+// ... and with the registry's device key ("cpu" | "hip"): every module of the block is built for that device, so the
+// scheduler puts them into a runtime segment of that device (src/scheduler_synchronous.cc:698-757)
+int ref_fg_block_on(void* h, const char* name, const char* type, const char* config_lines, const char* inputs_lines,
+                    const char* provider, const char* device) {
+    auto* s = static_cast<FgSession*>(h);
+    if (!IsDeviceName(device)) return (int)Result::ERROR;
+    TensorMap in;
+    if (inputs_lines) {
+        std::istringstream is(inputs_lines);
+        std::string line;
+        while (std::getline(is, line)) {
+            const auto eq = line.find('=');
+            const auto colon = line.find(':', eq == std::string::npos ? 0 : eq);
+            if (eq == std::string::npos || colon == std::string::npos) continue;
+            in[line.substr(0, eq)].requested(line.substr(eq + 1, colon - eq - 1), line.substr(colon + 1));
+        }
+    }
+    return (int)s->fg->blockCreate(name, std::string(type), parse_config(config_lines), in, StringToDevice(device), RuntimeType::NATIVE,
                                    std::string(provider));
 }
 // state of a block: Block::State value, or -1 when the block does not exist

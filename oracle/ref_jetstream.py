@@ -25,6 +25,9 @@ _PATH = os.path.join(_HERE, "_ref", "libref_jetstream.so")
 # the same reference objects + integration/mi355x_provider, linked against cyberether_amd/lib/libjetstream_hip.so
 # (oracle/ref_jetstream_build.sh): select with use_hip_library() BEFORE the first call, one library per process
 _PATH_HIP = os.path.join(_HERE, "_ref", "libref_jetstream_hip.so")
+# the reference's core PATCHED with DeviceType::HIP (integration/device_hip/) + the HIP buffer backend, runtime and modules:
+# device-resident, select with use_device_hip_library() BEFORE the first call
+_PATH_DEVHIP = os.path.join(_HERE, "_ref", "libref_jetstream_devhip.so")
 
 RESULT_SUCCESS = 0
 
@@ -40,7 +43,10 @@ _CI = {"CI8": (np.int8, 13), "CI16": (np.int16, 14), "CU8": (np.uint8, 17), "CU1
 class _Desc(C.Structure):
     _fields_ = [("data", C.c_void_p), ("offset", C.c_uint64), ("dtype", C.c_uint32), ("rank", C.c_uint32),
                 ("shape", C.c_uint64 * 8), ("stride", C.c_uint64 * 8),
-                ("sample_axis", C.c_int64), ("batch_axis", C.c_int64), ("channel_axis", C.c_int64)]
+                ("sample_axis", C.c_int64), ("batch_axis", C.c_int64), ("channel_axis", C.c_int64),
+                ("device", C.c_uint64), ("buffer_bytes", C.c_uint64)]
+
+DEVICE_CPU, DEVICE_HIP = 1 << 1, 1 << 6   # include/jetstream/memory/types.hh:22-29 (+ integration/device_hip/core_hip_device.patch)
 
 
 _lib = None
@@ -57,24 +63,64 @@ def available() -> bool:
 
 
 def hip_library_available() -> bool:
-    return os.path.exists(_PATH_HIP)
+    return os.path.exists(_PATH_HIP) or os.path.exists(_PATH_DEVHIP)
 
 
 def use_hip_library() -> None:
-    """The reference linked against the HIP library (provider "mi355x" registered): for tests/test_gpu_reference_drives_library.py."""
+    """The reference linked against the HIP library (provider "mi355x" registered): for tests/test_gpu_reference_drives_library.py.
+    The device-resident build holds the provider modules too and is preferred: ONE reference build per process."""
     global _PATH
-    assert _lib is None or _PATH == _PATH_HIP, "the CPU-only reference library is already loaded in this process"
-    _PATH = _PATH_HIP
+    want = _PATH_DEVHIP if os.path.exists(_PATH_DEVHIP) else _PATH_HIP
+    assert _lib is None or _PATH == want, "another build of the reference is already loaded in this process"
+    _PATH = want
 
 
-def registry_has(mtype: str, provider: str) -> bool:
+def device_hip_library_available() -> bool:
+    return os.path.exists(_PATH_DEVHIP)
+
+
+def use_device_hip_library() -> None:
+    """The reference with DeviceType::HIP (patched core + integration/device_hip): for tests/test_gpu_reference_device_hip.py."""
+    global _PATH
+    assert _lib is None or _PATH == _PATH_DEVHIP, "another build of the reference is already loaded in this process"
+    _PATH = _PATH_DEVHIP
+
+
+def hip_runtime_configure(hand_off: bool = True, defer_cycles: int = 0) -> None:
+    """integration/device_hip/runtime_native_hip_impl.cc: knobs of the HIP runtimes created from here on."""
+    lib().jetstream_hip_runtime_configure(C.c_int(1 if hand_off else 0), C.c_uint64(defer_cycles))
+
+
+def hip_runtime_flush() -> None:
+    assert lib().jetstream_hip_runtime_flush() == 0, "a deferred span failed"
+
+
+def hip_runtime_units() -> str:
+    """Units of every live handed-off HIP runtime ('|' between runtimes, '[batched]' behind a cycle-batched one)."""
+    l = lib()
+    l.jetstream_hip_runtime_units.restype = C.c_size_t
+    buf = C.create_string_buffer(8192)
+    l.jetstream_hip_runtime_units(buf, C.c_size_t(8192))
+    return buf.value.decode()
+
+
+def hip_directory(module: str, port: str) -> np.ndarray:
+    """The library tensor behind `port` (or "state:<key>") of the reference's HIP module `module`, read back (copy)."""
+    d = _Desc()
+    assert lib().ref_hip_directory(module.encode(), port.encode(), C.byref(d)) == 0, f"no library tensor for {module}:{port}"
+    return _view(d)
+
+
+def registry_has(mtype: str, provider: str, device: str = "cpu") -> bool:
+    if device != "cpu":
+        return bool(lib().ref_registry_has_on(mtype.encode(), provider.encode(), device.encode()))
     return bool(lib().ref_registry_has(mtype.encode(), provider.encode()))
 
 
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if _PATH != _PATH_HIP:
+        if _PATH not in (_PATH_HIP, _PATH_DEVHIP):
             build()
         _lib = C.CDLL(_PATH)
         assert _lib.ref_jst_desc_size() == C.sizeof(_Desc)
@@ -98,9 +144,24 @@ def _cfg(config: Optional[Dict]) -> bytes:
     return "\n".join(f"{k}={enc(v)}" for k, v in (config or {}).items()).encode()
 
 
+def _device_image(d: _Desc, nbytes: int) -> int:
+    """Host copy of the first `nbytes` of a device tensor's buffer; returns its address (kept alive on the descriptor)."""
+    host = np.empty(max(nbytes, 1), np.uint8)
+    assert lib().ref_dev_read(C.c_void_p(d.data), host.ctypes.data_as(C.c_void_p), C.c_uint64(nbytes)) == 0, "device read failed"
+    d._host = host
+    return host.ctypes.data
+
+
 def _view(d: _Desc) -> np.ndarray:
-    """numpy view (no copy) of a reference tensor: element strides and offset as Tensor::stride() / offset()."""
+    """numpy view (no copy) of a reference tensor: element strides and offset as Tensor::stride() / offset().  A tensor on
+    another device than the CPU is read back first (ref_dev_read): the result is then a view of a host COPY."""
     code = int(d.dtype)
+    if int(d.device) not in (0, DEVICE_CPU) and d.data:
+        h = _Desc()
+        C.memmove(C.byref(h), C.byref(d), C.sizeof(_Desc))
+        h.data = _device_image(d, int(d.buffer_bytes))
+        h.device = DEVICE_CPU
+        return _Kept(_view(h), d._host)
     rank = int(d.rank)
     shape = [int(d.shape[a]) for a in range(rank)]
     stride = [int(d.stride[a]) for a in range(rank)]
@@ -127,6 +188,24 @@ def _view(d: _Desc) -> np.ndarray:
     return np.lib.stride_tricks.as_strided(flat, shape=shape, strides=[st * dt.itemsize for st in stride])
 
 
+def _upload(d: _Desc, x: np.ndarray, byte_offset: int = 0) -> None:
+    """Dense host array -> the buffer of a device tensor (at byte_offset), through ref_dev_write."""
+    x = np.ascontiguousarray(x)
+    assert byte_offset + x.nbytes <= int(d.buffer_bytes), "upload exceeds the device buffer"
+    assert lib().ref_dev_write(C.c_void_p(d.data + byte_offset), x.ctypes.data_as(C.c_void_p), C.c_uint64(x.nbytes)) == 0, "device write failed"
+
+
+class _Kept(np.ndarray):
+    """ndarray that keeps the host image it views alive."""
+    def __new__(cls, view, keep):
+        obj = view.view(cls)
+        obj._keep = keep
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._keep = getattr(obj, "_keep", None)
+
+
 def _attr_args(value):
     if isinstance(value, (list, tuple, np.ndarray)):
         arr = np.asarray(value, dtype=np.float64).reshape(-1)
@@ -140,11 +219,14 @@ ATTR_INDEX, ATTR_F32, ATTR_VEC_F32, ATTR_VEC_U64, ATTR_VEC_F64, ATTR_F64 = range
 class RefModule:
     """One module of the reference behind Registry::BuildModule / Module::create / Runtime::compute."""
 
-    def __init__(self, mtype: str, config: Optional[Dict] = None, provider: str = "generic"):
+    def __init__(self, mtype: str, config: Optional[Dict] = None, provider: str = "generic", device: str = "cpu"):
         self._l = lib()
         self._h = C.c_void_p(self._l.ref_mod_new(mtype.encode(), _cfg(config)))
         if provider != "generic":
             self._l.ref_mod_set_provider(self._h, provider.encode())
+        self._device = device
+        if device != "cpu":   # the registry's device key: inputs are allocated there, the runtime is that device's
+            assert self._l.ref_mod_set_device(self._h, device.encode()) == 0, f"unknown device {device}"
         self._in: Dict[str, np.ndarray] = {}
         self._in_desc: Dict[str, _Desc] = {}
 
@@ -164,8 +246,12 @@ class RefModule:
         shape = (C.c_uint64 * max(x.ndim, 1))(*x.shape)
         d = _Desc()
         assert self._l.ref_mod_input(self._h, port.encode(), _NAMES[x.dtype].encode(), x.ndim, shape, C.byref(d)) == 0
-        v = _view(d)
-        v[...] = x
+        if self._device == "cpu":
+            v = _view(d)
+            v[...] = x
+        else:   # a device tensor: the host keeps a shadow, write() uploads it
+            v = np.ascontiguousarray(x).copy()
+            _upload(d, v)
         self._in[port] = v
         self._in_desc[port] = d
         for key, val in (("sampleAxis", sample), ("batchAxis", batch), ("channelAxis", channel)):
@@ -204,6 +290,8 @@ class RefModule:
 
     def write(self, port: str, x: np.ndarray):
         self._in[port][...] = x
+        if self._device != "cpu":
+            _upload(self._in_desc[port], self._in[port])
 
     def start(self) -> int:
         return int(self._l.ref_mod_start(self._h))
@@ -281,14 +369,32 @@ class RefFlowgraph:
         return v
 
     def block(self, name: str, btype: str, config: Optional[Dict] = None, inputs: Optional[Dict[str, str]] = None,
-              provider: str = "generic") -> int:
+              provider: str = "generic", device: str = "cpu") -> int:
         ins = "\n".join(f"{port}={src}" for port, src in (inputs or {}).items()).encode()
+        if device != "cpu":
+            return int(self._l.ref_fg_block_on(self._h, name.encode(), btype.encode(), _cfg(config), ins, provider.encode(), device.encode()))
         if provider != "generic":
             return int(self._l.ref_fg_block_provider(self._h, name.encode(), btype.encode(), _cfg(config), ins, provider.encode()))
         return int(self._l.ref_fg_block(self._h, name.encode(), btype.encode(), _cfg(config), ins))
 
     def state(self, name: str) -> int:
         return int(self._l.ref_fg_block_state(self._h, name.encode()))
+
+    def desc(self, block: str, port: str) -> _Desc:
+        d = _Desc()
+        assert self._l.ref_fg_tensor(self._h, block.encode(), port.encode(), C.byref(d)) == 0, f"no {block}:{port}"
+        return d
+
+    def ring_source(self, name: str, batches: int, samples: int, slots: int = 1, provider: str = "generic") -> int:
+        """integration/device_hip/modules/ring_source.cc: `slots` batches resident in HBM, a cycle selects the next one."""
+        return self.block(name, "ring_source", {"batches": batches, "samples": samples, "slots": slots}, provider=provider, device="hip")
+
+    def ring_write(self, name: str, slot: int, x: np.ndarray) -> None:
+        """Fill ring slot `slot` (the reference's tensor borrows slot 0: the slots follow one another in the allocation)."""
+        d = self.desc(name, "buffer")
+        x = np.ascontiguousarray(x)
+        d.buffer_bytes = (slot + 1) * x.nbytes     # the borrowed tensor knows one slot; the allocation holds them all
+        _upload(d, x, slot * x.nbytes)
 
     def tensor(self, block: str, port: str) -> np.ndarray:
         d = _Desc()

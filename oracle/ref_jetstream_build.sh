@@ -91,3 +91,77 @@ if [ -f "$HIPLIB" ]; then
   g++ -shared -fPIC -o "$OUT/libref_jetstream_hip.so" $OBJS "$OBJ/harness.o" "$OBJ/render_stubs.o" $SHIM_OBJS -L"$REPO/cyberether_amd/lib" -l:libjetstream_hip.so \
       -Wl,--no-undefined -Wl,-rpath,'$ORIGIN/../../cyberether_amd/lib' -lpthread && echo "built _ref/libref_jetstream_hip.so (reference + mi355x provider -> libjetstream_hip.so)"
 fi
+
+# ---- the reference DEVICE-RESIDENT on the library: DeviceType::HIP (round 6) ---------------------------------------------
+# A third library, oracle/_ref/libref_jetstream_devhip.so: the reference's core compiled with integration/device_hip/
+# core_hip_device.patch (the DeviceType bit, MakeBackend, the Runtime factory, the CPU mirror of a host-accessible HIP buffer,
+# duplicate's HasBufferBackend) + the reference-side units beside the patch: buffer_hip.cc (HBM tensor store),
+# runtime_native_hip_impl.cc (the segment runtime: module by module, or handed to ONE jst_runtime with graph capture and
+# fusion) and modules/*.cc (one module_impl_native_hip.cc per module of the spectrum chain: the reference's own Impl on device
+# tensors, its compute hooks on the library module).  The patch is applied to a TEMPORARY copy of the seven files it touches
+# (mktemp, removed afterwards: no reference source enters the repository or travels to the GPU box); every translation unit
+# is recompiled with -DJETSTREAM_BACKEND_HIP_AVAILABLE and the patched headers first on the include path, so the whole
+# library agrees on the enum; everything else is compiled where it lies under /root/reference, as above.
+# tests/test_gpu_reference_device_hip.py runs the reference's Flowgraph / scheduler / Runtime on it: tensors stay in HBM
+# between modules, outputs and Spectrogram bins bit-equal to the reference's CPU modules.
+DEV=$REPO/integration/device_hip
+if [ -f "$HIPLIB" ] && [ -f "$DEV/core_hip_device.patch" ] && [ -f /opt/rocm/include/hip/hip_runtime_api.h ]; then
+  TREE=$(mktemp -d /tmp/ref_hip_tree.XXXXXX)
+  trap 'rm -rf "$TREE"' EXIT
+  TOUCHED="include/jetstream/memory/types.hh src/memory/types.cc src/memory/buffer_backend.hh src/memory/buffer.cc src/memory/buffer_cpu.cc
+           src/runtime/runtime.cc src/domains/core/duplicate/module_impl.cc"
+  for f in $TOUCHED; do mkdir -p "$TREE/$(dirname $f)"; cp "$REF/$f" "$TREE/$f"; done
+  (cd "$TREE" && patch -s -p1 --no-backup-if-mismatch -i "$DEV/core_hip_device.patch") || { echo "core_hip_device.patch does not apply"; exit 1; }
+  cp "$DEV/runtime_context_native_hip.hh" "$TREE/include/jetstream/"
+  OBJD=$OUT/obj_jetstream_devhip
+  mkdir -p "$OBJD"
+  DEVFLAGS="-O3 -std=c++20 -fPIC -ffp-contract=off -w -DFMT_HEADER_ONLY=1 -DJETSTREAM_BACKEND_HIP_AVAILABLE -D__HIP_PLATFORM_AMD__
+            -I$TREE/include -I$TREE/src -I$TREE/src/memory -I$HERE/ref_shim -I$REF/include -I$REF/src -I$TORCH_INC -I$REPO/include -I$DEV -I/opt/rocm/include"
+  STAMP="$OBJD/.patch_stamp"
+  # a changed patch (or header of the HIP glue) invalidates every object: the enum is in everybody's headers
+  if [ ! -f "$STAMP" ] || [ "$DEV/core_hip_device.patch" -nt "$STAMP" ] || [ "$DEV/runtime_context_native_hip.hh" -nt "$STAMP" ]; then
+    rm -f "$OBJD"/*.o; touch "$STAMP"
+  fi
+  compile_dev() {
+    u=$1
+    o=$OBJD/$(echo "$u" | tr '/' '_' | sed 's/\.cc$//').o
+    src=$REF/$u
+    [ -f "$TREE/$u" ] && src=$TREE/$u            # a patched unit
+    if [ ! -f "$o" ] || [ "$REF/$u" -nt "$o" ]; then
+      g++ $DEVFLAGS -I"$(dirname "$REF/$u")" -c "$src" -o "$o" 2> "$o.err" || { echo "FAILED (devhip) $u"; head -5 "$o.err"; rm -f "$o"; return 1; }
+    fi
+    rm -f "$o.err"
+  }
+  export -f compile_dev; export OBJD TREE DEVFLAGS
+  xargs -a "$LIST" -P "$JOBS" -I{} bash -c 'compile_dev {}' || { echo "libref_jetstream_devhip.so: some units failed"; exit 1; }
+  GLUE_OBJS=""
+  for pair in buffer_hip:. runtime_native_hip_impl:. cast:core/cast window:dsp/window invert:dsp/invert reshape:core/reshape multiply:core/multiply \
+              fft:dsp/fft amplitude:dsp/amplitude range:core/range spectrogram:visualization/spectrogram ring_source:. ${DEVHIP_EXTRA_MODULES:-}; do
+    f=${pair%%:*}; d=${pair##*:}
+    src=$DEV/modules/$f.cc; [ -f "$DEV/$f.cc" ] && src=$DEV/$f.cc
+    o=$OBJD/glue_$f.o
+    if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$DEV/hip_library_module.hh" -nt "$o" ] || [ "$DEV/native_hip_module.hh" -nt "$o" ] || [ "$REPO/include/jetstream_hip.h" -nt "$o" ]; then
+      g++ $DEVFLAGS -I"$REF/src/domains/$d" -c "$src" -o "$o" || { echo "FAILED integration/device_hip/$f.cc"; exit 1; }
+    fi
+    GLUE_OBJS="$GLUE_OBJS $o"
+  done
+  # the `provider: mi355x` modules of the second library too (CPU-device modules: nothing of theirs depends on the patch), so
+  # that ONE reference build serves a whole pytest process: host-staged provider AND device-resident HIP modules
+  for pair in fft:dsp/fft amplitude:dsp/amplitude range:core/range multiply:core/multiply invert:dsp/invert window:dsp/window \
+              reshape:core/reshape cast:core/cast spectrogram:visualization/spectrogram ${MI355X_EXTRA_MODULES:-}; do
+    f=${pair%%:*}; d=${pair##*:}
+    o=$OBJD/mi355x_$f.o
+    if [ ! -f "$o" ] || [ "$SHIM/$f.cc" -nt "$o" ] || [ "$SHIM/mi355x_bridge.hh" -nt "$o" ]; then
+      g++ $DEVFLAGS -I"$REF/src/domains/$d" -I"$SHIM" -c "$SHIM/$f.cc" -o "$o" || { echo "FAILED (devhip) integration/mi355x_provider/$f.cc"; exit 1; }
+    fi
+    GLUE_OBJS="$GLUE_OBJS $o"
+  done
+  if [ ! -f "$OBJD/harness.o" ] || [ "$HERE/ref_jetstream.cc" -nt "$OBJD/harness.o" ] || [ "$DEV/hip_library_module.hh" -nt "$OBJD/harness.o" ]; then
+    g++ $DEVFLAGS -c "$HERE/ref_jetstream.cc" -o "$OBJD/harness.o" || exit 1
+  fi
+  g++ $DEVFLAGS -c "$HERE/ref_render_stubs.cc" -o "$OBJD/render_stubs.o" || exit 1
+  DOBJS=$(sed 's|/|_|g; s|\.cc$|.o|' "$LIST" | sed "s|^|$OBJD/|")
+  g++ -shared -fPIC -o "$OUT/libref_jetstream_devhip.so" $DOBJS "$OBJD/harness.o" "$OBJD/render_stubs.o" $GLUE_OBJS -L"$REPO/cyberether_amd/lib" -l:libjetstream_hip.so \
+      -L/opt/rocm/lib -lamdhip64 -Wl,--no-undefined -Wl,-rpath,'$ORIGIN/../../cyberether_amd/lib' -Wl,-rpath,/opt/rocm/lib -lpthread \
+    && echo "built _ref/libref_jetstream_devhip.so (reference core + core_hip_device.patch + HIP backend / runtime / modules -> libjetstream_hip.so)"
+fi

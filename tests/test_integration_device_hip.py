@@ -1,9 +1,10 @@
-"""CPU: INTEGRATION.md section 3 is real code.  integration/device_hip/core_hip_device.patch (the closed switches of the
-reference's core: DeviceType enum + name maps, MakeBackend, the Runtime factory) is applied with `patch -p1` to a TEMPORARY copy
-of the five reference files it touches, and every touched unit plus the new reference-side units beside it (buffer_hip.cc,
-runtime_native_hip_impl.cc, fft_module_impl_native_hip.cc, runtime_context_native_hip.hh) is compiled to an object against
-the reference's real headers, the HIP runtime's headers and this repo's include/ with -DJETSTREAM_BACKEND_HIP_AVAILABLE.
-Also: the integration/mi355x_provider/ units compile (they are linked and RUN by tests/test_gpu_reference_drives_library.py).
+"""CPU: INTEGRATION.md section 3 is real, LINKED code.  integration/device_hip/core_hip_device.patch (the closed switches of the
+reference's core: DeviceType enum + name maps, MakeBackend, the Runtime factory, the CPU mirror of a host-accessible HIP buffer,
+duplicate's HasBufferBackend) applies to the reference tree, and oracle/ref_jetstream_build.sh links the patched core with the
+reference-side units beside it (buffer_hip.cc, runtime_native_hip_impl.cc, modules/*.cc) and libjetstream_hip.so into
+oracle/_ref/libref_jetstream_devhip.so.  Here, without a GPU: the patch applies, the library exists, exports the new factories,
+loads, knows the device name and holds every module of the spectrum chain under (DeviceType::HIP, NATIVE) -- the RUN is
+tests/test_gpu_reference_device_hip.py.  Also: the integration/mi355x_provider/ units compile against the UNPATCHED reference.
 Skipped where the reference tree is absent (the GPU box)."""
 import os
 import shutil
@@ -15,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 DEV = os.path.join(ROOT, "integration", "device_hip")
 TOUCHED = ["include/jetstream/memory/types.hh", "src/memory/types.cc", "src/memory/buffer_backend.hh", "src/memory/buffer.cc",
-           "src/runtime/runtime.cc"]
+           "src/memory/buffer_cpu.cc", "src/runtime/runtime.cc", "src/domains/core/duplicate/module_impl.cc"]
+DEVHIP = os.path.join(ROOT, "oracle", "_ref", "libref_jetstream_devhip.so")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "include", "jetstream", "registry.hh")),
                                 reason="reference tree not present")
@@ -24,14 +26,6 @@ pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "include", 
 def torch_include():
     import torch
     return os.path.join(os.path.dirname(torch.__file__), "include")
-
-
-def flags(tree):
-    return ["g++", "-std=c++20", "-c", "-O0", "-w", "-fPIC", "-DFMT_HEADER_ONLY=1", "-DJETSTREAM_BACKEND_HIP_AVAILABLE",
-            "-D__HIP_PLATFORM_AMD__",
-            "-I" + os.path.join(tree, "include"), "-I" + os.path.join(tree, "src", "memory"),   # the PATCHED headers first
-            "-I" + os.path.join(ROOT, "oracle", "ref_shim"), "-I" + os.path.join(REF, "include"), "-I" + os.path.join(REF, "src"),
-            "-I" + torch_include(), "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include"]
 
 
 @pytest.fixture(scope="module")
@@ -43,8 +37,6 @@ def patched(tmp_path_factory):
     r = subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", os.path.join(DEV, "core_hip_device.patch")],
                        cwd=tree, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    # the new header goes where the patch says it lives
-    shutil.copy(os.path.join(DEV, "runtime_context_native_hip.hh"), os.path.join(tree, "include", "jetstream"))
     return tree
 
 
@@ -55,24 +47,44 @@ def test_the_patch_adds_the_device(patched):
     assert "JST_DEVICE_HIP = 1 << 6" in header
     assert "CreateHipBackend" in open(os.path.join(patched, "src/memory/buffer.cc")).read()
     assert "NativeHipRuntimeFactory" in open(os.path.join(patched, "src/runtime/runtime.cc")).read()
+    assert "Mirroring HIP buffer" in open(os.path.join(patched, "src/memory/buffer_cpu.cc")).read()
+    assert "case DeviceType::HIP" in open(os.path.join(patched, "src/domains/core/duplicate/module_impl.cc")).read()
 
 
-@pytest.mark.parametrize("unit", ["src/memory/types.cc", "src/memory/buffer.cc", "src/runtime/runtime.cc"])
-def test_touched_units_compile(patched, tmp_path, unit):
-    r = subprocess.run(flags(patched) + [os.path.join(patched, unit), "-o", str(tmp_path / "unit.o")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
+@pytest.fixture(scope="module")
+def devhip():
+    if not os.path.exists(os.path.join(ROOT, "cyberether_amd", "lib", "libjetstream_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    if not os.path.exists(DEVHIP):
+        subprocess.check_call([os.path.join(ROOT, "oracle", "ref_jetstream_build.sh"), "-j", "8"], stdout=subprocess.DEVNULL)
+    assert os.path.exists(DEVHIP), "oracle/ref_jetstream_build.sh did not link the DeviceType::HIP build of the reference"
+    return DEVHIP
 
 
-@pytest.mark.parametrize("unit,extra", [("buffer_hip.cc", []), ("runtime_native_hip_impl.cc", []),
-                                        ("fft_module_impl_native_hip.cc", ["-I" + os.path.join(REF, "src/domains/dsp/fft")])])
-def test_new_units_compile(patched, tmp_path, unit, extra):
-    obj = str(tmp_path / "unit.o")
-    r = subprocess.run(flags(patched) + extra + [os.path.join(DEV, unit), "-o", obj], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-3000:]
-    syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True).stdout
-    want = {"buffer_hip.cc": "Jetstream::detail::CreateHipBackend()", "runtime_native_hip_impl.cc": "Jetstream::NativeHipRuntimeFactory()",
-            "fft_module_impl_native_hip.cc": "FftImplNativeHip"}[unit]
-    assert want in syms, f"{unit}: {want} not defined (is the unit compiled out?)"
+def test_the_patched_reference_links_with_the_hip_units(devhip):
+    syms = subprocess.run(["nm", "-DC", "--defined-only", devhip], capture_output=True, text=True).stdout
+    for want in ("Jetstream::detail::CreateHipBackend()", "Jetstream::NativeHipRuntimeFactory()", "jetstream_hip_runtime_configure",
+                 "jetstream_hip_runtime_flush", "jetstream_hip_runtime_units"):
+        assert want in syms, f"{want} not defined in libref_jetstream_devhip.so"
+    needed = subprocess.run(["readelf", "-d", devhip], capture_output=True, text=True).stdout
+    assert "libjetstream_hip.so" in needed and "libamdhip64" in needed
+
+
+def test_the_registry_of_the_patched_reference_holds_the_hip_modules(devhip):
+    """A separate process: one build of the reference per process (the CPU suite's checker is libref_jetstream.so)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from oracle import ref_jetstream as rj\n"
+            "rj.use_device_hip_library()\n"
+            "l = rj.lib()\n"
+            "assert l.ref_device_known(b'hip') == 1\n"
+            "for m in ('cast','window','invert','reshape','multiply','fft','amplitude','range','spectrogram','ring_source'):\n"
+            "    assert rj.registry_has(m, 'generic', device='hip'), m\n"
+            "assert rj.registry_has('amplitude', 'fast', device='hip') and rj.registry_has('fft', 'mi355x')\n"
+            "assert not rj.registry_has('fft', 'generic', device='cuda')\n"
+            "print('ok')\n" % ROOT)
+    r = subprocess.run(["python3", "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
 PROVIDER = {"fft": "dsp/fft", "amplitude": "dsp/amplitude", "range": "core/range", "multiply": "core/multiply", "invert": "dsp/invert",
