@@ -34,6 +34,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                   runs one more ring period cycle by cycle, then a whole-period graph replay and a tail; a sample of
                   rows of every slot's range output and the full spectrogram state are recomputed by the oracle
                   (the checker; the timed leg never touches it) and compared bit for bit.
+  reference_driven -- the same workload with the REFERENCE's own Flowgraph, scheduler and Runtime in charge, device-resident on
+                  DeviceType::HIP (integration/device_hip/ linked into oracle/_ref/libref_jetstream_devhip.so): synchronous
+                  cycles, asynchronous cycles, deferred cycle-batched spans, module by module -- with a parity stamp taken
+                  from the reference module's own state tensor (tools/reference_driven_bench.py).
   host_fed     -- the same chain fed from PINNED HOST memory: every cycle's batch is uploaded with
                   jst_tensor_copy_from_host_async on the library's side stream into the next ring slot while
                   the previous slot computes (the HBM replacement of the Soapy CircularBuffer hand-over,
@@ -310,6 +314,21 @@ def other_configs(js, budget_s: float = 45.0) -> list:
     guarded("configs[3]: WBFM 20 MS/s -> Filter(/100) -> FM wide 75us -> Decimator(/4)", c4)
     guarded("configs[4] per GPU: Window -> 65536-pt FFT -> Amplitude -> Range -> Lineplot average, 16 batches", c5)
     return out
+
+
+def reference_driven(slots: int, steps: int, provider: str) -> dict:
+    """The headline workload driven by the REFERENCE's own Flowgraph / scheduler / Runtime on DeviceType::HIP (the patched core of
+    integration/device_hip/ linked with the library: oracle/_ref/libref_jetstream_devhip.so), in a process of its own (one build
+    of the reference per process; the cpu_baseline leg loads the unpatched one).  tools/reference_driven_bench.py has the forms."""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_jetstream_devhip.so")):
+        return {"available": False, "why": "oracle/_ref/libref_jetstream_devhip.so not built (the reference tree was absent at build time)"}
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "reference_driven_bench.py"), "--slots", str(slots),
+                              "--cycles", str(steps), "--provider", provider], cwd=ROOT, capture_output=True, text=True, timeout=240)
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    except Exception as exc:  # the headline must not depend on it
+        return {"available": False, "error": repr(exc)}
 
 
 def baseline_metric() -> str:
@@ -840,6 +859,8 @@ def main() -> None:
     rt.destroy()
     if rank == 0 and world == 1 and not args.no_alt and not args.no_configs:
         line["configs"] = other_configs(js)
+    if rank == 0 and world == 1 and not args.no_alt:
+        line["reference_driven"] = reference_driven(args.slots, args.steps, args.provider)
     if world > 1:
         barrier()
         dist.destroy_process_group()

@@ -14,12 +14,14 @@
 // of its own) keeps the module-by-module loop.  What is visible when compute() returns is bit-identical either way, except
 // that intermediates a fused unit never materialises (the product, the spectrum, the amplitude) are not written.
 //
-// DEFERRED CYCLES (opt-in, jetstream_hip_runtime_configure(.., deferCycles > 1)): for a RESIDENT source (a ring whose next
-// cycles' inputs are already in HBM: file replay, benchmarks) compute() only counts the cycle; every `deferCycles` cycles --
-// and on jetstream_hip_runtime_flush() / destroy() -- the counted cycles run as ONE jst_runtime_compute(n) with
-// JST_RUNTIME_BATCH: one launch per unit for the whole span.  Outputs the library turned into rings are copied (latest
-// slot, device to device, on the runtime's stream) into the reference's tensors at each flush, so a reader that
-// synchronised through flush() sees what n synchronous cycles would have left.  Default: every cycle is synchronous.
+// DEFERRED CYCLES (opt-in, jetstream_hip_runtime_configure(.., deferCycles >= 1)): for a RESIDENT source (a ring whose next
+// cycles' inputs are already in HBM: file replay, benchmarks) compute() only counts the cycle; every `deferCycles` cycles
+// the counted cycles are ENQUEUED as ONE jst_runtime_compute(n) -- with JST_RUNTIME_BATCH: one launch per unit for the whole
+// span -- and compute() returns without waiting, so the scheduler's bookkeeping of the next span overlaps the device's work
+// on this one.  jetstream_hip_runtime_flush() (and destroy()) is the synchronisation point: it enqueues what is still
+// counted, copies the outputs the library turned into rings (latest slot, device to device, on the runtime's stream) into
+// the reference's tensors and waits -- a reader behind flush() sees what n synchronous cycles would have left.
+// deferCycles = 1: every cycle is enqueued at once, still without a wait.  Default (0): every cycle is synchronous.
 #ifdef JETSTREAM_BACKEND_HIP_AVAILABLE
 
 #include <atomic>
@@ -77,7 +79,7 @@ struct NativeHipRuntime : public Runtime::Impl {
                 library = {};
                 return Result::ERROR;
             }
-            if (deferCycles > 1 && !jst_runtime_batched(library)) deferCycles = 0;  // not a chain the library can batch
+            batchedSpans = deferCycles > 1 && jst_runtime_batched(library);   // else: spans of per-cycle launches
         } else if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
             JST_ERROR("[RUNTIME_IMPL_NATIVE_HIP] Failed to create the stream of runtime '{}'.", name);
             return Result::ERROR;
@@ -144,14 +146,15 @@ struct NativeHipRuntime : public Runtime::Impl {
 
     // everything counted so far runs now; on return the reference's tensors hold the latest cycle
     Result flush() {
-        if (!library || pending == 0) return Result::SUCCESS;
-        const uint64_t cycles = pending;
-        pending = 0;
-        jst_result r = jst_runtime_compute(library, cycles, 0);
-        if (r == JST_SUCCESS) r = publishLatest();
+        if (!library) return Result::SUCCESS;
+        jst_result r = launchPending();
+        if (r == JST_SUCCESS && unpublished) {
+            r = publishLatest();
+            unpublished = false;
+        }
         if (r == JST_SUCCESS) r = jst_runtime_synchronize(library);
         if (r != JST_SUCCESS) {
-            JST_ERROR("[RUNTIME_IMPL_NATIVE_HIP] Runtime '{}': {} deferred cycles failed: {}", name, cycles, jst_last_error());
+            JST_ERROR("[RUNTIME_IMPL_NATIVE_HIP] Runtime '{}': deferred cycles failed: {}", name, jst_last_error());
             return static_cast<Result>(r);
         }
         return Result::SUCCESS;
@@ -164,11 +167,20 @@ struct NativeHipRuntime : public Runtime::Impl {
         text.resize(std::strlen(text.c_str()));
         return text;
     }
-    bool batched() const { return library && deferCycles > 1; }
+    bool batched() const { return library && batchedSpans; }
 
  private:
     static std::shared_ptr<NativeHipRuntimeContext> context(const std::shared_ptr<Module>& module) {
         return std::dynamic_pointer_cast<NativeHipRuntimeContext>(module->context()->runtime());
+    }
+
+    // the counted cycles go to the device as ONE span -- not waited for: the scheduler counts the next span meanwhile
+    jst_result launchPending() {
+        if (pending == 0) return JST_SUCCESS;
+        const uint64_t cycles = pending;
+        pending = 0;
+        unpublished = true;
+        return jst_runtime_compute(library, cycles, 0);
     }
 
     jst_result publishLatest() {
@@ -192,8 +204,12 @@ struct NativeHipRuntime : public Runtime::Impl {
             }
         }
         const auto start = std::chrono::steady_clock::now();
-        if (deferCycles > 1 && settled) {
-            if (++pending >= deferCycles) JST_CHECK(flush());
+        if (deferCycles >= 1 && settled) {
+            if (++pending >= deferCycles && launchPending() != JST_SUCCESS) {
+                JST_ERROR("[RUNTIME_IMPL_NATIVE_HIP] Runtime '{}': {}", name, jst_last_error());
+                for (const auto& n : targets) failedModules.insert(n);
+                return Result::ERROR;
+            }
         } else {
             const jst_result r = jst_runtime_compute(library, 1, 1);
             if (r == JST_YIELD || r == JST_TIMEOUT || r == JST_SKIP) {
@@ -260,7 +276,7 @@ struct NativeHipRuntime : public Runtime::Impl {
     hipStream_t stream = nullptr;
     jst_runtime library{};
     uint64_t deferCycles = 0, pending = 0;
-    bool settled = false;
+    bool settled = false, unpublished = false, batchedSpans = false;
     Runtime::Modules modulesMap;
     std::vector<std::string> moduleNames;
 };

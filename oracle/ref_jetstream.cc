@@ -565,6 +565,13 @@ int ref_fg_compute_timed(void* h, double epoch_s, uint32_t epochs, double* rates
     }
     return (int)r;
 }
+// n x Flowgraph::compute() in a C loop (the caller times it); returns the Result of the last one
+int ref_fg_compute_n(void* h, uint64_t n) {
+    auto* s = static_cast<FgSession*>(h);
+    Result r = Result::SUCCESS;
+    for (uint64_t i = 0; i < n && r == Result::SUCCESS; ++i) r = s->fg->compute();
+    return (int)r;
+}
 void ref_fg_free(void* h) { delete static_cast<FgSession*>(h); }
 
 }  // extern "C"

@@ -434,3 +434,7 @@ class RefFlowgraph:
 
     def compute(self) -> int:
         return int(self._l.ref_fg_compute(self._h))
+
+    def compute_n(self, n: int) -> int:
+        """n x Flowgraph::compute() in a C loop."""
+        return int(self._l.ref_fg_compute_n(self._h, C.c_uint64(n)))
