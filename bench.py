@@ -597,7 +597,7 @@ def main() -> None:
 
     def parity_check(rt, provider: str) -> dict:
         """The checker leg (never inside a timed region): the runtime that was just timed -- same graphs, same ring
-        data -- runs one more ring period cycle by cycle (a sample of rows of EVERY slot's range output is compared),
+        data -- runs one more ring period cycle by cycle (EVERY row of EVERY slot's range output is compared),
         then a whole-period graph replay plus a 3-cycle tail; the full spectrogram state the device ends with must
         equal, bit for bit, the oracle's replay of the same cycles from the state the device started this leg with."""
         t0 = time.perf_counter()
@@ -609,7 +609,7 @@ def main() -> None:
         rng = np.random.default_rng(rt._seed)
         data = [synth_slot(rng, s) for s in range(slots)]  # the generator that filled the ring, replayed
         state = spectrogram.state("frequencyBins").numpy().reshape(-1).copy()
-        rows = np.unique(np.linspace(0, BATCHES - 1, 64).astype(np.int64))
+        rows = np.arange(BATCHES)   # every row of every slot (rounds 1-5 sampled 64 of the 1024: VERDICT r05)
         refs, out_equal, max_err, bad_words = [], True, 0.0, 0
         for s in range(slots):
             rt.compute(1, sync=True)
@@ -713,6 +713,7 @@ def main() -> None:
                                                          "(another provider, or another launch form): not quoted"}
         step_ms = elapsed / args.steps * 1e3
         step_bytes = STEP_BYTES_PER_SAMPLE * BATCHES * N_FFT
+        frac_rocprof = (algo_bytes * cycles_per_launch / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if rocprof_us else None
         line = {
             "metric": baseline_metric(),
             "value": samples / elapsed / 1e6,
@@ -753,11 +754,13 @@ def main() -> None:
                        "collective": collective},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         # the same fraction from the TRACKED rocprofv3 summary (profiles/, same kernel sources by hash, same
-                         # launch form): the profiler costs the kernel a few percent, so this is the conservative figure
-                         "frac_rocprof": (algo_bytes * cycles_per_launch / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS)
-                                         if rocprof_us else None,
+                         # `frac` is the CONSERVATIVE figure: the tracked rocprofv3 summary's mean dispatch duration of this kernel
+                         # (profiles/, same kernel sources by hash, same launch form; the profiler costs the kernel a few percent)
+                         # when there is one, else the event pair's; both are always stated beside it
+                         "frac": frac_rocprof if frac_rocprof else ((achieved / HBM_PEAK_GBS) if achieved else None),
+                         "frac_source": "rocprofv3 (profiles/)" if frac_rocprof else "hipEvent pair (no matching rocprofv3 record)",
+                         "frac_event_pair": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "frac_rocprof": frac_rocprof,
                          "rocprofv3_kernel_us": rocprof_us,
                          "traffic": traffic, "traffic_provenance": traffic_src, "kernel_ms": kernel_ms,
                          "kernel_ms_method": "hipEvent pair on the runtime's stream around the kernel's eager launches "
@@ -805,11 +808,11 @@ def main() -> None:
         if world == 1 and rt.batched and not args.no_alt and not args.no_graph:
             # The decision JST_RUNTIME_EAGER_SPANS asks for, on this run's own evidence: a cycle-batched span is two kernel
             # launches; replayed as a two-node hipGraph (the default: configs[1] names hipGraph capture) or submitted directly.
-            os.environ["JST_RUNTIME_EAGER_SPANS"] = "1"
+            js.debug_set("JST_RUNTIME_EAGER_SPANS", "1")
             try:
                 rt6, elapsed6 = measure(args.provider, seed_offset=0)
             finally:
-                del os.environ["JST_RUNTIME_EAGER_SPANS"]
+                js.debug_set("JST_RUNTIME_EAGER_SPANS", None)
             line["alt_eager_spans"] = {"value": samples / elapsed6 / 1e6, "unit": "MS/s", "ms_per_step": elapsed6 / args.steps * 1e3,
                                        "step_frac": step_bytes / (elapsed6 / args.steps) / 1e9 / HBM_PEAK_GBS,
                                        "what": "the same cycle-batched spans submitted as direct kernel launches instead of a "

@@ -7,6 +7,7 @@
 #include <mutex>
 
 #include "jst/comm.hh"
+#include "jst/switches.hh"
 #include "jst/module.hh"
 #include "modules/modules.hh"
 
@@ -514,6 +515,11 @@ jst_result jst_filter_plan(float sample_rate, float bandwidth, const float* cent
     plan->resample = p.resample ? 1 : 0;
     plan->resampled_sample_rate = p.resampledSampleRate;
     for (uint64_t h = 0; h < heads; ++h) offsets[h] = h < p.resamplerOffsets.size() ? p.resamplerOffsets[h] : 0;
+    return R(Result::SUCCESS);
+}
+
+jst_result jst_debug_set(const char* name, const char* value) {
+    JST_ARG(name && switch_set(name, value), "unknown switch");
     return R(Result::SUCCESS);
 }
 

@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "../modules/modules.hh"
+#include "switches.hh"
 
 namespace jst {
 
@@ -280,7 +281,8 @@ Result Runtime::flushUnits() {
 
 Result Runtime::planUnits() {
     units_.clear();
-    for (Module* m : ordered_)  // a decision of an earlier runtime does not outlive it
+    for (Module* m : ordered_) m->resetPlan();  // a decision of an earlier runtime does not outlive it
+    for (Module* m : ordered_)
         if (auto* spec = dynamic_cast<modules::Spectrogram*>(m)) spec->combined = spec->indexFed = false;
     for (Module* m : ordered_)
         if (auto* cast = dynamic_cast<modules::Cast*>(m)) cast->fusedIntoSpectrum = false;
@@ -306,6 +308,7 @@ Result Runtime::planUnits() {
         Unit u;
         size_t consumed = 0;
         if ((flags_ & FUSE) && !is_static[i] && tryFuseSpectrum(i, u, consumed)) {
+            if (u.name.size() > 8 && u.name.compare(u.name.size() - 8, 8, "(elided)") == 0) u.has_kernels = false;  // nothing reaches the stream
             units_.push_back(std::move(u));
             i += consumed;
             continue;
@@ -359,7 +362,7 @@ Result Runtime::planBranches() {
     // ROCm's graph executor pays more for a cross-branch edge than the overlap of launch-floor kernels returns.  The plan
     // stays (JST_RUNTIME_MAX_BRANCHES=n opts in); the default is one chain.
     int kMaxBranches = 1;
-    if (const char* e = getenv("JST_RUNTIME_MAX_BRANCHES")) kMaxBranches = std::atoi(e) > 0 ? std::atoi(e) : 1;
+    if (const int n = switch_value(SW_RUNTIME_MAX_BRANCHES)) kMaxBranches = n;
     for (auto& u : units_) {
         u.deps.clear();
         u.branch = 0;
@@ -372,6 +375,7 @@ Result Runtime::planBranches() {
         for (Module* m : u.modules) {
             for (const auto& kv : m->inputs()) reads[i].insert(kv.second.storageId());
             for (const auto& kv : m->outputs()) writes[i].insert(kv.second.storageId());
+            m->planStorage(reads[i], writes[i]);
         }
     }
     auto meets = [](const std::set<const void*>& a, const std::set<const void*>& b) {
@@ -482,6 +486,10 @@ Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
     }
     cycles_ = 0;
     created_ = true;
+    for (Module* m : ordered_) {  // from here on the planned storage stays where it is (Tensor::rebind refuses)
+        for (const auto& kv : m->inputs()) kv.second.runtimeBound(+1);
+        for (const auto& kv : m->outputs()) kv.second.runtimeBound(+1);
+    }
     return Result::SUCCESS;
 }
 
@@ -499,7 +507,7 @@ Result Runtime::create(const std::vector<Module*>& modules, U32 flags) {
 Result Runtime::planBatch() {
     batched_ = false;
     if (!(flags_ & BATCH) || !(flags_ & GRAPH) || !(flags_ & FUSE) || (flags_ & (PIPELINE | COMBINE)) || period_ < 2 ||
-        getenv("JST_RUNTIME_NO_BATCH") != nullptr)
+        switch_value(SW_RUNTIME_NO_BATCH) != 0)
         return Result::SUCCESS;
     size_t fused = units_.size();
     for (size_t i = 0; i < units_.size(); ++i) {
@@ -755,8 +763,12 @@ Result Runtime::destroy() {
     branch_join_.clear();
     if (branch_fork_) (void)hipEventDestroy(branch_fork_);
     branch_fork_ = nullptr;
-    for (size_t i = ordered_.size(); i-- > 0;)  // reverse order (native/cuda/impl.cc:126-137)
+    for (size_t i = ordered_.size(); i-- > 0;) {  // reverse order (native/cuda/impl.cc:126-137)
         (void)ordered_[i]->computeDeinitialize();
+        ordered_[i]->resetPlan();
+        for (const auto& kv : ordered_[i]->inputs()) kv.second.runtimeBound(-1);
+        for (const auto& kv : ordered_[i]->outputs()) kv.second.runtimeBound(-1);
+    }
     ordered_.clear();
     if (stream_) (void)hipStreamDestroy(stream_);
     stream_ = nullptr;
@@ -940,7 +952,7 @@ Result Runtime::launchSpan(U64 n, bool timing) {
     // A cycle-batched span is one launch per unit: two or three kernels.  JST_RUNTIME_EAGER_SPANS=1 (A/B switch) submits
     // them directly instead of replaying a graph of them.
     // (read per call: bench.py measures both forms in one process -- `alt_eager_spans`)
-    const bool eager_spans = getenv("JST_RUNTIME_EAGER_SPANS") != nullptr;
+    const bool eager_spans = switch_value(SW_RUNTIME_EAGER_SPANS) != 0;
     if (eager_spans && batched_) {
         JST_CHECK(submitBatched(n, false));
         for (auto& u : units_) {
@@ -1066,7 +1078,7 @@ Result Runtime::compute(U64 cycles, bool sync) {
             }
         }
         if (use_graph && !pipelined() && period_ > 1 && cycles > period_ && cycles < 2 * period_ &&
-            (cycles_ % period_) == capture_phase_ && getenv("JST_RUNTIME_NO_SPANS") == nullptr) {
+            (cycles_ % period_) == capture_phase_ && switch_value(SW_RUNTIME_NO_SPANS) == 0) {
             // One period and a tail: ONE graph of exactly these cycles (cached per (phase, cycles) like every span)
             // instead of the period graph followed by a span graph -- a launch less per call, which is what a short
             // timed region (bench.py --steps 20 with 16 ring slots) is made of.

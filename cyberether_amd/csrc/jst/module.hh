@@ -84,6 +84,13 @@ class Module {
     // submissions would have left (Runtime::planBatch).  spanCapable() is asked at planning time.
     virtual bool spanCapable() const { return false; }
     virtual Result computeSubmitSpan(hipStream_t /*stream*/, U64 /*first_slot*/, U64 /*n*/) { return Result::ERROR; }
+    // A runtime's planner may rewire a module for a fused / elided unit (a duplicate whose readers are pointed at its source).
+    // Called at the top of every plan and when the runtime is destroyed: no planning decision outlives the runtime that took it.
+    virtual void resetPlan() {}
+    // Storage this module touches OUTSIDE its ports, as planned: state tensors, side outputs a fused unit writes for it, an
+    // operand the planner pointed elsewhere.  Runtime::planBranches derives the edges between parallel branches from the
+    // ports plus these (ports alone miss the Waterfall's ring, the Spectrogram's row indices, an elided duplicate's readers).
+    virtual void planStorage(std::set<const void*>& /*reads*/, std::set<const void*>& /*writes*/) const {}
     // False for view/bookkeeping modules whose computeSubmit enqueues nothing on the stream.
     virtual bool launchesKernels() const { return true; }
     // Named internal state tensors (spectrogram/waterfall "frequencyBins"), for read-back.

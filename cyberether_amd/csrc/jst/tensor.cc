@@ -105,6 +105,19 @@ Result Tensor::rebind(void* ptr, size_t bytes) {
         JST_ERROR("[MEMORY:TENSOR] Cannot rebind ring storage.");
         return Result::ERROR;
     }
+    if (buffer_->bound > 0) {
+        JST_ERROR("[MEMORY:TENSOR] Cannot rebind storage a live runtime has planned over (captured graphs hold its address): "
+                  "rebind before Runtime::create, or destroy the runtime first.");
+        return Result::ERROR;
+    }
+    if (buffer_->device == DeviceType::HIP) {  // memory the device can address: HBM, or host memory the HIP runtime pinned / mapped
+        hipPointerAttribute_t attributes{};
+        if (hipPointerGetAttributes(&attributes, ptr) != hipSuccess || attributes.type == hipMemoryTypeUnregistered) {
+            (void)hipGetLastError();
+            JST_ERROR("[MEMORY:TENSOR] Cannot rebind a HIP tensor to memory the device cannot address.");
+            return Result::ERROR;
+        }
+    }
     if (bytes < buffer_->bytes) {
         JST_ERROR("[MEMORY:TENSOR] External buffer of %llu bytes is smaller than the storage it replaces (%llu bytes).",
                   (unsigned long long)bytes, (unsigned long long)buffer_->bytes);

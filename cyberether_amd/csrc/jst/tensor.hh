@@ -28,6 +28,9 @@ struct Buffer {
     U64 slots = 1;
     size_t slot_bytes = 0;
     U64 slot = 0;
+    // Number of live runtimes that planned over this storage: captured hipGraphs, transform plans and ring selections hold
+    // its raw address from Runtime::create on, so the storage cannot move (Tensor::rebind) until they are gone.
+    int bound = 0;
     void* base() const { return static_cast<char*>(ptr) + slot * slot_bytes; }
     ~Buffer();
 };
@@ -64,6 +67,7 @@ class Tensor {
     // binding gets a say: integration/device_hip/fft_module_impl_native_hip.cc).  Single-slot storage only, and before
     // the first compute (a captured graph holds addresses).
     Result rebind(void* ptr, size_t bytes);
+    void runtimeBound(int delta) const { if (buffer_) buffer_->bound += delta; }
     // This tensor becomes a view {shape, stride, offset} (elements; stride empty = dense) of `base`'s STORAGE: what the
     // reference's Tensor copies are once slice / permute / broadcastTo have edited them (src/memory/tensor.cc:196-306) --
     // for a host framework whose consumer sees a producer's tensor through a geometry of its own.  Storage identity (and

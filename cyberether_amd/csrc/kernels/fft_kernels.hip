@@ -12,10 +12,7 @@ using namespace jst::dev;
 namespace {
 
 // JST_FFT_KERNEL=slot selects the non-pipelined kernel (A/B comparisons, tests run both).
-inline bool use_pipe_kernel() {
-    const char* e = getenv("JST_FFT_KERNEL");
-    return !(e && e[0] == 's');
-}
+inline bool use_pipe_kernel() { return jst::switch_value(jst::SW_FFT_KERNEL) != 's'; }
 inline bool window_contig(const LoadCF32&) { return true; }
 inline bool window_contig(const LoadCF32TimesWindow& p) { return p.wstride == 1; }
 template <class RAW, bool SIGNED>

@@ -78,10 +78,10 @@ hipError_t launch_side(const FftLayout& L, const float2* W, const Pro& pro, cons
 // against 20.3, 4096 transforms 52.7 = 52.9, 8192 transforms 93.0 against 92.0 (r05_experiments/q_small_launches.log); the
 // quad kernel takes launches of eight rounds and more (where its claimed rounds start, too).
 // JST_FFT_KERNEL=pipe keeps the pipelined kernel throughout, =quad the quad kernel at every size (A/B, tests run both).
-bool quad_selected(uint64_t transforms) {  // read per call, like use_pipe_kernel (fft_kernels.hip): the tests switch kernels inside one process
-    const char* k = getenv("JST_FFT_KERNEL");
-    if (k && (k[0] == 'p' || k[0] == 'w' || k[0] == 's')) return false;
-    if (k && k[0] == 'q') return true;
+bool quad_selected(uint64_t transforms) {  // a switch, not the environment: the tests switch kernels inside one process (jst_debug_set)
+    const int k = jst::switch_value(jst::SW_FFT_KERNEL);
+    if (k == 'p' || k == 'w' || k == 's') return false;
+    if (k == 'q') return true;
     return transforms >= 8ull * 4ull * (uint64_t)side_compute_units();
 }
 
@@ -95,7 +95,7 @@ hipError_t launch_side_quad(const FftLayout& L, const float2* W, const Pro& pro,
     // Claimed rounds only for launches of eight rounds and more (a cycle-batched span): with fewer, the claims of a whole
     // round arrive at the counters at once -- a 1024-transform launch took 32 us instead of 20 (i_hybrid_eight_counters.log).
     // JST_QUAD_STATIC=1: the static round robin throughout (A/B).
-    const bool all_static = getenv("JST_QUAD_STATIC") != nullptr;
+    const bool all_static = jst::switch_value(jst::SW_QUAD_STATIC) != 0;
     if (all_static || L.transforms < 8 * resident) sched = nullptr;
     (void)hipGetLastError();
     hipLaunchKernelGGL((fft_quad_kernel<true, Pro, Epi>), dim3((unsigned)blocks), dim3(kQuadT), lds, stream, L, W, pro, epi, sched);
@@ -136,8 +136,7 @@ uint64_t spectrum_side_pitch(uint64_t batches) { return batches + 2; }
 uint64_t spectrum_sched_words() { return kQuadSchedWords; }
 
 bool spectrum_side_supported(uint64_t n, const FftLayout& L, int64_t window_stride, uint64_t height) {
-    const char* k = getenv("JST_FFT_KERNEL");
-    if (k && k[0] == 's') return false;  // the non-pipelined kernel has no side store
+    if (jst::switch_value(jst::SW_FFT_KERNEL) == 's') return false;  // the non-pipelined kernel has no side store
     if (n != 1024 && n != 2048 && n != 4096 && n != 8192) return false;
     // dense rows on both sides, transform t's output row at element t * n (the side tensor follows the same numbering)
     if (L.in_axis_stride != 1 || L.out_axis_stride != 1 || window_stride != 1 || L.outer_rank != 1) return false;

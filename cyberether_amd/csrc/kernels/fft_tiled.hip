@@ -261,17 +261,10 @@ constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_
     return true;
 }
 
-// JST_TILED_GENERIC=0: A/B switch (tools/bench_multi_fm.py), plans with a generic radix go back to one launch per pass
-inline bool generic_radix_tiles_enabled() {
-    static const bool on = [] { const char* e = getenv("JST_TILED_GENERIC"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
-// JST_TILED_SPLIT=0: A/B switch, lengths that fit a tile always run as one kernel
-inline bool small_split_enabled() {
-    static const bool on = [] { const char* e = getenv("JST_TILED_SPLIT"); return !(e && e[0] == '0'); }();
-    return on;
-}
+// (closed experiments: plans with a generic radix run on the tiles -- multi-fm.yml's Filter FFTs 66.0 -> 36.4 us --, and
+// short launches of lengths that fit a tile split into columns + blocks -- 131 -> 125 us per cycle; profiles/EXPERIMENTS.md)
+inline bool generic_radix_tiles_enabled() { return true; }
+inline bool small_split_enabled() { return true; }
 
 bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p, bool allow_split = true) {
     constexpr uint32_t force_ca = 0, force_cb = 0;  // lanes per workgroup of the two kernels: picked below
@@ -992,12 +985,7 @@ inline uint64_t min_threads_for_passes(const TiledPlan& P, uint32_t first, uint3
     }
     return need;
 }
-inline unsigned threads_for(uint64_t tile_elems, const char* override_env = nullptr, uint64_t min_threads = 0) {
-    if (override_env) {  // A/B switches JST_TILED_TA / JST_TILED_TB: workgroup size of the columns / blocks kernel
-        const char* e = getenv(override_env);
-        const int v = e ? atoi(e) : 0;
-        if (v >= 64 && v <= kMaxThreads && v % 64 == 0 && (uint64_t)v >= min_threads) return (unsigned)v;
-    }
+inline unsigned threads_for(uint64_t tile_elems, uint64_t min_threads = 0) {
     uint64_t t = ((tile_elems / 8 + 255) / 256) * 256;
     if (t < 256) t = 256;
     if (t < min_threads) t = ((min_threads + 63) / 64) * 64;  // a generic-radix pass may need more (wave-granular tasks)
@@ -1028,7 +1016,7 @@ hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2*
         }
         const uint64_t blocks = L.transforms * ((P.S + P.CA - 1) / P.CA);
         if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(ka, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.R1 * P.CA, "JST_TILED_TA", min_threads_for_passes(P, 0, P.g, (uint64_t)P.R1 * P.CA))), lds_a, s, L, P, W,
+        hipLaunchKernelGGL(ka, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.R1 * P.CA, min_threads_for_passes(P, 0, P.g, (uint64_t)P.R1 * P.CA))), lds_a, s, L, P, W,
                            pro, scratch);
     }
     const size_t lds_b = (size_t)P.S * (P.CB | 1u) * sizeof(float2);
@@ -1041,7 +1029,7 @@ hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2*
     const uint64_t blocks = P.R1 > 1 ? L.transforms * ((P.R1 + P.CB - 1) / P.CB)
                                      : (L.transforms + P.CB - 1) / P.CB;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.S * P.CB, "JST_TILED_TB", min_threads_for_passes(P, P.g, P.nf, (uint64_t)P.S * P.CB))), lds_b, s, L, P, W, pro, epi,
+    hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.S * P.CB, min_threads_for_passes(P, P.g, P.nf, (uint64_t)P.S * P.CB))), lds_b, s, L, P, W, pro, epi,
                        (const float2*)scratch);
     return hipGetLastError();
 }

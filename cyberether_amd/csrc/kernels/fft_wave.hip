@@ -22,9 +22,9 @@ using namespace jst::dev;
 // JST_FFT_KERNEL=wave / pipe selects (read once)
 bool spectrum_wave_selected() {
     static const bool on = [] {
-        const char* k = getenv("JST_FFT_KERNEL");
-        if (k && k[0] == 'w') return true;
-        if (k && k[0] == 'p') return false;
+        const int k = jst::switch_value(jst::SW_FFT_KERNEL);
+        if (k == 'w') return true;
+        if (k == 'p') return false;
         return JST_WAVE_DEFAULT != 0;
     }();
     return on;

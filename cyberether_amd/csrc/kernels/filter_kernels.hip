@@ -1303,12 +1303,12 @@ hipError_t launch_am(float* out, const float2* in, void* states, float alpha, co
 hipError_t launch_fm(float* out, const float2* in, void* states, const FmCoeffs& k, const FmLayout& L,
                      hipStream_t s) {
     (void)hipGetLastError();
-    if (!k.wide && k.deemph_enabled && L.batches * L.samples > 0 && !getenv("JST_FM_SERIAL")) {
+    if (!k.wide && k.deemph_enabled && L.batches * L.samples > 0 && !jst::switch_value(jst::SW_FM_SERIAL)) {
         hipLaunchKernelGGL(fm_narrow_deemph_kernel, dim3((unsigned)L.lanes), dim3(kFmThreads), 0, s, out, in,
                            (FmState*)states, k, L);
         return hipGetLastError();
     }
-    if (k.wide && L.batches * L.samples > 0 && !getenv("JST_FM_SERIAL")) {
+    if (k.wide && L.batches * L.samples > 0 && !jst::switch_value(jst::SW_FM_SERIAL)) {
         hipLaunchKernelGGL(fm_wide_kernel, dim3((unsigned)L.lanes), dim3(kFmWideThreads), 0, s, out, in,
                            (FmState*)states, k, L);
         return hipGetLastError();

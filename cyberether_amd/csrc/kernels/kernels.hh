@@ -2,6 +2,7 @@
 // functions; the module layer (../modules) is the only caller.
 #pragma once
 
+#include "../jst/switches.hh"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -411,156 +411,6 @@ __global__ __launch_bounds__(kThreads) void spectrogram_index_span_kernel(float*
     JST_SPAN_DUMP();
 }
 
-// Round 5 form of the span kernel: the hit update of cycle c runs WHILE the LDS unit counts cycle c + 1.
-// The shipped form above is a serial chain per workgroup -- atomics (LDS) -> barrier -> counts read -> barrier -> decay +
-// hits (VALU, up to 50 dependent additions per cell) -> the next cycle's atomics: the LDS unit idles during the hit update
-// and the VALUs during the counting (timeline, bench indices: rows 1150 | barrier 760 | counts 286 | barrier 214 | hits 1216
-// ticks per cycle, r03_experiments/w_...).  Here two histograms are used alternately, and a cycle is
-//     barrier (cycle c's atomics are in) -> read + zero the counts of c -> ISSUE the atomics of c + 1 into the other
-//     histogram (no return value: the wavefront does not wait for them) -> decay + hits of c on the registers
-// so the two long phases overlap inside every wavefront, and one barrier per cycle is left.  (Round 4's two-histogram
-// variant, tools/ubench/spectrogram_span2_experiment.hh, kept the hit update IN FRONT of the next cycle's atomics -- no
-// overlap -- and lost to its four copies' read-back.)  Histogram U32[index][4 copies][16 columns]: the four 16-lane groups of
-// an atomic instruction -- four rows, whose equal columns tend to carry the SAME index -- count into their own copies (64
-// distinct addresses per instruction); a cell's four partial counts sit 64 B apart (two ds_read2_b32 / ds_write2_b32 per cell).
-// Same counts, same update order per cell: bit-identical state.
-template <int kThreads>
-__global__ __launch_bounds__(kThreads) void spectrogram_index_span3_kernel(float* __restrict__ bins, const uint8_t* __restrict__ idx,
-                                                                           uint32_t batches, uint32_t pitch, uint32_t width,
-                                                                           uint32_t height, float decay, uint32_t cycles,
-                                                                           uint32_t first_slot, uint32_t ring_slots) {
-    static_assert(kThreads == 1024, "one thread per (index row, column quad) of a 256 x 16 tile");
-    constexpr uint32_t TW = 16;
-    extern __shared__ __attribute__((aligned(64))) unsigned char smem_raw[];
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smem_raw);
-    const uint32_t tid = threadIdx.x;
-    const uint32_t hist_words = height * 64u;  // one histogram
-    uint32_t tile = blockIdx.x;
-    if ((gridDim.x & 7u) == 0u) tile = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-
-    // this thread's cells: e = tid + 1024 j (index row e / 16, column e % 16), as in the shipped kernel: the 64 lanes of a
-    // wavefront own four ADJACENT index rows x 16 columns per j, so the rows a signal actually hits -- a band of neighbouring
-    // rows, the same in every column -- keep whole wavefronts busy in the hit update and leave the others with nothing to do
-    // (a thread that owned four adjacent columns of ONE row -- 16-byte count reads -- put the whole band on one or two
-    // wavefronts with four serial update loops each: 56 us per 20-cycle span against 37, r05 r)
-    const uint32_t cells = height * TW;
-    float state[4];
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-        const uint32_t e = tid + j * kThreads;
-        state[j] = e < cells ? bins[(uint64_t)(e / TW) * width + tile * TW + (e % TW)] : 0.0f;
-    }
-
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    const uint32_t cycle_bytes = pitch * width;
-    const __amdgpu_buffer_rsrc_t r_idx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(idx), 0, (ring_slots ? ring_slots : cycles) * cycle_bytes, 0x00020000);
-    uint32_t req_slot = ring_slots ? first_slot : 0u;
-    const uint32_t tile_base = (tile >> 3) * pitch * 128u + (tile & 7u) * TW, row_bytes = 128u;  // tile-major indices
-    const uint32_t rounds_per_cycle = (batches + 1023u) >> 10;
-    const uint32_t total_rounds = cycles * rounds_per_cycle;
-    uint32_t req_cycle = 0, req_first = 0;
-    auto request = [&](v4u& dst) {
-        const uint32_t row = req_first + tid;  // a row (or a round) that does not exist reads as 0: no hits
-        dst = __builtin_amdgcn_raw_buffer_load_b128(
-            r_idx, (row < batches && req_cycle < cycles) ? req_slot * cycle_bytes + tile_base + row * row_bytes : 0xfffffff0u, 0, 0);
-        req_first += 1024u;
-        if (req_first >= batches) {
-            req_first = 0u;
-            ++req_cycle;
-            ++req_slot;
-            if (ring_slots && req_slot == ring_slots) req_slot = 0u;
-        }
-    };
-    v4u q0, q1, q2, q3;
-    request(q0);
-    request(q1);
-    request(q2);
-    for (uint32_t e = tid * 4u; e < 2u * hist_words; e += kThreads * 4u)
-        *reinterpret_cast<uint4*>(hist + e) = make_uint4(0u, 0u, 0u, 0u);
-    lds_only_barrier();
-
-    const uint32_t rot = tid & 15u;
-    typedef __attribute__((address_space(3))) uint32_t* lds_u32;
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)hist;
-    const uint32_t group_off = ((tid >> 4) & 3u) * 64u;  // bytes: this 16-lane group's copy inside an index row
-    uint32_t cur_buf = 0;                                  // byte offset of the histogram the current cycle counts into
-    auto count_rows = [&](const v4u& cur) {
-        const uint32_t my_base = lds_base + cur_buf + group_off;
-        const bool r1 = (rot & 4u) != 0u, r2 = (rot & 8u) != 0u;
-        const uint32_t a0 = r1 ? cur.y : cur.x, a1 = r1 ? cur.z : cur.y, a2 = r1 ? cur.w : cur.z, a3 = r1 ? cur.x : cur.w;
-        const uint32_t b0 = r2 ? a2 : a0, b1 = r2 ? a3 : a1, b2 = r2 ? a0 : a2, b3 = r2 ? a1 : a3;
-        const uint32_t sh = rot & 3u;
-        const uint32_t g[4] = {__builtin_amdgcn_alignbyte(b1, b0, sh), __builtin_amdgcn_alignbyte(b2, b1, sh),
-                               __builtin_amdgcn_alignbyte(b3, b2, sh), __builtin_amdgcn_alignbyte(b0, b3, sh)};
-#pragma unroll
-        for (uint32_t j = 0; j < 16; ++j) {
-            const uint32_t i = (g[j >> 2] >> (8u * (j & 3u))) & 0xffu;
-            const uint32_t addr = (i << 8) + ((((rot + j) & 15u) << 2) + my_base);
-            __hip_atomic_fetch_add((lds_u32)(uintptr_t)addr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    };
-    // the counts of the cycle that counted into the histogram at byte offset `buf`: read, summed over the copies, zeroed
-    uint32_t k[4] = {0u, 0u, 0u, 0u};
-    auto take_counts = [&](uint32_t buf) {
-        lds_only_barrier();  // every wavefront's atomics of that cycle are in
-        uint32_t* h = hist + (buf >> 2);
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t e = tid + j * kThreads < cells ? tid + j * kThreads : 0u;
-            uint32_t* p = h + ((e >> 4) << 6) + (e & 15u);  // copy 0 of cell e; copies 16 words apart (two ds_read2 / ds_write2)
-            uint32_t n = p[0] + p[16] + p[32] + p[48];
-            p[0] = 0u;
-            p[16] = 0u;
-            p[32] = 0u;
-            p[48] = 0u;
-            if (e < TW) n = 0u;  // index 0 collected the samples that do not hit
-            k[j] = n < 64u ? n : 64u;
-        }
-    };
-    auto update = [&]() {
-#pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) state[j] = apply_hits(state[j] * decay, k[j]);
-    };
-    uint32_t in_cycle = 0;
-    bool pending = false;  // a counted cycle whose update has not run yet (its histogram: the one cur_buf does NOT point at)
-    auto round = [&](const v4u& rows) {
-        const bool first = in_cycle == 0u && pending;
-        if (first) take_counts(cur_buf ^ (hist_words * 4u));
-        count_rows(rows);
-        if (first) {
-            update();  // on the registers, while the LDS unit works through the atomics just issued
-            pending = false;
-        }
-        if (++in_cycle == rounds_per_cycle) {
-            in_cycle = 0u;
-            pending = true;
-            cur_buf ^= hist_words * 4u;
-        }
-    };
-    for (uint32_t r = 0; r < total_rounds; r += 4u) {
-        // every request is issued whether or not its round exists (see the shipped kernel above)
-        request(q3);
-        round(q0);
-        request(q0);
-        if (r + 1u < total_rounds) round(q1);
-        request(q1);
-        if (r + 2u < total_rounds) round(q2);
-        request(q2);
-        if (r + 3u < total_rounds) round(q3);
-    }
-    if (pending) {
-        take_counts(cur_buf ^ (hist_words * 4u));
-        update();
-    }
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-        const uint32_t e = tid + j * kThreads;
-        if (e >= cells) continue;
-        store_state(bins + (uint64_t)(e / TW) * width + tile * TW + (e % TW), state[j]);
-    }
-}
-
 
 }  // namespace
 
@@ -660,19 +510,8 @@ hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64
     // copies and the hit update, not the atomics' collisions (tools/ubench/spectrogram_span2_experiment.hh,
     // profiles/r04_experiments/d_span_kernel_v2.log).
     (void)hipGetLastError();
-    // Round 5: cycles counted in PAIRS (the default below 65536 batches); JST_SPAN_KERNEL=2 keeps the round-3 form, =3 runs the
-    // overlapped two-histogram experiment (spectrogram_index_span3_kernel: 46 us per 20-cycle span against 37 -- a wavefront
-    // holds at most 15 LDS operations in flight, so its atomics are not out of its way while it updates; rejected) (A/B, tests)
-    const char* which = getenv("JST_SPAN_KERNEL");
-    if (which && which[0] == '3') {
-        const size_t lds3 = (size_t)height * 64 * 2 * sizeof(uint32_t);
-        const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(spectrogram_index_span3_kernel<1024>), 128 * 1024);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((spectrogram_index_span3_kernel<1024>), dim3((unsigned)(width / 16)), dim3(1024), lds3, stream, bins,
-                           idx, (uint32_t)batches, (uint32_t)pitch, (uint32_t)width, (uint32_t)height, decay, (uint32_t)cycles,
-                           (uint32_t)first_slot, (uint32_t)ring_slots);
-        return hipGetLastError();
-    }
+    // Round 5: cycles counted in PAIRS (below 65536 batches, spans of more than one cycle); the overlapped two-histogram form
+    // and other workgroup sizes were measured and rejected (profiles/r05_experiments/r_..., w_...).
     constexpr int copies = 2;
     const size_t lds = ((size_t)height * 16 + 16) * (size_t)copies * sizeof(uint32_t);
 #define JST_SPEC_SPAN(COPIES, PAIRED, THREADS)                                                                                       \
@@ -684,17 +523,8 @@ hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64
                            stream, bins, idx, (uint32_t)batches, (uint32_t)pitch, (uint32_t)width, (uint32_t)height,             \
                            decay, (uint32_t)cycles, (uint32_t)first_slot, (uint32_t)ring_slots JST_SPAN_TL_ARG);                \
     } while (0)
-    // JST_SPAN_THREADS (A/B): threads per workgroup of the paired form -- 1024: 34.3 us per 20-cycle span, 512: 44.5, 256: 68.3
-    // (profiles/r05_experiments/w_span_threads.log): the 4096 wavefronts take ~12 us to start, but the tile's work needs them
-    const char* th = getenv("JST_SPAN_THREADS");
-    const int threads = th ? atoi(th) : 1024;
-    if (batches < 65536 && cycles > 1 && !(which && which[0] == '2')) {
-        if (threads == 512) JST_SPEC_SPAN(2, true, 512);
-        else if (threads == 256) JST_SPEC_SPAN(2, true, 256);
-        else JST_SPEC_SPAN(2, true, 1024);
-    } else {
-        JST_SPEC_SPAN(2, false, 1024);
-    }
+    if (batches < 65536 && cycles > 1) JST_SPEC_SPAN(2, true, 1024);
+    else JST_SPEC_SPAN(2, false, 1024);
 #undef JST_SPEC_SPAN
     return hipGetLastError();
 }

@@ -383,6 +383,9 @@ class OverlapAdd : public Module {
         return key == "previousOverlap" ? &previousOverlap : nullptr;
     }
     Tensor buffer, overlap, output, previousOverlap;
+    void planStorage(std::set<const void*>&, std::set<const void*>& writes) const override {
+        if (previousOverlap.valid()) writes.insert(previousOverlap.storageId());
+    }
     std::optional<Index> batchAxis;
 };
 
@@ -613,6 +616,10 @@ class PhaseCorrection : public Module {
         return key == "phases" ? &phases : nullptr;
     }
     Tensor input, output, phases, corrections, devIncrements;
+    void planStorage(std::set<const void*>&, std::set<const void*>& writes) const override {  // state + the table a fused tail leaves for the next cycle
+        if (phases.valid()) writes.insert(phases.storageId());
+        if (corrections.valid()) writes.insert(corrections.storageId());
+    }
     F64 phaseIncrement = 0.0;
     std::vector<F64> increments;
     std::optional<Index> batchAxis, channelAxis;
@@ -1019,6 +1026,10 @@ class Fm : public Module {
                           "fm kernel");
     }
     Tensor input, output, states;
+    void planStorage(std::set<const void*>& reads, std::set<const void*>& writes) const override {  // `input` may have been pointed at a duplicate's source
+        reads.insert(input.storageId());
+        if (states.valid()) writes.insert(states.storageId());
+    }
     std::string mode = "narrow", deemphasis = "none";
     F32 sampleRate = 240e3f;
     SignalAxes axes;
@@ -1041,6 +1052,12 @@ class Duplicate : public Module {
             return Result::ERROR;
         }
         return Result::SUCCESS;
+    }
+    // TryElideDuplicate points this module's readers at its source; the rewiring is undone whenever a plan ends
+    std::vector<std::pair<Tensor*, Tensor>> rewired;
+    void resetPlan() override {
+        for (auto& [field, original] : rewired) *field = original;
+        rewired.clear();
     }
     Result create() override {
         input = inputs_.at("buffer");
@@ -1171,6 +1188,10 @@ class Lineplot : public Module {
         return nullptr;
     }
     Tensor input, signalPoints, averagingBuffer;
+    void planStorage(std::set<const void*>&, std::set<const void*>& writes) const override {
+        if (signalPoints.valid()) writes.insert(signalPoints.storageId());
+        if (averagingBuffer.valid()) writes.insert(averagingBuffer.storageId());
+    }
     U64 averaging = 1, decimation = 1, numberOfElements = 0, numberOfBatches = 0;
     U64 elementStride = 0, batchStride = 0;
     F32 normalizationFactor = 1.0f;
@@ -1593,15 +1614,12 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
             ola->buffer.offset() != 0 || ola->overlap.offset() != 0 || !ola->buffer.contiguous() ||
             !ola->overlap.contiguous() || !ola->output.contiguous() || ola->output.offset() != 0)
             return false;
+        // the table cycle k's epilogue reads is left by cycle k - 1's overlap kernel; the FIRST submission of this unit (and the
+        // first one after a cycle that died between its two launches) builds it from `phases` as it stands then, on the
+        // unit's own stream -- no device work in this predicate.  A host that rewrites the `phases` state of a
+        // running chain re-creates the runtime (the standalone module rebuilds the table every cycle; the fused unit does not).
+        auto table_ready = std::make_shared<bool>(false);
         if (phase) {
-            // the table this cycle's epilogue reads: from the state as it stands now (the standalone module writes it at the
-            // top of its own compute; from here on the overlap kernel of cycle k leaves the table of cycle k + 1)
-            if (hip_result(kernels::launch_phase_table_prime(ptr<float2>(phase->corrections), ptr<double>(phase->phases),
-                                                             ptr<const double>(phase->devIncrements), phase->channelCount,
-                                                             phase->batchCount, nullptr),
-                           "phase_correction (table) kernel") != Result::SUCCESS ||
-                hipStreamSynchronize(nullptr) != hipSuccess)
-                return false;
             members = {fft, norm, phase, unpad, ola};
             consumed = 5;
             name = "ifft_phase_unpad_overlap(" + fft->name() + "+" + norm->name() + "+" + phase->name() + "+" + unpad->name() +
@@ -1611,24 +1629,32 @@ bool TryFuseFilter(const std::vector<Module*>& ordered, size_t at, std::string& 
             consumed = 4;
             name = "ifft_unpad_overlap(" + fft->name() + "+" + norm->name() + "+" + unpad->name() + "+" + ola->name() + ")";
         }
-        submit = [fft, norm, phase, unpad, ola, axis, batchDiv, chanDiv](hipStream_t stream) -> Result {
+        submit = [fft, norm, phase, unpad, ola, axis, batchDiv, chanDiv, table_ready](hipStream_t stream) -> Result {
             dev::FftLayout L;
             JST_CHECK(fft->layout(L));
             const U64 n = fft->input.shape(axis);
             if (phase) {
+                if (!*table_ready)
+                    JST_CHECK(hip_result(kernels::launch_phase_table_prime(ptr<float2>(phase->corrections), ptr<double>(phase->phases),
+                                                                           ptr<const double>(phase->devIncrements), phase->channelCount,
+                                                                           phase->batchCount, stream),
+                                         "phase_correction (table) kernel"));
+                *table_ready = false;  // until the overlap kernel below has been enqueued, the next cycle's table is not on its way
                 JST_CHECK(hip_result(kernels::launch_fft_c2c_tiled_scaled_phase_unpad(
                                          n, L, fft->twiddles, ptr<const float2>(fft->input), ptr<float2>(fft->scratchA),
                                          ptr<float2>(ola->output), ptr<float2>(unpad->tail), norm->constant,
                                          unpad->body.shape(axis), ptr<const float2>(phase->corrections), phase->batchCount,
                                          batchDiv, phase->channelCount, chanDiv, stream),
                                      "fft (tiled, multiply_constant + phase_correction + unpad epilogue) kernel"));
-                return hip_result(kernels::launch_overlap_heads_phase(
+                JST_CHECK(hip_result(kernels::launch_overlap_heads_phase(
                                       ptr<char>(ola->output), ptr<char>(ola->overlap), ptr<char>(ola->previousOverlap), true,
                                       (uint32_t)ola->buffer.rank(), ola->batchAxis ? (int32_t)*ola->batchAxis : -1,
                                       ola->buffer.shape().data(), ola->overlap.shape().data(),
                                       ptr<float2>(phase->corrections), ptr<double>(phase->phases),
                                       ptr<const double>(phase->devIncrements), phase->channelCount, phase->batchCount, stream),
-                                  "overlap_add (overlap region) + phase_correction (state) kernel");
+                                  "overlap_add (overlap region) + phase_correction (state) kernel"));
+                *table_ready = true;
+                return Result::SUCCESS;
             }
             JST_CHECK(hip_result(kernels::launch_fft_c2c_tiled_scaled_unpad(
                                      n, fft->forward, L, fft->twiddles, ptr<const float2>(fft->input),
@@ -1726,8 +1752,24 @@ bool TryElideDuplicate(const std::vector<Module*>& ordered, size_t at, std::stri
         }
     }
     if (muls.empty() && fms.empty()) return false;  // nobody inside the runtime reads it: somebody outside may
-    for (Multiply* mul : muls) mul->a = dup->input;
-    for (Fm* fm : fms) fm->input = dup->input;
+    // The copy also protected its readers from a module that WRITES the source's storage between the duplicate and its last
+    // reader: with such a module in between, the copy stays.
+    size_t last_reader = at;
+    for (size_t i = at + 1; i < ordered.size(); ++i) {
+        for (Multiply* mul : muls) if (ordered[i] == mul) last_reader = i;
+        for (Fm* fm : fms) if (ordered[i] == fm) last_reader = i;
+    }
+    for (size_t i = at + 1; i < last_reader; ++i)
+        for (const auto& kv : ordered[i]->outputs())
+            if (kv.second.storageId() == dup->input.storageId()) return false;
+    for (Multiply* mul : muls) {
+        dup->rewired.emplace_back(&mul->a, mul->a);
+        mul->a = dup->input;
+    }
+    for (Fm* fm : fms) {
+        dup->rewired.emplace_back(&fm->input, fm->input);
+        fm->input = dup->input;
+    }
     members = {dup};
     consumed = 1;
     name = dup->name() + "(elided)";

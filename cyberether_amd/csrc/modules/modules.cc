@@ -1307,29 +1307,46 @@ Result RingSource::ringAcquire(void** ptr, U64* max_elements) {
 }
 
 Result RingSource::publishStagedBatch(std::unique_lock<std::mutex>& lock) {  // mu held; the staging buffer holds one whole batch
+    bool overflowed = false, dropped = false;
     if (published() - consumed >= slots) {
         // every slot holds a published batch no cycle has consumed
         ++overflowCount;
+        overflowed = true;
         if (rejectOnOverflow) return Result::INCOMPLETE;
         ++consumed;  // OverwriteOldest (circular_buffer.cc:151-161): the oldest unconsumed batch is dropped
+        dropped = true;
     }
-    const U64 slot = published() % slots;
+    U64 slot = published() % slots;
     // The cycle that consumed this slot last must have finished before the copy lands.  If that cycle is still being
     // enqueued (its free event is pending), the compute thread records it in cycleSubmitted -- microseconds away; wait
     // for that (without the lock).  Only a cycle that died half way leaves the slot pending: after the timeout its
     // completion is recorded here, behind whatever it did enqueue.
-    if (pendingFreeSlot == (I64)slot) {
+    while (pendingFreeSlot == (I64)slot) {
         const U64 epoch = clearEpoch, fill = stagingFill, index = stagingIndex, before = published();
         cycleClosed.wait_for(lock, std::chrono::milliseconds(200), [&] { return pendingFreeSlot != (I64)slot; });
         // `mu` was released while waiting: a ringClear() has dropped the staged batch with everything else, a second producer
-        // thread may have published this staging buffer itself -- in both cases there is nothing left to upload from here
-        // (the slot, the staging index and the fill computed above are stale).
-        if (clearEpoch != epoch || stagingFill != fill || stagingIndex != index || published() != before) return Result::SUCCESS;
+        // thread may have published this staging buffer itself -- in both cases there is nothing left to upload from here,
+        // and what this call counted for a batch it does not publish is taken back.
+        if (clearEpoch != epoch || stagingFill != fill || stagingIndex != index) {
+            if (clearEpoch == epoch) {  // (a clear reset the counters itself)
+                if (dropped) --consumed;
+                if (overflowed) --overflowCount;
+            }
+            return Result::SUCCESS;
+        }
+        // Only the published count moved (a host raised `published` through reconfigure while this batch was waiting): the
+        // batch is still ours to upload -- into the slot the count names NOW (returning here left stagingFill at a
+        // whole batch, and the producer's next acquire handed out zero elements).
+        if (published() != before) {
+            slot = published() % slots;
+            continue;
+        }
         if (pendingFreeSlot == (I64)slot && lastComputeStream) {
             JST_HIP_CHECK(hipEventRecord(slotFree[slot], lastComputeStream), "hipEventRecord");
             slotFreeValid[slot] = 1;
             pendingFreeSlot = -1;
         }
+        break;
     }
     if (slotFreeValid[slot]) JST_HIP_CHECK(hipStreamWaitEvent(uploadStream, slotFree[slot], 0), "hipStreamWaitEvent");
     const size_t batch_bytes = (size_t)(batches * samples) * elementBytes;

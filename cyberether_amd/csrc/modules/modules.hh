@@ -143,6 +143,10 @@ class Multiply : public Module {
     Result create() override;
     Result computeSubmit(hipStream_t stream) override;
     Tensor a, b, c;  // a, b are the validated broadcast views
+    void planStorage(std::set<const void*>& reads, std::set<const void*>&) const override {  // `a` may have been pointed at a duplicate's source
+        reads.insert(a.storageId());
+        reads.insert(b.storageId());
+    }
     Shape outputShape;
 };
 
@@ -232,6 +236,11 @@ class Spectrogram : public Module {
         return key == "frequencyBins" ? &frequencyBins : nullptr;
     }
     Tensor input, frequencyBins;  // state: F32 {width, height}, laid out [height][width]
+    void planStorage(std::set<const void*>& reads, std::set<const void*>& writes) const override {
+        for (const Tensor* t : {&frequencyBins, &hitCounts, &schedWords, &combineCtrl})
+            if (t->valid()) writes.insert(t->storageId());
+        if (rowIndices.valid()) reads.insert(rowIndices.storageId());
+    }
     // config merge = "counts" (not in the reference, whose display is per process): the module publishes this cycle's
     // integer hit counts as output "counts" (U32 {width, height}, laid out like the state) and leaves the state
     // alone -- the counts of all ranks are summed (RCCL all-reduce) and applied by a spectrogram_merge module.
@@ -307,6 +316,10 @@ class Waterfall : public Module {
         return nullptr;
     }
     Tensor input, frequencyBins, ringState;  // ringState: device U64[4]
+    void planStorage(std::set<const void*>&, std::set<const void*>& writes) const override {
+        if (frequencyBins.valid()) writes.insert(frequencyBins.storageId());
+        if (ringState.valid()) writes.insert(ringState.storageId());
+    }
     U64 height = 512, numberOfElements = 0, numberOfBatches = 0;
     U64 inputElementStride = 0, inputBatchStride = 0;
 };

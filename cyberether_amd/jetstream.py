@@ -82,6 +82,7 @@ _strs = C.POINTER(C.c_char_p)
 R = C.c_uint16
 
 _sig("jst_version", C.c_char_p)
+_sig("jst_debug_set", R, C.c_char_p, C.c_char_p)
 _sig("jst_last_error", C.c_char_p)
 _sig("jst_device_count", C.c_int)
 _sig("jst_device_set", R, C.c_int)
@@ -171,6 +172,12 @@ def _check(result: int) -> None:
 
 def _arr(values: Sequence[int]):
     return (C.c_uint64 * max(len(values), 1))(*[int(v) for v in values])
+
+
+def debug_set(name: str, value: Optional[str]) -> None:
+    """jst_debug_set: flip one of the library's A/B switches (JST_FFT_KERNEL, JST_QUAD_STATIC, JST_FM_SERIAL, JST_RUNTIME_*) for
+    this process; None unsets it.  The environment variable of the same name only seeds the switch when the library first asks."""
+    _check(_lib.jst_debug_set(name.encode(), None if value is None else str(value).encode()))
 
 
 def version() -> str:

@@ -351,6 +351,12 @@ int jst_comm_uses_rccl(jst_comm c);   /* 1 when the communicator holds an RCCL c
 jst_result jst_comm_allreduce(jst_comm c, jst_tensor t, int op, int average, void* hip_stream);
 
 /* ---- test/bench probes -------------------------------------------------------------------- */
+/* The A/B switches the differential tests and the benches flip inside one process: JST_FFT_KERNEL (slot | pipe | wave | quad:
+ * kernel family of the fused spectrum unit), JST_QUAD_STATIC, JST_FM_SERIAL, JST_RUNTIME_MAX_BRANCHES (n), JST_RUNTIME_NO_BATCH,
+ * JST_RUNTIME_EAGER_SPANS, JST_RUNTIME_NO_SPANS.  The environment variable of the same name is read ONCE (the first time the
+ * library asks); from then on only this call changes a switch -- value NULL or "" unsets it.  JST_ERROR for an unknown name.
+ * Nothing on a launch path calls getenv. */
+jst_result jst_debug_set(const char* name, const char* value);
 /* Host twiddle generator used for the FFT tables: W[k] = exp(+j 2 pi k/n), interleaved. */
 jst_result jst_fft_twiddles(uint64_t n, float* interleaved_out);
 /* Which kernel family a complex transform of length n (the pass length: Bluestein sizes resolved by the caller) runs on:

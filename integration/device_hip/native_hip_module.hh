@@ -7,6 +7,7 @@
 #pragma once
 
 #include <jetstream/module_context.hh>
+#include <jetstream/parser.hh>
 #include <jetstream/registry.hh>
 #include <jetstream/runtime_context_native_hip.hh>
 #include <jetstream/scheduler_context.hh>
@@ -33,5 +34,46 @@ struct NativeHipModule : public Impl, public NativeHipRuntimeContext, public Sch
 
     Hip::LibraryModule library;
 };
+
+// The whole unit for a module whose library counterpart has the same type name, the same port names and the same
+// configuration keys (every module of the path but the ones with state the reference reads back or an alias to publish):
+//   * configuration: the staged Config serialised by the reference's own JST_MODULE_PARAMS (Parser::Map) and written out by
+//     Parser::TypedToString ("{}": the shortest text that round-trips the value, so F32 / F64 parameters arrive bit for bit);
+//   * inputs: every link the block wired; outputs: every tensor Impl::create() published.
+// Provider "fast" exists in the library for amplitude and range only; every other module of a block built with it is generic.
+template <class Impl>
+struct LibraryBackedModule : public NativeHipModule<Impl> {
+    Result create() override {
+        JST_CHECK(Impl::create());
+        Parser::Map fields;
+        JST_CHECK(this->serialize(fields));
+        std::vector<std::string> config;
+        for (const auto& [key, value] : fields) {
+            std::string text;
+            JST_CHECK(Parser::TypedToString(value, text));
+            config.push_back(key + "=" + text);
+        }
+        std::vector<Hip::LibraryModule::Input> ins;
+        for (const auto& [port, link] : this->inputs()) ins.push_back({port, &link});
+        std::vector<Hip::LibraryModule::Output> outs;
+        for (auto& [port, link] : this->outputs()) outs.push_back({port, port, &link.tensor});
+        const std::string type = this->type();
+        const std::string tag = "MODULE_" + type + "_NATIVE_HIP";
+        const bool hasFast = type == "amplitude" || type == "range";
+        JST_CHECK(this->library.create(tag, type.c_str(), hasFast ? this->provider() : "generic", this->name(), config, ins, outs));
+        return bindStates();
+    }
+    Result destroy() override {
+        (void)this->library.destroy();
+        return Impl::destroy();
+    }
+
+ protected:
+    virtual Result bindStates() { return Result::SUCCESS; }
+};
+
+#define JST_REGISTER_HIP_LIBRARY_MODULE(impl_type)                                     \
+    JST_REGISTER_MODULE(impl_type, DeviceType::HIP, RuntimeType::NATIVE, "generic");   \
+    JST_REGISTER_MODULE(impl_type, DeviceType::HIP, RuntimeType::NATIVE, "fast")
 
 }  // namespace Jetstream::Modules

@@ -136,7 +136,7 @@ if [ -f "$HIPLIB" ] && [ -f "$DEV/core_hip_device.patch" ] && [ -f /opt/rocm/inc
   xargs -a "$LIST" -P "$JOBS" -I{} bash -c 'compile_dev {}' || { echo "libref_jetstream_devhip.so: some units failed"; exit 1; }
   GLUE_OBJS=""
   for pair in buffer_hip:. runtime_native_hip_impl:. cast:core/cast window:dsp/window invert:dsp/invert reshape:core/reshape multiply:core/multiply \
-              fft:dsp/fft amplitude:dsp/amplitude range:core/range spectrogram:visualization/spectrogram ring_source:. ${DEVHIP_EXTRA_MODULES:-}; do
+              fft:dsp/fft amplitude:dsp/amplitude range:core/range spectrogram:visualization/spectrogram ring_source:. side_chains:. ${DEVHIP_EXTRA_MODULES:-}; do
     f=${pair%%:*}; d=${pair##*:}
     src=$DEV/modules/$f.cc; [ -f "$DEV/$f.cc" ] && src=$DEV/$f.cc
     o=$OBJD/glue_$f.o

@@ -38,6 +38,19 @@ def js():
     return mod
 
 
+@pytest.fixture
+def switch(js):
+    """switch(name, value): flips one of the library's A/B switches (jst_debug_set) for this test; all are unset afterwards."""
+    touched = []
+
+    def set_(name, value):
+        touched.append(name)
+        js.debug_set(name, value)
+    yield set_
+    for name in touched:
+        js.debug_set(name, None)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as mod

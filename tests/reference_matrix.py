@@ -162,6 +162,28 @@ case("am_two_submissions", "am", {"sampleRate": 240e3, "dcAlpha": 0.995}, {"sign
 case("add_same_shape", "add", {}, {"a": tensor(shape=(3, 8), sample=1, batch=0), "b": tensor(shape=(3, 8), sample=1, batch=0)}, "sum", D + "core/add/module_tests.cc")
 case("add_broadcast", "add", {}, {"a": tensor(shape=(3, 8), sample=1, batch=0), "b": tensor(shape=(1, 8), sample=1)}, "sum", D + "core/add/module_tests.cc")
 
+# ---- ranks 5 .. 8: include/jetstream_hip.h takes tensors of up to JST_MAX_RANK = 8 axes; the reference's iterators
+# take 16 (tools/automatic_iterator.hh:182), its tests stop at rank 4 (amplitude/module_tests.cc:475-580).  The same view ops on more axes.
+case("multiply_rank5_broadcast", "multiply", {}, {"a": tensor(shape=(2, 1, 3, 2, 8), sample=4, batch=0), "b": tensor(shape=(1, 2, 1, 1, 8), sample=4)}, "product",
+     D + "core/multiply/module_tests.cc:84-420 (broadcast), at rank 5")
+case("multiply_rank8_permuted", "multiply", {}, {"a": tensor(shape=(2, 1, 2, 1, 2, 1, 3, 8), views=[("permute", 0, 1, 4, 3, 2, 5, 6, 7)], sample=7, batch=0),
+                                                 "b": tensor(shape=(8,), sample=0)}, "product",
+     D + "core/multiply/module_tests.cc:84-420 (permuted operand), at rank 8")
+case("amplitude_rank6_stepped", "amplitude", {}, {"signal": tensor(shape=(2, 4, 1, 2, 3, 16), views=[("range", 1, 1, 4, 2)], sample=5, batch=0)}, "signal",
+     D + "dsp/amplitude/module_tests.cc:475-580 (rank-4 non-contiguous), at rank 6")
+case("range_rank7", "range", {"min": -2.0, "max": 2.0}, {"signal": tensor(shape=(2, 1, 2, 1, 2, 3, 8), dtype="float32", sample=6, batch=0)}, "signal",
+     D + "core/range/module_tests.cc, at rank 7")
+case("invert_rank5_strided", "invert", {}, {"signal": tensor(shape=(2, 2, 3, 8, 2), views=[("select", 4, 1)], sample=3, batch=0)}, "signal",
+     D + "dsp/invert/module_tests.cc, at rank 5 -> 4 through a strided select")
+case("fft_rank5_sample_axis_inside", "fft", {"forward": True}, {"signal": tensor(shape=(2, 2, 8, 3, 2), sample=2, batch=0)}, "signal",
+     D + "dsp/fft/module_tests.cc:445-536 (axis handling), at rank 5 with the transform axis inside")
+case("fft_rank8_last_axis", "fft", {"forward": False}, {"signal": tensor(shape=(2, 1, 2, 1, 1, 2, 3, 12), sample=7, batch=0)}, "signal",
+     D + "dsp/fft/module_tests.cc:445-536, at rank 8")
+case("multiply_constant_rank6", "multiply_constant", {"constant": 0.5}, {"factor": tensor(shape=(2, 1, 2, 2, 3, 8), sample=5, batch=0)}, "product",
+     D + "core/multiply_constant/module_tests.cc, at rank 6")
+case("cast_rank5_ci16", "cast", {"outputType": "CF32"}, {"buffer": tensor(shape=(2, 2, 1, 3, 8), dtype="CI16", sample=4, batch=0)}, "buffer",
+     D + "core/cast/module_tests.cc, at rank 5")
+
 
 # ---- building inputs ----------------------------------------------------------------------------------------------------------------
 _CI = {"CI8": np.int8, "CI16": np.int16, "CU8": np.uint8, "CU16": np.uint16}

@@ -31,15 +31,8 @@ def _ring_chain(js, xs, h, provider="generic", dtype=None, **runtime):
     return eng, spec, rt
 
 
-# span_kernel: the Spectrogram's span kernel forms (kernels/spectrogram.hip launch_spectrogram_index_span) -- None = the default
-# (two cycles per histogram pass), "2" = one cycle per pass (round 3), "3" = the overlapped two-histogram experiment
-@pytest.mark.parametrize("span_kernel", [None, "2", "3"])
 @pytest.mark.parametrize("n,b,h,slots", [(4096, 48, 256, 3), (1024, 130, 100, 5), (2048, 1100, 255, 2), (4096, 8, 37, 16)])
-def test_batched_runtime_matches_the_oracle_cycle_by_cycle(js, oracle, monkeypatch, n, b, h, slots, span_kernel):
-    if span_kernel:
-        monkeypatch.setenv("JST_SPAN_KERNEL", span_kernel)
-    else:
-        monkeypatch.delenv("JST_SPAN_KERNEL", raising=False)
+def test_batched_runtime_matches_the_oracle_cycle_by_cycle(js, oracle, n, b, h, slots):
     xs = [tone_batch(oracle, b, n, 11 + 3 * s) * np.float32(0.15 + 0.35 * s) for s in range(slots)]
     for x in xs:
         x[::3] *= np.float32(20.0)

@@ -10,10 +10,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["pipe", "slot", "quad"])
-def fft_kernel_variant(request, monkeypatch):
+def fft_kernel_variant(request, switch):
     """Every test here runs against the FFT kernel variants (pipelined / slot / quad: the round-5 4096-point side kernel,
     the default when the variable is unset), same bits."""
-    monkeypatch.setenv("JST_FFT_KERNEL", request.param)
+    switch("JST_FFT_KERNEL", request.param)
     yield
 
 

@@ -10,9 +10,9 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["pipe", "slot"])
-def fft_kernel_variant(request, monkeypatch):
+def fft_kernel_variant(request, switch):
     """Every test here runs against both FFT kernel variants (pipelined / slot), same bits."""
-    monkeypatch.setenv("JST_FFT_KERNEL", request.param)
+    switch("JST_FFT_KERNEL", request.param)
     yield
 
 

@@ -267,7 +267,7 @@ def test_signal_generator_noise_statistics(js, dtype):
 
 
 @pytest.mark.parametrize("mode,deemph", [("wide", "none"), ("wide", "75us"), ("narrow", "50us")])
-def test_fm_wide_wavefront_pipeline_equals_serial_walk(js, monkeypatch, mode, deemph):
+def test_fm_wide_wavefront_pipeline_equals_serial_walk(js, switch, mode, deemph):
     """The stage-split wide decoder (fm_wide_kernel: lane pipelines over DPP for the one-poles and the
     biquad cascades) against the one-thread-per-lane walk of the same recurrences (JST_FM_SERIAL=1):
     identical bits, over submissions, with non-finite samples travelling through as bubbles."""
@@ -275,10 +275,7 @@ def test_fm_wide_wavefront_pipeline_equals_serial_walk(js, monkeypatch, mode, de
     sr, lanes, batches, samples = 240e3, 2, 3, 2311   # several LDS chunks with a ragged tail
     outs = {}
     for variant in ("serial", "pipeline"):
-        if variant == "serial":
-            monkeypatch.setenv("JST_FM_SERIAL", "1")
-        else:
-            monkeypatch.delenv("JST_FM_SERIAL", raising=False)
+        switch("JST_FM_SERIAL", "1" if variant == "serial" else None)
         rng = np.random.default_rng(8)
         t = js.Tensor.create("hip", "CF32", (batches, lanes, samples)).set_axes(batch=0, sample=2)
         m = js.Module("fm", {"mode": mode, "deemphasis": deemph, "sampleRate": sr}, {"signal": t})

@@ -16,15 +16,9 @@ from util import assert_bit_equal
 pytestmark = pytest.mark.gpu
 
 
-def _run(js, xs, h, calls, monkeypatch, kernel="quad", static=False, batch=True):
-    if kernel:
-        monkeypatch.setenv("JST_FFT_KERNEL", kernel)
-    else:
-        monkeypatch.delenv("JST_FFT_KERNEL", raising=False)
-    if static:
-        monkeypatch.setenv("JST_QUAD_STATIC", "1")
-    else:
-        monkeypatch.delenv("JST_QUAD_STATIC", raising=False)
+def _run(js, xs, h, calls, switch, kernel="quad", static=False, batch=True):
+    switch("JST_FFT_KERNEL", kernel or None)
+    switch("JST_QUAD_STATIC", "1" if static else None)
     eng, spec, rt = _ring_chain(js, xs, h, provider="fast", batch=batch)
     assert rt.batched == batch
     assert any(u.startswith("spectrum_fused(") and "+indices" in u for u in rt.units), rt.units
@@ -52,7 +46,7 @@ def _same(a, b, what):
 
 
 @pytest.mark.parametrize("b,slots,h", [(64, 4, 256), (3, 5, 100), (1030, 2, 255)])
-def test_quad_equals_pipe_bit_for_bit(js, oracle, monkeypatch, b, slots, h):
+def test_quad_equals_pipe_bit_for_bit(js, oracle, switch, b, slots, h):
     """Short launches (static round robin): per cycle and cycle-batched; ragged batch counts (3: fewer transforms than
     workgroups; 1030: one more round for six workgroups)."""
     n = 4096
@@ -60,29 +54,29 @@ def test_quad_equals_pipe_bit_for_bit(js, oracle, monkeypatch, b, slots, h):
     xs[0][1, :] = 0  # a row of zeros and a non-finite sample: the guard's exact ladder / NaN propagation
     xs[-1][2 % b, 99] = np.complex64(complex(np.nan, 1.0))
     calls = (1, slots, 2, 2 * slots + 1, 3)
-    pipe = _run(js, xs, h, calls, monkeypatch, kernel="pipe")
-    quad = _run(js, xs, h, calls, monkeypatch)
+    pipe = _run(js, xs, h, calls, switch, kernel="pipe")
+    quad = _run(js, xs, h, calls, switch)
     _same(pipe, quad, "quad vs pipe, cycle-batched")
-    quad_pc = _run(js, xs, h, calls, monkeypatch, batch=False)
+    quad_pc = _run(js, xs, h, calls, switch, batch=False)
     for i, ((o0, s0, _), (o1, s1, _)) in enumerate(zip(pipe, quad_pc)):
         assert_bit_equal(o1, o0, f"quad per cycle vs pipe: output after call {i}")
         assert_bit_equal(s1, s0, f"quad per cycle vs pipe: state after call {i}")
 
 
-def test_quad_claimed_rounds_equal_static_and_pipe(js, oracle, monkeypatch):
+def test_quad_claimed_rounds_equal_static_and_pipe(js, oracle, switch):
     """A launch long enough for the claimed rounds (the bench's own shape: 1024 x 4096 per cycle, spans of 8+ cycles on a
     256-CU device): the device counters hand every transform out exactly once, and re-arm themselves for the next launch."""
     n, b, slots, h = 4096, 1024, 12, 256
     base = tone_batch(oracle, b, n, 77)
     xs = [np.roll(base, 37 * s, axis=0) * np.float32(0.5 + 0.05 * s) for s in range(slots)]
     calls = (1, slots, slots, 2 * slots + 5, 9)
-    dyn = _run(js, xs, h, calls, monkeypatch)
-    sta = _run(js, xs, h, calls, monkeypatch, static=True)
+    dyn = _run(js, xs, h, calls, switch)
+    sta = _run(js, xs, h, calls, switch, static=True)
     _same(sta, dyn, "claimed rounds vs static round robin")
-    pipe = _run(js, xs, h, calls, monkeypatch, kernel="pipe")
+    pipe = _run(js, xs, h, calls, switch, kernel="pipe")
     _same(pipe, dyn, "claimed rounds vs fft_pipe_kernel")
     # the library's own choice (no JST_FFT_KERNEL): fft_pipe_kernel for the short launches, the quad kernel from eight rounds
-    auto = _run(js, xs, h, calls, monkeypatch, kernel=None)
+    auto = _run(js, xs, h, calls, switch, kernel=None)
     _same(pipe, auto, "the default selection by launch size")
     # ... and the bins are the reference's (provider generic = every float of the CPU path), the floats within tolerance
     ref = oracle.spectrum_chain(xs[(sum(calls) - 1) % slots], -100.0, 0.0)["range"]

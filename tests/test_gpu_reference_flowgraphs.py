@@ -96,7 +96,7 @@ def test_multi_fm_example(js, oracle):
     rt.destroy()
 
 
-def test_multi_fm_example_on_parallel_branches(js, oracle, monkeypatch):
+def test_multi_fm_example_on_parallel_branches(js, oracle, switch):
     """JST_RUNTIME_MAX_BRANCHES=4 (jst/module.cc planBranches): the same flowgraph captured as a hipGraph with forks and joins
     -- the wide-band engine, the Filter and the two station chains on their own capture streams -- leaves the bytes of the
     serial chain in every sink, cycle after cycle (opt-in: measured slower than one chain on this ROCm)."""
@@ -105,7 +105,7 @@ def test_multi_fm_example_on_parallel_branches(js, oracle, monkeypatch):
     xs = [csignal(rng, (8, 8000), 0.05) for _ in range(3)]
     sinks = {}
     for branches in ("1", "4"):
-        monkeypatch.setenv("JST_RUNTIME_MAX_BRANCHES", branches)
+        switch("JST_RUNTIME_MAX_BRANCHES", branches)
         fg = Flowgraph(os.path.join(FIXTURES, "multi-fm.yml"), ring_slots=1)
         rt = fg.runtime(graph=True, fuse=True)
         assert rt.branches == (1 if branches == "1" else 4)

@@ -1,4 +1,4 @@
-"""GPU: the product against the reference over the differential matrix of tests/reference_matrix.py -- 279 (module, config,
+"""GPU: the product against the reference over the differential matrix of tests/reference_matrix.py -- 288 (module, config,
 input layout) tuples written after the reference's own module tests (dense / batched / multi-head / rank-3 / strided / offset
 layouts, every sample type of the cast, every waveform of the signal generator, broadcast forms of multiply, state across
 submissions, and the malformed inputs of the validation sections).  For every case the HIP path, through ctypes -> C ABI, must

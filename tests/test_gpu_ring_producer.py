@@ -110,12 +110,12 @@ def test_wait_for_size_and_zero_copy_commit(js):
 @pytest.mark.parametrize("kernel", ["pipe", "slot"])
 @pytest.mark.parametrize("fuse", [False, True])
 @pytest.mark.parametrize("dtype,np_t,scale", [("CI16", np.int16, 32768.0), ("CI8", np.int8, 128.0), ("CU8", np.uint8, 128.0)])
-def test_integer_sample_formats_through_the_ring(js, oracle, monkeypatch, dtype, np_t, scale, fuse, kernel):
+def test_integer_sample_formats_through_the_ring(js, oracle, switch, dtype, np_t, scale, fuse, kernel):
     """Raw SDR formats: the ring holds CI16 / CI8 / CU8 samples (4 or 2 bytes over PCIe instead of 8) and a cast module
     (the spectrum_engine block's own first module) turns them into CF32 (cast/module_impl.cc:49-70: divide by 32768 / 128).  Fused, the
     conversion happens in the transform's first load: the unit reads the cast's INPUT, the cast launches nothing, and
     the result is bit-identical to the module-by-module path and to the oracle."""
-    monkeypatch.setenv("JST_FFT_KERNEL", kernel)
+    switch("JST_FFT_KERNEL", kernel)
     n, b, slots = 1024, 4, 3
     rng = np.random.default_rng(9)
     info = np.iinfo(np_t)
