@@ -203,7 +203,7 @@ Result Runtime::planOrder(const std::vector<Module*>& modules) {
     // hash map: integration/device_hip/runtime_native_hip_impl.cc).  An input handle remembers the module that published
     // it (ProducerAttribute travels with every clone / view of the handle): that is the exact edge, also through view
     // modules (reshape, a bypassing cast) whose output shares its input's storage.  A tensor without that attribute falls
-    // back to storage identity, where a module that WRITES the storage goes before one that merely re-publishes a view.
+    // back to storage identity: the module that WRITES the storage.
     const size_t n = modules.size();
     std::map<const Module*, size_t> index_of;
     for (size_t i = 0; i < n; ++i) index_of.emplace(modules[i], i);
@@ -212,15 +212,16 @@ Result Runtime::planOrder(const std::vector<Module*>& modules) {
             if (kv.second.storageId() == storage) return true;
         return false;
     };
-    std::map<const void*, size_t> producer;
-    for (int pass = 0; pass < 2; ++pass)
-        for (size_t i = 0; i < n; ++i)
-            for (const auto& kv : modules[i]->outputs()) {
-                const void* storage = kv.second.storageId();
-                if (storage && republishes(i, storage) == (pass == 1)) producer.emplace(storage, i);
-            }
+    std::map<const void*, size_t> producer;  // storage -> the module that WRITES it (a re-publisher of a view is reached through its tag only:
+                                             // as a storage-level producer it could sit behind its own reader and close a cycle)
+    for (size_t i = 0; i < n; ++i)
+        for (const auto& kv : modules[i]->outputs()) {
+            const void* storage = kv.second.storageId();
+            if (storage && !republishes(i, storage)) producer.emplace(storage, i);
+        }
     std::vector<std::set<size_t>> deps(n);
     std::vector<std::vector<size_t>> users(n);
+    std::vector<size_t> outside_inputs(n, 0);
     for (size_t i = 0; i < n; ++i)
         for (const auto& kv : modules[i]->inputs()) {
             size_t from = n;
@@ -233,11 +234,12 @@ Result Runtime::planOrder(const std::vector<Module*>& modules) {
                 const auto it = producer.find(kv.second.storageId());
                 if (it != producer.end()) from = it->second;
             }
+            if (from == n) ++outside_inputs[i];  // a tensor nobody in this runtime produces: new data every cycle, as far as we know
             if (from != n && from != i && deps[i].insert(from).second) users[from].push_back(i);
         }
     std::vector<size_t> indeg(n);
     for (size_t i = 0; i < n; ++i) indeg[i] = deps[i].size();
-    std::vector<bool> done(n, false);
+    std::vector<bool> done(n, false), placed_static(n, false);
     ordered_.clear();
     size_t last = n;
     for (size_t placed = 0; placed < n; ++placed) {
@@ -248,6 +250,15 @@ Result Runtime::planOrder(const std::vector<Module*>& modules) {
                     pick = u;
                     break;
                 }
+        // then a ready module of a STATIC chain (a table: window -> invert -> reshape, filter_taps -> pad -> fft -> reshape):
+        // tables first, whatever order the caller listed them in, so that they never sit between the members of a dynamic
+        // chain the fusion hooks want adjacent (pad -> fft | taps ... | multiply -> fold)
+        for (size_t i = 0; pick == n && i < n; ++i) {
+            if (done[i] || indeg[i] != 0 || !(modules[i]->taint() & (STATIC_OUTPUT | STATELESS))) continue;
+            bool settles = modules[i]->inputs().empty() ? (modules[i]->taint() & STATIC_OUTPUT) != 0 : outside_inputs[i] == 0;
+            for (size_t d : deps[i]) settles = settles && placed_static[d];
+            if (settles) pick = i, placed_static[i] = true;
+        }
         for (size_t i = 0; pick == n && i < n; ++i)
             if (!done[i] && indeg[i] == 0) pick = i;
         if (pick == n) {

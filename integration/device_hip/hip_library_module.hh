@@ -159,8 +159,14 @@ class LibraryModule {
             JST_ERROR("[{}] The library's '{}' state does not match the reference module's.", tag, key);
             return Result::ERROR;
         }
-        if (d.data != state.data() && jst_tensor_rebind(handle, state.data(), state.buffer().sizeBytes()) != JST_SUCCESS)
-            return fail("jst_tensor_rebind");
+        if (d.data != state.data()) {
+            // what the library's create() put there (a lineplot's x coordinates, a waterfall's cleared rows) moves along
+            if (hipMemcpy(state.data(), d.data, state.sizeBytes(), hipMemcpyDeviceToDevice) != hipSuccess) {
+                JST_ERROR("[{}] Failed to move the '{}' state.", tag, key);
+                return Result::ERROR;
+            }
+            if (jst_tensor_rebind(handle, state.data(), state.buffer().sizeBytes()) != JST_SUCCESS) return fail("jst_tensor_rebind");
+        }
         TensorDirectory::Get().publish(owner, std::string("state:") + key, handle);  // for debuggers and tests
         return Result::SUCCESS;
     }

@@ -177,3 +177,82 @@ def test_deferred_cycles_run_as_spans(oracle):
     assert "[batched]" in units and "+indices" in units, units
     assert_bit_equal(got_out, want_out, "deferred spans: the engine's output after the last cycle")
     assert_bit_equal(got_bins.reshape(-1), want_bins.reshape(-1), "deferred spans: Spectrogram bins")
+
+
+# ---- the side chains: Filter block, slice, FM, the AGC'd spectrum engine of multi-fm.yml, the sinks with state ---------------------
+def multi_fm_flowgraph(fg, device, source_block, source_port):
+    """The chains of the reference's examples/flowgraphs/multi-fm.yml behind a source: filter (2 heads at +-400 kHz, /10) ->
+    slice [:, 1, :] -> spectrum_engine{enableAgc}; slice [:, 0, :] -> fm -> decimator; every block on `device`."""
+    kw = {} if device == "cpu" else {"device": device}
+    src = f"{source_block}:{source_port}"
+    assert fg.block("flt", "filter", {"taps": 51, "heads": 2, "center": [400000.0, -400000.0], "bandwidth": 200000.0, "sampleRate": 2000000.0},
+                    {"signal": src}, **kw) == 0
+    assert fg.state("flt") == 2, f"filter ({device}) did not reach CREATED"
+    assert fg.block("slice", "slice", {"contiguous": True, "slice": "[:, 1, :]"}, {"buffer": "flt:buffer"}, **kw) == 0
+    assert fg.block("spectrum_engine", "spectrum_engine", {"rangeMin": -270.0, "enableAgc": True, "rangeMax": 1.0, "enableScale": True},
+                    {"buffer": "slice:buffer"}, **kw) == 0
+    assert fg.block("sli23", "slice", {"contiguous": True, "slice": "[:, 0, :]"}, {"buffer": "flt:buffer"}, **kw) == 0
+    assert fg.block("fm", "fm", {"sampleRate": 200000.0}, {"signal": "sli23:buffer"}, **kw) == 0
+    assert fg.block("dec", "decimator", {"ratio": 4}, {"buffer": "fm:signal"}, **kw) == 0
+    for name in ("slice", "spectrum_engine", "sli23", "fm", "dec"):
+        assert fg.state(name) == 2, f"{name} ({device}) did not reach CREATED"
+
+
+def test_filter_block_and_fm_chain_device_resident(oracle):
+    """The reference's own `filter` block (src/domains/dsp/filter/block_impl.cc:350-582: filter_taps, cast, expand_dims, pad x 2,
+    fft x 2, reshape, multiply, fold, ifft, multiply_constant, phase_correction, unpad, overlap_add), `slice` (slice +
+    duplicate), `fm`, `decimator` (reshape + arithmetic) and the AGC'd `spectrum_engine` of multi-fm.yml, every module on
+    DeviceType::HIP inside the reference's scheduler, handed to ONE library runtime (fused Filter head and tail) -- against
+    the same blocks on DeviceType::CPU, three cycles (overlap, phase and demodulator state carried), bit for bit."""
+    rng = np.random.default_rng(91)
+    b, n = 8, 8000
+    xs = [((rng.standard_normal((b, n)) + 1j * rng.standard_normal((b, n))) * 0.05).astype(np.complex64) for _ in range(3)]
+    ports = [("flt", "buffer"), ("fm", "signal"), ("dec", "buffer"), ("spectrum_engine", "buffer")]
+    want, got = [], []
+    with rj.RefFlowgraph() as fg:
+        src = fg.source("src", xs[0], sample=1, batch=0)
+        fg.set_attr("src", "signal", "sampleRate", rj.ATTR_F32, 2.0e6)
+        fg.set_attr("src", "signal", "frequency", rj.ATTR_F32, 96.9e6)
+        multi_fm_flowgraph(fg, "cpu", "src", "signal")
+        for x in xs:
+            src[...] = x
+            assert fg.compute() == 0
+            want.append([np.array(fg.tensor(*p)) for p in ports])
+    with rj.RefFlowgraph() as fg:
+        assert fg.ring_source("src", b, n, 1) == 0
+        multi_fm_flowgraph(fg, "hip", "src", "buffer")
+        for x in xs:
+            fg.ring_write("src", 0, x)
+            assert fg.compute() == 0
+            got.append([np.array(fg.tensor(*p)) for p in ports])
+        units = rj.hip_runtime_units()
+    # the Filter's fused head and tail, the elided copies behind the slices, the AGC chain: fused from the reference's side
+    for unit in ("fft_padded_fold(", "ifft_phase_unpad_overlap(", "duplicate(elided)", "fft_windowed(", "agc_amplitude_range("):
+        assert unit in units, (unit, units)
+    for c, (w, g) in enumerate(zip(want, got)):
+        for (block, port), a, d in zip(ports, w, g):
+            assert_bit_equal(d, a, f"{block}:{port} on DeviceType::HIP vs DeviceType::CPU, cycle {c}")
+    assert np.abs(got[-1][0]).max() > 1e-3 and np.isfinite(got[-1][1]).all()
+
+
+@pytest.mark.parametrize("mtype,cfg,state,shape", [("waterfall", {"height": 48}, "frequencyBins", (20, 512)),
+                                                   ("waterfall", {"height": 16}, "frequencyBins", (40, 256)),   # more batches than rows
+                                                   ("lineplot", {"averaging": 4, "decimation": 2}, "signalPoints", (16, 1024))])
+def test_sinks_with_state_on_the_device(mtype, cfg, state, shape):
+    """waterfall / lineplot as (DeviceType::HIP, NATIVE) modules: the library's state lives in the reference module's own state
+    tensor (what its present half reads), bit-equal to the CPU module's over three submissions."""
+    rng = np.random.default_rng(17)
+    xs = [rng.uniform(0.0, 1.0, shape).astype(np.float32) for _ in range(3)]
+    states = []
+    for device in ("cpu", "hip"):
+        with rj.RefModule(mtype, cfg, device=device) as m:
+            m.input("signal", xs[0], sample=1, batch=0)
+            assert m.start() == 0, f"{mtype} ({device}): Module::create failed"
+            trace = []
+            for x in xs:
+                m.write("signal", x)
+                assert m.compute() == 0
+                trace.append(np.array(m.state(state)))
+            states.append(trace)
+    for k, (cpu, hip) in enumerate(zip(*states)):
+        assert_bit_equal(hip, cpu, f"{mtype} {state} after submission {k}")
