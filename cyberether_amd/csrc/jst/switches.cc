@@ -16,6 +16,7 @@ struct Entry {
 constexpr Entry kEntries[SW_COUNT] = {
     {"JST_FFT_KERNEL", true},       {"JST_QUAD_STATIC", false},        {"JST_FM_SERIAL", false},       {"JST_RUNTIME_MAX_BRANCHES", false},
     {"JST_RUNTIME_NO_BATCH", false}, {"JST_RUNTIME_EAGER_SPANS", false}, {"JST_RUNTIME_NO_SPANS", false},
+    {"JST_FIR_DIRECT", false},
 };
 std::atomic<int> g_value[SW_COUNT];
 std::once_flag g_once;

@@ -14,6 +14,7 @@ enum Switch : int {
     SW_RUNTIME_NO_BATCH,     // JST_RUNTIME_NO_BATCH
     SW_RUNTIME_EAGER_SPANS,  // JST_RUNTIME_EAGER_SPANS
     SW_RUNTIME_NO_SPANS,     // JST_RUNTIME_NO_SPANS
+    SW_FIR_DIRECT,           // JST_FIR_DIRECT: provider fast's FIR on the vector FMAs (the round-1 direct form) instead of the MFMA form
     SW_COUNT
 };
 

@@ -26,6 +26,8 @@
 // enters the FMAs as SGPR operands.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <type_traits>
 
 #include "kernels.hh"
 
@@ -71,15 +73,15 @@ __global__ void fir_taps_kernel(float* __restrict__ hp, const float2* __restrict
     }
 }
 
+// One tile (OW consecutive outputs of one row) of the direct form; `block` = row * tiles_per_row + tile.  The workgroup may
+// have more threads than the tile has output slots (the MFMA kernel's fix-up workgroup, below): the extra ones only stage.
 template <int J>
-__global__ __launch_bounds__(kFirThreads) void fir_decimate_kernel(float2* __restrict__ out,
-                                                                   const float2* __restrict__ in,
-                                                                   const float2* hist,
-                                                                   const float* __restrict__ hp, FirDims d) {
+__device__ __forceinline__ void fir_tile(float2* __restrict__ out, const float2* __restrict__ in, const float2* hist,
+                                         const float* __restrict__ hp, const FirDims& d, uint32_t block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* lds = reinterpret_cast<float2*>(smem_raw);  // [r][UL]
     const uint32_t tid = threadIdx.x;
-    const uint32_t row = blockIdx.x / d.tiles_per_row, m0 = (blockIdx.x % d.tiles_per_row) * d.OW;
+    const uint32_t row = block / d.tiles_per_row, m0 = (block % d.tiles_per_row) * d.OW;
 
     // stage samples n = n_base + e = u*r - p into slot p*UL + s (s = e / r, p = r - 1 - e % r).
     // One buffer descriptor per row: [row start - back, row end) with back = T-1 samples of the
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(kFirThreads) void fir_decimate_kernel(float2* __res
         for (uint32_t i = tid; i < d.T - 1; i += threads) hw[i] = tail[i];
     }
 
-    const bool active = m0 + tid * J < d.M;
+    const bool active = tid * J < d.OW && m0 + tid * J < d.M;
+    if (tid * J >= d.OW) return;  // (no barrier below this point)
     for (uint32_t head = 0; head < d.heads; ++head) {
         // iteration i of branch p feeds sample s = J*t + i into output j with tap q = j - i + Q - 1.
         // One step = one chunk of kFirChunk samples of one branch: its LDS reads and its scalar tap
@@ -190,6 +193,162 @@ __global__ __launch_bounds__(kFirThreads) void fir_decimate_kernel(float2* __res
                 if (m0 + tid * J + j < d.M) dst[j] = acc[j];
         }
     }
+}
+
+template <int J>
+__global__ __launch_bounds__(kFirThreads) void fir_decimate_kernel(float2* __restrict__ out,
+                                                                   const float2* __restrict__ in,
+                                                                   const float2* hist,
+                                                                   const float* __restrict__ hp, FirDims d) {
+    fir_tile<J>(out, in, hist, hp, d, blockIdx.x);
+}
+
+// =============================================================================================================================
+// The same sums on the MATRIX cores (round 6).  The direct form above is LDS-bandwidth bound at half the vector FMA rate (a
+// sample read from LDS feeds 2 * J FMAs); v_mfma_f32_16x16x4_f32 issues at the same 64 FLOP / clk / SIMD as the vector FMA
+// but takes each operand ONCE from a register for 16 uses, and runs in a pipe of its own.  The FIR as a banded-Toeplitz
+// product: the rows of one cycle are ONE continuous stream (row k + 1 continues row k).  A wavefront takes 128 consecutive
+// outputs at a time -- 8 segments of 16 outputs: 16 real streams (re and im of each segment) -- and forms
+//
+//     D[stream m][output n] = sum_s A[m][s] * B[s][n],   A[m][s] = x_m[s0 + s],   B[s][n] = h[n*R + lead - s]   (0 outside the taps)
+//
+// over the 4 * NT samples s a 16-output tile can see (15 R + T of them carry a tap: 62 % of the products for 251 taps at R = 10).
+// B is the same for every tile: NT registers per lane, loaded once per wavefront (fir_taps builds the table).  A: lane l holds
+// stream l % 16, sample 4 j + l / 16 of step j -- one ds_read_b32 per MFMA from the wavefront's OWN LDS image of the 1280 + 4 NT - 160
+// consecutive samples its 8 windows cover (12 KiB, loaded as twelve 1 KiB dwordx4 bursts per tile: the first attempt read the
+// operand straight from global memory, 32 bytes per segment and step, and the 8192 interleaved sequential streams it made of
+// the input ran the HBM at 1.5 TB/s).  The image carries 16 pad bytes per 160 samples, so that the 16 streams of a step --
+// 8 addresses 1296 bytes apart, 2 dwords each, times four k -- fall on 64 different banks.  Two images per wavefront: the next
+// tile's bursts are in flight while this tile's 101 steps run, and go to LDS behind them.  No barrier anywhere: a wavefront
+// reads only what it wrote.  Even and odd steps accumulate separately (an MFMA on the accumulator of the previous one would wait
+// 40 cycles for a 32-cycle issue slot).  Outputs whose taps reach back into the PREVIOUS cycle (the history tensor) are left to one
+// extra workgroup that runs the direct form's first tile (it also renews the history, as before): every other sample before the
+// stream reads as zero through the buffer descriptor's range check.  Same sums as the direct form up to the order of the
+// additions; against the bit-exact FFT chain 1.2e-6 of the peak (tests/test_gpu_filter_fast.py).
+struct FirMfmaDims {
+    uint32_t tiles;       // wave tiles of 128 outputs
+    uint32_t total;       // outputs of the whole stream (rows * M)
+    uint32_t skip;        // outputs [0, skip) belong to the fix-up workgroup
+    uint32_t in_bytes;    // the stream's size
+    int32_t lead;         // samples a window starts before its first output's sample 0
+    uint32_t lds_fixup;   // bytes the fix-up tile needs (the MFMA images start behind them)
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+constexpr int kMfmaWaves = 4;       // wavefronts per workgroup, one per SIMD
+constexpr int kMfmaPieces = 12;     // 16-byte pieces per lane and image: 64 * 12 * 2 = 1536 samples >= 1280 + 4 NT - 160
+
+template <int R, int NT>
+__global__ __launch_bounds__(kMfmaWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void fir_mfma_kernel(float2* __restrict__ out, const float2* __restrict__ in,
+                                                                      const float2* hist, const float* __restrict__ hp,
+                                                                      const float* __restrict__ btab, FirDims d, FirMfmaDims md) {
+    if (blockIdx.x == gridDim.x - 1) {  // the tile that reads (and renews) the history: the direct form, 64 outputs
+        fir_tile<1>(out, in, hist, hp, d, 0);
+        return;
+    }
+    static_assert(R == 10, "the image's pad rule is written for 160 samples per segment");
+    static_assert(8 * 16 * R + 4 * NT - 16 * R <= 64 * kMfmaPieces * 2, "the image does not hold a tile's windows");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr uint32_t kImageBytes = (64u * kMfmaPieces + (64u * kMfmaPieces) / 80u + 1u) * 16u;  // pieces + one pad piece per 80
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    unsigned char* image0 = smem_raw + (size_t)wv * 2u * kImageBytes;
+    const uint32_t stream = lane & 15u, k = lane >> 4;
+    float tb[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) tb[j] = btab[j * 64 + lane];
+    const rsrc_t rs = make_rsrc(in, md.in_bytes);
+    // staging: piece p = lane + 64 i holds image samples 2p, 2p + 1; in LDS behind p / 80 pads
+    uint32_t wr[kMfmaPieces];
+#pragma unroll
+    for (int i = 0; i < kMfmaPieces; ++i) {
+        const uint32_t p = lane + 64u * (uint32_t)i;
+        wr[i] = (p + p / 80u) * 16u;
+    }
+    // operand reads: segment sigma = stream / 2 starts at image sample 160 sigma -> byte 1296 sigma; sample k, component stream & 1
+    const uint32_t rd = (stream >> 1) * 1296u + k * 8u + (stream & 1u) * 4u;
+    const uint32_t q = lane >> 4, n = lane & 15u;
+    const uint32_t waves_total = (gridDim.x - 1u) * (uint32_t)kMfmaWaves;
+    uint32_t tile = blockIdx.x * (uint32_t)kMfmaWaves + wv;
+
+    auto fetch = [&](uint32_t t, v4u (&v)[kMfmaPieces]) {
+        // first image sample of tile t: t * 128 * R - lead (before the stream: the offset wraps far out of range -> 0)
+        const uint32_t base = (uint32_t)(((int64_t)t * 128 * R - md.lead) * 8) + lane * 16u;
+#pragma unroll
+        for (int i = 0; i < kMfmaPieces; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + (uint32_t)(i * 1024), 0u, 0);
+    };
+    auto stash = [&](unsigned char* image, const v4u (&v)[kMfmaPieces]) {
+#pragma unroll
+        for (int i = 0; i < kMfmaPieces; ++i) *reinterpret_cast<v4u*>(image + wr[i]) = v[i];
+    };
+    auto put = [&](uint64_t g, float re, float im) {
+        if (g >= md.skip && g < md.total) out[g] = make_float2(re, im);
+    };
+
+    auto compute = [&](const unsigned char* image, uint32_t t) {
+        v4f acc0 = v4f{0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+        const unsigned char* a_ptr = image + rd;
+        // step j reads image samples 160 sigma + 4 j + k: one more pad behind every 160 samples (40 steps).  The operands
+        // of the NEXT chunk of steps are requested before this chunk's MFMAs issue (the scheduler is held to that order:
+        // left alone it waited for every operand pair right in front of its two MFMAs -- an LDS round trip per 64 cycles of MFMA).
+        constexpr int kChunk = 12;
+        constexpr int kChunks = (NT + kChunk - 1) / kChunk;
+        float a_op[2][kChunk];
+        auto request = [&](int c, float (&dst)[kChunk]) {
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) {
+                const int j = c * kChunk + i;
+                if (j < NT) dst[i] = *reinterpret_cast<const float*>(a_ptr + j * 32 + (j / 40) * 16);
+            }
+        };
+        request(0, a_op[0]);
+#pragma unroll
+        for (int c = 0; c < kChunks; ++c) {
+            if (c + 1 < kChunks) request(c + 1, a_op[(c + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) {
+                const int j = c * kChunk + i;
+                if (j < NT) {
+                    if (j & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op[c & 1][i], tb[j], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op[c & 1][i], tb[j], acc0, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // registers 0,1 = (re, im) of segment 2 q, registers 2,3 = of segment 2 q + 1; the lane's output within the segment: n
+        const uint64_t g0 = (uint64_t)t * 128u + 32u * q + n, g1 = g0 + 16u;
+        put(g0, acc0[0] + acc1[0], acc0[1] + acc1[1]);
+        put(g1, acc0[2] + acc1[2], acc0[3] + acc1[3]);
+    };
+
+    // Two tiles in the pipe per wavefront: tile i runs out of one image while the bursts of tile i + 1 are in flight; they go
+    // to the other image behind tile i's steps.  (Measured, same box: a third tile in flight -- bursts requested two tiles
+    // ahead, with hipcc's waits 32.5 us, with inline-asm bursts and our own vmcnt accounting 32.3 us -- against 29.5 us for
+    // this form; two wavefronts per SIMD on one image each: 32.5 us.  The kernel moves 4.8 TB/s: it does not wait for latency.)
+    v4u stage[kMfmaPieces];
+    if (tile < md.tiles) {
+        fetch(tile, stage);
+        stash(image0, stage);
+    }
+    uint32_t flip = 0;
+    for (; tile < md.tiles; tile += waves_total, flip ^= 1u) {
+        const uint32_t next = tile + waves_total;
+        if (next < md.tiles) fetch(next, stage);  // in flight behind this tile's steps
+        compute(image0 + flip * kImageBytes, tile);
+        if (next < md.tiles) stash(image0 + (flip ^ 1u) * kImageBytes, stage);
+    }
+}
+
+// B operand of the MFMA form, [NT][64]: lane l of step j holds h[n*R + lead - 4j - k], n = l % 16, k = l / 16
+__global__ void fir_mfma_taps_kernel(float* __restrict__ btab, const float2* __restrict__ taps, uint32_t T, uint32_t R, uint32_t NT,
+                                     int32_t lead) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NT * 64u) return;
+    const uint32_t lane = e & 63u, j = e >> 6;
+    const int32_t idx = (int32_t)((lane & 15u) * R) + lead - 4 * (int32_t)j - (int32_t)(lane >> 4);
+    btab[e] = (idx >= 0 && idx < (int32_t)T) ? taps[idx].x : 0.0f;
 }
 
 // history <- the last T-1 samples of the stream (the tail of the last row)
@@ -268,10 +427,25 @@ bool fir_dims(FirDims& d, FirPlan& plan, uint64_t rows, uint64_t row_samples, ui
 
 }  // namespace
 
-size_t fir_table_floats(uint64_t taps, uint64_t decimation, uint64_t heads) {
+namespace {
+// MFMA form: the (R, NT) pairs fir_mfma_kernel is instantiated for; NT steps of 4 samples must cover 15 R + T samples
+constexpr int kFirMfmaMaxSteps = 101;
+int fir_mfma_steps(uint64_t taps, uint64_t decimation, uint64_t heads) {
+    if (heads != 1 || decimation != 10) return 0;
+    if (taps + 150 <= 4 * 51) return 51;     // <= 54 taps (multi-fm.yml's 51)
+    if (taps + 150 <= 4 * 101) return 101;   // <= 254 taps (BASELINE config 3's 251)
+    return 0;
+}
+size_t fir_direct_table_floats(uint64_t taps, uint64_t decimation, uint64_t heads) {
     const uint64_t Q = (taps + decimation - 1) / decimation;
     const uint64_t chunks = (kFirMaxJ + Q - 1 + kFirChunk - 1) / kFirChunk;  // the most any J needs
     return (size_t)(heads * decimation * chunks * kFirWin);
+}
+}  // namespace
+
+// the direct form's step-major tap windows, then (when the MFMA form takes the shape) its B operand [NT][64]
+size_t fir_table_floats(uint64_t taps, uint64_t decimation, uint64_t heads) {
+    return fir_direct_table_floats(taps, decimation, heads) + (size_t)kFirMfmaMaxSteps * 64;
 }
 
 hipError_t launch_fir_table(float* table, const float2* taps, uint64_t ntaps, uint64_t decimation,
@@ -283,6 +457,12 @@ hipError_t launch_fir_table(float* table, const float2* taps, uint64_t ntaps, ui
         return hipErrorInvalidValue;
     (void)hipGetLastError();
     hipLaunchKernelGGL(fir_taps_kernel, dim3(4), dim3(256), 0, s, table, taps, d);
+    if (const int nt = fir_mfma_steps(ntaps, decimation, heads)) {
+        const int32_t lead = 4 * nt - 1 - 15 * (int32_t)decimation;
+        hipLaunchKernelGGL(fir_mfma_taps_kernel, dim3((unsigned)((nt * 64 + 255) / 256)), dim3(256), 0, s,
+                           table + fir_direct_table_floats(ntaps, decimation, heads), taps, (uint32_t)ntaps, (uint32_t)decimation,
+                           (uint32_t)nt, lead);
+    }
     return hipGetLastError();
 }
 
@@ -296,6 +476,52 @@ hipError_t launch_fir_decimate(float2* out, const float2* in, const float* table
     const int J = plan.J, threads = plan.threads;
     const size_t lds = plan.lds;
     (void)hipGetLastError();
+    // The MFMA form: one head, the instantiated (R, NT) shapes, a stream the buffer descriptor can address, and a direct-form
+    // first tile of (J = 2, 256 threads) for the outputs that reach into the history.  JST_FIR_DIRECT (switch) keeps the direct form.
+    const int nt = switch_value(SW_FIR_DIRECT) ? 0 : fir_mfma_steps(ntaps, decimation, heads);
+    const uint64_t total = rows * d.M, in_bytes = rows * row_samples * sizeof(float2);
+    // the fix-up tile: the direct form at its smallest (J = 1, 64 output slots) -- it only has to cover the outputs whose taps
+    // reach into the history (Q of them), and it is ONE workgroup beside 255 that each do 1/255 of the rest
+    FirDims fix = d;
+    FirPlan small;
+    small.J = 1;
+    small.threads = 64;
+    small.chunks = (uint32_t)((1 + d.Q - 1 + kFirChunk - 1) / kFirChunk);
+    small.UL = ((uint32_t)(small.threads - 1) + small.chunks * kFirChunk) | 1u;
+    small.lds = (size_t)small.UL * d.r * sizeof(float2);
+    fix.OW = 64;
+    fix.UL = small.UL;
+    fix.chunks = small.chunks;
+    fix.tiles_per_row = (d.M + fix.OW - 1) / fix.OW;
+    fix.update_history = (d.Q <= fix.OW && ntaps > 1) ? 1u : 0u;
+    // (the tap windows fir_taps built are laid out for plan.chunks chunks per branch: the fix-up tile must walk the same layout)
+    if (nt && fix.update_history && small.chunks == plan.chunks && in_bytes < (1ull << 31) && total >= 4096 && d.M >= 64) {
+        int cus = 256, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        FirMfmaDims md;
+        md.tiles = (uint32_t)((total + 127) / 128);  // 8 segments x 16 outputs per wavefront and tile
+        uint64_t groups = (uint64_t)(cus > 1 ? cus - 1 : 255);  // + the fix-up workgroup: every workgroup resident at once
+        if (groups * kMfmaWaves > md.tiles) groups = (md.tiles + kMfmaWaves - 1) / kMfmaWaves;
+        md.total = (uint32_t)total;
+        md.skip = fix.OW;  // the fix-up workgroup's tile: outputs [0, 64) of row 0
+        md.in_bytes = (uint32_t)in_bytes;
+        md.lead = 4 * nt - 1 - 15 * (int32_t)decimation;
+        md.lds_fixup = (uint32_t)small.lds;
+        const size_t image = (size_t)(64 * kMfmaPieces + (64 * kMfmaPieces) / 80 + 1) * 16;
+        const size_t lds_m = std::max(small.lds, (size_t)kMfmaWaves * 2 * image);
+        const float* btab = table + fir_direct_table_floats(ntaps, decimation, heads);
+        const dim3 grid_m((unsigned)(groups + 1));
+        if (nt == 101) {
+            const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(fir_mfma_kernel<10, 101>), 160 * 1024);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fir_mfma_kernel<10, 101>), grid_m, dim3(kMfmaWaves * 64), lds_m, s, out, in, (const float2*)history, table, btab, fix, md);
+        } else {
+            const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(fir_mfma_kernel<10, 51>), 160 * 1024);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((fir_mfma_kernel<10, 51>), grid_m, dim3(kMfmaWaves * 64), lds_m, s, out, in, (const float2*)history, table, btab, fix, md);
+        }
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)(rows * d.tiles_per_row));
 #define JST_FIR(JJ)                                                                                   \
     do {                                                                                              \
