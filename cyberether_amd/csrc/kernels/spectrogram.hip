@@ -511,7 +511,11 @@ hipError_t launch_spectrogram_index_span(float* bins, const uint8_t* idx, uint64
     // profiles/r04_experiments/d_span_kernel_v2.log).
     (void)hipGetLastError();
     // Round 5: cycles counted in PAIRS (below 65536 batches, spans of more than one cycle); the overlapped two-histogram form
-    // and other workgroup sizes were measured and rejected (profiles/r05_experiments/r_..., w_...).
+    // and other workgroup sizes were measured and rejected (profiles/r05_experiments/r_..., w_...).  Round 6 tried the overlap
+    // once more -- two histograms, one barrier per pair, the next pair's atomics leaving in eight groups of four between the
+    // eight hit updates, the counts forced into registers first (lgkmcnt counts to 15 and retires in order) -- bit-exact and
+    // 37.3 us per 20-cycle span against 33.7: the wavefronts without hot cells hand the LDS unit their 32 atomics at once,
+    // and a hot wavefront's first group queues behind all of them (profiles/r06_experiments/b_span_overlap.log).
     constexpr int copies = 2;
     const size_t lds = ((size_t)height * 16 + 16) * (size_t)copies * sizeof(uint32_t);
 #define JST_SPEC_SPAN(COPIES, PAIRED, THREADS)                                                                                       \
