@@ -292,12 +292,19 @@ def other_configs(js, budget_s: float = 45.0) -> list:
         ok = same(eng.buffer.numpy(), oracle.spectrum_chain(x, -100.0, 0.0)["range"])
         batched = bool(rt.batched)
         dt = timed(rt, 320, 48)
+        # the stamp of the form that was TIMED: one more whole ring period as cycle-batched span launches, then every slot of
+        # the output ring against the oracle (slot s holds the spectrum of np.roll(x, s): a row permutation of the first)
+        rt.compute((-(1 + 320 + 48)) % slots + slots)
+        first = oracle.spectrum_chain(x, -100.0, 0.0)["range"]
+        ok_span = all(same(eng.buffer.ring_select(sl).numpy(), np.roll(first, sl, axis=0)) for sl in range(slots)) if batched else None
         rt.destroy()
         rec = {"us_per_cycle": dt * 1e6, "MS_per_s": b * n / dt / 1e6, "roofline": roof(28.0, b * n, dt),
                "source": f"resident ring of {slots} slots, runtime defaults", "cycle_batched": batched,
-               "parity": {"checked": True, "bit_exact": ok, "what": "range output of the FIRST cycle -- which runs eagerly, before "
-                          "the cycle-batched span launches that are timed -- vs oracle.spectrum_chain (16 x 65536); the batched "
-                          "form is compared with the oracle slot by slot in tests/test_gpu_batch.py"}}
+               "parity": {"checked": True, "bit_exact": bool(ok and ok_span is not False), "first_cycle_bit_exact": ok,
+                          "batched_span_bit_exact": ok_span, "slots_compared": slots if batched else 0,
+                          "what": "range output of the first (eager) cycle AND of every slot of the output ring after a whole "
+                                  "ring period of cycle-batched span launches -- the form that is timed -- vs "
+                                  "oracle.spectrum_chain (16 x 65536 per slot)"}}
         # one launch per unit and cycle on a plain tensor (rounds 1-3 quoted this form)
         src = js.Tensor.from_numpy(x, batch=0, sample=1)
         eng = js.SpectrumEngine(src, enable_scale=True, range_min=-100.0, range_max=0.0)
@@ -308,6 +315,22 @@ def other_configs(js, budget_s: float = 45.0) -> list:
         dt1 = timed(rt, 100, 10)
         rt.destroy()
         rec["launch_per_cycle"] = {"us_per_cycle": dt1 * 1e6, "roofline_frac": roof(28.0, b * n, dt1)["frac"], "bit_exact": ok1}
+        # north_star's own reading of the config -- EIGHT streams -- on one GPU: 8 x 16 = 128 transforms per cycle fill the CUs
+        # (16 transforms leave half of them idle and three launch floors dominate); one launch per unit and cycle
+        b8 = 8 * b
+        x8 = np.concatenate([np.roll(x, 3 * k, axis=1) * np.float32(1.0 + 0.125 * k) for k in range(8)], axis=0)
+        src8 = js.Tensor.from_numpy(x8, batch=0, sample=1)
+        eng8 = js.SpectrumEngine(src8, enable_scale=True, range_min=-100.0, range_max=0.0)
+        lp8 = js.Module("lineplot", {"averaging": 8}, {"signal": eng8.buffer}, "psd")
+        rt8 = js.Runtime(eng8.modules + [lp8], graph=True, fuse=True, batch=False)
+        rt8.compute(1)
+        rows8 = np.r_[0:4, b8 - 4:b8]
+        ok8 = same(eng8.buffer.numpy()[rows8], oracle.spectrum_chain(x8[rows8], -100.0, 0.0)["range"])
+        dt8 = timed(rt8, 60, 6)
+        rt8.destroy()
+        rec["streams_8"] = {"transforms_per_cycle": b8, "us_per_cycle": dt8 * 1e6, "MS_per_s": b8 * n / dt8 / 1e6,
+                            "roofline_frac": roof(28.0, b8 * n, dt8)["frac"], "bit_exact_rows_0_3_and_124_127": ok8,
+                            "what": "all 8 streams of configs[4] resident on ONE GPU: CF32[128, 65536] per cycle, one launch per unit and cycle"}
         return rec
 
     guarded("configs[2]: 251-tap FIR (FFT overlap-add) + /10 on CF32[100,159750] (16 MS per cycle)", c3)
@@ -395,6 +418,13 @@ def main() -> None:
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                                   f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
+    # ONE JSON line on stdout, nothing else: native libraries write there too (RCCL prints a five-line version banner through
+    # C stdio when a communicator is created -- flushed at exit, BEHIND the JSON line).  File descriptor 1 points at stderr for
+    # the whole run; the line goes to the saved descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -660,9 +690,12 @@ def main() -> None:
     # collectives the path has: the U32[256, 4096] hit counts of the exact multi-GPU Spectrogram (4 MiB) and config 5's
     # averaged F32[65536] trace (256 KiB).  The line reports how many ranks RCCL saw.
     collective = None
-    if world > 1 and backend != "gloo":
+    c5_multi = None
+    if backend != "gloo" and (world > 1 or (js.comm_available() and not args.no_alt)):
         import cyberether_amd.distributed as D
-        comm = D.library_comm()
+        # N = 1: a REAL one-rank RCCL communicator (jst_comm_init(0, 1, id)): the same dlopen, enum slice, stream ordering and
+        # divide kernel as at N > 1, on this GPU -- so that the collective's own cost is a measured number at every N
+        comm = D.library_comm() if world > 1 else js.Comm(0, 1, js.comm_unique_id())
         counts = js.Tensor.from_numpy(np.full((HEIGHT, N_FFT), rank + 1, np.uint32))
         trace = js.Tensor.from_numpy(np.full((65536,), float(rank + 1), np.float32))
 
@@ -681,10 +714,53 @@ def main() -> None:
         rt.synchronize()
         ok = bool(np.all(counts.numpy() == world * (world + 1) // 2))
         collective = {"library": "RCCL behind the C ABI (jst_comm_allreduce, csrc/jst/comm.cc)", "rccl_ranks": comm.world,
-                      "uses_rccl": comm.uses_rccl, "sum_of_counts_exact": ok,
+                      "rccl_ranks_match_world": bool(comm.world == world), "uses_rccl": comm.uses_rccl, "sum_of_counts_exact": ok,
                       "allreduce_us": {"u32_counts_4MiB": round(timed_allreduce(counts, False), 1),
                                        "f32_trace_256KiB_average": round(timed_allreduce(trace, True), 1)},
                       "in_timed_region": False}
+        if comm.world != world or not comm.uses_rccl:
+            print(f"[bench] WARNING: RCCL saw {comm.world} ranks (uses_rccl={comm.uses_rccl}) for a world of {world}", file=sys.stderr)
+        if world > 1:
+            # BASELINE configs[4] as it reads: one 65536-point spectrum stream per GPU (16 batches per cycle, Window -> FFT ->
+            # Amplitude -> Range -> Lineplot average), the averaged PSD all-reduced over RCCL / xGMI once per reporting interval
+            # -- INSIDE this timed loop, through the library's communicator on the runtime's stream (no torch on the data).
+            n5, b5, interval, cycles5 = 65536, 16, 25, 200
+            rng5 = np.random.default_rng(1240 + rank)   # seeds 1240..1247
+            t5 = np.arange(n5) / 2.0e6
+            x5 = (np.exp(2j * np.pi * (100.25 + rank) * 2.0e6 / n5 * t5)[None, :] +
+                  1e-3 * (rng5.standard_normal((b5, n5)) + 1j * rng5.standard_normal((b5, n5)))).astype(np.complex64)
+            src5 = js.Tensor.from_numpy(x5, batch=0, sample=1)
+            eng5 = js.SpectrumEngine(src5, enable_scale=True, range_min=-100.0, range_max=0.0)
+            lp5 = js.Module("lineplot", {"averaging": 8}, {"signal": eng5.buffer}, "psd")
+            rt5 = js.Runtime(eng5.modules + [lp5], graph=True, fuse=True)
+            own = lp5.state("averagingBuffer")
+            merged = js.Tensor.create("hip", "F32", (n5,))   # the mean goes to a trace of its own: a rank's IIR state stays its own
+            rt5.compute(interval, sync=True)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            done = 0
+            while done < cycles5:
+                rt5.compute(interval, sync=False)
+                merged.copy_from_tensor(own, stream=rt5.stream)   # 256 KiB device copy behind the span, in front of the collective
+                comm.all_reduce(merged, "sum", average=True, stream=rt5.stream)
+                done += interval
+            rt5.synchronize()
+            torch.cuda.synchronize()
+            dt5 = time.perf_counter() - t0
+            t_max = torch.tensor([dt5], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+            dt5 = float(t_max.item())
+            # the merged trace must be the mean of the ranks' own traces
+            mine = torch.from_numpy(own.numpy().astype(np.float64)).cuda()
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+            mean_ok = bool(np.allclose(merged.numpy(), (mine / world).cpu().numpy(), rtol=0, atol=1e-6))
+            c5_multi = {"config": f"configs[4]: {world} independent 65536-point spectrum streams (one per GPU), PSD all-reduce "
+                                  f"(RCCL, library communicator) every {interval} cycles inside the timed loop",
+                        "n_gpus": world, "value": world * b5 * n5 * cycles5 / dt5 / 1e6, "unit": "MS/s",
+                        "us_per_cycle": dt5 / cycles5 * 1e6, "merged_trace_is_mean_of_rank_traces": mean_ok,
+                        "roofline_frac_per_gpu": 28.0 * b5 * n5 / (dt5 / cycles5) / 8e12}
+            rt5.destroy()
     samples = float(args.steps) * BATCHES * N_FFT * world
     kernel_ms_raw, pair_ms, kernel_ms, achieved = kernel_time(rt)
     cycles_per_launch = kernel_time.cycles
@@ -864,13 +940,16 @@ def main() -> None:
         line["configs"] = other_configs(js)
     if rank == 0 and world == 1 and not args.no_alt:
         line["reference_driven"] = reference_driven(args.slots, args.steps, args.provider)
+    if rank == 0 and c5_multi is not None:
+        line["configs"] = [c5_multi]
     if world > 1:
         barrier()
         dist.destroy_process_group()
     if rank == 0:
         # after the process group is gone (N > 1: the other ranks have left), so a SCALE line carries it too
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -180,6 +180,10 @@ jst_result jst_tensor_clone(jst_tensor t, jst_tensor* out) {
     *out = h.release();
     return R(Result::SUCCESS);
 }
+jst_result jst_tensor_copy(jst_tensor dst, jst_tensor src, void* hip_stream) {
+    JST_ARG(dst && src, "null tensor");
+    return R(dst->t.copyFrom(src->t, static_cast<hipStream_t>(hip_stream)));
+}
 jst_result jst_tensor_destroy(jst_tensor t) {
     delete t;
     return R(Result::SUCCESS);

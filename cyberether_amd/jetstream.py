@@ -94,6 +94,7 @@ _sig("jst_tensor_wrap", R, C.c_void_p, C.c_size_t, C.c_uint8, C.c_uint8, C.c_uin
 _sig("jst_tensor_rebind", R, _h, C.c_void_p, C.c_size_t)
 _sig("jst_tensor_clone", R, _h, _hp)
 _sig("jst_tensor_view", R, _h, C.c_uint32, _u64p, _u64p, C.c_uint64, _hp)
+_sig("jst_tensor_copy", R, _h, _h, C.c_void_p)
 _sig("jst_tensor_destroy", R, _h)
 _sig("jst_tensor_describe", R, _h, C.POINTER(_Desc))
 _sig("jst_tensor_ring_select", R, _h, C.c_uint64)
@@ -391,6 +392,11 @@ class Tensor:
             array = np.ascontiguousarray(array, dtype=NP_DTYPE[code])
         fn = _lib.jst_tensor_copy_from_host_async if asynchronous else _lib.jst_tensor_copy_from_host
         _check(fn(self._h, array.ctypes.data_as(C.c_void_p), array.nbytes))
+        return self
+
+    def copy_from_tensor(self, source: "Tensor", stream: int = 0):
+        """jst_tensor_copy: dense device-to-device copy of `source` into this tensor, enqueued on `stream`."""
+        _check(_lib.jst_tensor_copy(self._h, source._h, C.c_void_p(stream) if stream else None))
         return self
 
     def numpy(self) -> np.ndarray:

@@ -182,6 +182,10 @@ jst_result jst_tensor_get_attribute_f64v(jst_tensor t, const char* key, double* 
 /* dense copies, synchronous on return (tensor.cc:882-963) */
 jst_result jst_tensor_copy_from_host(jst_tensor t, const void* src, size_t bytes);
 jst_result jst_tensor_copy_to_host(jst_tensor t, void* dst, size_t bytes);
+/* Tensor::copyFrom(source, context) (include/jetstream/memory/tensor.hh:52): dense device-to-device copy of `src` into `dst`
+ * (same byte size), enqueued on `hip_stream` (NULL: the null stream) -- e.g. a trace taken out of a module's state before a
+ * collective overwrites it in place. */
+jst_result jst_tensor_copy(jst_tensor dst, jst_tensor src, void* hip_stream);
 /* asynchronous H2D on the library's side stream (pinned source recommended); the returned
  * work is ordered before the next jst_runtime_compute of any runtime via an event. */
 jst_result jst_tensor_copy_from_host_async(jst_tensor t, const void* src, size_t bytes);

@@ -91,3 +91,15 @@ def test_bench_single_gpu_line_carries_the_other_configs():
     assert cfgs[2]["us_per_cycle"] < cfgs[2]["launch_per_cycle"]["us_per_cycle"]
     assert line["value_generic_per_cycle"]["value"] > 0
     assert "frac_rocprof" in line["roofline"] and "rocprofv3_kernel_us" in line["roofline"]
+    # round 6: the stamp of config 5 covers a cycle-batched span (every slot of the output ring), the 8-stream form rides along
+    assert cfgs[2]["parity"]["batched_span_bit_exact"] is True and cfgs[2]["parity"]["slots_compared"] == 16
+    assert cfgs[2]["streams_8"]["transforms_per_cycle"] == 128 and cfgs[2]["streams_8"]["bit_exact_rows_0_3_and_124_127"]
+    # config 3's provider fast runs on the matrix cores, within north_star's tolerance of the bit-exact chain
+    assert cfgs[0]["fast"]["parity"]["within_1e-5"]
+    # the collective executes at N = 1 too: a real one-rank RCCL communicator
+    coll = line["config"]["collective"]
+    assert coll is None or (coll["rccl_ranks"] == 1 and coll["uses_rccl"] and coll["sum_of_counts_exact"] and coll["allreduce_us"]["u32_counts_4MiB"] > 0)
+    # the reference's own scheduler in charge of the same workload, device-resident (where the patched reference was built)
+    ref = line["reference_driven"]
+    assert ref["available"] is False or (ref["parity"]["spectrogram_bit_exact"] and ref["parity"]["output_within_1e-5"]
+                                         and "+indices" in ref["deferred_spans"]["units"] and ref["deferred_spans_sustained"]["us_per_cycle"] > 0)
