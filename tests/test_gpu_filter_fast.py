@@ -27,6 +27,11 @@ def peak_err(got, ref):
     dict(sr=6e6, bw=2e6, taps=7, s=30, b=5),           # /3, tiny rows: T-1 = 6 history samples
     dict(sr=20e6, bw=2e6, taps=251, s=4000, b=None),   # rank-1 input
     dict(sr=20e6, bw=2e6, taps=101, s=900, b=2, heads=2),
+    # round 6, the MFMA form (fir_mfma_kernel: /10, one head, >= 4096 outputs per cycle): both instantiated tap-step counts,
+    # totals that are no multiple of a wavefront's 128 outputs, more wave tiles than wavefronts, rows that are no multiple of 16
+    dict(sr=20e6, bw=2e6, taps=51, s=40000, b=7),      # fir_mfma_kernel<10, 51>: 28000 outputs, 219 wave tiles
+    dict(sr=20e6, bw=2e6, taps=241, s=11110, b=9),     # <10, 101> with fewer taps than it holds; rows of 1111 outputs
+    dict(sr=20e6, bw=2e6, taps=251, s=159750, b=12),   # 191700 outputs: 1498 wave tiles on 1020 wavefronts (two rounds)
 ])
 def test_fast_filter_matches_reference_chain(js, oracle, case):
     rng = np.random.default_rng(77)
@@ -64,6 +69,32 @@ def test_fast_filter_matches_reference_chain(js, oracle, case):
     for head in range(heads):
         got = np.concatenate([y[:, head, :] for y in ys], axis=0).reshape(-1)
         assert peak_err(got, full) <= TOL
+
+
+def test_mfma_form_against_the_direct_form(js, switch):
+    """The same provider-fast Filter on the matrix cores (default where the shape allows) and on the vector FMAs
+    (JST_FIR_DIRECT): the same sums up to the order of the additions, over three cycles of carried history -- and the
+    outputs whose taps reach into the previous cycle come from the same direct-form tile in both."""
+    rng = np.random.default_rng(5)
+    b, s, taps = 6, 25600, 251
+    xs = [csignal(rng, (b, s)) for _ in range(3)]
+    outs = {}
+    for form in ("direct", "mfma"):
+        switch("JST_FIR_DIRECT", "1" if form == "direct" else None)
+        src = js.Tensor.create("hip", "CF32", (b, s)).set_axes(batch=0, sample=1)
+        blk = js.Filter(src, 20e6, 2e6, [0.0], taps, 1, provider="fast")
+        rt = js.Runtime(blk.modules, graph=True)
+        got = []
+        for x in xs:
+            src.copy_from(x)
+            rt.compute()
+            got.append(blk.buffer.numpy().copy())
+        outs[form] = got
+        rt.destroy()
+    for c, (d, m) in enumerate(zip(outs["direct"], outs["mfma"])):
+        assert peak_err(m, d) <= 2e-6, (c, peak_err(m, d))
+        assert np.array_equal(m.reshape(-1)[:26].view(np.uint32), d.reshape(-1)[:26].view(np.uint32)), c   # the fix-up tile's outputs
+    assert not np.array_equal(outs["direct"][1].view(np.uint32), outs["mfma"][1].view(np.uint32))   # two different kernels did run
 
 
 def test_fast_provider_keeps_the_fft_chain_when_a_head_is_off_centre(js):
