@@ -271,7 +271,7 @@ class LibraryModule {
             JST_ERROR("[{}] The library's '{}' tensor does not have the layout the reference's module published.", tag, port);
             return Result::ERROR;
         }
-        if (d.data == host.data()) return Result::SUCCESS;
+        if (d.data == host.data() || host.size() == 0) return Result::SUCCESS;  // (an empty tensor has no buffer to write)
         if (jst_tensor_rebind(dev, host.data(), host.buffer().sizeBytes()) != JST_SUCCESS) return fail("jst_tensor_rebind");
         if (host.contiguous() && host.offset() == 0) adopted.push_back({dev, host.data(), host.sizeBytes()});
         return Result::SUCCESS;

@@ -191,6 +191,8 @@ def _view(d: _Desc) -> np.ndarray:
 def _upload(d: _Desc, x: np.ndarray, byte_offset: int = 0) -> None:
     """Dense host array -> the buffer of a device tensor (at byte_offset), through ref_dev_write."""
     x = np.ascontiguousarray(x)
+    if x.nbytes == 0:
+        return
     assert byte_offset + x.nbytes <= int(d.buffer_bytes), "upload exceeds the device buffer"
     assert lib().ref_dev_write(C.c_void_p(d.data + byte_offset), x.ctypes.data_as(C.c_void_p), C.c_uint64(x.nbytes)) == 0, "device write failed"
 
@@ -268,8 +270,12 @@ class RefModule:
         shape = (C.c_uint64 * max(x.ndim - 1, 1))(*x.shape[:-1])
         d = _Desc()
         assert self._l.ref_mod_input(self._h, port.encode(), dtype.encode(), x.ndim - 1, shape, C.byref(d)) == 0
-        v = _view(d)
-        v[...] = x
+        if self._device == "cpu":
+            v = _view(d)
+            v[...] = x
+        else:
+            v = x.copy()
+            _upload(d, v)
         self._in[port] = v
         self._in_desc[port] = d
         return v

@@ -220,10 +220,12 @@ def by_name(name):
 
 
 # ---- the reference ---------------------------------------------------------------------------------------------------------------------
-def run_reference(c):
-    """(Result code of Module::create / the first failing compute, outputs per cycle or None, output axes)."""
+def run_reference(c, device="cpu"):
+    """(Result code of Module::create / the first failing compute, outputs per cycle or None, output axes).  device "hip": the
+    same calls on the reference's DeviceType::HIP (oracle/_ref/libref_jetstream_devhip.so: inputs allocated on the device, the
+    module of (HIP, NATIVE), Runtime(HIP)) -- tests/test_gpu_reference_matrix_device_hip.py."""
     from oracle import ref_jetstream as rj
-    with rj.RefModule(c["module"], c["config"]) as m:
+    with rj.RefModule(c["module"], c["config"], device=device) as m:
         for port, spec in c["inputs"].items():
             x = storage(c["name"], port, spec)
             if spec["dtype"] in _CI:
