@@ -692,75 +692,79 @@ def main() -> None:
     collective = None
     c5_multi = None
     if backend != "gloo" and (world > 1 or (js.comm_available() and not args.no_alt)):
-        import cyberether_amd.distributed as D
-        # N = 1: a REAL one-rank RCCL communicator (jst_comm_init(0, 1, id)): the same dlopen, enum slice, stream ordering and
-        # divide kernel as at N > 1, on this GPU -- so that the collective's own cost is a measured number at every N
-        comm = D.library_comm() if world > 1 else js.Comm(0, 1, js.comm_unique_id())
-        counts = js.Tensor.from_numpy(np.full((HEIGHT, N_FFT), rank + 1, np.uint32))
-        trace = js.Tensor.from_numpy(np.full((65536,), float(rank + 1), np.float32))
+        try:  # the measured line must not depend on the exchange step (a rank-symmetric failure skips it on every rank)
+            import cyberether_amd.distributed as D
+            # N = 1: a REAL one-rank RCCL communicator (jst_comm_init(0, 1, id)): the same dlopen, enum slice, stream ordering and
+            # divide kernel as at N > 1, on this GPU -- so that the collective's own cost is a measured number at every N
+            comm = D.library_comm() if world > 1 else js.Comm(0, 1, js.comm_unique_id())
+            counts = js.Tensor.from_numpy(np.full((HEIGHT, N_FFT), rank + 1, np.uint32))
+            trace = js.Tensor.from_numpy(np.full((65536,), float(rank + 1), np.float32))
 
-        def timed_allreduce(t, average):
-            for _ in range(3):
-                comm.all_reduce(t, "sum", average=average, stream=rt.stream)
+            def timed_allreduce(t, average):
+                for _ in range(3):
+                    comm.all_reduce(t, "sum", average=average, stream=rt.stream)
+                rt.synchronize()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    comm.all_reduce(t, "sum", average=average, stream=rt.stream)
+                rt.synchronize()
+                return (time.perf_counter() - t0) / 20 * 1e6
+            counts.copy_from(np.full((HEIGHT, N_FFT), rank + 1, np.uint32))
+            comm.all_reduce(counts, "sum", stream=rt.stream)
             rt.synchronize()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(20):
-                comm.all_reduce(t, "sum", average=average, stream=rt.stream)
-            rt.synchronize()
-            return (time.perf_counter() - t0) / 20 * 1e6
-        counts.copy_from(np.full((HEIGHT, N_FFT), rank + 1, np.uint32))
-        comm.all_reduce(counts, "sum", stream=rt.stream)
-        rt.synchronize()
-        ok = bool(np.all(counts.numpy() == world * (world + 1) // 2))
-        collective = {"library": "RCCL behind the C ABI (jst_comm_allreduce, csrc/jst/comm.cc)", "rccl_ranks": comm.world,
-                      "rccl_ranks_match_world": bool(comm.world == world), "uses_rccl": comm.uses_rccl, "sum_of_counts_exact": ok,
-                      "allreduce_us": {"u32_counts_4MiB": round(timed_allreduce(counts, False), 1),
-                                       "f32_trace_256KiB_average": round(timed_allreduce(trace, True), 1)},
-                      "in_timed_region": False}
-        if comm.world != world or not comm.uses_rccl:
-            print(f"[bench] WARNING: RCCL saw {comm.world} ranks (uses_rccl={comm.uses_rccl}) for a world of {world}", file=sys.stderr)
-        if world > 1:
-            # BASELINE configs[4] as it reads: one 65536-point spectrum stream per GPU (16 batches per cycle, Window -> FFT ->
-            # Amplitude -> Range -> Lineplot average), the averaged PSD all-reduced over RCCL / xGMI once per reporting interval
-            # -- INSIDE this timed loop, through the library's communicator on the runtime's stream (no torch on the data).
-            n5, b5, interval, cycles5 = 65536, 16, 25, 200
-            rng5 = np.random.default_rng(1240 + rank)   # seeds 1240..1247
-            t5 = np.arange(n5) / 2.0e6
-            x5 = (np.exp(2j * np.pi * (100.25 + rank) * 2.0e6 / n5 * t5)[None, :] +
-                  1e-3 * (rng5.standard_normal((b5, n5)) + 1j * rng5.standard_normal((b5, n5)))).astype(np.complex64)
-            src5 = js.Tensor.from_numpy(x5, batch=0, sample=1)
-            eng5 = js.SpectrumEngine(src5, enable_scale=True, range_min=-100.0, range_max=0.0)
-            lp5 = js.Module("lineplot", {"averaging": 8}, {"signal": eng5.buffer}, "psd")
-            rt5 = js.Runtime(eng5.modules + [lp5], graph=True, fuse=True)
-            own = lp5.state("averagingBuffer")
-            merged = js.Tensor.create("hip", "F32", (n5,))   # the mean goes to a trace of its own: a rank's IIR state stays its own
-            rt5.compute(interval, sync=True)
-            barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            done = 0
-            while done < cycles5:
-                rt5.compute(interval, sync=False)
-                merged.copy_from_tensor(own, stream=rt5.stream)   # 256 KiB device copy behind the span, in front of the collective
-                comm.all_reduce(merged, "sum", average=True, stream=rt5.stream)
-                done += interval
-            rt5.synchronize()
-            torch.cuda.synchronize()
-            dt5 = time.perf_counter() - t0
-            t_max = torch.tensor([dt5], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-            dt5 = float(t_max.item())
-            # the merged trace must be the mean of the ranks' own traces
-            mine = torch.from_numpy(own.numpy().astype(np.float64)).cuda()
-            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
-            mean_ok = bool(np.allclose(merged.numpy(), (mine / world).cpu().numpy(), rtol=0, atol=1e-6))
-            c5_multi = {"config": f"configs[4]: {world} independent 65536-point spectrum streams (one per GPU), PSD all-reduce "
-                                  f"(RCCL, library communicator) every {interval} cycles inside the timed loop",
-                        "n_gpus": world, "value": world * b5 * n5 * cycles5 / dt5 / 1e6, "unit": "MS/s",
-                        "us_per_cycle": dt5 / cycles5 * 1e6, "merged_trace_is_mean_of_rank_traces": mean_ok,
-                        "roofline_frac_per_gpu": 28.0 * b5 * n5 / (dt5 / cycles5) / 8e12}
-            rt5.destroy()
+            ok = bool(np.all(counts.numpy() == world * (world + 1) // 2))
+            collective = {"library": "RCCL behind the C ABI (jst_comm_allreduce, csrc/jst/comm.cc)", "rccl_ranks": comm.world,
+                          "rccl_ranks_match_world": bool(comm.world == world), "uses_rccl": comm.uses_rccl, "sum_of_counts_exact": ok,
+                          "allreduce_us": {"u32_counts_4MiB": round(timed_allreduce(counts, False), 1),
+                                           "f32_trace_256KiB_average": round(timed_allreduce(trace, True), 1)},
+                          "in_timed_region": False}
+            if comm.world != world or not comm.uses_rccl:
+                print(f"[bench] WARNING: RCCL saw {comm.world} ranks (uses_rccl={comm.uses_rccl}) for a world of {world}", file=sys.stderr)
+            if world > 1:
+                # BASELINE configs[4] as it reads: one 65536-point spectrum stream per GPU (16 batches per cycle, Window -> FFT ->
+                # Amplitude -> Range -> Lineplot average), the averaged PSD all-reduced over RCCL / xGMI once per reporting interval
+                # -- INSIDE this timed loop, through the library's communicator on the runtime's stream (no torch on the data).
+                n5, b5, interval, cycles5 = 65536, 16, 25, 200
+                rng5 = np.random.default_rng(1240 + rank)   # seeds 1240..1247
+                t5 = np.arange(n5) / 2.0e6
+                x5 = (np.exp(2j * np.pi * (100.25 + rank) * 2.0e6 / n5 * t5)[None, :] +
+                      1e-3 * (rng5.standard_normal((b5, n5)) + 1j * rng5.standard_normal((b5, n5)))).astype(np.complex64)
+                src5 = js.Tensor.from_numpy(x5, batch=0, sample=1)
+                eng5 = js.SpectrumEngine(src5, enable_scale=True, range_min=-100.0, range_max=0.0)
+                lp5 = js.Module("lineplot", {"averaging": 8}, {"signal": eng5.buffer}, "psd")
+                rt5 = js.Runtime(eng5.modules + [lp5], graph=True, fuse=True)
+                own = lp5.state("averagingBuffer")
+                merged = js.Tensor.create("hip", "F32", (n5,))   # the mean goes to a trace of its own: a rank's IIR state stays its own
+                rt5.compute(interval, sync=True)
+                barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                done = 0
+                while done < cycles5:
+                    rt5.compute(interval, sync=False)
+                    merged.copy_from_tensor(own, stream=rt5.stream)   # 256 KiB device copy behind the span, in front of the collective
+                    comm.all_reduce(merged, "sum", average=True, stream=rt5.stream)
+                    done += interval
+                rt5.synchronize()
+                torch.cuda.synchronize()
+                dt5 = time.perf_counter() - t0
+                t_max = torch.tensor([dt5], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+                dt5 = float(t_max.item())
+                # the merged trace must be the mean of the ranks' own traces
+                mine = torch.from_numpy(own.numpy().astype(np.float64)).cuda()
+                dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+                mean_ok = bool(np.allclose(merged.numpy(), (mine / world).cpu().numpy(), rtol=0, atol=1e-6))
+                c5_multi = {"config": f"configs[4]: {world} independent 65536-point spectrum streams (one per GPU), PSD all-reduce "
+                                      f"(RCCL, library communicator) every {interval} cycles inside the timed loop",
+                            "n_gpus": world, "value": world * b5 * n5 * cycles5 / dt5 / 1e6, "unit": "MS/s",
+                            "us_per_cycle": dt5 / cycles5 * 1e6, "merged_trace_is_mean_of_rank_traces": mean_ok,
+                            "roofline_frac_per_gpu": 28.0 * b5 * n5 / (dt5 / cycles5) / 8e12}
+                rt5.destroy()
+        except Exception as exc:
+            print(f"[bench] collective leg failed: {exc!r}", file=sys.stderr)
+            collective = collective or {"error": repr(exc)}
     samples = float(args.steps) * BATCHES * N_FFT * world
     kernel_ms_raw, pair_ms, kernel_ms, achieved = kernel_time(rt)
     cycles_per_launch = kernel_time.cycles

@@ -201,3 +201,35 @@ def test_duplicate_is_elided_only_when_every_reader_walks_strides(js, oracle):
         assert_bit_equal(got[1], base[1], f"fm output {key}")
     want, _ = _oracle(oracle, np.ascontiguousarray(x[:, 1, :]))
     assert_bit_equal(base[0], want, "engine output vs the oracle")
+
+
+def test_an_elided_duplicate_comes_back_with_the_next_plan(js):
+    """TryElideDuplicate points the copy's readers at its source; that is a decision of ONE plan.  The same
+    modules under a later runtime without fusion must make the copy again -- its output tensor (the slice block's exposed port)
+    holds the dense slice, not stale zeros -- and a module that WRITES the source's storage between the duplicate and its
+    last reader keeps the copy even when fusing."""
+    rng = np.random.default_rng(5)
+    b, heads, n = 4, 2, 805
+    x = ((rng.standard_normal((b, heads, n)) + 1j * rng.standard_normal((b, heads, n))) * 0.3).astype(np.complex64)
+    src = js.Tensor.from_numpy(x, batch=0, channel=1, sample=2)
+    sl = js.Module("slice", {"slice": "[:, 1, :]"}, {"buffer": src}, "st.slice")
+    dup = js.Module("duplicate", {}, {"buffer": sl.output("buffer")}, "st.duplicate")
+    fm = js.Module("fm", {"mode": "narrow", "deemphasis": "none", "sampleRate": 200e3}, {"signal": dup.output("buffer")}, "fm")
+    mods = [sl, dup, fm]
+    rt = js.Runtime(mods, graph=True, fuse=True)
+    assert "st.duplicate(elided)" in rt.units, rt.units
+    rt.compute(2)
+    fused = fm.output("signal").numpy().copy()
+    assert not dup.output("buffer").numpy().any()          # the copy was not made: an intermediate nobody inside reads
+    rt.destroy()
+    rt = js.Runtime(mods, graph=True, fuse=False)          # the SAME modules, planned again without fusion
+    assert "st.duplicate" in rt.units and "st.duplicate(elided)" not in rt.units, rt.units
+    rt.compute(1)
+    assert_bit_equal(dup.output("buffer").numpy(), np.ascontiguousarray(x[:, 1, :]), "the copy is made again")
+    rt.destroy()
+    # same input twice through fresh demodulator state would differ by the carried phase: compare the per-cycle results instead
+    fm2 = js.Module("fm", {"mode": "narrow", "deemphasis": "none", "sampleRate": 200e3}, {"signal": dup.output("buffer")}, "fm2")
+    rt = js.Runtime([sl, dup, fm2], graph=True, fuse=False)
+    rt.compute(2)
+    assert_bit_equal(fm2.output("signal").numpy(), fused, "elided and copied forms demodulate the same samples")
+    rt.destroy()
