@@ -331,6 +331,47 @@ def other_configs(js, budget_s: float = 45.0) -> list:
         rec["streams_8"] = {"transforms_per_cycle": b8, "us_per_cycle": dt8 * 1e6, "MS_per_s": b8 * n / dt8 / 1e6,
                             "roofline_frac": roof(28.0, b8 * n, dt8)["frac"], "bit_exact_rows_0_3_and_124_127": ok8,
                             "what": "all 8 streams of configs[4] resident on ONE GPU: CF32[128, 65536] per cycle, one launch per unit and cycle"}
+        # round 6: provider fast on the tiled path (the headline's provider: floats within 4e-7 of the reference CPU path, north_star
+        # allows 1e-5; the lean epilogue instead of the libm restatement) -- one stream cycle-batched, 8 streams per cycle and
+        # cycle-batched (a ring of 4 slots: 512 transforms per span launch, the persistent blocks kernel)
+        fast = {}
+        ring = js.Module("ring_source", {"batches": b, "samples": n, "slots": slots}, {}, "iq")
+        buf = ring.output("buffer")
+        for sl in range(slots):
+            buf.ring_select(sl).copy_from(np.roll(x, sl, axis=0))
+        buf.ring_select(0)
+        eng = js.SpectrumEngine(buf, enable_scale=True, range_min=-100.0, range_max=0.0, provider="fast")
+        lp = js.Module("lineplot", {"averaging": 8}, {"signal": eng.buffer}, "psd")
+        rt = js.Runtime([ring] + eng.modules + [lp], graph=True, fuse=True)
+        dtf = timed(rt, 320, 48)
+        rt.compute((-(320 + 48)) % slots + slots)
+        errf = max(float(np.max(np.abs(eng.buffer.ring_select(sl).numpy() - np.roll(first, sl, axis=0)))) for sl in range(slots))
+        rt.destroy()
+        fast["one_stream_batched"] = {"us_per_cycle": dtf * 1e6, "roofline_frac": roof(28.0, b * n, dtf)["frac"],
+                                      "max_abs_err_vs_oracle_all_slots": errf, "within_1e-5": bool(errf <= 1e-5)}
+        eng8 = js.SpectrumEngine(src8, enable_scale=True, range_min=-100.0, range_max=0.0, provider="fast")
+        lp8 = js.Module("lineplot", {"averaging": 8}, {"signal": eng8.buffer}, "psd")
+        rt8 = js.Runtime(eng8.modules + [lp8], graph=True, fuse=True, batch=False)
+        rt8.compute(1)
+        err8 = float(np.max(np.abs(eng8.buffer.numpy()[rows8] - oracle.spectrum_chain(x8[rows8], -100.0, 0.0)["range"])))
+        dt8f = timed(rt8, 60, 6)
+        rt8.destroy()
+        fast["streams_8"] = {"us_per_cycle": dt8f * 1e6, "roofline_frac": roof(28.0, b8 * n, dt8f)["frac"],
+                             "max_abs_err_vs_oracle_rows_0_3_and_124_127": err8, "within_1e-5": bool(err8 <= 1e-5)}
+        ring8 = js.Module("ring_source", {"batches": b8, "samples": n, "slots": 4}, {}, "iq8")
+        buf8 = ring8.output("buffer")
+        for sl in range(4):
+            buf8.ring_select(sl).copy_from(np.roll(x8, sl, axis=0))
+        buf8.ring_select(0)
+        eng8 = js.SpectrumEngine(buf8, enable_scale=True, range_min=-100.0, range_max=0.0, provider="fast")
+        lp8 = js.Module("lineplot", {"averaging": 8}, {"signal": eng8.buffer}, "psd")
+        rt8 = js.Runtime([ring8] + eng8.modules + [lp8], graph=True, fuse=True)
+        dt8b = timed(rt8, 80, 12)
+        batched8 = bool(rt8.batched)
+        rt8.destroy()
+        fast["streams_8_batched"] = {"us_per_cycle": dt8b * 1e6, "roofline_frac": roof(28.0, b8 * n, dt8b)["frac"], "cycle_batched": batched8,
+                                     "what": "a resident ring of 4 slots x CF32[128, 65536]: 512 transforms per span launch"}
+        rec["provider_fast"] = fast
         return rec
 
     guarded("configs[2]: 251-tap FIR (FFT overlap-add) + /10 on CF32[100,159750] (16 MS per cycle)", c3)

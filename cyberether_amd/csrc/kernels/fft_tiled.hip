@@ -338,6 +338,25 @@ constexpr bool same_plan(const TiledPlan& a, const TiledPlan& b) {
     return true;
 }
 
+// Twiddles of the BLOCK passes (g..nf-1) are the same for every block of every transform -- PT[(c-1)*ido + i], a few hundred
+// entries -- so a static-plan kernel keeps them in LDS behind its tile (round 6): a pass then has no global load between its
+// two barriers (the L2 round trip of seven twiddles per butterfly was half of a radix-8 pass under load: tools/ubench/
+// tiled_timeline_c5.hip, profiles/r06_experiments/c_...log).  0: the plan keeps its twiddles in global memory (generic radix,
+// whole transforms per lane, tables beyond 8 KiB).
+#ifndef JST_TILED_TW_LDS
+#define JST_TILED_TW_LDS 1
+#endif
+constexpr uint32_t block_twiddle_entries(const TiledPlan& p) {
+    if (!JST_TILED_TW_LDS || p.g == 0) return 0;
+    uint64_t total = 0, ido = p.S;
+    for (uint32_t q = p.g; q < p.nf; ++q) {
+        if (is_generic_radix(p.fact[q])) return 0;
+        ido /= p.fact[q];
+        total += pass_table_entries(p.fact[q], ido);
+    }
+    return total <= 1024 ? (uint32_t)total : 0u;
+}
+
 // ---- Multiply -> Fold behind the last pass (filter/block_impl.cc:444-497: fftSignal -> multiply -> fold) -----------
 // fold (dsp/fold/module_impl_native_cpu.cc:103-172) sums the `decim` aliases idx = (m - off + g * fold) mod n of output
 // bin m, in F64, g ascending, and divides by decim; the addends are products spectrum[idx] * h[idx] formed with the
@@ -445,7 +464,15 @@ __device__ __forceinline__ void outer_bases(const FftLayout& L, uint64_t t, int6
 template <int IP>
 constexpr int butterflies_per_thread() { return IP <= 3 ? 4 : (IP <= 7 ? 2 : 1); }
 
-template <int IP, bool FWD>
+// LB: the barrier of a kernel that keeps global loads in flight ACROSS its passes (the persistent blocks kernel's prefetch of
+// the next tile): release / acquire on LDS only -- `__syncthreads()` waits for vmcnt(0), i.e. for the prefetch.
+template <bool LB>
+__device__ __forceinline__ void tile_barrier() {
+    if constexpr (LB) lds_barrier();
+    else __syncthreads();
+}
+
+template <int IP, bool FWD, bool LB = false>
 __device__ __forceinline__ void tile_pass(float2* __restrict__ buf, const float2* __restrict__ PT,
                                           uint32_t len, uint32_t lane_shift, uint32_t live_lanes,
                                           uint32_t pitch, uint32_t ido, uint32_t ido_magic,
@@ -471,7 +498,7 @@ __device__ __forceinline__ void tile_pass(float2* __restrict__ buf, const float2
             step[r] = tw_i0 + lane * tw_lane + tw_is * i;
         }
     }
-    __syncthreads();  // every input of this pass is in registers
+    tile_barrier<LB>();  // every input of this pass is in registers
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
         if (step[r] == 0xffffffffu) continue;
@@ -485,7 +512,7 @@ __device__ __forceinline__ void tile_pass(float2* __restrict__ buf, const float2
 #pragma unroll
         for (int c = 0; c < IP; ++c) wr[(uint32_t)c * l1loc * ido * pitch] = x[r][c];
     }
-    __syncthreads();  // outputs visible before the next pass (or the store) reads them
+    tile_barrier<LB>();  // outputs visible before the next pass (or the store) reads them
 }
 
 // One GENERIC odd-radix pass (any prime 13 <= ip <= kMaxGenericRadix) over an LDS tile, in place: pocketfft's passg
@@ -652,14 +679,14 @@ __device__ __forceinline__ void tile_pass_generic(uint32_t ip, float2* __restric
 
 // GEN: the kernel is compiled for plans that hold a generic radix (a second set of kernels: with the generic pass
 // inlined into the one set, every kernel of this file paid registers / scratch for a pass most plans never run)
-template <bool FWD, bool GEN>
+template <bool FWD, bool GEN, bool LB = false>
 __device__ __forceinline__ void tile_pass_any(uint32_t ip, float2* buf, const float2* PT, uint32_t len,
                                               uint32_t lane_shift, uint32_t live_lanes, uint32_t pitch,
                                               uint32_t ido, uint32_t ido_magic, uint32_t l1loc,
                                               uint32_t ido_glob, uint32_t tw_is, uint32_t tw_i0,
                                               uint32_t tw_lane) {
 #define JST_TP(IP)                                                                                \
-    tile_pass<IP, FWD>(buf, PT, len, lane_shift, live_lanes, pitch, ido, ido_magic, l1loc,        \
+    tile_pass<IP, FWD, LB>(buf, PT, len, lane_shift, live_lanes, pitch, ido, ido_magic, l1loc,    \
                        ido_glob, tw_is, tw_i0, tw_lane)
     switch (ip) {
         case 2: JST_TP(2); break;
@@ -678,6 +705,32 @@ __device__ __forceinline__ void tile_pass_any(uint32_t ip, float2* buf, const fl
             break;
     }
 #undef JST_TP
+}
+
+// at least tile/8 threads (the in-place passes hold <= 8 points per thread); a multiple of 256 so
+// that every SIMD of the CU gets the same number of wavefronts and a second / third workgroup fits
+// the fewest threads the passes [first, last) of a plan need on a tile of `tile_elems` elements: a thread owns at most
+// butterflies_per_thread(radix) butterflies of a pass (tile_pass)
+constexpr uint64_t min_threads_for_passes(const TiledPlan& P, uint32_t first, uint32_t last, uint64_t tile_elems) {
+    uint64_t need = 64;
+    for (uint32_t q = first; q < last; ++q) {
+        const uint32_t ip = P.fact[q];
+        if (is_generic_radix(ip)) {
+            if (generic_pass_threads(ip, tile_elems) > need) need = generic_pass_threads(ip, tile_elems);
+            continue;
+        }
+        const uint64_t per = ip <= 3 ? 4 : (ip <= 7 ? 2 : 1);
+        const uint64_t nb = tile_elems / ip;
+        if ((nb + per - 1) / per > need) need = (nb + per - 1) / per;
+    }
+    return need;
+}
+constexpr unsigned threads_for(uint64_t tile_elems, uint64_t min_threads = 0) {
+    uint64_t t = ((tile_elems / 8 + 255) / 256) * 256;
+    if (t < 256) t = 256;
+    if (t < min_threads) t = ((min_threads + 63) / 64) * 64;  // a generic-radix pass may need more (wave-granular tasks)
+    if (t > (uint64_t)kMaxThreads) t = kMaxThreads;
+    return (unsigned)t;
 }
 
 // ---- kernel A: passes 0..g-1 on CA adjacent columns ---------------------------------------------
@@ -745,12 +798,23 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
 }
 
 // ---- kernel B: passes g..nf-1 on CB adjacent blocks (or whole transforms when g == 0) -----------
-template <bool FWD, class Pro, class Epi, int SP = 0, bool GEN = false>
+// PERSIST (round 6; static plans with R1 > 1 whose block twiddles live in LDS and whose tile is at most eight elements per
+// thread: persist_eligible): the workgroup takes the tiles blockIdx.x, + gridDim.x, ... of `ntiles` and requests the NEXT
+// tile's elements into registers before it runs the passes of this one.  One workgroup per tile these kernels are bound by the
+// rate at which the chip STARTS wavefronts (~450 per microsecond: 2048 tiles x 8 wavefronts of config 5's 128-transform
+// launch = 36 us whatever a tile's load -> passes -> store chain costs -- shortening the chain only lowered the number of
+// workgroups alive; tools/ubench/tiled_timeline_c5.hip, profiles/r06_experiments/c_...log), and a persistent loop without
+// the prefetch serialises load and passes in the two or three workgroups a CU holds (round 5, u_...log).  With both, a tile
+// costs max(load, passes + epilogue).  All barriers are LDS-only (tile_barrier<true>): the ordinary workgroup barrier waits
+// for vmcnt(0), i.e. for the prefetch.
+template <bool FWD, class Pro, class Epi, int SP = 0, bool GEN = false, bool PERSIST = false>
 __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void fft_tile_blocks_kernel(const FftLayout L,
                                                                    const TiledPlan Prt,
                                                                    const float2* __restrict__ W,
                                                                    const Pro pro, const Epi epi,
-                                                                   const float2* __restrict__ scratch) {
+                                                                   const float2* __restrict__ scratch,
+                                                                   const uint32_t ntiles) {
+    static_assert(!PERSIST || (SP > 0 && !GEN), "persistent form: static plans only");
     constexpr TiledPlan PS = static_plan(SP);  // SP > 0: the plan is a constant and the argument is ignored
     const TiledPlan& P = SP > 0 ? PS : Prt;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -758,21 +822,95 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
     __shared__ uint32_t lane_off[32];              // fold epilogue: per lane, the fold offset of its transform (mod n)
     const uint32_t pitch = P.CB | 1u;  // odd pitch: the x-major global loops stay conflict-free
     float2* buf0 = reinterpret_cast<float2*>(smem_raw);
+    // static plans: the block passes' twiddle tables behind the tile (block_twiddle_entries), requested with the tile's loads
+    constexpr uint32_t kTwLds = SP > 0 && !GEN ? block_twiddle_entries(PS) : 0u;
+    float2* twl = buf0 + (size_t)PS.S * (PS.CB | 1u);
+    if constexpr (kTwLds > 0 && !PERSIST)
+        for (uint32_t e = threadIdx.x; e < kTwLds; e += blockDim.x) twl[e] = W[PS.tw_off[PS.g] + e];
     JST_TSTAMP(0);
+    const uint32_t grp_gap = P.grp_stride - P.grp_w;  // blocks skipped between two groups of lanes (see block_of below)
+    const uint32_t tile_count = PERSIST ? ntiles : gridDim.x;
     // R1 > 1: a tile is CB adjacent blocks of ONE transform; R1 == 1: CB adjacent transforms
+    auto decode = [&](uint32_t tile_index, uint64_t& t0, uint32_t& k0, uint32_t& live) {
+        const uint32_t bid = xcd_contiguous_tile(tile_index, tile_count);
+        if (P.R1 > 1) {
+            const uint32_t tiles_per_t = (P.R1 + P.CB - 1) >> P.cb_shift;
+            t0 = bid / tiles_per_t;
+            k0 = (bid % tiles_per_t) * P.grp_w;  // grp_w == CB unless the lanes are split into alias groups
+            live = P.grp_w != P.CB ? P.CB : ((P.R1 - k0 < P.CB) ? (P.R1 - k0) : P.CB);
+        } else {
+            t0 = (uint64_t)bid << P.cb_shift;
+            k0 = 0;
+            live = (uint32_t)((L.transforms - t0 < P.CB) ? (L.transforms - t0) : P.CB);
+        }
+    };
+    // PERSIST: the elements idx = threadIdx.x + k * blockDim.x (k < 8) of a tile, requested one tile ahead
+    float2 pv[8];
+    auto prefetch = [&](uint32_t tile_index) {
+        uint64_t t0;
+        uint32_t k0, live;
+        decode(tile_index, t0, k0, live);
+        const uint32_t tile = P.S * live;
+        // one descriptor per tile (wave-uniform: SGPRs) and a 32-bit byte offset per element -- with flat addresses hipcc keeps
+        // eight 64-bit pointers alive through the loop (80 VGPRs and scratch); elements past the tile read as zeros (the
+        // descriptor's bound), nobody commits them.  The thread index is made opaque per tile so that the offsets are
+        // recomputed (two or three VALU instructions) instead of living in registers across the passes.
+        const uint32_t span = P.grp_w == P.CB ? tile : (P.CB / P.grp_w - 1u) * P.grp_stride * P.S + P.grp_w * P.S;
+#ifdef JST_TILED_DIAG_NOLOAD  // timing diagnostics only: every tile reads the first one (cache resident)
+        t0 = 0; k0 = 0;
+#endif
+        const rsrc_t r_tile = make_rsrc(scratch + (t0 * P.R1 + k0) * P.S, span * (uint32_t)sizeof(float2));
+        uint32_t tid = threadIdx.x;
+        __asm__ volatile("" : "+v"(tid));
+        typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t idx = tid + (uint32_t)k * blockDim.x;
+            uint32_t off = idx;
+            if (P.grp_w != P.CB) {  // lanes in groups grp_stride blocks apart (fold epilogue)
+                const uint32_t cidx = idx < tile ? idx : tile - 1u;
+                off = cidx + ((cidx / P.S) >> P.grp_shift) * grp_gap * P.S;
+            }
+            const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r_tile, off * (uint32_t)sizeof(float2), 0, JST_TILED_STREAM_LOADS ? 2 : 0));
+            pv[k] = mk(v.x, v.y);
+        }
+    };
+    uint32_t tile_index = blockIdx.x;
+    if constexpr (PERSIST) {
+        prefetch(tile_index);
+        // the twiddle table behind the first tile's requests: both round trips overlap (2.3 us in front of the first tile
+        // otherwise; the table's LDS writes wait for its own loads, which retire behind the tile's)
+        if constexpr (kTwLds > 0)
+            for (uint32_t e = threadIdx.x; e < kTwLds; e += blockDim.x) twl[e] = W[PS.tw_off[PS.g] + e];
+        // hipcc's waits for the prefetched registers count the VMEM instructions issued BEHIND the requests -- at the loop's
+        // head it takes the minimum over the ways in: none on the way in from here, the epilogue's stores on the back edge,
+        // so every commit waited vmcnt(7..0): for all of the previous tile's stores to be acknowledged.  As many stores on
+        // this way in: out of bounds of an empty descriptor, dropped by the memory unit, counted by the compiler.
+        if constexpr (!is_tile_epilogue<Epi>) {
+            constexpr uint32_t kT = threads_for((uint64_t)PS.S * PS.CB, min_threads_for_passes(PS, PS.g, PS.nf, (uint64_t)PS.S * PS.CB));
+            constexpr uint32_t iters = ((PS.S << PS.cb_shift) + kT - 1) / kT;
+            const rsrc_t r_none = make_rsrc(scratch, 0u);
+#pragma unroll
+            for (uint32_t it = 0; it < iters; ++it) __builtin_amdgcn_raw_buffer_store_b32(it, r_none, threadIdx.x * 4u, it * 4096u, 0);
+        }
+    }
+    while (true) {
     uint64_t t0;
     uint32_t k0, live;
-    const uint32_t bid = xcd_contiguous_tile(blockIdx.x, gridDim.x);
-    if (P.R1 > 1) {
-        const uint32_t tiles_per_t = (P.R1 + P.CB - 1) >> P.cb_shift;
-        t0 = bid / tiles_per_t;
-        k0 = (bid % tiles_per_t) * P.grp_w;  // grp_w == CB unless the lanes are split into alias groups
-        live = P.grp_w != P.CB ? P.CB : ((P.R1 - k0 < P.CB) ? (P.R1 - k0) : P.CB);
+    if constexpr (PERSIST) JST_TSTAMP(11);  // top of a tile
+#ifdef JST_TILED_TIMELINE
+    if constexpr (PERSIST && !is_tile_epilogue<Epi>) { const uint32_t round_ = (tile_index - blockIdx.x) / gridDim.x; if (round_ < 3) JST_TSTAMP(6 + round_); }
+#endif
+    decode(tile_index, t0, k0, live);
+    // PERSIST (R1 > 1): every lane of the tile belongs to transform t0 -- its bases and fold offset are wave-uniform values in
+    // scalar registers, not a table in LDS (and one barrier less per tile)
+    int64_t tile_in = 0, tile_out = 0;
+    uint32_t tile_off = 0;
+    if constexpr (PERSIST) {
+        outer_bases(L, t0, tile_in, tile_out);
+        if constexpr (is_tile_epilogue<Epi>)
+            tile_off = epi.chan_offsets ? (uint32_t)(epi.chan_offsets[(t0 / epi.chan_div) % epi.chan_count] % P.n) : epi.off;
     } else {
-        t0 = (uint64_t)bid << P.cb_shift;
-        k0 = 0;
-        live = (uint32_t)((L.transforms - t0 < P.CB) ? (L.transforms - t0) : P.CB);
-    }
     if (threadIdx.x < live) {
         int64_t ib, ob;
         outer_bases(L, P.R1 > 1 ? t0 : t0 + threadIdx.x, ib, ob);
@@ -785,9 +923,9 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
         }
     }
     __syncthreads();
+    }
     const uint32_t tile = P.S * live;
     // block of lane kb: CB adjacent blocks, or CB / grp_w groups of grp_w adjacent blocks grp_stride apart
-    const uint32_t grp_gap = P.grp_stride - P.grp_w;  // blocks skipped between two groups
     auto block_of = [&](uint32_t kb) { return k0 + kb + (kb >> P.grp_shift) * grp_gap; };
     // load: x fastest (contiguous in memory for both the dense scratch and a dense input row)
     const float2* blk = scratch + (t0 * P.R1 + k0) * P.S;  // only dereferenced when g > 0
@@ -811,18 +949,39 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
                 if (slot[k] != 0xffffffffu) buf0[slot[k]] = v[k];
         }
     };
-    if (P.g == 0) load_tile(std::false_type{});
-    else load_tile(std::true_type{});
-    __syncthreads();
+    if constexpr (PERSIST) {  // the tile arrived in registers (requested while the previous tile was in the passes)
+        JST_TSTAMP(12);  // bases known
+        uint32_t tid = threadIdx.x;
+        __asm__ volatile("" : "+v"(tid));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t idx = tid + (uint32_t)k * blockDim.x;
+            const uint32_t kb = idx / P.S, x = idx - kb * P.S;
+            if (idx < tile) buf0[x * pitch + kb] = pv[k];
+        }
+        JST_TSTAMP(14);  // tile committed (thread 0's share)
+    } else {
+        if (P.g == 0) load_tile(std::false_type{});
+        else load_tile(std::true_type{});
+    }
+    tile_barrier<PERSIST>();
     JST_TSTAMP(1);  // tile loaded
+    const uint32_t next_tile = tile_index + gridDim.x;
+    const bool more = PERSIST && next_tile < tile_count;
+    if constexpr (PERSIST)
+        if (more) prefetch(next_tile);  // in flight through the passes and the epilogue
     const float2* src = buf0;
     uint32_t l1 = P.R1, ido = P.S;
 #pragma unroll
     for (uint32_t p = P.g; p < P.nf; ++p) {
         const uint32_t ip = P.fact[p];
         ido /= ip;
-        tile_pass_any<FWD, GEN>(ip, buf0, W + P.tw_off[p], P.S, P.cb_shift, live, pitch, ido, P.magic[p],
-                           l1 / P.R1, ido, 1u, 0u, 0u);
+        if constexpr (kTwLds > 0)
+            tile_pass_any<FWD, GEN, PERSIST>(ip, buf0, twl + (P.tw_off[p] - P.tw_off[P.g]), P.S, P.cb_shift, live, pitch, ido, P.magic[p],
+                                        l1 / P.R1, ido, 1u, 0u, 0u);
+        else
+            tile_pass_any<FWD, GEN, PERSIST>(ip, buf0, W + P.tw_off[p], P.S, P.cb_shift, live, pitch, ido, P.magic[p],
+                                        l1 / P.R1, ido, 1u, 0u, 0u);
         l1 *= ip;
         JST_TSTAMP(2 + (p - P.g));  // pass done
     }
@@ -844,7 +1003,7 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
         // threads, products on the fly 2.0 us against 4.4 us, profiles/r04_experiments/h_tiled_timeline_8050.log).
         const bool in_place = hd + 1u == epi.heads && (epi.heads == 1u || total * 4u < blockDim.x);
         if (in_place) {
-        if (epi.heads > 1) __syncthreads();  // every walk of the earlier heads has read the spectrum tile
+        if (epi.heads > 1) tile_barrier<PERSIST>();  // every walk of the earlier heads has read the spectrum tile
         for (uint32_t e0 = threadIdx.x; e0 < elems; e0 += 8 * blockDim.x) {
             float2 hv[8];
             uint32_t slot[8];
@@ -862,7 +1021,7 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
                 if (slot[k] != 0xffffffffu)
                     buf0[slot[k]] = epi.spectrum_first ? cmul_full(buf0[slot[k]], hv[k]) : cmul_full(hv[k], buf0[slot[k]]);
         }
-        __syncthreads();
+        tile_barrier<PERSIST>();
         JST_TSTAMP(8);  // products of the last head in place
         }
         for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
@@ -871,7 +1030,8 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
             const uint32_t r = P.R1 > 1 ? block_of(kb) + P.R1 * q : q;
             if (r >= F) continue;
             const uint64_t t = P.R1 > 1 ? t0 : t0 + kb;
-            const uint32_t off = epi.heads > 1 ? (epi.chan_offsets ? (uint32_t)(epi.chan_offsets[hd] % P.n) : epi.off) : lane_off[kb];
+            const uint32_t off = epi.heads > 1 ? (epi.chan_offsets ? (uint32_t)(epi.chan_offsets[hd] % P.n) : epi.off)
+                                               : (PERSIST ? tile_off : lane_off[kb]);
             const uint32_t off_q = off / F, off_r = off - off_q * F;
             uint32_t m = r + off_r;  // output bin whose addends are the alias class of r
             uint32_t steps = epi.decim - off_q;  // r is alias number `decim - steps` of bin m ...
@@ -950,10 +1110,60 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
     } else
     // store result q of block (t, k) at k + R1*q: block index fastest when R1 > 1 (adjacent k are
     // adjacent in memory), q fastest for whole transforms
-    if (P.R1 > 1) {
+    if constexpr (PERSIST) {
+        // The same stores with a compile-time trip count and no loop: hipcc counts the VMEM instructions issued behind the
+        // prefetch only through straight-line code -- behind a loop of stores it waits for the prefetched registers with
+        // vmcnt(7..0), i.e. for every store of this epilogue to be acknowledged (profiles/r06_experiments/c_...log).
+        constexpr uint32_t kT = threads_for((uint64_t)PS.S * PS.CB, min_threads_for_passes(PS, PS.g, PS.nf, (uint64_t)PS.S * PS.CB));
+        constexpr uint32_t total = PS.S << PS.cb_shift, iters = (total + kT - 1) / kT;
+        if constexpr (requires(rsrc_t rr) { epi.store_buf(rr, 0u, 0u, float2{}); } && PS.grp_w == PS.CB && kT % PS.CB == 0) {
+            // dense rows (the launcher checks out_axis_stride == 1): one descriptor on the transform's output row, ONE byte
+            // offset per thread -- (kb + R1 q) elements -- and a wave-uniform offset per store; with a 64-bit address per
+            // store the eight unrolled epilogues ran the kernel out of its 80 VGPRs, and a scratch reload waits vmcnt(0)
+            using E = std::remove_cv_t<std::remove_reference_t<decltype(epi)>>;
+            const rsrc_t r_out = make_rsrc(epi.row(tile_out), P.n * E::kElemBytes);
+            const uint32_t kb = threadIdx.x & (P.CB - 1u), q0 = threadIdx.x >> P.cb_shift;
+            const uint32_t voff = (kb + P.R1 * q0) * E::kElemBytes;
+            const float2* sp = src + (q0 * pitch + kb);
+#pragma unroll
+            for (uint32_t it = 0; it < iters; ++it) {
+                constexpr uint32_t dq = kT >> PS.cb_shift;  // rows between two of a thread's outputs
+                if (total % kT == 0 || threadIdx.x + it * kT < total) {
+                    // F32 epilogues: PLAIN stores.  A workgroup's outputs are CB x 4 = 32-byte runs R1 x 4 bytes apart; four
+                    // neighbouring tiles complete a 128-byte line.  Written through at agent scope (the register kernels'
+                    // policy for their full-line stores) every run is a partial write to HBM and the whole kernel ran at
+                    // the memory system's partial-write rate (2.8 TB/s, the prefetch arriving 8 us late); left dirty in
+                    // L2 the neighbours' runs merge (JST_TILED_EPI_SC1=1: A/B)
+#if !defined(JST_TILED_EPI_SC1)
+                    if constexpr (requires { epi.value(float2{}); } && E::kElemBytes == 4)
+#ifdef JST_TILED_DIAG_NOSTORE  // timing diagnostics only: the store goes out of the descriptor's bounds (dropped)
+                        __builtin_amdgcn_raw_buffer_store_b32(f2u(epi.value(sp[it * dq * pitch])), r_out, voff + 0x40000000u,
+                                                              (k0 + P.R1 * (it * dq)) * E::kElemBytes, 0);
+#else
+                        __builtin_amdgcn_raw_buffer_store_b32(f2u(epi.value(sp[it * dq * pitch])), r_out, voff,
+                                                              (k0 + P.R1 * (it * dq)) * E::kElemBytes, 0);
+#endif
+                    else
+#endif
+                        epi.store_buf(r_out, voff, (k0 + P.R1 * (it * dq)) * E::kElemBytes, sp[it * dq * pitch]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (uint32_t it = 0; it < iters; ++it) {
+                const uint32_t idx = threadIdx.x + it * kT;
+                const uint32_t kb = idx & (P.CB - 1u), q = idx >> P.cb_shift;
+                if (total % kT == 0 || idx < total)  // every lane is live (persist_eligible)
+                    epi.template store<false>(tile_out, L.out_axis_stride, (int)(block_of(kb) + P.R1 * q), src[q * pitch + kb]);
+            }
+        }
+    } else if (P.R1 > 1) {
         const uint32_t total = P.S << P.cb_shift;
         for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
             const uint32_t kb = idx & (P.CB - 1u), q = idx >> P.cb_shift;
+            // (short launches keep the epilogues' agent-scope stores: with plain ones the launch ends on the write-back of
+            // its dirty lines -- 16 x 65536 per cycle 23.6 against 22.2 us, run_r06g.sh; the persistent form above, which only
+            // long launches take, stores plainly)
             if (kb < live)
                 epi.template store<false>(lane_out[kb], L.out_axis_stride,
                                           (int)(block_of(kb) + P.R1 * q), src[q * pitch + kb]);
@@ -964,33 +1174,52 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
             epi.template store<false>(lane_out[kb], L.out_axis_stride, (int)q, src[q * pitch + kb]);
         }
     }
+    JST_TSTAMP(5);  // epilogue done
+    if (!more) break;
+    tile_barrier<PERSIST>();  // every thread is done with the tile (and the lane tables) before the next one is written
+    tile_index = next_tile;
+    }
     JST_TSTAMP_FLUSH();  // stores issued
 }
 
-// at least tile/8 threads (the in-place passes hold <= 8 points per thread); a multiple of 256 so
-// that every SIMD of the CU gets the same number of wavefronts and a second / third workgroup fits
-// the fewest threads the passes [first, last) of a plan need on a tile of `tile_elems` elements: a thread owns at most
-// butterflies_per_thread(radix) butterflies of a pass (tile_pass)
-inline uint64_t min_threads_for_passes(const TiledPlan& P, uint32_t first, uint32_t last, uint64_t tile_elems) {
-    uint64_t need = 64;
-    for (uint32_t q = first; q < last; ++q) {
-        const uint32_t ip = P.fact[q];
-        if (is_generic_radix(ip)) {
-            need = std::max<uint64_t>(need, generic_pass_threads(ip, tile_elems));
-            continue;
-        }
-        const uint64_t per = ip <= 3 ? 4 : (ip <= 7 ? 2 : 1);
-        const uint64_t nb = tile_elems / ip;
-        need = std::max<uint64_t>(need, (nb + per - 1) / per);
-    }
-    return need;
+// The blocks kernel's persistent form (fft_tile_blocks_kernel<..., PERSIST>): see there.  JST_TILED_PERSIST=0: A/B switch.
+#ifndef JST_TILED_PERSIST
+#define JST_TILED_PERSIST 1
+#endif
+constexpr bool persist_eligible(const TiledPlan& p) {
+    if (!JST_TILED_PERSIST || p.g == 0 || p.R1 <= 1 || block_twiddle_entries(p) == 0) return false;
+    if (p.grp_w == p.CB && p.R1 % p.CB != 0) return false;  // no ragged last tile: every lane of every tile is live
+    const uint64_t tile = (uint64_t)p.S * p.CB;
+    return tile <= 8ull * threads_for(tile, min_threads_for_passes(p, p.g, p.nf, tile));
 }
-inline unsigned threads_for(uint64_t tile_elems, uint64_t min_threads = 0) {
-    uint64_t t = ((tile_elems / 8 + 255) / 256) * 256;
-    if (t < 256) t = 256;
-    if (t < min_threads) t = ((min_threads + 63) / 64) * 64;  // a generic-radix pass may need more (wave-granular tasks)
-    if (t > (uint64_t)kMaxThreads) t = kMaxThreads;
-    return (unsigned)t;
+int tiled_compute_units() {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    return cus;
+}
+// grid of a persistent launch: as many workgroups as the chip holds at once (occupancy x CUs), lowered to the count that
+// gives every workgroup the same number of rounds (2048 tiles on 768 slots: 3 rounds -> 683 workgroups -> 688, a multiple of
+// eight for the XCD-contiguous tile order)
+inline unsigned persistent_grid(const void* kernel, unsigned threads, size_t lds, uint64_t tiles) {
+    struct Seen { const void* kernel; unsigned threads; size_t lds; int per_cu; };
+    thread_local Seen seen[8] = {};  // the occupancy query costs microseconds of host time: once per (kernel, shape) and thread
+    thread_local int used = 0;
+    int per_cu = 0;
+    for (int i = 0; i < used; ++i)
+        if (seen[i].kernel == kernel && seen[i].threads == threads && seen[i].lds == lds) per_cu = seen[i].per_cu;
+    if (per_cu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        seen[used < 8 ? used++ : 7] = Seen{kernel, threads, lds, per_cu};
+    }
+    const uint64_t slots = (uint64_t)per_cu * (uint64_t)tiled_compute_units();
+    if (tiles <= slots) return (unsigned)tiles;
+    const uint64_t rounds = (tiles + slots - 1) / slots;
+    uint64_t grid = (tiles + rounds - 1) / rounds;
+    grid = (grid + 7) & ~7ull;
+    return (unsigned)(grid < slots ? grid : slots);
 }
 
 inline bool plan_has_generic_radix(const TiledPlan& P) {
@@ -998,6 +1227,10 @@ inline bool plan_has_generic_radix(const TiledPlan& P) {
         if (is_generic_radix(P.fact[q])) return true;
     return false;
 }
+
+template <bool FWD, class Pro, class Epi, int SP, bool GEN, bool kPersist>
+hipError_t launch_tiled_blocks(const TiledPlan& P, const FftLayout& L, const float2* W, const Pro& pro,
+                               const Epi& epi, float2* scratch, hipStream_t s);
 
 template <bool FWD, class Pro, class Epi, int SP = 0, bool GEN = false>
 hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2* W, const Pro& pro,
@@ -1019,8 +1252,27 @@ hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2*
         hipLaunchKernelGGL(ka, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.R1 * P.CA, min_threads_for_passes(P, 0, P.g, (uint64_t)P.R1 * P.CA))), lds_a, s, L, P, W,
                            pro, scratch);
     }
-    const size_t lds_b = (size_t)P.S * (P.CB | 1u) * sizeof(float2);
-    auto kb = fft_tile_blocks_kernel<FWD, Pro, Epi, SP, GEN>;
+    // The persistent form for LONG launches of the plain epilogues only.  Measured, same box, alternating (tools/ubench/
+    // run_r06f.sh, profiles/r06_experiments/c_...log): config 5 cycle-batched (4096 / 8192 tiles on 768 slots) 10.1-10.4 against
+    // 10.9 us and 77-78 against 80-81 us per cycle; one launch per cycle (256 / 2048 tiles) 23.5 against 22.3 and 79 against
+    // 77.5 us -- below four rounds the start-up (every workgroup's first tile arrives together) costs more than the
+    // prefetch saves --; the fold epilogue's own loads and store loop put vmcnt(0) in front of every commit (config 3:
+    // 0.225 against 0.205 ms).  It addresses dense output rows.
+    constexpr bool kPersist = SP > 0 && !GEN && !is_tile_epilogue<Epi> && persist_eligible(static_plan(SP));
+    if constexpr (kPersist) {
+        const uint64_t tiles = L.transforms * ((P.R1 + P.CB - 1) / P.CB);
+        if (L.out_axis_stride == 1 && tiles >= 4ull * 3ull * (uint64_t)tiled_compute_units())
+            return launch_tiled_blocks<FWD, Pro, Epi, SP, GEN, true>(P, L, W, pro, epi, scratch, s);
+    }
+    return launch_tiled_blocks<FWD, Pro, Epi, SP, GEN, false>(P, L, W, pro, epi, scratch, s);
+}
+
+template <bool FWD, class Pro, class Epi, int SP, bool GEN, bool kPersist>
+hipError_t launch_tiled_blocks(const TiledPlan& P, const FftLayout& L, const float2* W, const Pro& pro,
+                               const Epi& epi, float2* scratch, hipStream_t s) {
+    size_t lds_b = (size_t)P.S * (P.CB | 1u) * sizeof(float2);
+    if constexpr (SP > 0 && !GEN) lds_b += (size_t)block_twiddle_entries(static_plan(SP)) * sizeof(float2);
+    auto kb = fft_tile_blocks_kernel<FWD, Pro, Epi, SP, GEN, kPersist>;
     {  // pitch CB|1 adds at most one lane of padding per row
         const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kb), (int)(2 * kTileElems * sizeof(float2)));
         if (e != hipSuccess) return e;
@@ -1029,8 +1281,9 @@ hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2*
     const uint64_t blocks = P.R1 > 1 ? L.transforms * ((P.R1 + P.CB - 1) / P.CB)
                                      : (L.transforms + P.CB - 1) / P.CB;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kb, dim3((unsigned)blocks), dim3(threads_for((uint64_t)P.S * P.CB, min_threads_for_passes(P, P.g, P.nf, (uint64_t)P.S * P.CB))), lds_b, s, L, P, W, pro, epi,
-                       (const float2*)scratch);
+    const unsigned threads_b = threads_for((uint64_t)P.S * P.CB, min_threads_for_passes(P, P.g, P.nf, (uint64_t)P.S * P.CB));
+    const unsigned grid_b = kPersist ? persistent_grid(reinterpret_cast<const void*>(kb), threads_b, lds_b, blocks) : (unsigned)blocks;
+    hipLaunchKernelGGL(kb, dim3(grid_b), dim3(threads_b), lds_b, s, L, P, W, pro, epi, (const float2*)scratch, (uint32_t)blocks);
     return hipGetLastError();
 }
 
@@ -1256,10 +1509,10 @@ hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const flo
     if (!make_tiled_plan(n, L.transforms, p)) return hipErrorInvalidValue;
     const LoadCF32TimesWindow pro{in, window, window_stride};
     if (with_range) {
-        if (fast)
-            return launch_tiled<true>(p, L, W, pro,
-                                      StoreAmplitudeRangeT<true>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}},
-                                      scratch, s);
+        if (fast)  // config 5's plan as a constant for provider fast too (round 6: the lean epilogue, 17 instead of ~105 VALU per output)
+            return launch_tiled<true, LoadCF32TimesWindow, StoreAmplitudeRangeT<true>, 4>(
+                p, L, W, pro, StoreAmplitudeRangeT<true>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}},
+                scratch, s);
         return launch_tiled<true, LoadCF32TimesWindow, StoreAmplitudeRangeT<false>, 1, 4, 5, 6>(
             p, L, W, pro, StoreAmplitudeRangeT<false>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}}, scratch, s);
     }

@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
         name = r.get("Kernel_Name", "")
         if needle not in name:
             continue
-        key = (name.split("(")[0][:80], r["Counter_Name"])
+        key = (name.replace("(anonymous namespace)::", "").replace("jst::kernels::", "").replace("jst::dev::", "").split("(")[0][:80], r["Counter_Name"])
         s = acc.setdefault(key, [0.0, 0])
         s[0] += float(r["Counter_Value"])
         s[1] += 1

@@ -98,7 +98,7 @@ int main() {
     for (int rep = 0; rep < 3; ++rep) {
         hipMemset(tl, 0, (size_t)gmax * 16 * 8);
         hipEventRecord(e0);
-        kb<<<gridB, threads_for((uint64_t)P.S * P.CB), lds_b>>>(L, P, Wp, pro, epi, scratch);
+        kb<<<gridB, threads_for((uint64_t)P.S * P.CB), lds_b>>>(L, P, Wp, pro, epi, scratch, gridB);
         hipEventRecord(e1); hipEventSynchronize(e1);
     }
     hipEventElapsedTime(&ms, e0, e1);
@@ -119,7 +119,8 @@ int main() {
         fe.nq = PF.n / PF.R1;
         fe.grp_step = PF.grp_stride ? fe.dk / PF.grp_stride : 0;
         printf("fold plan: grp_w %u grp_stride %u CB %u dq %u dk %u grp_step %u\n", PF.grp_w, PF.grp_stride, PF.CB, fe.dq, fe.dk, fe.grp_step);
-        auto kf = fft_tile_blocks_kernel<true, LoadCF32Padded, FoldProductEpi, 8>;
+        constexpr bool kPersist = persist_eligible(static_plan(8));
+        auto kf = fft_tile_blocks_kernel<true, LoadCF32Padded, FoldProductEpi, 8, false, kPersist>;
         hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTileElems * 8));
         const bool is_static = same_plan(PF, static_plan(8));
         printf("constant plan 8 %s the run-time plan\n", is_static ? "equals" : "DIFFERS FROM");
@@ -127,7 +128,7 @@ int main() {
         for (int rep = 0; rep < 3; ++rep) {
             hipMemset(tl, 0, (size_t)gmax * 16 * 8);
             hipEventRecord(e0);
-            kf<<<gridF, threads_for((uint64_t)PF.S * PF.CB), (size_t)PF.S * (PF.CB | 1u) * 8>>>(L, PF, Wp, pro, fe, scratch);
+            kf<<<kPersist ? persistent_grid((const void*)kf, threads_for((uint64_t)PF.S * PF.CB), (size_t)PF.S * (PF.CB | 1u) * 8 + (size_t)block_twiddle_entries(static_plan(8)) * 8, gridF) : gridF, threads_for((uint64_t)PF.S * PF.CB), (size_t)PF.S * (PF.CB | 1u) * 8 + (size_t)block_twiddle_entries(static_plan(8)) * 8>>>(L, PF, Wp, pro, fe, scratch, gridF);
             hipEventRecord(e1); hipEventSynchronize(e1);
         }
         hipEventElapsedTime(&ms, e0, e1);
