@@ -89,6 +89,10 @@ __device__ __forceinline__ float2 stream_load(const float2* p) {
 struct LoadCF32Padded {
     const float2* in;
     uint32_t valid;
+    static constexpr bool kHasOperand = false;
+    __device__ __forceinline__ const void* row(int64_t base) const { return in + base; }
+    __device__ __forceinline__ const void* operand_row() const { return in; }
+    __device__ __forceinline__ float2 apply(float2 v, float2) const { return v; }
     template <bool CONTIG>
     __device__ __forceinline__ float2 load(int64_t base, int64_t axis_stride, int pos) const {
         // branch-free: a conditional load is a branch, and hipcc drains vmcnt at every such branch when eight of them
@@ -346,6 +350,9 @@ constexpr bool same_plan(const TiledPlan& a, const TiledPlan& b) {
 #ifndef JST_TILED_TW_LDS
 #define JST_TILED_TW_LDS 1
 #endif
+#ifndef JST_TILED_PERSIST  // A/B switch: 0 = one workgroup per tile everywhere (no persistent columns / blocks kernels)
+#define JST_TILED_PERSIST 1
+#endif
 constexpr uint32_t block_twiddle_entries(const TiledPlan& p) {
     if (!JST_TILED_TW_LDS || p.g == 0) return 0;
     uint64_t total = 0, ido = p.S;
@@ -472,7 +479,9 @@ __device__ __forceinline__ void tile_barrier() {
     else __syncthreads();
 }
 
-template <int IP, bool FWD, bool LB = false>
+// REG: PT is the thread's own table, PT[r * (IP - 1) + c - 1] for its butterfly r -- registers of a kernel whose threads meet the
+// same (lane, i) in every tile (the persistent columns kernel) -- instead of the pass's table in memory.
+template <int IP, bool FWD, bool LB = false, bool REG = false>
 __device__ __forceinline__ void tile_pass(float2* __restrict__ buf, const float2* __restrict__ PT,
                                           uint32_t len, uint32_t lane_shift, uint32_t live_lanes,
                                           uint32_t pitch, uint32_t ido, uint32_t ido_magic,
@@ -506,7 +515,7 @@ __device__ __forceinline__ void tile_pass(float2* __restrict__ buf, const float2
         if (step[r] != 0) {
 #pragma unroll
             for (int c = 1; c < IP; ++c)
-                x[r][c] = special_mul<FWD>(x[r][c], PT[(uint32_t)(c - 1) * ido_glob + step[r]]);
+                x[r][c] = special_mul<FWD>(x[r][c], REG ? PT[r * (IP - 1) + (c - 1)] : PT[(uint32_t)(c - 1) * ido_glob + step[r]]);
         }
         float2* wr = buf + wr_base[r];
 #pragma unroll
@@ -795,6 +804,163 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
 #endif
     }
     JST_TSTAMP_FLUSH();  // stores issued
+}
+
+// ---- kernel A, persistent (round 6) --------------------------------------------------------------------------------
+// Static plans, dense rows, launches of several transforms per workgroup.  A workgroup owns ONE column tile c0 and walks the
+// transforms lane, lane + lanes, ...: what a thread needs besides the data is then the same in every tile -- the twiddles
+// W[c * l1 * (c0 + column + S i')] of its butterflies (18-20 per thread: a column tile's table is as large as the tile and was
+// re-read from L2 for every tile) and its eight window taps -- and stays in registers; the next transform's elements are
+// requested into registers before the passes of this one (buffer loads: one descriptor per row, one byte offset per thread,
+// wave-uniform offsets per element); all barriers are LDS-only; the passes have no memory instruction, so the requests stay in
+// flight until the next commit.  One workgroup per tile, the tile's load -> passes -> store chain ran once per workgroup
+// and a CU's slots were two-thirds full (tools/ubench/tiled_timeline_c5.hip: 6.5 of 8 workgroups alive, load 5.6 of 11.4 us).
+template <int SP>
+constexpr uint32_t columns_twiddle_count() {
+    constexpr TiledPlan P = static_plan(SP);
+    uint32_t n = 0;
+    for (uint32_t p = 0; p < P.g; ++p) {
+        const uint32_t ip = P.fact[p];
+        n += (ip <= 3 ? 4u : (ip <= 7 ? 2u : 1u)) * (ip - 1u);
+    }
+    return n;
+}
+template <int SP>
+constexpr uint32_t columns_twiddle_offset(uint32_t pass) {
+    constexpr TiledPlan P = static_plan(SP);
+    uint32_t n = 0;
+    for (uint32_t p = 0; p < pass; ++p) {
+        const uint32_t ip = P.fact[p];
+        n += (ip <= 3 ? 4u : (ip <= 7 ? 2u : 1u)) * (ip - 1u);
+    }
+    return n;
+}
+constexpr bool columns_pipe_eligible(const TiledPlan& p) {
+    if (!JST_TILED_PERSIST || p.g == 0) return false;
+    for (uint32_t q = 0; q < p.g; ++q)
+        if (is_generic_radix(p.fact[q])) return false;
+    const uint64_t tile = (uint64_t)p.R1 * p.CA;
+    const uint64_t t = threads_for(tile, min_threads_for_passes(p, 0, p.g, tile));
+    return tile == 8ull * t && t % p.CA == 0;  // eight elements per thread, a thread's elements in ONE column
+}
+template <int SP>
+constexpr unsigned columns_pipe_threads() {
+    constexpr TiledPlan P = static_plan(SP);
+    return threads_for((uint64_t)P.R1 * P.CA, min_threads_for_passes(P, 0, P.g, (uint64_t)P.R1 * P.CA));
+}
+
+template <bool FWD, int SP, uint32_t PASS>
+__device__ __forceinline__ void columns_pipe_passes(float2* buf0, const float2* tw, uint32_t live, uint32_t c0) {
+    constexpr TiledPlan P = static_plan(SP);
+    if constexpr (PASS < P.g) {
+        constexpr uint32_t ip = P.fact[PASS];
+        uint32_t l1 = 1, m = P.R1;
+        for (uint32_t q = 0; q <= PASS; ++q) {
+            m /= P.fact[q];
+            if (q < PASS) l1 *= P.fact[q];
+        }
+        tile_pass<(int)ip, FWD, true, true>(buf0, tw + columns_twiddle_offset<SP>(PASS), P.R1, P.ca_shift, live, P.CA, m, P.magic[PASS], l1,
+                                            m * P.S, P.S, c0, 1u);
+        columns_pipe_passes<FWD, SP, PASS + 1>(buf0, tw, live, c0);
+    }
+}
+
+template <bool FWD, class Pro, int SP>
+__global__ __launch_bounds__(columns_pipe_threads<SP>(), 4) void fft_tile_columns_pipe_kernel(const FftLayout L, const float2* __restrict__ W,
+                                                                                             const Pro pro, float2* __restrict__ scratch) {
+    constexpr TiledPlan P = static_plan(SP);
+    constexpr uint32_t T = columns_pipe_threads<SP>();
+    constexpr uint32_t kTw = columns_twiddle_count<SP>();
+    constexpr uint32_t dr = T >> P.ca_shift;  // rows between two of a thread's elements
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* buf0 = reinterpret_cast<float2*>(smem_raw);
+    const uint32_t tiles_per_t = (P.S + P.CA - 1) >> P.ca_shift;
+    const uint32_t j = xcd_contiguous_tile(blockIdx.x, gridDim.x);  // neighbours in j: the same XCD (they share cache lines)
+    const uint32_t ct = j % tiles_per_t, lanes = gridDim.x / tiles_per_t;
+    uint32_t t = j / tiles_per_t;
+    if (t >= lanes || t >= (uint32_t)L.transforms) return;  // (a grid that is not a multiple of the tile count)
+    const uint32_t c0 = ct << P.ca_shift;
+    const uint32_t live = (P.S - c0 < P.CA) ? (P.S - c0) : P.CA;
+    const uint32_t tid = threadIdx.x, col = tid & (P.CA - 1u), r0 = tid >> P.ca_shift;
+    // element k of this thread: row r0 + k dr of column c0 + col, i.e. position c0 + col + S (r0 + k dr) of the transform
+    const uint32_t voff = (c0 + col + P.S * r0) * (uint32_t)sizeof(float2);
+    // a column past the (ragged last) tile: out of every descriptor's bounds -- loads return zeros, stores are dropped.  Only the
+    // VGPR offset is bounds-checked (the scalar offset is added behind the check), so the padded prologue, whose rows end
+    // at `valid`, carries the whole position in the VGPR offset.
+    const uint32_t voff_lane = col < live ? voff : 0x80000000u;
+    constexpr bool kBoundInVgpr = requires { pro.valid; };
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    uint32_t row_bytes = P.n * (uint32_t)sizeof(float2);
+    if constexpr (requires { pro.valid; }) row_bytes = pro.valid * (uint32_t)sizeof(float2);  // the pad reads as zeros: the descriptor's bound
+    float2 pv[8];
+    auto prefetch = [&](uint32_t tt) {
+        int64_t ib, ob;
+        outer_bases(L, tt, ib, ob);
+        const rsrc_t r_in = make_rsrc(pro.row(ib), row_bytes);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t step = (uint32_t)k * dr * P.S * (uint32_t)sizeof(float2);
+            const v2f v = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r_in, kBoundInVgpr ? voff_lane + step : voff_lane,
+                                                                                          kBoundInVgpr ? 0u : step, JST_TILED_STREAM_LOADS ? 2 : 0));
+            pv[k] = mk(v.x, v.y);
+        }
+    };
+    prefetch(t);
+    // this thread's twiddles: butterfly r of pass p is b = tid + r T -> (lane, i); step = c0 + lane + S i (tile_pass)
+    float2 tw[kTw];
+    {
+        uint32_t at = 0, m = P.R1;
+#pragma unroll
+        for (uint32_t p = 0; p < P.g; ++p) {
+            const uint32_t ip = P.fact[p];
+            m /= ip;
+            const uint32_t nbt = ip <= 3 ? 4u : (ip <= 7 ? 2u : 1u);
+#pragma unroll
+            for (uint32_t r = 0; r < nbt; ++r) {
+                const uint32_t b = tid + r * T, lane = b & (P.CA - 1u), rest = b >> P.ca_shift;
+                const uint32_t i = rest % m;
+                uint32_t step = c0 + lane + P.S * i;
+                if (lane >= live || b >= ((P.R1 / ip) << P.ca_shift)) step = 0;  // an idle slot: any entry
+#pragma unroll
+                for (uint32_t c = 1; c < ip; ++c) tw[at++] = W[P.tw_off[p] + (c - 1u) * (m * P.S) + step];
+            }
+        }
+    }
+    // the window taps of this thread's eight positions: a second tile in LDS behind the first (in registers beside the twiddles
+    // the kernel spilled 16 dwords, and a scratch reload waits vmcnt(0)); each thread reads back what it wrote itself
+    float2* winl = buf0 + (P.R1 << P.ca_shift);
+    if constexpr (Pro::kHasOperand) {
+        const rsrc_t r_w = make_rsrc(pro.operand_row(), P.n * (uint32_t)sizeof(float2));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) winl[tid + (uint32_t)k * T] = buf_load_f2(r_w, voff_lane, (uint32_t)k * dr * P.S * (uint32_t)sizeof(float2));
+    }
+    // Everything requested so far has landed before the loop is entered: inside it hipcc then waits for the prefetched registers
+    // only (vmcnt(15..8): the eight requests, the eight stores behind them) -- with the twiddles' loads still pending at the
+    // loop's head it put `s_waitcnt vmcnt(10)` / `vmcnt(7)` in front of their first use in EVERY iteration, i.e. waited for
+    // part of the prefetch in the middle of the passes.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    while (true) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if constexpr (Pro::kHasOperand) buf0[tid + (uint32_t)k * T] = pro.apply(pv[k], winl[tid + (uint32_t)k * T]);
+            else buf0[tid + (uint32_t)k * T] = pv[k];
+        }
+        lds_barrier();
+        const uint32_t tn = t + lanes;
+        const bool more = tn < (uint32_t)L.transforms;
+        if (more) prefetch(tn);
+        columns_pipe_passes<FWD, SP, 0>(buf0, tw, live, c0);
+        const rsrc_t r_out = make_rsrc(scratch + (size_t)t * P.n, P.n * (uint32_t)sizeof(float2));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {  // plain stores: the second kernel re-reads the image at once (see the one-tile form)
+            const float2 v = buf0[tid + (uint32_t)k * T];
+            __builtin_amdgcn_raw_buffer_store_b64(v2u{f2u(v.x), f2u(v.y)}, r_out, voff_lane, (uint32_t)k * dr * P.S * (uint32_t)sizeof(float2), 0);
+        }
+        if (!more) break;
+        lds_barrier();  // every thread has read its results before the next tile is committed
+        t = tn;
+    }
 }
 
 // ---- kernel B: passes g..nf-1 on CB adjacent blocks (or whole transforms when g == 0) -----------
@@ -1182,10 +1348,7 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
     JST_TSTAMP_FLUSH();  // stores issued
 }
 
-// The blocks kernel's persistent form (fft_tile_blocks_kernel<..., PERSIST>): see there.  JST_TILED_PERSIST=0: A/B switch.
-#ifndef JST_TILED_PERSIST
-#define JST_TILED_PERSIST 1
-#endif
+// The blocks kernel's persistent form (fft_tile_blocks_kernel<..., PERSIST>): see there.
 constexpr bool persist_eligible(const TiledPlan& p) {
     if (!JST_TILED_PERSIST || p.g == 0 || p.R1 <= 1 || block_twiddle_entries(p) == 0) return false;
     if (p.grp_w == p.CB && p.R1 % p.CB != 0) return false;  // no ragged last tile: every lane of every tile is live
@@ -1203,7 +1366,7 @@ int tiled_compute_units() {
 // grid of a persistent launch: as many workgroups as the chip holds at once (occupancy x CUs), lowered to the count that
 // gives every workgroup the same number of rounds (2048 tiles on 768 slots: 3 rounds -> 683 workgroups -> 688, a multiple of
 // eight for the XCD-contiguous tile order)
-inline unsigned persistent_grid(const void* kernel, unsigned threads, size_t lds, uint64_t tiles) {
+inline uint64_t persistent_slots(const void* kernel, unsigned threads, size_t lds) {  // workgroups the chip holds at once
     struct Seen { const void* kernel; unsigned threads; size_t lds; int per_cu; };
     thread_local Seen seen[8] = {};  // the occupancy query costs microseconds of host time: once per (kernel, shape) and thread
     thread_local int used = 0;
@@ -1214,7 +1377,10 @@ inline unsigned persistent_grid(const void* kernel, unsigned threads, size_t lds
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
         seen[used < 8 ? used++ : 7] = Seen{kernel, threads, lds, per_cu};
     }
-    const uint64_t slots = (uint64_t)per_cu * (uint64_t)tiled_compute_units();
+    return (uint64_t)per_cu * (uint64_t)tiled_compute_units();
+}
+inline unsigned persistent_grid(const void* kernel, unsigned threads, size_t lds, uint64_t tiles) {
+    const uint64_t slots = persistent_slots(kernel, threads, lds);
     if (tiles <= slots) return (unsigned)tiles;
     const uint64_t rounds = (tiles + slots - 1) / slots;
     uint64_t grid = (tiles + rounds - 1) / rounds;
@@ -1239,7 +1405,31 @@ hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2*
     if constexpr (SP == 0 && !GEN)
         if (plan_has_generic_radix(P)) return launch_tiled_sp<FWD, Pro, Epi, 0, true>(P, L, W, pro, epi, scratch, s);
     (void)hipGetLastError();
-    if (P.g > 0) {
+    bool columns_done = false;
+    if constexpr (SP > 0 && !GEN && columns_pipe_eligible(static_plan(SP)) && requires { pro.row(0); pro.operand_row(); }) {
+        // the persistent columns kernel: dense rows and at least three transforms per workgroup (fewer: the start-up -- twiddles,
+        // window taps, the first tile -- is not paid back; config 5's single stream per cycle keeps one workgroup per tile)
+        if (!scratch) return hipErrorInvalidValue;
+        bool dense = L.in_axis_stride == 1;
+        if constexpr (requires { pro.wstride; }) dense = dense && pro.wstride == 1;
+        auto kp = fft_tile_columns_pipe_kernel<FWD, Pro, SP>;
+        constexpr unsigned threads_p = columns_pipe_threads<SP>();
+        constexpr size_t lds_p = (size_t)static_plan(SP).R1 * static_plan(SP).CA * sizeof(float2) * (Pro::kHasOperand ? 2 : 1);
+        const uint64_t tiles_per_t = (P.S + P.CA - 1) / P.CA;
+        if (dense && L.transforms < 0x7fffffffull) {
+            const hipError_t e = raise_dynamic_lds(reinterpret_cast<const void*>(kp), (int)(kTileElems * sizeof(float2)));
+            if (e != hipSuccess) return e;
+            const uint64_t slots = persistent_slots(reinterpret_cast<const void*>(kp), threads_p, lds_p);
+            uint64_t lanes = slots / tiles_per_t;
+            if (lanes >= 1 && L.transforms >= 3 * lanes) {
+                const uint64_t rounds = (L.transforms + lanes - 1) / lanes;
+                lanes = (L.transforms + rounds - 1) / rounds;  // the fewest lanes that keep the number of rounds
+                hipLaunchKernelGGL(kp, dim3((unsigned)(lanes * tiles_per_t)), dim3(threads_p), lds_p, s, L, W, pro, scratch);
+                columns_done = true;
+            }
+        }
+    }
+    if (P.g > 0 && !columns_done) {
         if (!scratch) return hipErrorInvalidValue;
         const size_t lds_a = (size_t)P.R1 * P.CA * sizeof(float2);
         auto ka = fft_tile_columns_kernel<FWD, Pro, SP, GEN>;
