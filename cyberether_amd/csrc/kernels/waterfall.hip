@@ -77,6 +77,11 @@ hipError_t launch_waterfall(float* ring, uint64_t* state, const float* in, uint6
 // The averaged trace is the reference's only "averaged spectrum": it is what the optional
 // cross-GPU all-reduce of BASELINE config 5 averages (cyberether_amd/distributed.py).
 namespace {
+// DEPTH loads in flight per thread.  The sum is ordered (left to right over the batch axis, F32, from +0: the reference's loop),
+// the loads are not: a thread requests DEPTH rows, then adds them in order.  16 covers config 5's one stream (16 batches: one
+// round trip); with 128 rows -- the 8-stream form -- 16 at a time are eight serial round trips of 1024 wavefronts, 4 MB in
+// flight on the whole chip: 8.9 us for 33.5 MB (3.7 TB/s); 64 at a time: round 6.
+template <int DEPTH>
 __global__ __launch_bounds__(256) void lineplot_kernel(float* __restrict__ points,
                                                        float* __restrict__ average,
                                                        const float* __restrict__ in,
@@ -86,22 +91,20 @@ __global__ __launch_bounds__(256) void lineplot_kernel(float* __restrict__ point
                                                        float normalization, float averaging) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= elements) return;
-    // Left-to-right F32 sum from +0 like the reference loop, but sixteen loads in flight at a time: the plain loop made
-    // every one of a thread's L2 / Infinity-Cache round trips wait for the previous one (config 5: 16 batches = 16
-    // serial round trips, 5.2 us for 4 MiB).  Rows past the last batch read a clamped address and add +0.0f, which
-    // leaves a sum that started at +0.0f unchanged (it can never be -0.0f).
+    // Rows past the last batch read a clamped address and add +0.0f, which leaves a sum that started at +0.0f unchanged (it
+    // can never be -0.0f).
     float sum = 0.0f;
     const float* col = in + in_offset + (int64_t)(i * decimation) * elem_stride;
-    for (uint64_t b0 = 0; b0 < batches; b0 += 16) {
-        float v[16];
+    for (uint64_t b0 = 0; b0 < batches; b0 += DEPTH) {
+        float v[DEPTH];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < DEPTH; ++k) {
             const uint64_t b = b0 + (uint64_t)k;
             const float x = col[(int64_t)(b < batches ? b : batches - 1) * batch_stride];
             v[k] = b < batches ? x : 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sum += v[k];
+        for (int k = 0; k < DEPTH; ++k) sum += v[k];
     }
     const float amplitude = fminf(fmaxf((sum * normalization) - 1.0f, -1.0f), 1.0f);
     float avg = average[i];
@@ -113,6 +116,13 @@ __global__ __launch_bounds__(256) void lineplot_kernel(float* __restrict__ point
 // The same over `cycles` consecutive compute cycles of a cycle-batched span in ONE launch: cycle c reads slot
 // (first_slot + c) mod ring_slots of the input ring (slots slot_stride elements apart), the moving average stays in a
 // register from the first cycle to the last -- the recursion is per bin, so the cycles of a bin are one thread's loop.
+// DEPTH rows of CYC consecutive cycles are requested together (round 6): the SUMS of different cycles do not depend on each
+// other, only the average's recursion does, so a span of config 5's one stream (16 rows per cycle) need not be one round trip
+// per cycle (17.8 us per 16-cycle span with <16, 1>), and 128 rows (8 streams) need not be eight per cycle.  Rows and cycles
+// past the end read a clamped address and are not added.  (A single stream of requests across cycle boundaries with a
+// running cursor was tried first -- per-thread 64-bit pointers, then a scalar cursor with uniform branches: 14-32 instructions
+// per load at one wavefront per SIMD, 23-54 us against 17.8-31.6: profiles/r06_experiments/d_lineplot_depth.log.)
+template <int DEPTH, int CYC>
 __global__ __launch_bounds__(256) void lineplot_span_kernel(float* __restrict__ points, float* __restrict__ average,
                                                             const float* __restrict__ in, uint64_t in_offset,
                                                             uint64_t slot_stride, uint32_t first_slot, uint32_t ring_slots,
@@ -123,24 +133,44 @@ __global__ __launch_bounds__(256) void lineplot_span_kernel(float* __restrict__ 
     if (i >= elements) return;
     float avg = average[i];
     uint32_t slot = first_slot;
-    for (uint32_t c = 0; c < cycles; ++c) {
-        const float* col = in + (uint64_t)slot * slot_stride + in_offset + (int64_t)(i * decimation) * elem_stride;
-        float sum = 0.0f;
-        for (uint64_t b0 = 0; b0 < batches; b0 += 16) {
-            float v[16];
+    const float* lane = in + in_offset + (int64_t)(i * decimation) * elem_stride;
+    for (uint32_t c = 0; c < cycles; c += CYC) {
+        const float* col[CYC];
+        {
+            uint32_t sl = slot;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint64_t b = b0 + (uint64_t)k;
-                const float x = col[(int64_t)(b < batches ? b : batches - 1) * batch_stride];
-                v[k] = b < batches ? x : 0.0f;
+            for (int cc = 0; cc < CYC; ++cc) {  // a cycle past the span: the last one's rows again, not added
+                col[cc] = lane + (uint64_t)sl * slot_stride;
+                if (c + (uint32_t)cc + 1u < cycles && ++sl == ring_slots) sl = 0;
             }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) sum += v[k];
         }
-        const float amplitude = fminf(fmaxf((sum * normalization) - 1.0f, -1.0f), 1.0f);
-        avg -= avg / averaging;
-        avg += amplitude / averaging;
-        if (++slot == ring_slots) slot = 0;
+        float sum[CYC];
+#pragma unroll
+        for (int cc = 0; cc < CYC; ++cc) sum[cc] = 0.0f;
+        for (uint64_t b0 = 0; b0 < batches; b0 += DEPTH) {
+            float v[CYC][DEPTH];
+#pragma unroll
+            for (int cc = 0; cc < CYC; ++cc)
+#pragma unroll
+                for (int k = 0; k < DEPTH; ++k) {
+                    const uint64_t b = b0 + (uint64_t)k;
+                    const float x = col[cc][(int64_t)(b < batches ? b : batches - 1) * batch_stride];
+                    v[cc][k] = b < batches ? x : 0.0f;
+                }
+#pragma unroll
+            for (int cc = 0; cc < CYC; ++cc)
+#pragma unroll
+                for (int k = 0; k < DEPTH; ++k) sum[cc] += v[cc][k];
+        }
+#pragma unroll
+        for (int cc = 0; cc < CYC; ++cc) {
+            if (c + (uint32_t)cc < cycles) {
+                const float amplitude = fminf(fmaxf((sum[cc] * normalization) - 1.0f, -1.0f), 1.0f);
+                avg -= avg / averaging;
+                avg += amplitude / averaging;
+                if (++slot == ring_slots) slot = 0;
+            }
+        }
     }
     average[i] = avg;
     points[(i * 2) + 1] = avg;
@@ -154,9 +184,14 @@ hipError_t launch_lineplot_span(float* points, float* average, const float* in_r
     if (elements == 0 || cycles == 0) return hipSuccess;
     if (ring_slots == 0 || first_slot >= ring_slots || cycles > 0xffffffffull) return hipErrorInvalidValue;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(lineplot_span_kernel, dim3((unsigned)((elements + 255) / 256)), dim3(256), 0, stream, points, average,
-                       in_ring, in_offset, slot_stride, (uint32_t)first_slot, (uint32_t)ring_slots, (uint32_t)cycles, batches,
-                       elements, batch_stride, elem_stride, decimation, normalization, averaging);
+#define JST_LP_SPAN(D, C)                                                                                                          \
+    hipLaunchKernelGGL((lineplot_span_kernel<D, C>), dim3((unsigned)((elements + 255) / 256)), dim3(256), 0, stream, points, average, \
+                       in_ring, in_offset, slot_stride, (uint32_t)first_slot, (uint32_t)ring_slots, (uint32_t)cycles, batches, elements,  \
+                       batch_stride, elem_stride, decimation, normalization, averaging)
+    if (batches >= 64) JST_LP_SPAN(64, 1);
+    else if (batches <= 16 && cycles >= 2) JST_LP_SPAN(16, 4);
+    else JST_LP_SPAN(16, 1);
+#undef JST_LP_SPAN
     return hipGetLastError();
 }
 
@@ -166,9 +201,14 @@ hipError_t launch_lineplot(float* points, float* average, const float* in, uint6
                            float averaging, hipStream_t stream) {
     if (elements == 0) return hipSuccess;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(lineplot_kernel, dim3((unsigned)((elements + 255) / 256)), dim3(256), 0,
-                       stream, points, average, in, in_offset, batches, elements, batch_stride,
-                       elem_stride, decimation, normalization, averaging);
+    if (batches >= 64)
+        hipLaunchKernelGGL(lineplot_kernel<64>, dim3((unsigned)((elements + 255) / 256)), dim3(256), 0,
+                           stream, points, average, in, in_offset, batches, elements, batch_stride,
+                           elem_stride, decimation, normalization, averaging);
+    else
+        hipLaunchKernelGGL(lineplot_kernel<16>, dim3((unsigned)((elements + 255) / 256)), dim3(256), 0,
+                           stream, points, average, in, in_offset, batches, elements, batch_stride,
+                           elem_stride, decimation, normalization, averaging);
     return hipGetLastError();
 }
 
