@@ -345,7 +345,7 @@ constexpr bool same_plan(const TiledPlan& a, const TiledPlan& b) {
 // Twiddles of the BLOCK passes (g..nf-1) are the same for every block of every transform -- PT[(c-1)*ido + i], a few hundred
 // entries -- so a static-plan kernel keeps them in LDS behind its tile (round 6): a pass then has no global load between its
 // two barriers (the L2 round trip of seven twiddles per butterfly was half of a radix-8 pass under load: tools/ubench/
-// tiled_timeline_c5.hip, profiles/r06_experiments/c_...log).  0: the plan keeps its twiddles in global memory (generic radix,
+// tiled_timeline_c5.hip, profiles/r06_experiments/c_tiled_persistent.log).  0: the plan keeps its twiddles in global memory (generic radix,
 // whole transforms per lane, tables beyond 8 KiB).
 #ifndef JST_TILED_TW_LDS
 #define JST_TILED_TW_LDS 1
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(columns_pipe_threads<SP>(), 4) void fft_tile_column
 // tile's elements into registers before it runs the passes of this one.  One workgroup per tile these kernels are bound by the
 // rate at which the chip STARTS wavefronts (~450 per microsecond: 2048 tiles x 8 wavefronts of config 5's 128-transform
 // launch = 36 us whatever a tile's load -> passes -> store chain costs -- shortening the chain only lowered the number of
-// workgroups alive; tools/ubench/tiled_timeline_c5.hip, profiles/r06_experiments/c_...log), and a persistent loop without
+// workgroups alive; tools/ubench/tiled_timeline_c5.hip, profiles/r06_experiments/c_tiled_persistent.log), and a persistent loop without
 // the prefetch serialises load and passes in the two or three workgroups a CU holds (round 5, u_...log).  With both, a tile
 // costs max(load, passes + epilogue).  All barriers are LDS-only (tile_barrier<true>): the ordinary workgroup barrier waits
 // for vmcnt(0), i.e. for the prefetch.
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
     if constexpr (PERSIST) {
         // The same stores with a compile-time trip count and no loop: hipcc counts the VMEM instructions issued behind the
         // prefetch only through straight-line code -- behind a loop of stores it waits for the prefetched registers with
-        // vmcnt(7..0), i.e. for every store of this epilogue to be acknowledged (profiles/r06_experiments/c_...log).
+        // vmcnt(7..0), i.e. for every store of this epilogue to be acknowledged (profiles/r06_experiments/c_tiled_persistent.log).
         constexpr uint32_t kT = threads_for((uint64_t)PS.S * PS.CB, min_threads_for_passes(PS, PS.g, PS.nf, (uint64_t)PS.S * PS.CB));
         constexpr uint32_t total = PS.S << PS.cb_shift, iters = (total + kT - 1) / kT;
         if constexpr (requires(rsrc_t rr) { epi.store_buf(rr, 0u, 0u, float2{}); } && PS.grp_w == PS.CB && kT % PS.CB == 0) {
@@ -1443,7 +1443,7 @@ hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2*
                            pro, scratch);
     }
     // The persistent form for LONG launches of the plain epilogues only.  Measured, same box, alternating (tools/ubench/
-    // run_r06f.sh, profiles/r06_experiments/c_...log): config 5 cycle-batched (4096 / 8192 tiles on 768 slots) 10.1-10.4 against
+    // run_r06f.sh, profiles/r06_experiments/c_tiled_persistent.log): config 5 cycle-batched (4096 / 8192 tiles on 768 slots) 10.1-10.4 against
     // 10.9 us and 77-78 against 80-81 us per cycle; one launch per cycle (256 / 2048 tiles) 23.5 against 22.3 and 79 against
     // 77.5 us -- below four rounds the start-up (every workgroup's first tile arrives together) costs more than the
     // prefetch saves --; the fold epilogue's own loads and store loop put vmcnt(0) in front of every commit (config 3:

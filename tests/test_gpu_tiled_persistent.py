@@ -114,3 +114,51 @@ def test_lineplot_behind_the_persistent_kernel(js, oracle):
         rt.destroy()
     assert_bit_equal(states[1][0], states[0][0], "lineplot average")
     assert_bit_equal(states[1][1], states[0][1], "lineplot points")
+
+
+@pytest.mark.parametrize("b", [1, 15, 16, 17, 63, 64, 65, 130])
+def test_lineplot_row_depths_against_the_oracle(js, oracle, b):
+    """The Lineplot's ordered batch sum with 16 or 64 rows in flight per thread (waterfall.hip: lineplot_kernel<16> / <64>): every
+    batch count around the two depths, with decimation, against the oracle (lineplot/module_impl_native_cpu.cc:80-118)."""
+    rng = np.random.default_rng(b)
+    x = rng.uniform(0, 1, (b, 1024)).astype(np.float32)
+    x[:, ::7] *= np.float32(1e-3)  # sums whose rounding depends on the order
+    for averaging, decimation in ((1, 1), (8, 4)):
+        t = js.Tensor.from_numpy(x, sample=1, batch=0)
+        m = js.Module("lineplot", {"averaging": averaging, "decimation": decimation}, {"signal": t})
+        rt = js.Runtime([m], graph=True)
+        avg = np.zeros(1024 // decimation, np.float32)
+        for cycle in range(3):
+            rt.compute()
+            oracle.lineplot(avg, x, averaging, decimation)
+            assert_bit_equal(m.state("averagingBuffer").numpy(), avg, f"{b} rows, cycle {cycle}")
+        rt.destroy()
+
+
+@pytest.mark.parametrize("b", [5, 40, 70])
+def test_lineplot_span_forms_equal_the_per_cycle_kernel(js, oracle, b):
+    """lineplot_span_kernel<16, 4> (few rows: four cycles' rows in flight), <16, 1> and <64, 1> behind a cycle-batched spectrum unit:
+    spans of 1..7 cycles that wrap a ring of 3 slots, against the per-cycle runtime, bit for bit, after every call."""
+    n, slots = 12000, 3  # a tiled length: the LDS-tiled spectrum unit has the span form the Lineplot rides behind
+    rng = np.random.default_rng(100 + b)
+    xs = [((rng.standard_normal((b, n)) + 1j * rng.standard_normal((b, n))) * (0.1 + 0.2 * s)).astype(np.complex64) for s in range(slots)]
+    traces = []
+    for batch in (False, True):
+        ring = js.Module("ring_source", {"batches": b, "samples": n, "slots": slots}, {}, "ring")
+        buf = ring.output("buffer")
+        for s, x in enumerate(xs):
+            buf.ring_select(s).copy_from(x)
+        buf.ring_select(0)
+        eng = js.SpectrumEngine(buf, enable_scale=True, range_min=-100.0, range_max=0.0)
+        lp = js.Module("lineplot", {"averaging": 4}, {"signal": eng.buffer}, "psd")
+        rt = js.Runtime([ring] + eng.modules + [lp], fuse=True, graph=True, batch=batch)
+        assert rt.batched == batch, rt.units
+        trace = []
+        for call in (1, 3, 2, 5, 7, 4):
+            rt.compute(call)
+            trace.append((lp.state("averagingBuffer").numpy().copy(), lp.state("signalPoints").numpy().copy()))
+        traces.append(trace)
+        rt.destroy()
+    for i, (per_cycle, batched) in enumerate(zip(*traces)):
+        assert_bit_equal(batched[0], per_cycle[0], f"lineplot average after call {i}")
+        assert_bit_equal(batched[1], per_cycle[1], f"lineplot points after call {i}")
