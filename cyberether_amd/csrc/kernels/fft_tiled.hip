@@ -1447,7 +1447,10 @@ hipError_t launch_tiled_sp(const TiledPlan& P, const FftLayout& L, const float2*
     // 10.9 us and 77-78 against 80-81 us per cycle; one launch per cycle (256 / 2048 tiles) 23.5 against 22.3 and 79 against
     // 77.5 us -- below four rounds the start-up (every workgroup's first tile arrives together) costs more than the
     // prefetch saves --; the fold epilogue's own loads and store loop put vmcnt(0) in front of every commit (config 3:
-    // 0.225 against 0.205 ms).  It addresses dense output rows.
+    // 0.225 against 0.205 ms), and rewritten without loops or branches around its VMEM instructions, operand in two halves,
+    // thread index opaque (80 VGPRs, no scratch) it ran 89.8 us against 86.3 for one workgroup per tile: two 768-thread
+    // workgroups per CU either way, and the kernel is within 2x of its VALU floor (33 M wavefront instructions).  It
+    // addresses dense output rows.
     constexpr bool kPersist = SP > 0 && !GEN && !is_tile_epilogue<Epi> && persist_eligible(static_plan(SP));
     if constexpr (kPersist) {
         const uint64_t tiles = L.transforms * ((P.R1 + P.CB - 1) / P.CB);
