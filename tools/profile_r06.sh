@@ -55,9 +55,14 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fir -- py
 python $ROOT/tools/kstats.py $O/fir > $O/kernel_stats_config_C3_fast.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -d $O/fir_pmc -- python $ROOT/tools/bench_fir.py > /dev/null 2> $O/fir_pmc.err
 python $ROOT/tools/pmc_kernel_means.py $O/fir_pmc fir_ > $O/pmc_counters_config_C3_fast.txt 2>&1
-# round 6: config 5 with all 8 streams resident (128 transforms per cycle)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5s -- python $ROOT/tools/bench_c5_streams.py > $O/c5_streams.json 2> $O/c5_streams.err
-python $ROOT/tools/kstats.py $O/c5s > $O/kernel_stats_config_C5_streams.txt 2>&1
+# round 6: config 5 with all 8 streams resident (128 transforms per cycle): both providers, every form (one JSON each), and kernel stats of ONE
+# form per trace (one launch per unit and cycle; cycle-batched spans of a 4-slot ring) for provider fast and generic
+python $ROOT/tools/bench_c5_streams.py generic > $O/c5_streams.json 2> $O/c5_streams.err
+python $ROOT/tools/bench_c5_streams.py fast > $O/c5_streams_fast.json 2>> $O/c5_streams.err
+for v in fast generic; do for f in per_cycle batched; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5s_${v}_$f -- python $ROOT/tools/bench_c5_streams.py $v 128 $f > /dev/null 2>> $O/c5_streams.err
+  python $ROOT/tools/kstats.py $O/c5s_${v}_$f > $O/kernel_stats_config_C5_streams_${v}_$f.txt 2>&1
+done; done
 # round 6: the REFERENCE's scheduler on DeviceType::HIP: kernel + memory-copy trace of N steady-state cycles at two values of N --
 # the number of copies must not depend on N (tensors stay in HBM between modules); and its bench object
 for n in 10 110; do
