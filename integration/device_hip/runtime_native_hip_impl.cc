@@ -46,7 +46,10 @@ namespace Jetstream {
 struct NativeHipRuntime;
 
 namespace {
-std::atomic<bool> gHandOff{true};
+// 0: module by module; 1: hand library segments over -- fused units replayed from a hipGraph when cycles are ENQUEUED (deferCycles
+// >= 1), launched directly when every cycle is synchronous (a replay and a wait per Flowgraph::compute(): 41.8 us per
+// 1024 x 4096 cycle against 34.7 us with direct launches, tools/reference_driven_bench.py); 2: direct launches always; 3: hipGraph always
+std::atomic<int> gHandOff{1};
 std::atomic<uint64_t> gDeferCycles{0};
 std::mutex gLiveMutex;
 std::set<NativeHipRuntime*> gLive;
@@ -60,7 +63,7 @@ struct NativeHipRuntime : public Runtime::Impl {
         modulesMap.clear();
         moduleNames.clear();
         std::vector<jst_module> handles;
-        bool everyModuleIsLibrary = gHandOff.load() && !modules.empty();
+        bool everyModuleIsLibrary = gHandOff.load() != 0 && !modules.empty();
         for (const auto& [moduleName, module] : modules) {
             if (module->device() != DeviceType::HIP || module->runtime() != RuntimeType::NATIVE || !context(module)) {
                 JST_ERROR("[RUNTIME_IMPL_NATIVE_HIP] Module '{}' is incompatible (DeviceType::{}, RuntimeType::{}).",
@@ -73,7 +76,9 @@ struct NativeHipRuntime : public Runtime::Impl {
         }
         if (everyModuleIsLibrary) {
             deferCycles = gDeferCycles.load();
-            const uint32_t flags = JST_RUNTIME_GRAPH | JST_RUNTIME_FUSE | (deferCycles > 1 ? (uint32_t)JST_RUNTIME_BATCH : 0u);
+            const int mode = gHandOff.load();
+            const bool graph = mode == 3 || (mode == 1 && deferCycles >= 1);
+            const uint32_t flags = (graph ? (uint32_t)JST_RUNTIME_GRAPH : 0u) | JST_RUNTIME_FUSE | (deferCycles > 1 ? (uint32_t)JST_RUNTIME_BATCH : 0u);
             if (jst_runtime_create(handles.data(), (uint32_t)handles.size(), flags, &library) != JST_SUCCESS) {
                 JST_ERROR("[RUNTIME_IMPL_NATIVE_HIP] Runtime '{}': the library refused the segment: {}", name, jst_last_error());
                 library = {};
@@ -286,9 +291,10 @@ std::shared_ptr<Runtime::Impl> NativeHipRuntimeFactory() { return std::make_shar
 }  // namespace Jetstream
 
 // Process-wide knobs of the HIP runtimes created from here on (a host application's settings page, a benchmark): handOff = 0
-// keeps every segment module by module; deferCycles > 1 turns on deferred cycles (see the top of this file).
+// keeps every segment module by module, 1 (the default) hands library segments over (hipGraph replay for enqueued cycles, direct
+// launches of the fused units for synchronous ones), 2 / 3 force direct launches / the hipGraph; deferCycles > 1 turns on deferred cycles (see the top of this file).
 extern "C" void jetstream_hip_runtime_configure(int handOff, uint64_t deferCycles) {
-    Jetstream::gHandOff.store(handOff != 0);
+    Jetstream::gHandOff.store(handOff);
     Jetstream::gDeferCycles.store(deferCycles);
 }
 // Runs what the live HIP runtimes still hold back and waits for it; returns the number of runtimes that failed.

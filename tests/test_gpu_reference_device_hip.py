@@ -96,11 +96,12 @@ def test_fft_module_on_the_device(oracle, forward):
     assert np.abs(outs[1]).max() > 100
 
 
-@pytest.mark.parametrize("hand_off", [True, False])
+@pytest.mark.parametrize("hand_off", [True, False, 2, 3])
 def test_spectrum_engine_and_spectrogram_device_resident(oracle, hand_off):
     """ring_source -> spectrum_engine -> spectrogram, every block on DeviceType::HIP, inside the reference's Flowgraph and
-    scheduler.  hand_off: the HIP runtime gives the segment to one jst_runtime (hipGraph + fusion) -- or submits module by
-    module on its own stream (the CUDA runtime's shape).  Either way: bit-equal to the CPU device."""
+    scheduler.  hand_off: the HIP runtime gives the segment to one jst_runtime (fusion; direct launches for synchronous cycles --
+    the default --, 2: direct launches always, 3: replayed from a hipGraph) -- or submits module by module on its own stream
+    (the CUDA runtime's shape).  Either way: bit-equal to the CPU device."""
     rows, n, h = 16, 4096, 256
     xs = [tones(oracle, rows, seed=40 + c, scale=0.5 + 0.25 * c) for c in range(3)]
     want_out, want_bins = cpu_flowgraph(xs, h)
