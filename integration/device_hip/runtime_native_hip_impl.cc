@@ -46,9 +46,10 @@ namespace Jetstream {
 struct NativeHipRuntime;
 
 namespace {
-// 0: module by module; 1: hand library segments over -- fused units replayed from a hipGraph when cycles are ENQUEUED (deferCycles
-// >= 1), launched directly when every cycle is synchronous (a replay and a wait per Flowgraph::compute(): 41.8 us per
-// 1024 x 4096 cycle against 34.7 us with direct launches, tools/reference_driven_bench.py); 2: direct launches always; 3: hipGraph always
+// 0: module by module; 1: hand library segments over -- cycle-batched SPANS (deferCycles > 1) replayed from a hipGraph, single cycles
+// launched directly: on this ROCm a hipGraphLaunch of the cycle's two or three kernel nodes costs more host time than their direct
+// launches (per 1024 x 4096 cycle, tools/reference_driven_bench.py: synchronous 41.5 us replayed against 34.1 direct, enqueued
+// without a wait 27.9 against 22.4; spans: equal); 2: direct launches always; 3: hipGraph always
 std::atomic<int> gHandOff{1};
 std::atomic<uint64_t> gDeferCycles{0};
 std::mutex gLiveMutex;
@@ -77,7 +78,7 @@ struct NativeHipRuntime : public Runtime::Impl {
         if (everyModuleIsLibrary) {
             deferCycles = gDeferCycles.load();
             const int mode = gHandOff.load();
-            const bool graph = mode == 3 || (mode == 1 && deferCycles >= 1);
+            const bool graph = mode == 3 || (mode == 1 && deferCycles > 1);
             const uint32_t flags = (graph ? (uint32_t)JST_RUNTIME_GRAPH : 0u) | JST_RUNTIME_FUSE | (deferCycles > 1 ? (uint32_t)JST_RUNTIME_BATCH : 0u);
             if (jst_runtime_create(handles.data(), (uint32_t)handles.size(), flags, &library) != JST_SUCCESS) {
                 JST_ERROR("[RUNTIME_IMPL_NATIVE_HIP] Runtime '{}': the library refused the segment: {}", name, jst_last_error());
@@ -291,8 +292,8 @@ std::shared_ptr<Runtime::Impl> NativeHipRuntimeFactory() { return std::make_shar
 }  // namespace Jetstream
 
 // Process-wide knobs of the HIP runtimes created from here on (a host application's settings page, a benchmark): handOff = 0
-// keeps every segment module by module, 1 (the default) hands library segments over (hipGraph replay for enqueued cycles, direct
-// launches of the fused units for synchronous ones), 2 / 3 force direct launches / the hipGraph; deferCycles > 1 turns on deferred cycles (see the top of this file).
+// keeps every segment module by module, 1 (the default) hands library segments over (hipGraph replay for cycle-batched spans, direct
+// launches of the fused units for single cycles), 2 / 3 force direct launches / the hipGraph; deferCycles > 1 turns on deferred cycles (see the top of this file).
 extern "C" void jetstream_hip_runtime_configure(int handOff, uint64_t deferCycles) {
     Jetstream::gHandOff.store(handOff);
     Jetstream::gDeferCycles.store(deferCycles);

@@ -88,8 +88,8 @@ def use_device_hip_library() -> None:
 
 def hip_runtime_configure(hand_off=True, defer_cycles: int = 0) -> None:
     """integration/device_hip/runtime_native_hip_impl.cc: knobs of the HIP runtimes created from here on (hand_off: False / 0 =
-    module by module, True / 1 = library segments as one jst_runtime (fusion; hipGraph replay for enqueued cycles, direct launches for
-    synchronous ones), 2 = direct launches always, 3 = hipGraph always)."""
+    module by module, True / 1 = library segments as one jst_runtime (fusion; hipGraph replay for cycle-batched spans, direct launches for
+    single cycles), 2 = direct launches always, 3 = hipGraph always)."""
     lib().jetstream_hip_runtime_configure(C.c_int(int(hand_off)), C.c_uint64(defer_cycles))
 
 

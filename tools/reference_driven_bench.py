@@ -90,7 +90,7 @@ def main() -> None:
     out = {"available": True, "workload": f"configs[1] through the reference's Flowgraph / scheduler / Runtime(HIP): ring_source[{args.slots} x "
                                          f"{BATCHES} x {N_FFT}] -> spectrum_engine -> spectrogram[{HEIGHT}], DeviceType::HIP, provider {args.provider}",
            "cycles_per_region": args.cycles,
-           "per_cycle_sync": timed(True, 0), "per_cycle_sync_hipgraph": timed(3, 0), "per_cycle_async": timed(True, 1), "deferred_spans": timed(True, args.slots),
+           "per_cycle_sync": timed(True, 0), "per_cycle_sync_hipgraph": timed(3, 0), "per_cycle_async": timed(True, 1), "per_cycle_async_hipgraph": timed(3, 1), "deferred_spans": timed(True, args.slots),
            "deferred_spans_sustained": timed(True, args.slots, 16 * args.slots), "module_by_module": timed(False, 0)}
 
     if not args.no_parity:
