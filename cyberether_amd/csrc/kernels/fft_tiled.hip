@@ -324,7 +324,7 @@ constexpr StaticPlanKey kStaticPlans[] = {{0, 0, 0, 0, 0},
                                           {65536, 16, 0, 0, 0}, {160000, 100, 16000, 0, 0}, {16000, 100, 0, 0, 0},
                                           {65536, 16, 0, 16, 0}, {65536, 16, 0, 32, 0}, {65536, 16, 0, 0, 16},
                                           {160000, 100, 16000, 0, 4}, {160000, 100, 16000, 32, 0}, {160000, 100, 16000, 8, 0}};
-constexpr int kStaticPlanCount = 10;
+[[maybe_unused]] constexpr int kStaticPlanCount = 10;
 constexpr TiledPlan static_plan(int sp) {
     TiledPlan p{};
     (void)build_tiled_plan(kStaticPlans[sp].n, kStaticPlans[sp].transforms, kStaticPlans[sp].force_ca,
