@@ -966,13 +966,16 @@ __global__ __launch_bounds__(columns_pipe_threads<SP>(), 4) void fft_tile_column
 // ---- kernel B: passes g..nf-1 on CB adjacent blocks (or whole transforms when g == 0) -----------
 // PERSIST (round 6; static plans with R1 > 1 whose block twiddles live in LDS and whose tile is at most eight elements per
 // thread: persist_eligible): the workgroup takes the tiles blockIdx.x, + gridDim.x, ... of `ntiles` and requests the NEXT
-// tile's elements into registers before it runs the passes of this one.  One workgroup per tile these kernels are bound by the
-// rate at which the chip STARTS wavefronts (~450 per microsecond: 2048 tiles x 8 wavefronts of config 5's 128-transform
-// launch = 36 us whatever a tile's load -> passes -> store chain costs -- shortening the chain only lowered the number of
-// workgroups alive; tools/ubench/tiled_timeline_c5.hip, profiles/r06_experiments/c_tiled_persistent.log), and a persistent loop without
-// the prefetch serialises load and passes in the two or three workgroups a CU holds (round 5, u_...log).  With both, a tile
-// costs max(load, passes + epilogue).  All barriers are LDS-only (tile_barrier<true>): the ordinary workgroup barrier waits
-// for vmcnt(0), i.e. for the prefetch.
+// tile's elements into registers before it runs the passes of this one.  One workgroup per tile, what a tile's load -> passes
+// -> store chain costs barely shows in the kernel: with the block twiddles in LDS a workgroup of config 5's 128-transform
+// launch lives 8.45 instead of 12.6 us and the launch takes 36.9 instead of 38.7 us -- fewer workgroups are alive on average
+// (1.8 per CU of 3-4 slots; synthetic workgroups of the same shape that only wait fill 88-95 % of their slots, refill gap
+// 0.5-0.8 us: tools/ubench/launch_rate.hip, so it is not the dispatcher), every workgroup pays its start-up (arguments, table,
+// the first tile's round trip with every other new workgroup's) and the two or three workgroups of a CU do not interleave
+// their phases (tools/ubench/tiled_timeline_c5.hip, profiles/r06_experiments/c_tiled_persistent.log); a persistent loop
+// WITHOUT the prefetch serialises load and passes in those few workgroups (round 5, u_...log).  With both, a tile costs
+// max(load, passes + epilogue) and the start-up is paid once per workgroup.  All barriers are LDS-only (tile_barrier<true>): the
+// ordinary workgroup barrier waits for vmcnt(0), i.e. for the prefetch.
 template <bool FWD, class Pro, class Epi, int SP = 0, bool GEN = false, bool PERSIST = false>
 __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void fft_tile_blocks_kernel(const FftLayout L,
                                                                    const TiledPlan Prt,
