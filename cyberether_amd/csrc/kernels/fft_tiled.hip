@@ -448,6 +448,11 @@ __device__ __forceinline__ void outer_bases(const FftLayout& L, uint64_t t, int6
                                             int64_t& out_base) {
     in_base = (int64_t)L.in_offset;
     out_base = (int64_t)L.out_offset;
+    if (L.outer_rank == 1) {  // one batch axis (every BASELINE config): no 64-bit division per workgroup / per tile
+        in_base += (int64_t)t * L.in_outer_stride[0];
+        out_base += (int64_t)t * L.out_outer_stride[0];
+        return;
+    }
     for (int a = L.outer_rank - 1; a >= 0; --a) {
         const uint64_t c = t % L.outer_shape[a];
         t /= L.outer_shape[a];
@@ -1079,7 +1084,11 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
         outer_bases(L, t0, tile_in, tile_out);
         if constexpr (is_tile_epilogue<Epi>)
             tile_off = epi.chan_offsets ? (uint32_t)(epi.chan_offsets[(t0 / epi.chan_div) % epi.chan_count] % P.n) : epi.off;
-    } else {
+    }
+    // one workgroup per tile: the per-lane table of row bases (and fold offsets).  The scratch image is addressed without it, so
+    // with g > 0 it is filled BETWEEN the requests for the tile and their commit (its divisions run while the loads are in
+    // flight, and the barrier behind the tile publishes it too); whole transforms (g == 0) need it for the loads themselves.
+    auto fill_lane_table = [&]() {
     if (threadIdx.x < live) {
         int64_t ib, ob;
         outer_bases(L, P.R1 > 1 ? t0 : t0 + threadIdx.x, ib, ob);
@@ -1091,8 +1100,12 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
                 ? (uint32_t)(epi.chan_offsets[(t / epi.chan_div) % epi.chan_count] % P.n) : epi.off;
         }
     }
-    __syncthreads();
-    }
+    };
+    if constexpr (!PERSIST)
+        if (P.g == 0) {
+            fill_lane_table();
+            __syncthreads();
+        }
     const uint32_t tile = P.S * live;
     // block of lane kb: CB adjacent blocks, or CB / grp_w groups of grp_w adjacent blocks grp_stride apart
     auto block_of = [&](uint32_t kb) { return k0 + kb + (kb >> P.grp_shift) * grp_gap; };
@@ -1101,6 +1114,7 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
     // eight loads in flight per thread: unconditional loads from clamped indices (a conditional load is a branch and
     // hipcc drains vmcnt at each of them), the g == 0 / g > 0 choice hoisted out of the unrolled body
     auto load_tile = [&](auto from_scratch) {
+        bool first = true;
         for (uint32_t i0 = threadIdx.x; i0 < tile; i0 += 8 * blockDim.x) {
             float2 v[8];
             uint32_t slot[8];
@@ -1113,10 +1127,15 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
                 else v[k] = pro.template load<false>(lane_in[kb], L.in_axis_stride, (int)x);
                 slot[k] = idx < tile ? x * pitch + kb : 0xffffffffu;
             }
+            if constexpr (decltype(from_scratch)::value)
+                if (first) fill_lane_table();
+            first = false;
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 if (slot[k] != 0xffffffffu) buf0[slot[k]] = v[k];
         }
+        if constexpr (decltype(from_scratch)::value)
+            if (first) fill_lane_table();  // (a thread without an element of the tile)
     };
     if constexpr (PERSIST) {  // the tile arrived in registers (requested while the previous tile was in the passes)
         JST_TSTAMP(12);  // bases known
