@@ -999,8 +999,18 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
     // static plans: the block passes' twiddle tables behind the tile (block_twiddle_entries), requested with the tile's loads
     constexpr uint32_t kTwLds = SP > 0 && !GEN ? block_twiddle_entries(PS) : 0u;
     float2* twl = buf0 + (size_t)PS.S * (PS.CB | 1u);
-    if constexpr (kTwLds > 0 && !PERSIST)
-        for (uint32_t e = threadIdx.x; e < kTwLds; e += blockDim.x) twl[e] = W[PS.tw_off[PS.g] + e];
+    // one workgroup per tile: the table is REQUESTED here and written to LDS behind the requests for the tile (fill_lane_table
+    // below) -- written at once, its L2 round trip stood in front of the tile's loads
+    constexpr uint32_t kTwThreads = SP > 0 ? threads_for((uint64_t)PS.S * PS.CB, min_threads_for_passes(PS, PS.g, PS.nf, (uint64_t)PS.S * PS.CB)) : 1u;
+    constexpr uint32_t kTwPer = (kTwLds > 0 && !PERSIST) ? (kTwLds + kTwThreads - 1) / kTwThreads : 0u;
+    float2 twv[kTwPer > 0 ? kTwPer : 1];
+    if constexpr (kTwPer > 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < kTwPer; ++j) {
+            const uint32_t e = threadIdx.x + j * kTwThreads;
+            twv[j] = W[PS.tw_off[PS.g] + (e < kTwLds ? e : kTwLds - 1u)];
+        }
+    }
     JST_TSTAMP(0);
     const uint32_t grp_gap = P.grp_stride - P.grp_w;  // blocks skipped between two groups of lanes (see block_of below)
     const uint32_t tile_count = PERSIST ? ntiles : gridDim.x;
@@ -1089,6 +1099,13 @@ __global__ __launch_bounds__(kMaxThreads, GEN ? 4 : JST_TILED_MIN_WAVES) void ff
     // with g > 0 it is filled BETWEEN the requests for the tile and their commit (its divisions run while the loads are in
     // flight, and the barrier behind the tile publishes it too); whole transforms (g == 0) need it for the loads themselves.
     auto fill_lane_table = [&]() {
+    if constexpr (kTwPer > 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < kTwPer; ++j) {
+            const uint32_t e = threadIdx.x + j * kTwThreads;
+            if (e < kTwLds) twl[e] = twv[j];
+        }
+    }
     if (threadIdx.x < live) {
         int64_t ib, ob;
         outer_bases(L, P.R1 > 1 ? t0 : t0 + threadIdx.x, ib, ob);

@@ -3,6 +3,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 L=cyberether_amd/lib/libjetstream_hip.so
 cp $L /tmp/base.so
+timeout 600 python -m pytest tests/test_gpu_fft.py tests/test_gpu_full_sizes.py tests/test_gpu_tiled_persistent.py tests/test_gpu_filter_modules.py -q -m gpu -x 2>&1 | tail -2
 for rep in 1 2 3; do for v in base tiled_prev; do
   if [ $v = base ]; then cp /tmp/base.so $L; else cp cyberether_amd/lib/variants/$v.so $L; fi
   echo "== $v (run $rep)"
