@@ -270,6 +270,23 @@ constexpr bool build_tiled_plan(uint64_t n, uint64_t transforms, uint32_t force_
 inline bool generic_radix_tiles_enabled() { return true; }
 inline bool small_split_enabled() { return true; }
 
+// (the table of constant plans: see "per-plan specialisation" below)
+struct StaticPlanKey { uint64_t n, transforms, fold; uint32_t force_ca, force_cb; };  // fold != 0: with the fold epilogue's lane groups
+// 1-3: the plans as build_tiled_plan picks them; 4-9: the same transforms with other lane counts (A/B through
+// JST_TILED_CA / JST_TILED_CB, which make the run-time plan match one of them)
+constexpr StaticPlanKey kStaticPlans[] = {{0, 0, 0, 0, 0},
+                                          {65536, 16, 0, 0, 0}, {160000, 100, 16000, 0, 0}, {16000, 100, 0, 0, 0},
+                                          {65536, 16, 0, 16, 0}, {65536, 16, 0, 32, 0}, {65536, 16, 0, 0, 16},
+                                          {160000, 100, 16000, 0, 4}, {160000, 100, 16000, 32, 0}, {160000, 100, 16000, 8, 0},
+                                          // 10-12 (round 6): the power-of-two lengths between the register kernels' 16384 and 2^18 that split into
+                                          // two tiles, both lane counts named (the plan is then the same for every transform count; make_tiled_plan
+                                          // takes them from a few dozen column tiles on): spectrum chains of these lengths get the constant-plan
+                                          // kernels -- LDS twiddles, the persistent forms -- instead of the run-time-plan ones: 256 x 32768 points
+                                          // 81.5 -> 66-70 us, 64 x 131072 90.6 -> 71.5-75.8, 32 x 262144 98.1 -> 80.5 us per cycle, provider fast
+                                          // (profiles/r06_experiments/c_tiled_persistent.log section 13)
+                                          {32768, 1, 0, 32, 8}, {131072, 1, 0, 8, 16}, {262144, 1, 0, 8, 8}};
+[[maybe_unused]] constexpr int kStaticPlanCount = 13;
+
 bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p, bool allow_split = true) {
     constexpr uint32_t force_ca = 0, force_cb = 0;  // lanes per workgroup of the two kernels: picked below
     // Lane counts measured per plan with the specialised kernels (rocprofv3, profiles/r03_experiments/k_static_plan_lanes.log):
@@ -284,6 +301,18 @@ bool make_tiled_plan(uint64_t n, uint64_t transforms, TiledPlan& p, bool allow_s
             transforms = 16;
         } else if (n == 160000 && transforms == 100) {
             ca = 32;
+        } else {
+            // the power-of-two plans 10-12: from 256 column tiles per launch on (fewer: the lane counts that follow the
+            // transform count give more workgroups)
+            for (int sp = 10; sp <= 12; ++sp)
+                if (n == kStaticPlans[sp].n) {
+                    TiledPlan q{};
+                    if (build_tiled_plan(n, 1, kStaticPlans[sp].force_ca, kStaticPlans[sp].force_cb, q) &&
+                        transforms * ((q.S + q.CA - 1) / q.CA) >= 256) {
+                        ca = kStaticPlans[sp].force_ca;
+                        cb = kStaticPlans[sp].force_cb;
+                    }
+                }
         }
     }
     if (!build_tiled_plan(n, transforms, ca, cb, p, allow_split && small_split_enabled())) return false;
@@ -317,14 +346,6 @@ constexpr bool plan_fold_groups(TiledPlan& p, uint64_t fold) {
 // pass loop folds, and what is left of a pass is its butterflies, twiddles and LDS traffic (the generic index
 // arithmetic was about a third of a pass's VALU work: quarter-rate v_mul_lo / v_mul_hi per butterfly).  The launcher
 // takes a specialisation only when the run-time plan equals the constant one field for field.
-struct StaticPlanKey { uint64_t n, transforms, fold; uint32_t force_ca, force_cb; };  // fold != 0: with the fold epilogue's lane groups
-// 1-3: the plans as build_tiled_plan picks them; 4-9: the same transforms with other lane counts (A/B through
-// JST_TILED_CA / JST_TILED_CB, which make the run-time plan match one of them)
-constexpr StaticPlanKey kStaticPlans[] = {{0, 0, 0, 0, 0},
-                                          {65536, 16, 0, 0, 0}, {160000, 100, 16000, 0, 0}, {16000, 100, 0, 0, 0},
-                                          {65536, 16, 0, 16, 0}, {65536, 16, 0, 32, 0}, {65536, 16, 0, 0, 16},
-                                          {160000, 100, 16000, 0, 4}, {160000, 100, 16000, 32, 0}, {160000, 100, 16000, 8, 0}};
-[[maybe_unused]] constexpr int kStaticPlanCount = 10;
 constexpr TiledPlan static_plan(int sp) {
     TiledPlan p{};
     (void)build_tiled_plan(kStaticPlans[sp].n, kStaticPlans[sp].transforms, kStaticPlans[sp].force_ca,
@@ -1742,10 +1763,10 @@ hipError_t launch_spectrum_fused_tiled(uint64_t n, const FftLayout& L, const flo
     const LoadCF32TimesWindow pro{in, window, window_stride};
     if (with_range) {
         if (fast)  // config 5's plan as a constant for provider fast too (round 6: the lean epilogue, 17 instead of ~105 VALU per output)
-            return launch_tiled<true, LoadCF32TimesWindow, StoreAmplitudeRangeT<true>, 4>(
+            return launch_tiled<true, LoadCF32TimesWindow, StoreAmplitudeRangeT<true>, 4, 10, 11, 12>(
                 p, L, W, pro, StoreAmplitudeRangeT<true>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{guard_h0, guard_h1}},
                 scratch, s);
-        return launch_tiled<true, LoadCF32TimesWindow, StoreAmplitudeRangeT<false>, 1, 4, 5, 6>(
+        return launch_tiled<true, LoadCF32TimesWindow, StoreAmplitudeRangeT<false>, 1, 4, 5, 6, 10, 11, 12>(
             p, L, W, pro, StoreAmplitudeRangeT<false>{out, amp_coeff, range_scale, range_offset, dev::BinGuard{}}, scratch, s);
     }
     if (fast) return launch_tiled<true>(p, L, W, pro, StoreAmplitudeT<true>{out, amp_coeff}, scratch, s);

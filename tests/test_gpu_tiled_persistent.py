@@ -162,3 +162,28 @@ def test_lineplot_span_forms_equal_the_per_cycle_kernel(js, oracle, b):
     for i, (per_cycle, batched) in enumerate(zip(*traces)):
         assert_bit_equal(batched[0], per_cycle[0], f"lineplot average after call {i}")
         assert_bit_equal(batched[1], per_cycle[1], f"lineplot points after call {i}")
+
+
+@pytest.mark.parametrize("n,b", [(32768, 16), (32768, 256), (131072, 8), (131072, 64), (262144, 4), (262144, 32)])
+@pytest.mark.parametrize("provider", ["generic", "fast"])
+def test_power_of_two_lengths_on_constant_plans(js, oracle, n, b, provider):
+    """Constant plans 10-12 (fft_tiled.hip): 32768 / 131072 / 262144 points -- the smallest transform count that takes them
+    (one workgroup per tile) and one large enough for the persistent columns / blocks kernels.  Bit-exact against the oracle
+    (pocketfft.hh:1476-1497 order) for provider generic, within 4e-7 for provider fast; rows from both ends of the batch."""
+    rng = np.random.default_rng(n + b)
+    t = np.arange(n)
+    x = (np.exp(2j * np.pi * 777.25 * t / n)[None, :] * (0.5 + rng.uniform(0, 1, (b, 1))) +
+         1e-2 * (rng.standard_normal((b, n)) + 1j * rng.standard_normal((b, n)))).astype(np.complex64)
+    src = js.Tensor.from_numpy(x, batch=0, sample=1)
+    eng = js.SpectrumEngine(src, enable_scale=True, range_min=-100.0, range_max=0.0, provider=provider)
+    rt = js.Runtime(eng.modules, graph=True, fuse=True)
+    rt.compute(2)
+    got = eng.buffer.numpy()
+    rows = np.r_[0:2, b // 2, b - 2:b]
+    ref = oracle.spectrum_chain(x[rows], -100.0, 0.0)["range"]
+    if provider == "generic":
+        assert_bit_equal(got[rows], ref, f"{b} x {n}")
+    else:
+        err = float(np.max(np.abs(got[rows] - ref)))
+        assert err <= 4e-7, err
+    rt.destroy()
