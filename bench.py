@@ -564,6 +564,8 @@ def main() -> None:
         elapsed = sum(times) / len(times)
         measure.repeats = len(times)
         measure.spread = (min(times), max(times))
+        srt = sorted(times)
+        measure.percentiles = [srt[int(q * (len(srt) - 1))] for q in (0.1, 0.5, 0.9)]
         return rt, elapsed
 
     def host_fed(provider: str, seconds: float = 0.3) -> dict:
@@ -724,6 +726,7 @@ def main() -> None:
 
     rt, elapsed = measure(args.provider)
     repeats_main, spread_main = measure.repeats, measure.spread
+    percentiles_main = getattr(measure, "percentiles", [])
 
     # The path's optional exchange step (north_star: "optional RCCL-over-xGMI reduce"), OUTSIDE the timed region -- no
     # collective sits on the data path.  With RCCL as the control plane's backend every rank builds the LIBRARY's
@@ -865,6 +868,7 @@ def main() -> None:
                                              + args.steps + (-args.steps) % max(rt.period, 1),
                        "repeats": repeats_main, "region_ms_min_max": [round(spread_main[0] * 1e3, 4),
                                                                       round(spread_main[1] * 1e3, 4)],
+                       "region_ms_p10_p50_p90": [round(v * 1e3, 4) for v in percentiles_main],  # `value` is the MEAN over the regions
                        "ring_period": rt.period, "backend": backend if world > 1 else None,
                        # what the Spectrogram reads: the fused kernel's one-byte row indices (its side output) or the values
                        "spectrogram_input": "row indices (U8 side output of the fused kernel)"
